@@ -1,0 +1,214 @@
+"""ctypes binding of libcloudsky.so (include/cloudsky.h).  Fails loudly: a missing library or a missing GPU is
+an error, never a silent fallback."""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = None
+
+OK, ERR_INVALID, ERR_NO_DEVICE, ERR_HIP, ERR_IO, ERR_STATE = 0, -1, -2, -3, -4, -5
+
+
+class CloudSkyError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__("libcloudsky error %d: %s" % (code, msg))
+        self.code = code
+
+
+class CloudParams(C.Structure):  # clouds.glsl:18-40
+    _fields_ = [("f", C.c_float * 28)]
+
+
+class SkyParams(C.Structure):  # sky-lut.glsl:12-18
+    _fields_ = [("f", C.c_float * 8)]
+
+
+class TransParams(C.Structure):  # transmittance-lut.glsl:12-15
+    _fields_ = [("f", C.c_float * 4)]
+
+
+class Bands(C.Structure):
+    _fields_ = [("band_rows", C.c_int), ("first_band", C.c_int), ("band_stride", C.c_int), ("n_bands", C.c_int)]
+
+
+class CloudStats(C.Structure):
+    _fields_ = [("rays", C.c_uint64), ("primary_samples", C.c_uint64), ("incloud_samples", C.c_uint64)]
+
+
+# every symbol include/cloudsky.h declares: (name, restype, argtypes)
+SYMBOLS = [
+    ("csky_abi_version", C.c_int, []),
+    ("csky_device_count", C.c_int, []),
+    ("csky_create", C.c_int, [C.POINTER(C.c_void_p), C.c_int]),
+    ("csky_destroy", None, [C.c_void_p]),
+    ("csky_last_error", C.c_char_p, [C.c_void_p]),
+    ("csky_set_noise", C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    ("csky_set_march", C.c_int, [C.c_void_p, C.c_int, C.c_int]),
+    ("csky_set_early_out", C.c_int, [C.c_void_p, C.c_float]),
+    ("csky_render_transmittance", C.c_int, [C.c_void_p, C.POINTER(TransParams), C.c_void_p]),
+    ("csky_render_sky_lut", C.c_int, [C.c_void_p, C.POINTER(SkyParams), C.c_void_p]),
+    ("csky_render_clouds", C.c_int, [C.c_void_p, C.POINTER(CloudParams), C.c_int, C.c_int, C.c_void_p, C.c_size_t]),
+    ("csky_render_sky_lut_device", C.c_int, [C.c_void_p, C.POINTER(SkyParams), C.c_void_p]),
+    ("csky_render_clouds_device", C.c_int, [C.c_void_p, C.POINTER(CloudParams), C.c_int, C.POINTER(Bands), C.c_void_p, C.c_size_t, C.c_void_p]),
+    ("csky_sync", C.c_int, [C.c_void_p]),
+    ("csky_read_transmittance", C.c_int, [C.c_void_p, C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
+    ("csky_read_sky_lut", C.c_int, [C.c_void_p, C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
+    ("csky_time_clouds", C.c_int, [C.c_void_p, C.POINTER(CloudParams), C.c_int, C.POINTER(Bands), C.c_int, C.c_int, C.POINTER(C.c_float), C.POINTER(CloudStats)]),
+    ("csky_get_cloud_stats", C.c_int, [C.c_void_p, C.POINTER(CloudStats)]),
+    ("csky_set_variant", C.c_int, [C.c_void_p, C.c_int]),
+    ("csky_variant_count", C.c_int, []),
+    ("csky_variant_name", C.c_char_p, [C.c_int]),
+    ("csky_load_bmp_rgb8", C.c_int, [C.c_char_p, C.POINTER(C.c_int), C.POINTER(C.c_int), C.c_void_p, C.c_size_t]),
+    ("csky_strip_to_volume", C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
+    ("csky_generate_shape_noise", C.c_int, [C.c_uint32, C.c_int, C.c_void_p]),
+    ("csky_mip_offset", C.c_size_t, [C.c_int, C.c_int, C.c_int]),
+    ("csky_build_mips", C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int]),
+    ("csky_assets_last_error", C.c_char_p, []),
+]
+
+
+def library_path():
+    return os.path.join(_HERE, "libcloudsky.so")
+
+
+def lib():
+    """Load libcloudsky.so (built in-tree by __graft_entry__.build() / csrc/Makefile)."""
+    global _LIB
+    if _LIB is None:
+        path = library_path()
+        if not os.path.exists(path):
+            raise CloudSkyError(ERR_IO, "%s not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                                        "(hipcc --offload-arch=gfx950); there is no CPU fallback" % path)
+        L = C.CDLL(path)
+        for name, res, args in SYMBOLS:
+            fn = getattr(L, name)  # AttributeError = ABI mismatch, surfaced loudly
+            fn.restype = res
+            fn.argtypes = args
+        _LIB = L
+    return _LIB
+
+
+def _ptr(a):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+def cloud_params(values):
+    p = CloudParams()
+    v = np.asarray(values, np.float32).reshape(-1)
+    if v.size != 28:
+        raise ValueError("cloud push-constant block is 28 floats (clouds.glsl:18-40), got %d" % v.size)
+    for i in range(28):
+        p.f[i] = float(v[i])
+    return p
+
+
+class Context:
+    """One csky_ctx = one GPU.  Thin, explicit wrapper; raises CloudSkyError on any non-zero return."""
+
+    def __init__(self, device_id=0):
+        self._L = lib()
+        h = C.c_void_p()
+        rc = self._L.csky_create(C.byref(h), int(device_id))
+        if rc != OK:
+            raise CloudSkyError(rc, (self._L.csky_last_error(None) or b"").decode())
+        self._h = h
+        self.device_id = int(device_id)
+
+    def _chk(self, rc):
+        if rc != OK:
+            raise CloudSkyError(rc, (self._L.csky_last_error(self._h) or b"").decode())
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._L.csky_destroy(self._h)
+            self._h = None
+
+    __del__ = close
+
+    # ---- inputs
+    def set_noise(self, large_rgba8, small_rgb8, weather_rgb8):
+        a = np.ascontiguousarray(large_rgba8, np.uint8)
+        b = np.ascontiguousarray(small_rgb8, np.uint8)
+        c = np.ascontiguousarray(weather_rgb8, np.uint8)
+        if a.size != 128 ** 3 * 4 or b.size != 32 ** 3 * 3 or c.size != 512 * 512 * 3:
+            raise ValueError("set_noise: expected 128^3 RGBA8, 32^3 RGB8, 512^2 RGB8")
+        self._chk(self._L.csky_set_noise(self._h, _ptr(a), _ptr(b), _ptr(c)))
+
+    def set_march(self, primary_steps=128, light_steps=6):
+        self._chk(self._L.csky_set_march(self._h, primary_steps, light_steps))
+
+    def set_early_out(self, eps):
+        self._chk(self._L.csky_set_early_out(self._h, float(eps)))
+
+    def set_variant(self, v):
+        self._chk(self._L.csky_set_variant(self._h, int(v)))
+
+    # ---- kernels, host-buffer forms
+    def render_transmittance(self, w=256, h=64):
+        p = TransParams()
+        p.f[0], p.f[1] = float(w), float(h)
+        out = np.zeros((h, w, 4), np.uint16)
+        self._chk(self._L.csky_render_transmittance(self._h, C.byref(p), _ptr(out)))
+        return out.view(np.float16)
+
+    def render_sky_lut(self, sun_dir, w=200, h=100, readback=True):
+        p = SkyParams()
+        p.f[0], p.f[1] = float(w), float(h)
+        p.f[4], p.f[5], p.f[6] = [float(x) for x in sun_dir]
+        out = np.zeros((h, w, 4), np.uint16) if readback else None
+        self._chk(self._L.csky_render_sky_lut(self._h, C.byref(p), _ptr(out) if readback else None))
+        return out.view(np.float16) if readback else None
+
+    def render_clouds(self, params, tile_w=None, tile_h=None):
+        p = cloud_params(params)
+        w = int(p.f[0]) if tile_w is None else int(tile_w)
+        h = int(p.f[1]) if tile_h is None else int(tile_h)
+        out = np.zeros((h, w, 4), np.uint16)
+        self._chk(self._L.csky_render_clouds(self._h, C.byref(p), w, h, _ptr(out), w * 8))
+        return out.view(np.float16)
+
+    # ---- device-buffer forms
+    def render_sky_lut_device(self, sun_dir, w=200, h=100, stream=None):
+        p = SkyParams()
+        p.f[0], p.f[1] = float(w), float(h)
+        p.f[4], p.f[5], p.f[6] = [float(x) for x in sun_dir]
+        self._chk(self._L.csky_render_sky_lut_device(self._h, C.byref(p), C.c_void_p(stream or 0)))
+
+    def render_clouds_device(self, params, tile_w, bands, d_out, pitch_bytes, stream=None):
+        p = cloud_params(params)
+        b = Bands(*[int(x) for x in bands])
+        self._chk(self._L.csky_render_clouds_device(self._h, C.byref(p), int(tile_w), C.byref(b), C.c_void_p(int(d_out)), int(pitch_bytes),
+                                                    C.c_void_p(stream or 0)))
+
+    def sync(self):
+        self._chk(self._L.csky_sync(self._h))
+
+    def read_transmittance(self):
+        w, h = C.c_int(), C.c_int()
+        self._chk(self._L.csky_read_transmittance(self._h, None, C.byref(w), C.byref(h)))
+        out = np.zeros((h.value, w.value, 4), np.uint16)
+        self._chk(self._L.csky_read_transmittance(self._h, _ptr(out), C.byref(w), C.byref(h)))
+        return out.view(np.float16)
+
+    def read_sky_lut(self):
+        w, h = C.c_int(), C.c_int()
+        self._chk(self._L.csky_read_sky_lut(self._h, None, C.byref(w), C.byref(h)))
+        out = np.zeros((h.value, w.value, 4), np.uint16)
+        self._chk(self._L.csky_read_sky_lut(self._h, _ptr(out), C.byref(w), C.byref(h)))
+        return out.view(np.float16)
+
+    # ---- measurement
+    def time_clouds(self, params, tile_w, bands, warmup=2, iters=10):
+        p = cloud_params(params)
+        b = Bands(*[int(x) for x in bands])
+        ms = C.c_float()
+        st = CloudStats()
+        self._chk(self._L.csky_time_clouds(self._h, C.byref(p), int(tile_w), C.byref(b), warmup, iters, C.byref(ms), C.byref(st)))
+        return ms.value, dict(rays=st.rays, primary_samples=st.primary_samples, incloud_samples=st.incloud_samples)
+
+    def cloud_stats(self):
+        st = CloudStats()
+        self._chk(self._L.csky_get_cloud_stats(self._h, C.byref(st)))
+        return dict(rays=st.rays, primary_samples=st.primary_samples, incloud_samples=st.incloud_samples)

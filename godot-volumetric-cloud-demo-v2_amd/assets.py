@@ -1,0 +1,73 @@
+"""Asset layer: what the reference gets from Godot's importers (weather.bmp.import, worlnoise.bmp.import,
+perlworlnoise.tga.import).  Host-only functions of libcloudsky; usable without a GPU."""
+import ctypes as C
+import hashlib
+import os
+
+import numpy as np
+
+from . import _lib
+
+ASSET_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), "assets")
+SHAPE_SEED = 1
+# SHA-256 of csky_generate_shape_noise(seed=1, n=128): integer hashing + IEEE +,-,*,/,sqrt only => machine independent
+SHAPE_SHA256 = None  # filled in by tests/test_assets.py expectations (see tests/golden/INPUTS.txt)
+
+
+def _chk(rc):
+    if rc != 0:
+        raise _lib.CloudSkyError(rc, (_lib.lib().csky_assets_last_error() or b"").decode())
+
+
+def load_bmp_rgb8(path):
+    L = _lib.lib()
+    w, h = C.c_int(), C.c_int()
+    _chk(L.csky_load_bmp_rgb8(path.encode(), C.byref(w), C.byref(h), None, 0))
+    out = np.zeros((h.value, w.value, 3), np.uint8)
+    _chk(L.csky_load_bmp_rgb8(path.encode(), C.byref(w), C.byref(h), out.ctypes.data_as(C.c_void_p), out.nbytes))
+    return out
+
+
+def strip_to_volume(strip, n):
+    """Godot 3-D import, slices/horizontal=n, vertical=1: voxel (x,y,z) = strip[y][n*z + x] -> [z,y,x,ch]."""
+    strip = np.ascontiguousarray(strip, np.uint8)
+    ch = strip.shape[2]
+    assert strip.shape[0] == n and strip.shape[1] == n * n
+    vol = np.zeros((n, n, n, ch), np.uint8)
+    _chk(_lib.lib().csky_strip_to_volume(strip.ctypes.data_as(C.c_void_p), n, ch, vol.ctypes.data_as(C.c_void_p)))
+    return vol
+
+
+def generate_shape_noise(seed=SHAPE_SEED, n=128):
+    """Deterministic stand-in for the missing cloud_sky/perlworlnoise.tga: [z,y,x,4] uint8."""
+    vol = np.zeros((n, n, n, 4), np.uint8)
+    _chk(_lib.lib().csky_generate_shape_noise(seed, n, vol.ctypes.data_as(C.c_void_p)))
+    return vol
+
+
+def build_mips(level0, levels):
+    level0 = np.ascontiguousarray(level0, np.uint8)
+    n, ch = level0.shape[0], level0.shape[3]
+    L = _lib.lib()
+    total = L.csky_mip_offset(n, levels, ch)
+    buf = np.zeros(total, np.uint8)
+    buf[: level0.size] = level0.reshape(-1)
+    _chk(L.csky_build_mips(buf.ctypes.data_as(C.c_void_p), n, ch, levels))
+    return buf
+
+
+_CACHE = {}
+
+
+def load_default_noise(seed=SHAPE_SEED):
+    """(large 128^3 RGBA8, small 32^3 RGB8, weather 512^2 RGB8): the benchmark inputs."""
+    if seed not in _CACHE:
+        weather = load_bmp_rgb8(os.path.join(ASSET_DIR, "weather.bmp"))
+        small = strip_to_volume(load_bmp_rgb8(os.path.join(ASSET_DIR, "worlnoise.bmp")), 32)
+        large = generate_shape_noise(seed, 128)
+        _CACHE[seed] = (large, small, weather)
+    return _CACHE[seed]
+
+
+def sha256(a):
+    return hashlib.sha256(np.ascontiguousarray(a).tobytes()).hexdigest()

@@ -1,0 +1,319 @@
+// api.cpp -- the C ABI of libcloudsky (include/cloudsky.h): context, device memory, texture baking, launches.
+// Mirrors the resource ownership of the reference's GDScript drivers: cloud_sky.gd (`_initialize_compute_code`,
+// `_render_process`, `cleanup`), sky_lut.gd (`render_lut`), transmittance_lut.gd (`_initialize_compute_code`).
+// There is no CPU render path here: every render entry point needs a live HIP device.
+#include <hip/hip_runtime_api.h>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <new>
+#include <vector>
+#include "../../include/cloudsky.h"
+#include "kernels.h"
+#include "bake.h"
+
+using namespace csky;
+
+static_assert(sizeof(csky_cloud_params) == sizeof(CloudParams), "ABI struct mismatch");
+
+struct csky_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    // noise set (cloud_sky.gd:298-341)
+    uint2* d_shape = nullptr; uint4* d_detail = nullptr; uint2* d_weather = nullptr; bool have_noise = false;
+    uint32_t shape_off[SHAPE_LEVELS] = {}, detail_off[DETAIL_LEVELS] = {};
+    // LUTs: RGBA16F image + float4 copy of the rounded values
+    uint16_t* d_trans_h = nullptr; float4* d_trans_f = nullptr; int tw = 0, th = 0; bool have_trans = false;
+    uint16_t* d_sky_h = nullptr; float4* d_sky_f = nullptr; int sw = 0, sh = 0; bool have_sky = false;
+    FrameConsts* d_fc = nullptr;
+    unsigned long long* d_stats = nullptr;
+    uint2* d_frame = nullptr; size_t frame_px = 0;  // internal frame for the host-buffer form / timing
+    int primary_steps = 128, light_steps = 6;        // clouds.glsl:228, :186
+    float early_eps = 0.0f;
+    int variant = 0;
+    csky_cloud_stats last_stats = {0, 0, 0};
+    char err[512] = {0};
+};
+
+namespace {
+thread_local char g_err[512];
+
+int fail(csky_ctx* c, int code, const char* fmt, ...) {
+    char* dst = c ? c->err : g_err;
+    va_list ap; va_start(ap, fmt); vsnprintf(dst, 512, fmt, ap); va_end(ap);
+    return code;
+}
+#define HIPCHK(c, call) do { hipError_t e_ = (call); if (e_ != hipSuccess) return fail((c), CSKY_ERR_HIP, "%s failed: %s", #call, hipGetErrorString(e_)); } while (0)
+
+int bind(csky_ctx* c) { HIPCHK(c, hipSetDevice(c->device)); return CSKY_OK; }
+
+template <class T> int dev_alloc(csky_ctx* c, T** p, size_t count) {
+    if (*p) { (void)hipFree(*p); *p = nullptr; }
+    HIPCHK(c, hipMalloc(reinterpret_cast<void**>(p), count * sizeof(T)));
+    return CSKY_OK;
+}
+
+int ensure_trans(csky_ctx* c, int w, int h) {
+    if (c->d_trans_h && c->tw == w && c->th == h) return CSKY_OK;
+    int rc; if ((rc = dev_alloc(c, &c->d_trans_h, (size_t)w * h * 4))) return rc;
+    if ((rc = dev_alloc(c, &c->d_trans_f, (size_t)w * h))) return rc;
+    c->tw = w; c->th = h; c->have_trans = false; return CSKY_OK;
+}
+int ensure_sky(csky_ctx* c, int w, int h) {
+    if (c->d_sky_h && c->sw == w && c->sh == h) return CSKY_OK;
+    int rc; if ((rc = dev_alloc(c, &c->d_sky_h, (size_t)w * h * 4))) return rc;
+    if ((rc = dev_alloc(c, &c->d_sky_f, (size_t)w * h))) return rc;
+    c->sw = w; c->sh = h; c->have_sky = false; return CSKY_OK;
+}
+int ensure_frame(csky_ctx* c, size_t px) {
+    if (c->d_frame && c->frame_px >= px) return CSKY_OK;
+    int rc; if ((rc = dev_alloc(c, &c->d_frame, px))) return rc;
+    c->frame_px = px; return CSKY_OK;
+}
+
+int render_trans_dev(csky_ctx* c, int w, int h, hipStream_t s) {
+    int rc; if ((rc = ensure_trans(c, w, h))) return rc;
+    HIPCHK(c, launch_transmittance(w, h, c->d_trans_h, c->d_trans_f, s));
+    c->have_trans = true; return CSKY_OK;
+}
+
+TexSet texset(const csky_ctx* c) {
+    TexSet t;
+    t.shape = c->d_shape; t.detail = c->d_detail; t.weather = c->d_weather; t.sky = c->d_sky_f; t.sky_w = c->sw; t.sky_h = c->sh;
+    memcpy(t.shape_off, c->shape_off, sizeof t.shape_off); memcpy(t.detail_off, c->detail_off, sizeof t.detail_off);
+    return t;
+}
+
+int check_bands(csky_ctx* c, const csky_bands* b, int tile_w) {
+    if (tile_w < 1 || !b || b->band_rows < 1 || b->n_bands < 0 || b->first_band < 0 || b->band_stride < 1)
+        return fail(c, CSKY_ERR_INVALID, "render_clouds: bad tile/bands description");
+    return CSKY_OK;
+}
+
+// frame_setup + clouds on stream s into d_out (compact rows).  stats: optional device counters.
+int clouds_dev(csky_ctx* c, const csky_cloud_params* p, int tile_w, const csky_bands* b, uint2* d_out, size_t pitch_bytes, hipStream_t s,
+               unsigned long long* d_stats, bool setup) {
+    if (!p) return fail(c, CSKY_ERR_INVALID, "render_clouds: params is NULL");
+    if (!c->have_noise) return fail(c, CSKY_ERR_STATE, "render_clouds: csky_set_noise has not been called");
+    if (!c->have_sky) return fail(c, CSKY_ERR_STATE, "render_clouds: no sky LUT yet (call csky_render_sky_lut first; cloud_sky.gd:187,242)");
+    if (!(p->texture_size[0] >= 1.0f) || !(p->texture_size[1] >= 1.0f)) return fail(c, CSKY_ERR_INVALID, "render_clouds: texture_size must be >= 1");
+    int rc; if ((rc = check_bands(c, b, tile_w))) return rc;
+    if (pitch_bytes % 8 || pitch_bytes < (size_t)tile_w * 8) return fail(c, CSKY_ERR_INVALID, "render_clouds: row pitch must be a multiple of 8 and >= tile_w*8");
+    if (b->n_bands == 0) return CSKY_OK;
+    CloudParams cp; memcpy(&cp, p, sizeof cp);
+    if (setup) HIPCHK(c, launch_frame_setup(cp, c->d_sky_f, c->sw, c->sh, c->primary_steps, c->light_steps, c->early_eps, c->d_fc, s));
+    RenderGeom g; g.tile_w = tile_w; g.band_rows = b->band_rows; g.first_band = b->first_band; g.band_stride = b->band_stride; g.n_bands = b->n_bands;
+    g.pitch_px = (uint32_t)(pitch_bytes / 8);
+    HIPCHK(c, launch_clouds(c->variant, texset(c), c->d_fc, g, d_out, d_stats, s));
+    return CSKY_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int csky_abi_version(void) { return CSKY_ABI_VERSION; }
+
+int csky_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+const char* csky_last_error(const csky_ctx* ctx) { return ctx ? ctx->err : g_err; }
+
+int csky_create(csky_ctx** out, int device_id) {
+    if (!out) return fail(nullptr, CSKY_ERR_INVALID, "csky_create: out is NULL");
+    *out = nullptr;
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess || n <= 0)
+        return fail(nullptr, CSKY_ERR_NO_DEVICE, "csky_create: no HIP device available (%s); libcloudsky has no CPU fallback",
+                    e == hipSuccess ? "device count is 0" : hipGetErrorString(e));
+    if (device_id < 0 || device_id >= n) return fail(nullptr, CSKY_ERR_INVALID, "csky_create: device_id %d out of range [0,%d)", device_id, n);
+    csky_ctx* c = new (std::nothrow) csky_ctx();
+    if (!c) return fail(nullptr, CSKY_ERR_INVALID, "csky_create: out of host memory");
+    c->device = device_id;
+    auto bail = [&](const char* what, hipError_t err) { fail(nullptr, CSKY_ERR_HIP, "csky_create: %s failed: %s", what, hipGetErrorString(err)); csky_destroy(c); return CSKY_ERR_HIP; };
+    if ((e = hipSetDevice(device_id)) != hipSuccess) return bail("hipSetDevice", e);
+    if ((e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking)) != hipSuccess) return bail("hipStreamCreate", e);
+    if ((e = hipEventCreate(&c->ev0)) != hipSuccess) return bail("hipEventCreate", e);
+    if ((e = hipEventCreate(&c->ev1)) != hipSuccess) return bail("hipEventCreate", e);
+    if ((e = hipMalloc(reinterpret_cast<void**>(&c->d_fc), sizeof(FrameConsts))) != hipSuccess) return bail("hipMalloc", e);
+    if ((e = hipMalloc(reinterpret_cast<void**>(&c->d_stats), 2 * sizeof(unsigned long long))) != hipSuccess) return bail("hipMalloc", e);
+    *out = c;
+    return CSKY_OK;
+}
+
+void csky_destroy(csky_ctx* c) {
+    if (!c) return;
+    (void)hipSetDevice(c->device);
+    if (c->stream) (void)hipStreamSynchronize(c->stream);
+    void* ptrs[] = {c->d_shape, c->d_detail, c->d_weather, c->d_trans_h, c->d_trans_f, c->d_sky_h, c->d_sky_f, c->d_fc, c->d_stats, c->d_frame};
+    for (void* p : ptrs) if (p) (void)hipFree(p);
+    if (c->ev0) (void)hipEventDestroy(c->ev0);
+    if (c->ev1) (void)hipEventDestroy(c->ev1);
+    if (c->stream) (void)hipStreamDestroy(c->stream);
+    delete c;
+}
+
+int csky_set_noise(csky_ctx* c, const uint8_t* large_rgba8, const uint8_t* small_rgb8, const uint8_t* weather_rgb8) {
+    if (!c) return fail(nullptr, CSKY_ERR_INVALID, "csky_set_noise: ctx is NULL");
+    if (!large_rgba8 || !small_rgb8 || !weather_rgb8) return fail(c, CSKY_ERR_INVALID, "csky_set_noise: NULL texture pointer");
+    int rc; if ((rc = bind(c))) return rc;
+    std::vector<uint8_t> lc(csky_mip_offset(SHAPE_N, SHAPE_LEVELS, 4)), sc(csky_mip_offset(DETAIL_N, DETAIL_LEVELS, 3));
+    memcpy(lc.data(), large_rgba8, (size_t)SHAPE_N * SHAPE_N * SHAPE_N * 4);
+    memcpy(sc.data(), small_rgb8, (size_t)DETAIL_N * DETAIL_N * DETAIL_N * 3);
+    csky_build_mips(lc.data(), SHAPE_N, 4, SHAPE_LEVELS);      // mipmaps/generate=true, perlworlnoise.tga.import:24
+    csky_build_mips(sc.data(), DETAIL_N, 3, DETAIL_LEVELS);    // worlnoise.bmp.import:24
+    std::vector<uint2> shape, weather; std::vector<uint4> detail;
+    bake_shape(lc, shape, c->shape_off);
+    bake_detail(sc, detail, c->detail_off);
+    bake_weather(weather_rgb8, weather);
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    if ((rc = dev_alloc(c, &c->d_shape, shape.size()))) return rc;
+    if ((rc = dev_alloc(c, &c->d_detail, detail.size()))) return rc;
+    if ((rc = dev_alloc(c, &c->d_weather, weather.size()))) return rc;
+    HIPCHK(c, hipMemcpy(c->d_shape, shape.data(), shape.size() * sizeof(uint2), hipMemcpyHostToDevice));
+    HIPCHK(c, hipMemcpy(c->d_detail, detail.data(), detail.size() * sizeof(uint4), hipMemcpyHostToDevice));
+    HIPCHK(c, hipMemcpy(c->d_weather, weather.data(), weather.size() * sizeof(uint2), hipMemcpyHostToDevice));
+    c->have_noise = true;
+    return CSKY_OK;
+}
+
+int csky_set_march(csky_ctx* c, int primary_steps, int light_steps) {
+    if (!c) return fail(nullptr, CSKY_ERR_INVALID, "csky_set_march: ctx is NULL");
+    if (primary_steps < 1 || primary_steps > 1024 || light_steps < 0 || light_steps > 6)
+        return fail(c, CSKY_ERR_INVALID, "csky_set_march: primary_steps in [1,1024], light_steps in [0,6] (RANDOM_VECTORS has 6 entries, clouds.glsl:140)");
+    c->primary_steps = primary_steps; c->light_steps = light_steps; return CSKY_OK;
+}
+
+int csky_set_early_out(csky_ctx* c, float eps) {
+    if (!c) return fail(nullptr, CSKY_ERR_INVALID, "csky_set_early_out: ctx is NULL");
+    if (!(eps >= 0.0f) || eps > 0.5f) return fail(c, CSKY_ERR_INVALID, "csky_set_early_out: eps must be in [0, 0.5]");
+    c->early_eps = eps; return CSKY_OK;
+}
+
+int csky_set_variant(csky_ctx* c, int variant) {
+    if (!c) return fail(nullptr, CSKY_ERR_INVALID, "csky_set_variant: ctx is NULL");
+    if (variant < 0 || variant >= cloud_variant_count()) return fail(c, CSKY_ERR_INVALID, "csky_set_variant: unknown variant %d", variant);
+    c->variant = variant; return CSKY_OK;
+}
+int csky_variant_count(void) { return cloud_variant_count(); }
+const char* csky_variant_name(int v) { return cloud_variant_name(v); }
+
+int csky_sync(csky_ctx* c) {
+    if (!c) return fail(nullptr, CSKY_ERR_INVALID, "csky_sync: ctx is NULL");
+    int rc; if ((rc = bind(c))) return rc;
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return CSKY_OK;
+}
+
+int csky_render_transmittance(csky_ctx* c, const csky_transmittance_params* p, uint16_t* out) {
+    if (!c) return fail(nullptr, CSKY_ERR_INVALID, "csky_render_transmittance: ctx is NULL");
+    if (!p) return fail(c, CSKY_ERR_INVALID, "csky_render_transmittance: params is NULL");
+    const int w = (int)p->texture_size[0], h = (int)p->texture_size[1];
+    if (w < 1 || h < 1 || w > 8192 || h > 8192) return fail(c, CSKY_ERR_INVALID, "csky_render_transmittance: texture_size out of range");
+    int rc; if ((rc = bind(c))) return rc;
+    if ((rc = render_trans_dev(c, w, h, c->stream))) return rc;
+    if (out) HIPCHK(c, hipMemcpyAsync(out, c->d_trans_h, (size_t)w * h * 8, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return CSKY_OK;
+}
+
+int csky_render_sky_lut_device(csky_ctx* c, const csky_sky_params* p, void* hip_stream) {
+    if (!c) return fail(nullptr, CSKY_ERR_INVALID, "csky_render_sky_lut: ctx is NULL");
+    if (!p) return fail(c, CSKY_ERR_INVALID, "csky_render_sky_lut: params is NULL");
+    const int w = (int)p->texture_size[0], h = (int)p->texture_size[1];
+    if (w < 1 || h < 1 || w > 8192 || h > 8192) return fail(c, CSKY_ERR_INVALID, "csky_render_sky_lut: texture_size out of range");
+    int rc; if ((rc = bind(c))) return rc;
+    hipStream_t s = hip_stream ? (hipStream_t)hip_stream : c->stream;
+    if (!c->have_trans && (rc = render_trans_dev(c, 256, 64, s))) return rc;   // transmittance_lut.gd:6 default size
+    if ((rc = ensure_sky(c, w, h))) return rc;
+    HIPCHK(c, launch_sky_lut(w, h, p->sun_direction, c->d_trans_f, c->tw, c->th, c->d_sky_h, c->d_sky_f, s));
+    c->have_sky = true;
+    return CSKY_OK;
+}
+
+int csky_render_sky_lut(csky_ctx* c, const csky_sky_params* p, uint16_t* out) {
+    int rc = csky_render_sky_lut_device(c, p, nullptr);
+    if (rc) return rc;
+    if (out) HIPCHK(c, hipMemcpyAsync(out, c->d_sky_h, (size_t)c->sw * c->sh * 8, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return CSKY_OK;
+}
+
+int csky_render_clouds_device(csky_ctx* c, const csky_cloud_params* p, int tile_w, const csky_bands* bands, void* d_out, size_t pitch, void* hip_stream) {
+    if (!c) return fail(nullptr, CSKY_ERR_INVALID, "csky_render_clouds_device: ctx is NULL");
+    if (!d_out) return fail(c, CSKY_ERR_INVALID, "csky_render_clouds_device: d_out is NULL");
+    int rc; if ((rc = bind(c))) return rc;
+    hipStream_t s = hip_stream ? (hipStream_t)hip_stream : c->stream;
+    return clouds_dev(c, p, tile_w, bands, (uint2*)d_out, pitch, s, nullptr, true);
+}
+
+int csky_render_clouds(csky_ctx* c, const csky_cloud_params* p, int tile_w, int tile_h, uint16_t* out, size_t pitch) {
+    if (!c) return fail(nullptr, CSKY_ERR_INVALID, "csky_render_clouds: ctx is NULL");
+    if (tile_w < 1 || tile_h < 1) return fail(c, CSKY_ERR_INVALID, "csky_render_clouds: empty tile");
+    if (out && (pitch < (size_t)tile_w * 8)) return fail(c, CSKY_ERR_INVALID, "csky_render_clouds: row_pitch_bytes < tile_w*8");
+    int rc; if ((rc = bind(c))) return rc;
+    if ((rc = ensure_frame(c, (size_t)tile_w * tile_h))) return rc;
+    csky_bands b = {tile_h, 0, 1, 1};
+    HIPCHK(c, hipMemsetAsync(c->d_stats, 0, 16, c->stream));
+    if ((rc = clouds_dev(c, p, tile_w, &b, c->d_frame, (size_t)tile_w * 8, c->stream, c->d_stats, true))) return rc;
+    unsigned long long st[2] = {0, 0};
+    HIPCHK(c, hipMemcpyAsync(st, c->d_stats, 16, hipMemcpyDeviceToHost, c->stream));
+    if (out) HIPCHK(c, hipMemcpy2DAsync(out, pitch, c->d_frame, (size_t)tile_w * 8, (size_t)tile_w * 8, tile_h, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    c->last_stats.rays = (uint64_t)tile_w * tile_h; c->last_stats.incloud_samples = st[0]; c->last_stats.primary_samples = st[1] * (uint64_t)c->primary_steps;
+    return CSKY_OK;
+}
+
+int csky_read_transmittance(csky_ctx* c, uint16_t* out, int* w, int* h) {
+    if (!c) return fail(nullptr, CSKY_ERR_INVALID, "csky_read_transmittance: ctx is NULL");
+    if (!c->have_trans) return fail(c, CSKY_ERR_STATE, "csky_read_transmittance: LUT not rendered yet");
+    int rc; if ((rc = bind(c))) return rc;
+    if (w) *w = c->tw; if (h) *h = c->th;
+    if (out) { HIPCHK(c, hipStreamSynchronize(c->stream)); HIPCHK(c, hipMemcpy(out, c->d_trans_h, (size_t)c->tw * c->th * 8, hipMemcpyDeviceToHost)); }
+    return CSKY_OK;
+}
+int csky_read_sky_lut(csky_ctx* c, uint16_t* out, int* w, int* h) {
+    if (!c) return fail(nullptr, CSKY_ERR_INVALID, "csky_read_sky_lut: ctx is NULL");
+    if (!c->have_sky) return fail(c, CSKY_ERR_STATE, "csky_read_sky_lut: LUT not rendered yet");
+    int rc; if ((rc = bind(c))) return rc;
+    if (w) *w = c->sw; if (h) *h = c->sh;
+    if (out) { HIPCHK(c, hipStreamSynchronize(c->stream)); HIPCHK(c, hipMemcpy(out, c->d_sky_h, (size_t)c->sw * c->sh * 8, hipMemcpyDeviceToHost)); }
+    return CSKY_OK;
+}
+
+int csky_time_clouds(csky_ctx* c, const csky_cloud_params* p, int tile_w, const csky_bands* bands, int warmup, int iters, float* mean_ms, csky_cloud_stats* stats) {
+    if (!c) return fail(nullptr, CSKY_ERR_INVALID, "csky_time_clouds: ctx is NULL");
+    if (iters < 1 || warmup < 0 || !mean_ms) return fail(c, CSKY_ERR_INVALID, "csky_time_clouds: bad iters/warmup/mean_ms");
+    int rc; if ((rc = bind(c))) return rc;
+    if ((rc = check_bands(c, bands, tile_w))) return rc;
+    const size_t rows = (size_t)bands->n_bands * bands->band_rows;
+    if ((rc = ensure_frame(c, (size_t)tile_w * (rows ? rows : 1)))) return rc;
+    const size_t pitch = (size_t)tile_w * 8;
+    HIPCHK(c, hipMemsetAsync(c->d_stats, 0, 16, c->stream));
+    if ((rc = clouds_dev(c, p, tile_w, bands, c->d_frame, pitch, c->stream, c->d_stats, true))) return rc;   // stats launch (+ frame setup)
+    for (int i = 0; i < warmup; i++) if ((rc = clouds_dev(c, p, tile_w, bands, c->d_frame, pitch, c->stream, nullptr, false))) return rc;
+    HIPCHK(c, hipEventRecord(c->ev0, c->stream));
+    for (int i = 0; i < iters; i++) if ((rc = clouds_dev(c, p, tile_w, bands, c->d_frame, pitch, c->stream, nullptr, false))) return rc;
+    HIPCHK(c, hipEventRecord(c->ev1, c->stream));
+    HIPCHK(c, hipEventSynchronize(c->ev1));
+    float ms = 0.0f;
+    HIPCHK(c, hipEventElapsedTime(&ms, c->ev0, c->ev1));
+    *mean_ms = ms / (float)iters;
+    unsigned long long st[2] = {0, 0};
+    HIPCHK(c, hipMemcpy(st, c->d_stats, 16, hipMemcpyDeviceToHost));
+    c->last_stats.rays = (uint64_t)tile_w * rows; c->last_stats.incloud_samples = st[0]; c->last_stats.primary_samples = st[1] * (uint64_t)c->primary_steps;
+    if (stats) *stats = c->last_stats;
+    return CSKY_OK;
+}
+
+int csky_get_cloud_stats(csky_ctx* c, csky_cloud_stats* stats) {
+    if (!c || !stats) return fail(c, CSKY_ERR_INVALID, "csky_get_cloud_stats: NULL argument");
+    *stats = c->last_stats; return CSKY_OK;
+}
+
+}  // extern "C"

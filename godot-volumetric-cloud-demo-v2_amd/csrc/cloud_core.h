@@ -1,0 +1,328 @@
+// cloud_core.h -- the per-ray cloud march of clouds.glsl, written for one ray per lane.
+//
+// Host+device (CSKY_HD) so that tests/hostsim can single-step the exact kernel maths on a CPU against the
+// oracle before it ever runs on a GPU.  The PRODUCT only ever instantiates it inside the HIP kernels of
+// cloud_kernels.hip; there is no CPU render path in libcloudsky.
+//
+// Section A is compiled with FP contraction OFF and IEEE-exact sqrt/div: it holds every expression whose
+// fp32 rounding decides WHERE a sample lands (ray set-up, |p|, texture coordinates).  Those reproduce the
+// reference's evaluation order bit for bit (positions are ~6e6 m, ulp 0.5 m; intersectSphere
+// cancels catastrophically).  Section B (filtering, remaps, shading) may contract and uses the hardware
+// exp2/log2/rcp approximations; its error is continuous and ~1e-6 relative (tests state the tolerance).
+#pragma once
+#include "csky_common.h"
+
+namespace csky {
+
+#if defined(__HIP_DEVICE_COMPILE__)
+CSKY_HD float fast_rcp(float x) { return __builtin_amdgcn_rcpf(x); }
+CSKY_HD float fast_exp2(float x) { return __builtin_amdgcn_exp2f(x); }
+CSKY_HD float fast_log2(float x) { return __builtin_amdgcn_logf(x); }
+#define CSKY_WAVE_ALL(x) (__all(x) != 0)
+#else
+CSKY_HD float fast_rcp(float x) { return 1.0f / x; }
+CSKY_HD float fast_exp2(float x) { return exp2f(x); }
+CSKY_HD float fast_log2(float x) { return log2f(x); }
+#define CSKY_WAVE_ALL(x) (x)
+#endif
+CSKY_HD float fast_exp(float x) { return fast_exp2(x * 1.44269504088896f); }
+CSKY_HD float fast_pow(float x, float y) { return fast_exp2(y * fast_log2(x)); }  // x >= 0; pow(0,y>0) = 0
+
+// =================================================================================================
+// Section A: exact fp32 (no contraction).
+// =================================================================================================
+#pragma clang fp contract(off)
+
+struct Ray {
+    float px, py, pz;     // current sample position (starts at the shell entry point)
+    float sx, sy, sz;     // dir*ss, the per-step increment (clouds.glsl:173)
+    float dx, dy, dz;     // normalised direction
+    float ss;             // step length (clouds.glsl:143)
+    bool above;           // dir.y > 0 (clouds.glsl:221)
+};
+
+CSKY_HD float length3_exact(float x, float y, float z) { return sqrtf(x * x + y * y + z * z); }
+
+// clouds.glsl:97-105 with pos = camPos = (0, g_radius, 0)
+CSKY_HD float intersect_sphere_cam(float dx, float dy, float dz, float r) {
+    const float a = dx * dx + dy * dy + dz * dz;
+    const float b = 2.0f * (dx * 0.0f + dy * G_RADIUS + dz * 0.0f);
+    const float c = (0.0f * 0.0f + G_RADIUS * G_RADIUS + 0.0f * 0.0f) - (r * r);
+    const float d = sqrtf((b * b) - 4.0f * a * c);
+    const float p = -b - d, p2 = -b + d;
+    return fmaxf(p, p2) / (2.0f * a);
+}
+
+// clouds.glsl:258-262 (main), :248-256 (oct_to_vec3), :218-231 (sky) and :143-145 (march prologue).
+// gx, gy = gl_GlobalInvocationID.xy.
+CSKY_HD Ray ray_setup(const FrameConsts& fc, int gx, int gy) {
+    Ray r;
+    const int px = gx + fc.upd_x, py = gy + fc.upd_y;
+    const float ex = (float)px / fc.tex_w, ey = (float)py / fc.tex_h;
+    float nx = ex - ey;
+    float ny = (ex + ey) - 1.0f;
+    const float nz = 1.0f - fabsf(nx) - fabsf(ny);
+    if (!(nz >= 0.0f)) {  // oct_wrap, clouds.glsl:239-244 (dead for uv in [0,1)^2, kept for fidelity)
+        const float sx = nx >= 0.0f ? 1.0f : -1.0f, sy = ny >= 0.0f ? 1.0f : -1.0f;
+        const float wx = (1.0f - fabsf(ny)) * sx, wy = (1.0f - fabsf(nx)) * sy;
+        nx = wx; ny = wy;
+    }
+    const float nl = length3_exact(nx, ny, nz);
+    const float dx = nx / nl, dy = nz / nl, dz = ny / nl;  // .xzy swizzle, clouds.glsl:262
+    r.above = dy > 0.0f;
+    if (!r.above) { r.px = r.py = r.pz = r.sx = r.sy = r.sz = r.dx = r.dy = r.dz = r.ss = 0.0f; return r; }
+    const float t0 = intersect_sphere_cam(dx, dy, dz, SKY_B_RADIUS);
+    const float t1 = intersect_sphere_cam(dx, dy, dz, SKY_T_RADIUS);
+    const float s0x = 0.0f + dx * t0, s0y = G_RADIUS + dy * t0, s0z = 0.0f + dz * t0;  // start, clouds.glsl:224
+    const float e0x = 0.0f + dx * t1, e0y = G_RADIUS + dy * t1, e0z = 0.0f + dz * t1;  // end,   clouds.glsl:225
+    const float shelldist = length3_exact(e0x - s0x, e0y - s0y, e0z - s0z);
+    const float rx = dx * shelldist / fc.steps_f, ry = dy * shelldist / fc.steps_f, rz = dz * shelldist / fc.steps_f;  // :230
+    r.ss = length3_exact(rx, ry, rz);                                                  // :143
+    r.dx = rx / r.ss; r.dy = ry / r.ss; r.dz = rz / r.ss;                              // :144
+    r.sx = r.dx * r.ss; r.sy = r.dy * r.ss; r.sz = r.dz * r.ss;
+    // clouds.glsl:145: p = pos + dir*hash(pos*10)*ss.  hash() == 0 for every ray in fp32: pos.y*10*0.3183099
+    // >= 1.9e7 > 2^24, so fract(...) of the y component is 0 and the product vanishes (SURVEY A.6.1;
+    // tests/test_oracle_structure.py checks the oracle's literal evaluation).  Hence p = pos exactly.
+    r.px = s0x; r.py = s0y; r.pz = s0z;
+    return r;
+}
+
+// weather texture coordinate, clouds.glsl:174 / :189 / :197 : p.xz * 0.00006 + 0.5 + weather_pos
+CSKY_HD void weather_coord(float px, float pz, float wx, float wy, float& sx, float& sy) {
+    sx = px * 0.00006f + 0.5f + wx;
+    sy = pz * 0.00006f + 0.5f + wy;
+}
+// shape-noise coordinate, clouds.glsl:114,117: (p + wind) * 0.00008 ; detail, :128-132: (p + wind - detail) * 0.001
+CSKY_HD void shape_coord(const FrameConsts& fc, float px, float py, float pz, float& qx, float& qy, float& qz, float& sx, float& sy, float& sz) {
+    qx = px + fc.cloud_off_x; qy = py; qz = pz + fc.cloud_off_z;
+    sx = qx * 0.00008f; sy = qy * 0.00008f; sz = qz * 0.00008f;
+}
+CSKY_HD void detail_coord(const FrameConsts& fc, float qx, float qy, float qz, float& sx, float& sy, float& sz) {
+    sx = (qx - fc.det_off_x) * 0.001f; sy = (qy - fc.det_off_y) * 0.001f; sz = (qz - fc.det_off_z) * 0.001f;
+}
+CSKY_HD void advance(float& x, float& y, float& z, float ix, float iy, float iz) { x = x + ix; y = y + iy; z = z + iz; }
+
+// Per-frame constants (clouds.glsl:114,128-129,148-150,160-170,187,195).  Runs once per frame (one lane).
+CSKY_HD float sky_lut_uv_x(float dz, float dx) { return atan2f(dz, dx) / CLOUD_PI * 0.5f + 0.5f; }
+CSKY_HD float sky_lut_uv_y(float dy) { const float th = asinf(dy); return sqrtf(fabsf(th) / (CLOUD_PI * 0.5f)) * signf(th) * 0.5f + 0.5f; }
+
+CSKY_HD void sky_lut_tap(const float4* sky, int w, int h, float sx, float sy, float out[3]) {  // CLAMP + LINEAR, cloud_sky.gd:381-390
+    const float ux = sx * (float)w - 0.5f, uy = sy * (float)h - 0.5f;
+    const float fx0 = floorf(ux), fy0 = floorf(uy), ax = ux - fx0, ay = uy - fy0;
+    int x0 = (int)fx0, y0 = (int)fy0, x1 = x0 + 1, y1 = y0 + 1;
+    x0 = x0 < 0 ? 0 : (x0 > w - 1 ? w - 1 : x0); x1 = x1 < 0 ? 0 : (x1 > w - 1 ? w - 1 : x1);
+    y0 = y0 < 0 ? 0 : (y0 > h - 1 ? h - 1 : y0); y1 = y1 < 0 ? 0 : (y1 > h - 1 ? h - 1 : y1);
+    const float4 a = sky[y0 * w + x0], b = sky[y0 * w + x1], c = sky[y1 * w + x0], d = sky[y1 * w + x1];
+    out[0] = lerpf(lerpf(a.x, b.x, ax), lerpf(c.x, d.x, ax), ay);
+    out[1] = lerpf(lerpf(a.y, b.y, ax), lerpf(c.y, d.y, ax), ay);
+    out[2] = lerpf(lerpf(a.z, b.z, ax), lerpf(c.z, d.z, ax), ay);
+}
+
+CSKY_HD void frame_setup(const CloudParams& P, const float4* sky, int sky_w, int sky_h, int primary_steps, int light_steps,
+                         float early_eps, FrameConsts& fc) {
+    const float RV[6][3] = {{0.38051305f, 0.92453449f, -0.02111345f}, {-0.50625799f, -0.03590792f, -0.86163418f},
+                            {-0.32509218f, -0.94557439f, 0.01428793f}, {0.09026238f, -0.27376545f, 0.95755165f},
+                            {0.28128598f, 0.42443639f, -0.86065785f}, {-0.16852403f, 0.14748697f, 0.97460106f}};  // clouds.glsl:140
+    fc.tex_w = P.texture_size[0]; fc.tex_h = P.texture_size[1];
+    fc.upd_x = (int)P.update_position[0]; fc.upd_y = (int)P.update_position[1];
+    fc.cloud_off_x = 20.0f * P.cloud_pos[0] * 0.6f; fc.cloud_off_z = 20.0f * P.cloud_pos[1] * 0.6f;
+    fc.det_off_x = P.detailed_pos[0] * 40.0f; fc.det_off_z = P.detailed_pos[1] * 40.0f; fc.det_off_y = P.time * 40.0f;
+    fc.wpos_x = P.weather_pos[0]; fc.wpos_y = P.weather_pos[1];
+    const float lx = P.LIGHT_DIRECTION[0], ly = P.LIGHT_DIRECTION[1], lz = P.LIGHT_DIRECTION[2];
+    const float ll = length3_exact(lx, ly, lz);
+    fc.ldir[0] = lx / ll; fc.ldir[1] = ly / ll; fc.ldir[2] = lz / ll;
+    const float lss = (SKY_T_RADIUS - SKY_B_RADIUS) / 64.0f;                              // clouds.glsl:148-149
+    for (int j = 0; j < 6; j++) for (int k = 0; k < 3; k++) fc.linc[j][k] = (fc.ldir[k] + RV[j][k] * (float)j) * lss;
+    for (int k = 0; k < 3; k++) fc.ldist[k] = fc.ldir[k] * 18.0f * lss;
+    fc.hg_g2 = 0.4f - 1.4f * fc.ldir[1];
+    float s[3];
+    sky_lut_tap(sky, sky_w, sky_h, sky_lut_uv_x(lz, lx), sky_lut_uv_y(ly), s);             // clouds.glsl:163 (unnormalised dir)
+    for (int k = 0; k < 3; k++) fc.sun_c[k] = s[k] * 0.1f * P.LIGHT_ENERGY * P.LIGHT_COLOR[k];
+    const float inv = 1.0f / sqrtf(1.0f * 1.0f + 1.0f * 1.0f + 0.0f * 0.0f);               // normalize(vec3(1,+-1,0))
+    sky_lut_tap(sky, sky_w, sky_h, sky_lut_uv_x(0.0f, inv), sky_lut_uv_y(inv), s);         // clouds.glsl:164
+    for (int k = 0; k < 3; k++) s[k] = s[k] * 0.05f;
+    float len = length3_exact(s[0], s[1], s[2]);
+    for (int k = 0; k < 3; k++) fc.amb_c[k] = s[k] * (1.0f - 0.5f) + len * 0.5f;           // clouds.glsl:165
+    sky_lut_tap(sky, sky_w, sky_h, sky_lut_uv_x(0.0f, inv), sky_lut_uv_y(-inv), s);        // clouds.glsl:166
+    for (int k = 0; k < 3; k++) s[k] = s[k] * 5.0f * 0.05f;
+    len = length3_exact(s[0], s[1], s[2]);
+    for (int k = 0; k < 3; k++) fc.gnd_c[k] = s[k] * (1.0f - 0.5f) + (P.ground_color[k] * len) * 0.5f;  // clouds.glsl:167
+    fc.density = P.density; fc.coverage = P.cloud_coverage;
+    fc.primary_steps = primary_steps; fc.light_steps = light_steps; fc.steps_f = (float)primary_steps;
+    fc.early_eps = early_eps;
+}
+
+// =================================================================================================
+// Section B: filtering + shading (contraction allowed).
+// =================================================================================================
+#pragma clang fp contract(fast)
+
+CSKY_HD float ub(uint32_t v, int k) { return (float)((v >> (8 * k)) & 0xffu); }   // -> v_cvt_f32_ubyteK
+CSKY_HD float lo16(uint32_t v) { return (float)(v & 0xffffu); }
+CSKY_HD float hi16(uint32_t v) { return (float)(v >> 16); }
+
+// REPEAT + LINEAR bilinear tap of the quad-packed weather map (clouds.glsl:174).  Returns r (cloud type), b (coverage).
+CSKY_HD void weather_tap(const uint2* __restrict__ w, float sx, float sy, float& wr, float& wb) {
+    const float ux = sx * 512.0f - 0.5f, uy = sy * 512.0f - 0.5f;
+    const float fx0 = floorf(ux), fy0 = floorf(uy);
+    const float ax = ux - fx0, ay = uy - fy0;
+    const int x0 = ((int)fx0) & 511, y0 = ((int)fy0) & 511;
+    const uint2 q = w[y0 * 512 + x0];
+    wr = lerpf(lerpf(ub(q.x, 0), ub(q.x, 1), ax), lerpf(ub(q.x, 2), ub(q.x, 3), ax), ay) * (1.0f / 255.0f);
+    wb = lerpf(lerpf(ub(q.y, 0), ub(q.y, 1), ax), lerpf(ub(q.y, 2), ub(q.y, 3), ax), ay) * (1.0f / 255.0f);
+}
+
+// REPEAT + LINEAR trilinear tap of the shape volume at integer level `lvl` (clouds.glsl:117).
+// Returns r = n.r and fbm = n.g*0.625 + n.b*0.25 + n.a*0.125 (clouds.glsl:118; exact integer numerators, filtered linearly).
+CSKY_HD void shape_tap(const TexSet& T, int lvl, float sx, float sy, float sz, float& r, float& fbm) {
+    const int n = SHAPE_N >> lvl, m = n - 1;
+    const float fn = (float)n;
+    const float ux = sx * fn - 0.5f, uy = sy * fn - 0.5f, uz = sz * fn - 0.5f;
+    const float fx0 = floorf(ux), fy0 = floorf(uy), fz0 = floorf(uz);
+    const float ax = ux - fx0, ay = uy - fy0, az = uz - fz0;
+    const int x0 = ((int)fx0) & m, y0 = ((int)fy0) & m, z0 = ((int)fz0) & m;
+    const int y1 = (y0 + 1) & m, z1 = (z0 + 1) & m;
+    const uint2* __restrict__ b = T.shape + T.shape_off[lvl];
+    const uint2 t00 = b[(z0 * n + y0) * n + x0], t10 = b[(z0 * n + y1) * n + x0];
+    const uint2 t01 = b[(z1 * n + y0) * n + x0], t11 = b[(z1 * n + y1) * n + x0];
+    const float r00 = lerpf(ub(t00.x, 0), ub(t00.y, 0), ax), r10 = lerpf(ub(t10.x, 0), ub(t10.y, 0), ax);
+    const float r01 = lerpf(ub(t01.x, 0), ub(t01.y, 0), ax), r11 = lerpf(ub(t11.x, 0), ub(t11.y, 0), ax);
+    const float f00 = lerpf(hi16(t00.x), hi16(t00.y), ax), f10 = lerpf(hi16(t10.x), hi16(t10.y), ax);
+    const float f01 = lerpf(hi16(t01.x), hi16(t01.y), ax), f11 = lerpf(hi16(t11.x), hi16(t11.y), ax);
+    r = lerpf(lerpf(r00, r10, ay), lerpf(r01, r11, ay), az) * (1.0f / 255.0f);
+    fbm = lerpf(lerpf(f00, f10, ay), lerpf(f01, f11, ay), az) * (1.0f / (8.0f * 255.0f));
+}
+
+// REPEAT + LINEAR trilinear tap of the oct-packed detail volume (clouds.glsl:132-133): returns hfbm.
+CSKY_HD float detail_tap(const TexSet& T, int lvl, float sx, float sy, float sz) {
+    const int n = DETAIL_N >> lvl, m = n - 1;
+    const float fn = (float)n;
+    const float ux = sx * fn - 0.5f, uy = sy * fn - 0.5f, uz = sz * fn - 0.5f;
+    const float fx0 = floorf(ux), fy0 = floorf(uy), fz0 = floorf(uz);
+    const float ax = ux - fx0, ay = uy - fy0, az = uz - fz0;
+    const int x0 = ((int)fx0) & m, y0 = ((int)fy0) & m, z0 = ((int)fz0) & m;
+    const uint4 q = T.detail[T.detail_off[lvl] + (z0 * n + y0) * n + x0];
+    const float c00 = lerpf(lo16(q.x), hi16(q.x), ax), c10 = lerpf(lo16(q.y), hi16(q.y), ax);
+    const float c01 = lerpf(lo16(q.z), hi16(q.z), ax), c11 = lerpf(lo16(q.w), hi16(q.w), ax);
+    return lerpf(lerpf(c00, c10, ay), lerpf(c01, c11, ay), az) * (1.0f / (8.0f * 255.0f));
+}
+
+CSKY_HD float height_fraction(float r) { return sat((r - SKY_B_RADIUS) * (1.0f / (SKY_T_RADIUS - SKY_B_RADIUS))); }  // clouds.glsl:77-80
+
+CSKY_HD float smoothstep_fast(float e0, float e1, float x) {
+    const float t = sat((x - e0) * fast_rcp(e1 - e0));
+    return t * t * (3.0f - 2.0f * t);
+}
+// clouds.glsl:82-95
+CSKY_HD float density_height_gradient(float hf, float ct) {
+    const float stratus = 1.0f - sat(ct * 2.0f);
+    const float stratocu = 1.0f - fabsf(ct - 0.5f) * 2.0f;
+    const float cumulus = sat(ct - 0.5f) * 2.0f;
+    const float gx = 0.02f * stratus + 0.02f * stratocu + 0.01f * cumulus;
+    const float gy = 0.05f * stratus + 0.2f * stratocu + 0.0625f * cumulus;
+    const float gz = 0.09f * stratus + 0.48f * stratocu + 0.78f * cumulus;
+    const float gw = 0.11f * stratus + 0.625f * stratocu + 1.0f * cumulus;
+    return smoothstep_fast(gx, gy, hf) - smoothstep_fast(gz, gw, hf);
+}
+
+// clouds.glsl:109-137 density().  (px,py,pz) sample point, hf its height fraction, (wr,wb) the weather
+// tap, lod_shape = clamp(mip-2), lod_detail = mip.  Two EXACT early rejects:
+//  (1) base_cloud in [0,1] so base_cloud*g <= g; if g <= 1-wc the remap at :124 is <= 0, the product with
+//      wc (>= 0) is <= 0, the remap at :135 (denominator 1 - hfbm*0.4*hf >= 0.6 > 0) stays <= 0, the clamp
+//      gives 0 and pow(0, e >= 0.5) = 0.  The shape tap is never needed.  wc == 0 (divide by zero -> NaN ->
+//      clamp -> 0 in the oracle) also lands here.
+//  (2) after :125, base_cloud <= 0 makes :135-136 return 0 for the same reason: the detail tap is dead.
+CSKY_HD float density(const TexSet& T, const FrameConsts& fc, float px, float py, float pz, float hf, float wr, float wb,
+                      int lod_shape, int lod_detail) {
+    const float wc = fc.coverage * wb;                                       // :123
+    const float g = density_height_gradient(hf, wr);                        // :121
+    const float omw = 1.0f - wc;
+    if (!(g > omw)) return 0.0f;                                             // exact reject (1)
+    float qx, qy, qz, sx, sy, sz;
+    shape_coord(fc, px, py, pz, qx, qy, qz, sx, sy, sz);
+    float nr, fbm;
+    shape_tap(T, lod_shape, sx, sy, sz, nr, fbm);                           // :117-118
+    const float omf = 1.0f - fbm;
+    float base = (nr + omf) * fast_rcp(1.0f + omf);                         // :122 remap(n.r, -(1-fbm), 1, 0, 1)
+    base = (base * g - omw) * fast_rcp(1.0f - omw);                         // :124
+    base *= wc;                                                             // :125
+    if (!(base > 0.0f)) return 0.0f;                                        // exact reject (2)
+    detail_coord(fc, qx, qy, qz, sx, sy, sz);                               // :128-129
+    float hfbm = detail_tap(T, lod_detail, sx, sy, sz);                     // :132-133
+    const float k = sat(hf * 4.0f);
+    hfbm = hfbm * (1.0f - k) + (1.0f - hfbm) * k;                           // :134
+    const float hm = hfbm * 0.4f * hf;
+    base = (base - hm) * fast_rcp(1.0f - hm);                               // :135
+    return fast_pow(sat(base), (1.0f - hf) * 0.8f + 0.5f);                  // :136
+}
+
+CSKY_HD float henyey_greenstein(float c, float g) {                         // clouds.glsl:72-75 (once per ray: accurate powf)
+    return 0.0795774715459f * (1.0f - g * g) / powf(1.0f + g * g - 2.0f * g * c, 1.5f);
+}
+
+struct MarchOut { float r, g, b, a; uint32_t incloud; };
+
+// clouds.glsl:139-215 march() for one ray.
+CSKY_HD MarchOut march(const TexSet& T, const FrameConsts& fc, Ray ray) {
+    MarchOut o; o.r = o.g = o.b = o.a = 0.0f; o.incloud = 0;
+    const float lss = (SKY_T_RADIUS - SKY_B_RADIUS) / 64.0f;
+    float phase = 0.0f;
+    if (ray.above) {
+        const float ct = fc.ldir[0] * ray.dx + fc.ldir[1] * ray.dy + fc.ldir[2] * ray.dz;   // :158
+        phase = fmaxf(fmaxf(henyey_greenstein(ct, 0.6f), henyey_greenstein(ct, fc.hg_g2)), henyey_greenstein(ct, -0.2f));  // :160
+    }
+    float Tr = 1.0f, alpha = 0.0f, Lr = 0.0f, Lg = 0.0f, Lb = 0.0f;
+    float px = ray.px, py = ray.py, pz = ray.pz;
+    const float nd = -fc.density;
+    const int steps = fc.primary_steps, ls = fc.light_steps;
+    for (int i = 0; i < steps; i++) {                                                        // :172
+        if (fc.early_eps > 0.0f && CSKY_WAVE_ALL(!ray.above || Tr < fc.early_eps)) break;    // build-side early-out
+        if (!ray.above) continue;
+        advance(px, py, pz, ray.sx, ray.sy, ray.sz);                                         // :173
+        float wsx, wsy, wr, wb;
+        weather_coord(px, pz, fc.wpos_x, fc.wpos_y, wsx, wsy);
+        weather_tap(T.weather, wsx, wsy, wr, wb);                                            // :174
+        const float hf = height_fraction(length3_exact(px, py, pz));                         // :175
+        const float t = density(T, fc, px, py, pz, hf, wr, wb, 0, 0);                        // :177
+        if (t > 0.0f) {                                                                      // :184
+            o.incloud++;
+            const float dt = fast_exp(nd * t * ray.ss);                                      // :178
+            float lx = px, ly = py, lz = pz, cd = 0.0f;
+            for (int j = 0; j < ls; j++) {                                                   // :186
+                advance(lx, ly, lz, fc.linc[j][0], fc.linc[j][1], fc.linc[j][2]);            // :187
+                const float lhf = height_fraction(length3_exact(lx, ly, lz));                // :188
+                float lwr, lwb;
+                weather_coord(lx, lz, fc.wpos_x, fc.wpos_y, wsx, wsy);
+                weather_tap(T.weather, wsx, wsy, lwr, lwb);                                  // :189
+                cd += density(T, fc, lx, ly, lz, lhf, lwr, lwb, j > 2 ? j - 2 : 0, j);       // :190-191 (LOD mip-2 clamps at 0)
+            }
+            {   // distant sample, :195-199
+                lx = px; ly = py; lz = pz;
+                advance(lx, ly, lz, fc.ldist[0], fc.ldist[1], fc.ldist[2]);
+                const float lhf = height_fraction(length3_exact(lx, ly, lz));
+                float lwr, lwb;
+                weather_coord(lx, lz, 0.0f, 0.0f, wsx, wsy);                                 // :197 has no weather_pos
+                weather_tap(T.weather, wsx, wsy, lwr, lwb);
+                const float ld = density(T, fc, lx, ly, lz, lhf, lwr, lwb, 3, 5);
+                cd += fast_pow(ld, (1.0f - lhf) * 0.8f + 0.5f);                              // :198 (second pow)
+            }
+            const float beers = fast_exp(nd * cd * lss * 3.0f);                              // :202
+            const float powder = 1.0f - fast_exp(nd * cd * lss * 3.0f * 2.0f);               // :203
+            const float bt = 2.0f * beers * powder;                                          // :204
+            const float sm = hf * hf * (3.0f - 2.0f * hf);                                   // smoothstep(0,1,hf), hf already in [0,1]
+            const float ar = fc.gnd_c[0] * (1.0f - sm) + fc.amb_c[0] * sm;                   // :206
+            const float ag = fc.gnd_c[1] * (1.0f - sm) + fc.amb_c[1] * sm;
+            const float ab = fc.gnd_c[2] * (1.0f - sm) + fc.amb_c[2] * sm;
+            alpha += (1.0f - dt) * (1.0f - alpha);                                           // :207
+            const float k = bt * phase;
+            const float rr = (ar + k * fc.sun_c[0]) * t, rg = (ag + k * fc.sun_c[1]) * t, rb = (ab + k * fc.sun_c[2]) * t;  // :208
+            const float w = Tr * fast_rcp(fmaxf(0.0000001f, t));                             // :209
+            Lr += (rr - rr * dt) * w; Lg += (rg - rg * dt) * w; Lb += (rb - rb * dt) * w;
+            Tr *= dt;                                                                        // :210
+        }
+    }
+    o.r = Lr; o.g = Lg; o.b = Lb; o.a = sat(alpha);                                          // :213-214
+    return o;
+}
+
+}  // namespace csky

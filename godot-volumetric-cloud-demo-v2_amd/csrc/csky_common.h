@@ -1,0 +1,112 @@
+// csky_common.h -- types and helpers shared by the HIP kernels, the host API and the host-compiled
+// kernel-core unit test (tests/hostsim).  Plain C++17; compiles under hipcc (host+device) and g++.
+#pragma once
+#include <stdint.h>
+#include <math.h>
+#include <string.h>
+
+#if defined(__HIPCC__)
+#include <hip/hip_runtime.h>
+#define CSKY_HD __host__ __device__ __forceinline__
+#define CSKY_D __device__ __forceinline__
+#else
+#define CSKY_HD inline
+#define CSKY_D inline
+struct uint2 { uint32_t x, y; };
+struct uint4 { uint32_t x, y, z, w; };
+struct float4 { float x, y, z, w; };
+#endif
+
+namespace csky {
+
+// ---- geometry literals, clouds.glsl:43-47 -------------------------------------------------------
+constexpr float G_RADIUS = 6000000.0f;
+constexpr float SKY_B_RADIUS = 6001500.0f;
+constexpr float SKY_T_RADIUS = 6004000.0f;
+constexpr float CLOUD_PI = 3.141592f;  // truncated literal of clouds.glsl:47, kept on purpose
+
+constexpr int SHAPE_N = 128, SHAPE_LEVELS = 8;   // perlworlnoise.tga.import:24-27 (128 slices, mips on)
+constexpr int DETAIL_N = 32, DETAIL_LEVELS = 6;  // worlnoise.bmp.import:24-27 (32 slices, mips on)
+constexpr int WEATHER_N = 512;                   // weather.bmp.import:25 (no mips)
+
+// ---- device texture layouts (baked by api.cpp::bake_*) ----------------------------
+// shape  : per texel u32  = r | (5g+2b+a) << 16     (fbm numerator, exact: fbm = num / (8*255))
+//          stored x-pair-packed: uint2{texel(x), texel(x+1 mod N)} -> 4 x 8-byte loads per trilinear tap
+// detail : per texel oct-packed 8 x u16 numerators (5r+2g+b) of the 2x2x2 neighbourhood (wrapped),
+//          order bit0 = +x, bit1 = +y, bit2 = +z -> ONE 16-byte load per trilinear tap
+// weather: per texel quad-packed bytes {r00,r10,r01,r11, b00,b10,b01,b11} of the 2x2 neighbourhood
+//          (wrapped) -> ONE 8-byte load per bilinear tap (G is never read: clouds.glsl:121,123)
+struct TexSet {
+    const uint2* shape;     // all levels, level l at shape_off[l] (in texels)
+    const uint4* detail;    // all levels, level l at detail_off[l]
+    const uint2* weather;   // 512*512
+    const float4* sky;      // sky LUT, fp16-rounded values widened to float, sky_w x sky_h
+    int sky_w, sky_h;
+    uint32_t shape_off[SHAPE_LEVELS];
+    uint32_t detail_off[DETAIL_LEVELS];
+};
+
+// Ray-invariant per-frame constants, computed once per frame by frame_setup() (clouds.glsl:143-170).
+struct FrameConsts {
+    float tex_w, tex_h;
+    int upd_x, upd_y;                 // ivec2(update_position), clouds.glsl:260
+    float cloud_off_x, cloud_off_z;   // 20*cloud_pos*0.6, clouds.glsl:114
+    float det_off_x, det_off_z, det_off_y;  // detailed_pos*40, time*40, clouds.glsl:128-129
+    float wpos_x, wpos_y;             // weather_pos, clouds.glsl:170
+    float ldir[3];                    // normalize(LIGHT_DIRECTION), clouds.glsl:150
+    float linc[6][3];                 // (ldir + RANDOM_VECTORS[j]*j)*lss, clouds.glsl:187
+    float ldist[3];                   // ldir*18*lss, clouds.glsl:195
+    float hg_g2;                      // 0.4 - 1.4*ldir.y, clouds.glsl:160
+    float sun_c[3], amb_c[3], gnd_c[3];  // clouds.glsl:163-167
+    float density, coverage;          // clouds.glsl:37-38
+    int primary_steps, light_steps;   // clouds.glsl:228 (128), :186 (6)
+    float steps_f;
+    float early_eps;                  // wave early-out threshold on T (0 = off; not in the reference)
+};
+
+// Which rows a launch renders (cloudsky.h csky_bands) + output addressing.
+struct RenderGeom {
+    int tile_w;        // pixels per row rendered (gl_GlobalInvocationID.x range)
+    int band_rows, first_band, band_stride, n_bands;
+    uint32_t pitch_px; // output row pitch in pixels (8 bytes each)
+};
+
+struct CloudParams {  // == csky_cloud_params (clouds.glsl:18-40)
+    float texture_size[2], update_position[2], cloud_pos[2], detailed_pos[2], weather_pos[2], pad1[2];
+    float ground_color[4], LIGHT_DIRECTION[3], LIGHT_ENERGY, LIGHT_COLOR[3], time, pad2, density, cloud_coverage, time_offset;
+};
+static_assert(sizeof(CloudParams) == 112, "push-constant block must be 112 bytes (clouds.glsl:18-40)");
+
+// ---- IEEE binary16 <-> float, round-to-nearest-even, identical on host and device ---------------
+CSKY_HD uint16_t f2h(float f) {
+    uint32_t x; memcpy(&x, &f, 4);
+    const uint32_t sign = (x >> 16) & 0x8000u, em = x & 0x7fffffffu;
+    if (em >= 0x7f800000u) return (uint16_t)(sign | (em > 0x7f800000u ? 0x7e00u : 0x7c00u));
+    if (em >= 0x477ff000u) return (uint16_t)(sign | 0x7c00u);
+    if (em < 0x33000001u) return (uint16_t)sign;
+    const int e = (int)(em >> 23) - 127;
+    const uint32_t m = (em & 0x7fffffu) | 0x800000u;
+    const int shift = (e < -14) ? (13 + (-14 - e)) : 13;
+    uint32_t q = m >> shift;
+    const uint32_t rem = m & ((1u << shift) - 1u), half = 1u << (shift - 1);
+    if (rem > half || (rem == half && (q & 1u))) q++;
+    const uint32_t h = (e < -14) ? q : (((uint32_t)(e + 15) << 10) + (q - 0x400u));
+    return (uint16_t)(sign | h);
+}
+CSKY_HD float h2f(uint16_t h) {
+    const uint32_t sign = ((uint32_t)h & 0x8000u) << 16, e = (h >> 10) & 0x1fu;
+    uint32_t m = h & 0x3ffu, x;
+    if (e == 0) {
+        if (m == 0) x = sign;
+        else { int s = 0; while (!(m & 0x400u)) { m <<= 1; s++; } x = sign | ((uint32_t)(113 - s) << 23) | ((m & 0x3ffu) << 13); }
+    } else if (e == 31) x = sign | 0x7f800000u | (m << 13);
+    else x = sign | ((e + 112u) << 23) | (m << 13);
+    float f; memcpy(&f, &x, 4); return f;
+}
+
+CSKY_HD float clampf(float x, float lo, float hi) { return fminf(fmaxf(x, lo), hi); }
+CSKY_HD float sat(float x) { return fminf(fmaxf(x, 0.0f), 1.0f); }
+CSKY_HD float lerpf(float a, float b, float f) { return a + (b - a) * f; }
+CSKY_HD float signf(float x) { return x > 0.0f ? 1.0f : (x < 0.0f ? -1.0f : 0.0f); }
+
+}  // namespace csky

@@ -1,0 +1,25 @@
+// kernels.h -- host-callable launchers of the gfx950 kernels (kernels.hip).  Internal to libcloudsky.
+#pragma once
+#include <hip/hip_runtime_api.h>
+#include "csky_common.h"
+
+namespace csky {
+
+// transmittance-lut.glsl main(): writes the RGBA16F image and a float4 copy of the fp16-ROUNDED values
+// (what a sampler would read back), so later kernels sample floats without per-tap half unpacking.
+hipError_t launch_transmittance(int w, int h, uint16_t* d_half, float4* d_float, hipStream_t s);
+// sky-lut.glsl main()
+hipError_t launch_sky_lut(int w, int h, const float sun[3], const float4* d_trans, int tw, int th, uint16_t* d_half,
+                          float4* d_float, hipStream_t s);
+// per-frame constants of clouds.glsl:143-170 (one wave)
+hipError_t launch_frame_setup(const CloudParams& p, const float4* d_sky, int sw, int sh, int primary_steps, int light_steps,
+                              float early_eps, FrameConsts* d_fc, hipStream_t s);
+// clouds.glsl main() over the rows described by `g`.  d_stats (may be null): [0] += in-cloud samples,
+// [1] += rays above the horizon.
+hipError_t launch_clouds(int variant, const TexSet& t, const FrameConsts* d_fc, const RenderGeom& g, uint2* d_out,
+                         unsigned long long* d_stats, hipStream_t s);
+
+int cloud_variant_count();
+const char* cloud_variant_name(int v);
+
+}  // namespace csky

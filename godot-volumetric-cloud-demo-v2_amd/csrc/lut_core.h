@@ -1,0 +1,143 @@
+// lut_core.h -- per-texel bodies of the two atmosphere LUT kernels (transmittance-lut.glsl, sky-lut.glsl),
+// one texel per lane.  Host+device so tests/hostsim can run them on a CPU; the product only instantiates
+// them in lut_kernels.hip.  These kernels are tiny (16 384 and 20 000 lanes), so everything is compiled with
+// FP contraction off and the accurate OCML exp/log/pow/sin/cos: parity (<= 1 fp16 ulp) matters, speed does not.
+// Citations: T: = cloud_sky/transmittance-lut.glsl, S: = cloud_sky/sky-lut.glsl.  Units: km.
+#pragma once
+#include "csky_common.h"
+
+namespace csky {
+#pragma clang fp contract(off)
+
+constexpr float EARTH_RADIUS = 6371.0f;          // T:50  S:58
+constexpr float ATMOSPHERE_THICKNESS = 100.0f;   // T:51  S:59
+constexpr float ATMOSPHERE_RADIUS = 6471.0f;     // T:52  S:60
+constexpr int TRANSMITTANCE_STEPS = 40;          // T:45
+constexpr int IN_SCATTERING_STEPS = 30;          // S:53
+constexpr double LUT_PI = 3.14159265358979323846;  // S:44 (glslang folds constants in double, then narrows)
+
+struct F4 { float x, y, z, w; };
+CSKY_HD F4 f4(float x, float y, float z, float w) { F4 r; r.x = x; r.y = y; r.z = z; r.w = w; return r; }
+CSKY_HD F4 operator+(F4 a, F4 b) { return f4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w); }
+CSKY_HD F4 operator-(F4 a, F4 b) { return f4(a.x - b.x, a.y - b.y, a.z - b.z, a.w - b.w); }
+CSKY_HD F4 operator*(F4 a, F4 b) { return f4(a.x * b.x, a.y * b.y, a.z * b.z, a.w * b.w); }
+CSKY_HD F4 operator/(F4 a, F4 b) { return f4(a.x / b.x, a.y / b.y, a.z / b.z, a.w / b.w); }
+CSKY_HD F4 operator*(F4 a, float s) { return f4(a.x * s, a.y * s, a.z * s, a.w * s); }
+CSKY_HD F4 exp4(F4 a) { return f4(expf(a.x), expf(a.y), expf(a.z), expf(a.w)); }
+
+// T:89-98 / S:100-109
+CSKY_HD float ray_sphere_intersection(float ox, float oy, float oz, float dx, float dy, float dz, float radius) {
+    const float b = ox * dx + oy * dy + oz * dz;
+    const float c = (ox * ox + oy * oy + oz * oz) - radius * radius;
+    if (c > 0.0f && b > 0.0f) return -1.0f;
+    const float d = b * b - c;
+    if (d < 0.0f) return -1.0f;
+    if (d > b * b) return (-b + sqrtf(d));
+    return (-b - sqrtf(d));
+}
+
+struct Coeffs { F4 aerosol_scattering, molecular_scattering, extinction; };
+// T:104-145 / S:132-135,170-202
+CSKY_HD Coeffs atmosphere_collision_coefficients(float h) {
+    h = fmaxf(h, 0.0f);
+    const float aerosol_density = 1.3681e20f * (expf(-h / 0.73f) + (float)(2e6 / 1.3681e20));
+    const F4 aa = f4(2.8722e-24f, 4.6168e-24f, 7.9706e-24f, 1.3578e-23f) * aerosol_density;
+    const F4 as = f4(1.5908e-22f, 1.7711e-22f, 2.0942e-22f, 2.4033e-22f) * aerosol_density;
+    const float h2 = h + 1e-4f;
+    const float t = logf(h2) - 3.22261f;
+    const float ozone_density = 3.78547397e20f * (1.0f / h2) * expf(-t * t * 5.55555555f);
+    const F4 ma = f4((float)(3.472e-21 * 1e-4 * 350.0), (float)(3.914e-21 * 1e-4 * 350.0), (float)(1.349e-21 * 1e-4 * 350.0),
+                     (float)(11.03e-23 * 1e-4 * 350.0)) * ozone_density;
+    const F4 ms = f4(6.605e-3f, 1.067e-2f, 1.842e-2f, 3.156e-2f) * expf(-0.07771971f * powf(h, 1.16364243f));
+    Coeffs c; c.aerosol_scattering = as; c.molecular_scattering = ms; c.extinction = aa + as + ma + ms;
+    return c;
+}
+
+// T:157-196 main() for texel (px,py) of a w x h LUT.
+CSKY_HD F4 transmittance_texel(int px, int py, float w, float h) {
+    const float uvx = (float)px / w, uvy = (float)py / h;
+    const float c = uvx * 2.0f - 1.0f;
+    const float sdx = -sqrtf(1.0f - c * c), sdz = c;
+    const float d = EARTH_RADIUS * (1.0f - uvy) + ATMOSPHERE_RADIUS * uvy;  // mix()
+    const float t_d = ray_sphere_intersection(0.0f, 0.0f, d, sdx, 0.0f, sdz, ATMOSPHERE_RADIUS);
+    const float dt = t_d / (float)TRANSMITTANCE_STEPS;
+    F4 result = f4(0, 0, 0, 0);
+    for (int i = 0; i < TRANSMITTANCE_STEPS; ++i) {
+        const float t = ((float)i + 0.5f) * dt;
+        const float x = 0.0f + sdx * t, y = 0.0f + 0.0f * t, z = d + sdz * t;
+        const float altitude = sqrtf(x * x + y * y + z * z) - EARTH_RADIUS;
+        result = result + atmosphere_collision_coefficients(altitude).extinction * dt;
+    }
+    return exp4(f4(-result.x, -result.y, -result.z, -result.w));
+}
+
+// CLAMP + LINEAR tap of the transmittance LUT (fp16-rounded values widened to float), sky_lut.gd:62-68
+CSKY_HD F4 lut_tap_clamp(const float4* t, int w, int h, float sx, float sy) {
+    const float ux = sx * (float)w - 0.5f, uy = sy * (float)h - 0.5f;
+    const float fx0 = floorf(ux), fy0 = floorf(uy), ax = ux - fx0, ay = uy - fy0;
+    int x0 = (int)fx0, y0 = (int)fy0, x1 = x0 + 1, y1 = y0 + 1;
+    x0 = x0 < 0 ? 0 : (x0 > w - 1 ? w - 1 : x0); x1 = x1 < 0 ? 0 : (x1 > w - 1 ? w - 1 : x1);
+    y0 = y0 < 0 ? 0 : (y0 > h - 1 ? h - 1 : y0); y1 = y1 < 0 ? 0 : (y1 > h - 1 ? h - 1 : y1);
+    const float4 a = t[y0 * w + x0], b = t[y0 * w + x1], c = t[y1 * w + x0], d = t[y1 * w + x1];
+    return f4(lerpf(lerpf(a.x, b.x, ax), lerpf(c.x, d.x, ax), ay), lerpf(lerpf(a.y, b.y, ax), lerpf(c.y, d.y, ax), ay),
+              lerpf(lerpf(a.z, b.z, ax), lerpf(c.z, d.z, ax), ay), lerpf(lerpf(a.w, b.w, ax), lerpf(c.w, d.w, ax), ay));
+}
+// S:137-142
+CSKY_HD F4 transmittance_from_lut(const float4* t, int tw, int th, float cos_theta, float normalized_altitude) {
+    return lut_tap_clamp(t, tw, th, sat(cos_theta * 0.5f + 0.5f), sat(normalized_altitude));
+}
+
+// S:278-315 main() for texel (px,py); sun = params.sun_direction (S:16).  Returns linear sRGB, alpha 1.
+CSKY_HD F4 sky_texel(int px, int py, float w, float h, const float sun[3], const float4* trans, int tw, int th) {
+    const float uvx = (float)px / w, uvy = (float)py / h;
+    const float azimuth = (float)(2.0 * LUT_PI) * uvx;
+    const float l = uvy * 2.0f - 1.0f;
+    const float elev = l * l * signf(l) * (float)LUT_PI * 0.5f;
+    const float rdx = cosf(elev) * cosf(azimuth), rdy = cosf(elev) * sinf(azimuth), rdz = sinf(elev);
+    const float oz = 6371.5f;                                                        // S:61-62
+    const float atmos_dist = ray_sphere_intersection(0, 0, oz, rdx, rdy, rdz, ATMOSPHERE_RADIUS);
+    const float ground_dist = ray_sphere_intersection(0, 0, oz, rdx, rdy, rdz, EARTH_RADIUS);
+    const float t_d = (ground_dist < 0.0f) ? atmos_dist : ground_dist;               // S:303-309
+    // compute_inscattering, S:219-276
+    const float sdx = -sun[0], sdy = -sun[2], sdz = sun[1];                          // S:221-223
+    const float cos_theta = (-rdx) * sdx + (-rdy) * sdy + (-rdz) * sdz;              // S:224
+    const float molecular_phase = (float)((3.0 / 16.0) * (1.0 / LUT_PI)) * (1.0f + cos_theta * cos_theta);  // S:114-117
+    const float den = (float)(1.0 + 0.8 * 0.8) + (float)(2.0 * 0.8) * cos_theta;     // S:124
+    const float aerosol_phase = (float)(0.25 * (1.0 / LUT_PI)) * (1.0f - (float)(0.8 * 0.8)) / (den * sqrtf(den));  // S:125
+    const float dt = t_d / (float)IN_SCATTERING_STEPS;
+    F4 L = f4(0, 0, 0, 0), Tr = f4(1, 1, 1, 1);
+    const F4 irr = f4(1.679f, 1.828f, 1.986f, 1.307f);                               // S:67
+    for (int i = 0; i < IN_SCATTERING_STEPS; ++i) {
+        const float t = ((float)i + 0.5f) * dt;
+        const float x = 0.0f + rdx * t, y = 0.0f + rdy * t, z = oz + rdz * t;
+        const float dist = sqrtf(x * x + y * y + z * z);
+        const float zx = x / dist, zy = y / dist, zz = z / dist;
+        const float altitude = dist - EARTH_RADIUS;
+        const float nalt = altitude / ATMOSPHERE_THICKNESS;
+        const float sct = zx * sdx + zy * sdy + zz * sdz;                            // S:243
+        const Coeffs cf = atmosphere_collision_coefficients(altitude);
+        const F4 t_sun = transmittance_from_lut(trans, tw, th, sct, nalt);           // S:254
+        // get_multiple_scattering, S:144-164
+        const float omega = (float)(2.0 * LUT_PI) * (1.0f - sqrtf(dist * dist - EARTH_RADIUS * EARTH_RADIUS) / dist);
+        const F4 T_to_ground = transmittance_from_lut(trans, tw, th, sct, 0.0f);
+        const F4 T_g2s = transmittance_from_lut(trans, tw, th, 1.0f, 0.0f) / transmittance_from_lut(trans, tw, th, 1.0f, nalt);
+        const float ks = (float)(0.25 * (1.0 / LUT_PI)) * omega * (float)(0.3 / LUT_PI);
+        const F4 L_ground = f4(ks, ks, ks, ks) * T_to_ground * T_g2s * sct;
+        const float fm = 1.0f / (1.0f + 5.0f * expf(-17.92f * sct));
+        const F4 L_ms = f4((float)(0.02 * 0.217), (float)(0.02 * 0.347), (float)(0.02 * 0.594), (float)(0.02 * 1.0)) * fm;
+        const F4 ms = L_ms + L_ground;
+        const F4 S = irr * (cf.molecular_scattering * (t_sun * molecular_phase + ms) + cf.aerosol_scattering * (t_sun * aerosol_phase + ms));  // S:261-263
+        const F4 step_tr = exp4(cf.extinction * (-dt));                              // S:265
+        const F4 ext_c = f4(fmaxf(cf.extinction.x, 1e-7f), fmaxf(cf.extinction.y, 1e-7f), fmaxf(cf.extinction.z, 1e-7f), fmaxf(cf.extinction.w, 1e-7f));
+        const F4 S_int = (S - S * step_tr) / ext_c;                                  // S:270
+        L = L + Tr * S_int;
+        Tr = Tr * step_tr;
+    }
+    // S:207-217: mat4x3 M (column-major, 4 columns of 3)
+    const float r = 137.672389239975f * L.x + 32.549094028629234f * L.y + -38.91428392614275f * L.z + 8.572844237945445f * L.w;
+    const float g = -8.632904716299537f * L.x + 91.29801417199785f * L.y + 34.31665471469816f * L.z + -11.103384660054624f * L.w;
+    const float b = -1.7181567391931372f * L.x + -12.005406444382531f * L.y + 29.89044807197628f * L.z + 117.47585277566478f * L.w;
+    return f4(r, g, b, 1.0f);
+}
+
+}  // namespace csky

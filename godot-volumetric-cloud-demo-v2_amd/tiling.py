@@ -1,0 +1,59 @@
+"""Multi-GPU sharding of the hemisphere frame: one process per GPU (torch.distributed over RCCL), no data-path
+collective during the march, ONE gather of the finished bands to rank 0.
+
+The unit of sharding is a band of `band_rows` pixel rows; rank r of N renders bands r, r+N, r+2N, ...
+(interleaved, because cost per ray depends on cloud cover and elevation: contiguous eighths would leave the
+zenith rank idle while the horizon ranks work).  It generalises the reference's update_position tile walk
+(cloud_sky.gd:156-161): every band is rendered with the same frozen push-constant block (cloud_sky.gd:54-55,142)."""
+import numpy as np
+
+BAND_ROWS = 8  # one wavefront tile is 8x8 pixels; a band is one row of tiles
+
+
+def bands_for_rank(height, rank, world, band_rows=BAND_ROWS):
+    """(band_rows, first_band, band_stride, n_bands) for csky_render_clouds_device."""
+    if height % band_rows:
+        raise ValueError("frame height %d must be a multiple of the band height %d" % (height, band_rows))
+    total = height // band_rows
+    n = (total - rank + world - 1) // world if rank < total else 0
+    return (band_rows, rank, world, n)
+
+
+def max_bands(height, world, band_rows=BAND_ROWS):
+    return (height // band_rows + world - 1) // world
+
+
+def interleave(gathered, height, world, band_rows=BAND_ROWS):
+    """gathered: [world, max_bands*band_rows, W, C] (rank-major compact bands, zero padded) -> [height, W, C]."""
+    total = height // band_rows
+    mb = max_bands(height, world, band_rows)
+    xp = gathered
+    g = xp.reshape(world, mb, band_rows, *xp.shape[2:])
+    # band k of the frame = rank k % world, local band k // world
+    if hasattr(g, "permute"):   # torch
+        full = g.permute(1, 0, 2, *range(3, g.dim())).reshape(mb * world * band_rows, *xp.shape[2:])
+        return full[: total * band_rows].contiguous()
+    full = np.swapaxes(g, 0, 1).reshape(mb * world * band_rows, *xp.shape[2:])
+    return np.ascontiguousarray(full[: total * band_rows])
+
+
+def render_sharded(render_bands, height, width, rank, world, dist=None, device=None, band_rows=BAND_ROWS):
+    """Render this rank's bands and gather the frame on rank 0.
+
+    render_bands(bands, out) fills `out` ([n_bands*band_rows, width, 4] uint16/int16 view of RGBA16F, torch tensor)
+    for bands = (band_rows, first_band, band_stride, n_bands).  Returns the [height, width, 4] frame on rank 0,
+    None elsewhere.  `dist` = torch.distributed (None or world == 1: no collective)."""
+    import torch
+
+    mb = max_bands(height, world, band_rows)
+    local = torch.zeros((mb * band_rows, width, 4), dtype=torch.int16, device=device)
+    b = bands_for_rank(height, rank, world, band_rows)
+    render_bands(b, local[: b[3] * band_rows])
+    if world == 1 or dist is None:
+        return local[:height]
+    if rank == 0:
+        parts = [torch.empty_like(local) for _ in range(world)]
+        dist.gather(local, gather_list=parts, dst=0)
+        return interleave(torch.stack(parts, 0), height, world, band_rows)
+    dist.gather(local, gather_list=None, dst=0)
+    return None

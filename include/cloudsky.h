@@ -1,0 +1,152 @@
+/*
+ * cloudsky.h -- C ABI of libcloudsky.so: the MI355X (gfx950) HIP implementation of the compute path of
+ * clayjohn/godot-volumetric-cloud-demo-v2 (cloud_sky/clouds.glsl, sky-lut.glsl, transmittance-lut.glsl).
+ *
+ * The reference has no FFI: the path sits behind Godot's RenderingDevice compute API driven from GDScript
+ * (cloud_sky/cloud_sky.gd, sky_lut.gd, transmittance_lut.gd).  Each entry point below names the
+ * reference call site (file:line, relative to the reference root) it replaces; INTEGRATION.md shows the
+ * GDExtension / GDScript-side binding a maintainer would add.
+ *
+ * Conventions: plain C types only; 0 = success, < 0 = error (csky_last_error() gives the text); nothing
+ * throws or aborts across the ABI.  One context = one GPU = one caller thread (the reference marshals
+ * every RenderingDevice call onto the single render thread: cloud_sky.gd:118,154).  There is NO CPU
+ * fallback: without a usable HIP device csky_create fails with CSKY_ERR_NO_DEVICE.
+ *
+ * Images are tightly packed little-endian RGBA half floats (DATA_FORMAT_R16G16B16A16_SFLOAT,
+ * cloud_sky.gd:369; sky_lut.gd:84; transmittance_lut.gd:37), row-major, row 0 = pixel y == 0.
+ */
+#ifndef CLOUDSKY_H
+#define CLOUDSKY_H
+#include <stddef.h>
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define CSKY_OK 0
+#define CSKY_ERR_INVALID (-1)    /* bad argument / call order                               */
+#define CSKY_ERR_NO_DEVICE (-2)  /* no HIP device, or the device is not usable               */
+#define CSKY_ERR_HIP (-3)        /* a HIP runtime call failed                                */
+#define CSKY_ERR_IO (-4)         /* asset file problem                                       */
+#define CSKY_ERR_STATE (-5)      /* e.g. clouds requested before noise / LUTs exist          */
+
+#define CSKY_ABI_VERSION 1
+
+typedef struct csky_ctx csky_ctx; /* opaque: owns every device allocation, the HIP stream and events */
+
+/* Push-constant block of clouds.glsl:18-40, byte-identical (112 B), as packed by
+ * cloud_sky.gd:251-289 `_fill_push_constant()`; pass that PackedFloat32Array through unchanged. */
+typedef struct {
+    float texture_size[2];    /*   0 */
+    float update_position[2]; /*   8  pixel offset of the dispatched tile (clouds.glsl:260) */
+    float cloud_pos[2];       /*  16 */
+    float detailed_pos[2];    /*  24 */
+    float weather_pos[2];     /*  32 */
+    float pad1[2];            /*  40 */
+    float ground_color[4];    /*  48 */
+    float LIGHT_DIRECTION[3]; /*  64 */
+    float LIGHT_ENERGY;       /*  76 */
+    float LIGHT_COLOR[3];     /*  80 */
+    float time;               /*  92 */
+    float pad2;               /*  96 */
+    float density;            /* 100 */
+    float cloud_coverage;     /* 104 */
+    float time_offset;        /* 108 */
+} csky_cloud_params;
+
+/* Push-constant block of sky-lut.glsl:12-18 (32 B), as packed by sky_lut.gd:123-132. */
+typedef struct { float texture_size[2]; float pad2[2]; float sun_direction[3]; float pad; } csky_sky_params;
+/* Push-constant block of transmittance-lut.glsl:12-15 (16 B), as packed by transmittance_lut.gd:66-70. */
+typedef struct { float texture_size[2]; float pad2[2]; } csky_transmittance_params;
+
+/* Which pixel rows of the frame one call renders: bands of `band_rows` rows; this call renders bands
+ * first_band, first_band + band_stride, ... (n_bands of them) into a COMPACT output of n_bands*band_rows
+ * rows.  {rows=H, 0, 1, 1} is the whole frame.  It is the multi-GPU generalisation of the reference's
+ * update_position tile walk (cloud_sky.gd:156-161): rank r of N takes first_band=r, band_stride=N. */
+typedef struct { int band_rows, first_band, band_stride, n_bands; } csky_bands;
+
+typedef struct {
+    uint64_t rays;            /* pixels rendered by the last csky_render_clouds* call               */
+    uint64_t primary_samples; /* primary march samples evaluated (rays above the horizon x steps)    */
+    uint64_t incloud_samples; /* primary samples with density > 0 (clouds.glsl:184 branch taken)     */
+} csky_cloud_stats;
+
+/* ---- lifetime ------------------------------------------------------------------------------------
+ * replaces cloud_sky.gd:355-408 `_initialize_compute_code` (pipeline + texture creation) and
+ * cloud_sky.gd:197-212 `cleanup` / NOTIFICATION_PREDELETE.  device_id = HIP ordinal (one ctx per GPU;
+ * multi-GPU = one process per GPU).  csky_destroy(NULL) is a no-op. */
+int csky_abi_version(void);
+int csky_device_count(void);
+int csky_create(csky_ctx** out, int device_id);
+void csky_destroy(csky_ctx* ctx);
+const char* csky_last_error(const csky_ctx* ctx); /* ctx may be NULL: last create/asset error of this thread */
+
+/* ---- inputs --------------------------------------------------------------------------------------
+ * replaces cloud_sky.gd:298-341 `_create_noise_uniform_set` (REPEAT + LINEAR sampler, three textures).
+ * large_rgba8: 128^3 RGBA8, index ((z*128 + y)*128 + x)*4, z = slice index  (perlworlnoise.tga)
+ * small_rgb8 : 32^3  RGB8,  index ((z*32  + y)*32  + x)*3                    (worlnoise.bmp)
+ * weather_rgb8: 512x512 RGB8, row 0 = top row of the bitmap                  (weather.bmp)
+ * Level-0 data only; the library builds the mip chains (2x2x2 box) and its device layouts. */
+int csky_set_noise(csky_ctx* ctx, const uint8_t* large_rgba8, const uint8_t* small_rgb8, const uint8_t* weather_rgb8);
+/* clouds.glsl:228 (128 primary steps) and clouds.glsl:186 (6 light steps) are literals in the reference;
+ * this generalises them (BASELINE config 2 is 64 x 4).  light_steps in [0,6], primary_steps in [1,1024]. */
+int csky_set_march(csky_ctx* ctx, int primary_steps, int light_steps);
+/* Wave-level early-out threshold: a wavefront stops marching once every lane's transmittance T < eps.
+ * The reference has no early-out; eps = 0 disables it (bit-for-bit reference behaviour).  Default 0. */
+int csky_set_early_out(csky_ctx* ctx, float eps);
+
+/* ---- the three kernels, host-buffer forms (block until the image is in host memory) ---------------
+ * csky_render_transmittance: transmittance_lut.gd:66-77 (dispatch 32x8 groups of transmittance-lut.glsl).
+ * csky_render_sky_lut      : sky_lut.gd:122-148 `render_lut` (dispatch 25x13 groups of sky-lut.glsl);
+ *                            samples the context's transmittance LUT (rendering it first if needed).
+ * csky_render_clouds       : cloud_sky.gd:234-248 `_render_process` (dispatch of clouds.glsl) for the
+ *                            rectangle [0,tile_w) x [0,tile_h) of gl_GlobalInvocationID, offset by
+ *                            params->update_position exactly like clouds.glsl:260; binds the sky LUT
+ *                            rendered last (cloud_sky.gd:242).  tile = texture_size renders the whole
+ *                            hemisphere in one call.
+ * out may be NULL (render only; read back later with csky_read_*). */
+int csky_render_transmittance(csky_ctx* ctx, const csky_transmittance_params* p, uint16_t* out_rgba16f);
+int csky_render_sky_lut(csky_ctx* ctx, const csky_sky_params* p, uint16_t* out_rgba16f);
+int csky_render_clouds(csky_ctx* ctx, const csky_cloud_params* p, int tile_w, int tile_h, uint16_t* out_rgba16f,
+                       size_t row_pitch_bytes);
+
+/* ---- device-buffer forms (no host copy, asynchronous on `hip_stream`) -----------------------------
+ * d_out is a DEVICE pointer the caller owns (e.g. a torch tensor's data_ptr); hip_stream is a
+ * hipStream_t passed as void* (NULL = the context's own stream).  The LUT inputs of later calls are
+ * always the context's internal copies, so the chain transmittance -> sky -> clouds needs no host hop. */
+int csky_render_sky_lut_device(csky_ctx* ctx, const csky_sky_params* p, void* hip_stream);
+int csky_render_clouds_device(csky_ctx* ctx, const csky_cloud_params* p, int tile_w, const csky_bands* bands,
+                              void* d_out_rgba16f, size_t row_pitch_bytes, void* hip_stream);
+int csky_sync(csky_ctx* ctx); /* wait for the context's own stream */
+
+/* Read back the context's internal LUT copies (tests, the compositor, Texture2DRD.texture_update). */
+int csky_read_transmittance(csky_ctx* ctx, uint16_t* out_rgba16f, int* w, int* h);
+int csky_read_sky_lut(csky_ctx* ctx, uint16_t* out_rgba16f, int* w, int* h);
+
+/* ---- measurement ---------------------------------------------------------------------------------
+ * Times `iters` back-to-back launches of the cloud kernel alone with HIP events on the context's stream
+ * (after `warmup` untimed launches) and returns the mean per-launch milliseconds.  Also fills the
+ * sample counters of one launch (the kernel's own tallies). */
+int csky_time_clouds(csky_ctx* ctx, const csky_cloud_params* p, int tile_w, const csky_bands* bands, int warmup,
+                     int iters, float* mean_ms, csky_cloud_stats* stats);
+int csky_get_cloud_stats(csky_ctx* ctx, csky_cloud_stats* stats); /* tallies of the last stats-enabled launch */
+/* Kernel variant selector for A/B measurement (0 = default).  Unknown ids -> CSKY_ERR_INVALID. */
+int csky_set_variant(csky_ctx* ctx, int variant);
+int csky_variant_count(void);
+const char* csky_variant_name(int variant);
+
+/* ---- asset layer (host only; usable without a GPU) ------------------------------------------------
+ * What the reference gets from Godot's importers (weather.bmp.import, worlnoise.bmp.import,
+ * perlworlnoise.tga.import).  perlworlnoise.tga is missing from the reference checkout, hence the
+ * deterministic generator. */
+int csky_load_bmp_rgb8(const char* path, int* w, int* h, uint8_t* out_rgb8, size_t out_capacity);
+int csky_strip_to_volume(const uint8_t* strip, int n, int ch, uint8_t* vol);
+int csky_generate_shape_noise(uint32_t seed, int n, uint8_t* out_rgba8);
+size_t csky_mip_offset(int n, int level, int ch);
+int csky_build_mips(uint8_t* vol, int n, int ch, int levels);
+const char* csky_assets_last_error(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* CLOUDSKY_H */
