@@ -51,9 +51,11 @@ def render_sharded(render_bands, height, width, rank, world, dist=None, device=N
     render_bands(b, local[: b[3] * band_rows])
     if world == 1 or dist is None:
         return local[:height]
+    # the collective moves raw bytes: neither RCCL nor gloo has a 16-bit integer type, uint8 works on both
+    lb = local.view(torch.uint8)
     if rank == 0:
-        parts = [torch.empty_like(local) for _ in range(world)]
-        dist.gather(local, gather_list=parts, dst=0)
-        return interleave(torch.stack(parts, 0), height, world, band_rows)
-    dist.gather(local, gather_list=None, dst=0)
+        parts = [torch.empty_like(lb) for _ in range(world)]
+        dist.gather(lb, gather_list=parts, dst=0)
+        return interleave(torch.stack(parts, 0).view(local.dtype), height, world, band_rows)
+    dist.gather(lb, gather_list=None, dst=0)
     return None

@@ -1,0 +1,102 @@
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+GOLDEN = os.path.join(ROOT, "tests", "golden")
+SUNS = {"zenith": (0.0, 1.0, 0.0), "deg45": (1.0, 1.0, 0.0), "demo": (-0.998773, 0.0495291, 2.69869e-07)}
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+def _make(path):
+    subprocess.check_call(["make", "-C", path, "-s"])
+
+
+@pytest.fixture(scope="session")
+def pkg():
+    """The package with libcloudsky.so built (hipcc cross-compiles without a GPU)."""
+    if not os.path.exists(os.path.join(ROOT, "godot-volumetric-cloud-demo-v2_amd", "libcloudsky.so")):
+        _make(os.path.join(ROOT, "godot-volumetric-cloud-demo-v2_amd", "csrc"))
+    import gvcd_amd
+    return gvcd_amd
+
+
+@pytest.fixture(scope="session")
+def oracle():
+    from oracle import oracle as O
+    O.build()
+    return O
+
+
+@pytest.fixture(scope="session")
+def hostsim():
+    import ctypes as C
+    _make(os.path.join(ROOT, "tests", "hostsim"))
+    return C.CDLL(os.path.join(ROOT, "tests", "hostsim", "libhostsim.so"))
+
+
+@pytest.fixture(scope="session")
+def noise(pkg):
+    return pkg.assets.load_default_noise()
+
+
+@pytest.fixture(scope="session")
+def otex(oracle, noise):
+    return oracle.OracleTextures(*noise)
+
+
+@pytest.fixture(scope="session")
+def o_trans(oracle):
+    return oracle.transmittance_lut(256, 64)
+
+
+@pytest.fixture(scope="session")
+def o_skies(oracle, o_trans):
+    out = {}
+    for k, s in SUNS.items():
+        out[k] = oracle.sky_lut(norm(s), o_trans, 200, 100)
+    return out
+
+
+def norm(s):
+    s = np.asarray(s, np.float64)
+    return (s / np.linalg.norm(s)).astype(np.float32)
+
+
+def ulp_diff(a, b):
+    """|a-b| in fp16 ulps for same-sign finite halfs (bit pattern distance)."""
+    a = np.ascontiguousarray(a).view(np.int16).astype(np.int32)
+    b = np.ascontiguousarray(b).view(np.int16).astype(np.int32)
+    return np.abs(a - b)
+
+
+def cloud_close(test, ref, frac=0.999, atol=2e-3, rtol=1e-2):
+    """The stated cloud tolerance: per channel |d| <= 2e-3 + 1e-2*|ref| on >= 99.9 % of values, all
+    finite, and PSNR >= 50 dB on RGB."""
+    a, b = np.asarray(test, np.float32), np.asarray(ref, np.float32)
+    assert np.isfinite(a).all()
+    err = np.abs(a - b)
+    ok = (err <= atol + rtol * np.abs(b)).mean()
+    mse = float(((a[..., :3] - b[..., :3]) ** 2).mean())
+    peak = max(float(b[..., :3].max()), 1e-6)
+    psnr = 10 * np.log10(peak * peak / max(mse, 1e-20))
+    return ok >= frac and psnr >= 50.0, dict(ok=float(ok), psnr=float(psnr), max_err=float(err.max()))
+
+
+@pytest.fixture(scope="session")
+def gpu_ctx(pkg, noise):
+    if pkg.lib().csky_device_count() < 1:
+        pytest.fail("gpu test selected but no HIP device is visible (libcloudsky has no CPU fallback)")
+    ctx = pkg.Context(0)
+    ctx.set_noise(*noise)
+    yield ctx
+    ctx.close()

@@ -1,0 +1,74 @@
+"""Asset layer: BMP loader, Godot 3-D slicing, deterministic shape-noise generator, mip chains (CPU only)."""
+import os
+
+import numpy as np
+
+SHAPE_SHA256 = "d52ddc23e25fff16c39e6fd672ab28c4d39ac4167f6d167f719ea37cd7704c0d"   # tests/golden/INPUTS.txt
+SMALL_SHA256 = "9cfdc06c3ff2483aec9c6837fd83464509db609c1769a58430247f428561f6b6"
+WEATHER_SHA256 = "2c15fb3c19a0e5fca66644fc08b9a9a2ac71f12ea284d5f03b618bca2385154c"
+
+
+def test_bmp_loader_matches_pil(pkg):
+    from PIL import Image
+    for name in ("weather.bmp", "worlnoise.bmp"):
+        p = os.path.join(pkg.assets.ASSET_DIR, name)
+        assert (pkg.assets.load_bmp_rgb8(p) == np.array(Image.open(p).convert("RGB"))).all()
+
+
+def test_bmp_loader_errors(pkg, tmp_path):
+    import pytest
+    with pytest.raises(pkg.CloudSkyError):
+        pkg.assets.load_bmp_rgb8(str(tmp_path / "missing.bmp"))
+    bad = tmp_path / "bad.bmp"
+    bad.write_bytes(b"XX" + b"\0" * 100)
+    with pytest.raises(pkg.CloudSkyError):
+        pkg.assets.load_bmp_rgb8(str(bad))
+
+
+def test_strip_to_volume_layout(pkg):
+    # worlnoise.bmp.import:26-27: slices/horizontal=32, vertical=1 -> voxel(x,y,z) = strip[y][32 z + x]
+    strip = pkg.assets.load_bmp_rgb8(os.path.join(pkg.assets.ASSET_DIR, "worlnoise.bmp"))
+    vol = pkg.assets.strip_to_volume(strip, 32)
+    rng = np.random.default_rng(0)
+    for x, y, z in rng.integers(0, 32, (64, 3)):
+        assert (vol[z, y, x] == strip[y, 32 * z + x]).all()
+
+
+def test_inputs_pinned(pkg, noise):
+    large, small, weather = noise
+    assert pkg.assets.sha256(large) == SHAPE_SHA256      # integer hash + IEEE ops only: machine independent
+    assert pkg.assets.sha256(small) == SMALL_SHA256
+    assert pkg.assets.sha256(weather) == WEATHER_SHA256
+    assert large.shape == (128, 128, 128, 4) and small.shape == (32, 32, 32, 3) and weather.shape == (512, 512, 3)
+
+
+def test_shape_noise_is_tileable_and_calibrated(noise):
+    large = noise[0].astype(np.float32)
+    for ax in range(3):   # REPEAT sampler (cloud_sky.gd:302-304): the wrap seam must look like any interior step
+        seam = np.abs(np.take(large, 0, ax) - np.take(large, 127, ax)).mean()
+        inner = np.abs(np.take(large, 64, ax) - np.take(large, 63, ax)).mean()
+        assert seam < 2.0 * inner + 1.0
+    m = large.reshape(-1, 4).mean(0) / 255.0
+    assert 0.6 < m[0] < 0.9 and all(0.3 < v < 0.7 for v in m[1:])
+
+
+def test_generator_small_and_bad_args(pkg):
+    import pytest
+    a = pkg.assets.generate_shape_noise(7, 16)
+    b = pkg.assets.generate_shape_noise(7, 16)
+    c = pkg.assets.generate_shape_noise(8, 16)
+    assert (a == b).all() and (a != c).any()
+    with pytest.raises(pkg.CloudSkyError):
+        pkg.assets.generate_shape_noise(1, 12)
+
+
+def test_mips_match_oracle_and_numpy(pkg, oracle, noise):
+    from oracle import numpy_restatement as NR
+    large, small, _ = noise
+    for vol, n, ch, lv in ((large, 128, 4, 8), (small, 32, 3, 6)):
+        prod = pkg.assets.build_mips(vol, lv)
+        assert (prod == oracle.build_mip_chain(vol, n, ch, lv)).all()     # integer work: bit exact
+        chain = NR.mip_chain(vol)
+        flat = np.concatenate([l.reshape(-1) for l in chain[:lv]])
+        assert (prod == flat).all()
+    assert prod[-3:].tolist() == NR.mip_chain(small)[5].reshape(-1).tolist()   # LOD 5 = 1x1x1 mean texel

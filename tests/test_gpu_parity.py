@@ -1,0 +1,228 @@
+"""-m gpu: the HIP path through the C ABI (libcloudsky.so) vs the CPU oracle on the same seeded inputs, vs the
+committed numpy fixtures, and -- at BASELINE's full sizes -- through size-independent properties.
+Tolerances (stated): LUTs <= 2 fp16 ulp; clouds per channel |d| <= 2e-3 + 1e-2*|ref| on >= 99.9 % of
+values, PSNR >= 50 dB on RGB, in-cloud sample counts within 0.1 %."""
+import os
+
+import numpy as np
+import pytest
+
+from conftest import GOLDEN, SUNS, cloud_close, norm, ulp_diff
+
+pytestmark = pytest.mark.gpu
+
+
+def test_native_library_is_what_runs(pkg, gpu_ctx):
+    assert os.path.exists(pkg.library_path()) and pkg.lib().csky_device_count() >= 1
+    maps = open("/proc/self/maps").read()
+    assert "libcloudsky.so" in maps
+
+
+def test_transmittance_lut(gpu_ctx, o_trans):
+    t = gpu_ctx.render_transmittance(256, 64)
+    d = ulp_diff(t, o_trans)
+    assert d.max() <= 2, d.max()
+    g = np.load(os.path.join(GOLDEN, "transmittance_lut_np.npz"))["lut"].view(np.float16)
+    assert ulp_diff(t, g).max() <= 2
+    assert (gpu_ctx.read_transmittance().view(np.uint16) == t.view(np.uint16)).all()
+
+
+def test_transmittance_other_size(gpu_ctx, oracle):
+    t = gpu_ctx.render_transmittance(64, 16)
+    assert ulp_diff(t, oracle.transmittance_lut(64, 16)).max() <= 2
+    gpu_ctx.render_transmittance(256, 64)
+
+
+def test_sky_lut(gpu_ctx, o_skies):
+    gpu_ctx.render_transmittance(256, 64)
+    g = np.load(os.path.join(GOLDEN, "sky_lut_np.npz"))
+    for k, sun in SUNS.items():
+        s = gpu_ctx.render_sky_lut(norm(sun), 200, 100)
+        d = ulp_diff(s, o_skies[k])
+        assert d.max() <= 2 and (d > 0).mean() < 0.05, (k, d.max(), (d > 0).mean())
+        assert ulp_diff(s, g[k].view(np.float16)).max() <= 2
+        assert (gpu_ctx.read_sky_lut().view(np.uint16) == s.view(np.uint16)).all()
+
+
+@pytest.mark.parametrize("sun_name", list(SUNS))
+def test_clouds_vs_oracle_default_config(gpu_ctx, oracle, otex, o_skies, sun_name):
+    sun = SUNS[sun_name]
+    gpu_ctx.set_march(128, 6)
+    gpu_ctx.set_early_out(0.0)
+    gpu_ctx.render_sky_lut(norm(sun), 200, 100)
+    p = oracle.default_params(256, 128, sun)
+    img = gpu_ctx.render_clouds(p)
+    st = gpu_ctx.cloud_stats()
+    ref, st_o = oracle.clouds(otex, p, o_skies[sun_name], nthreads=oracle.max_threads(), return_stats=True)
+    ok, info = cloud_close(img, ref)
+    assert ok, info
+    assert abs(int(st["incloud_samples"]) - st_o["incloud_samples"]) <= 1e-3 * st_o["incloud_samples"]
+    assert st["primary_samples"] == st_o["primary_samples"]
+    f = img.astype(np.float32)
+    assert (f[0] == 0).all() and (f[:, 0] == 0).all()
+
+
+def test_clouds_vs_numpy_fixture(gpu_ctx, oracle):
+    g = np.load(os.path.join(GOLDEN, "clouds_np.npz"))
+    gpu_ctx.set_march(128, 6)
+    for k, sun in SUNS.items():
+        gpu_ctx.render_sky_lut(norm(sun), 200, 100)
+        img = gpu_ctx.render_clouds(oracle.default_params(64, 32, sun))
+        ok, info = cloud_close(img, g[k].view(np.float16))
+        assert ok, (k, info)
+
+
+def test_config_c2_512x256_64x4_zenith(gpu_ctx, oracle, otex, o_skies):
+    """BASELINE configs[1]: 512x256, 64 primary x 4 light steps, sun at zenith, default weather."""
+    gpu_ctx.set_march(64, 4)
+    gpu_ctx.render_sky_lut(norm((0, 1, 0)), 200, 100)
+    p = oracle.default_params(512, 256, (0, 1, 0))
+    img = gpu_ctx.render_clouds(p)
+    ref = oracle.clouds(otex, p, o_skies["zenith"], primary_steps=64, light_steps=4, nthreads=oracle.max_threads())
+    ok, info = cloud_close(img, ref)
+    assert ok, info
+    gpu_ctx.set_march(128, 6)
+
+
+def test_windy_offset_tile(gpu_ctx, oracle, otex):
+    """All push-constant fields non-default, update_position tile offset, ragged tile size (not a multiple of 8/32)."""
+    g = np.load(os.path.join(GOLDEN, "clouds_np.npz"))
+    pw = g["windy_params"].copy()
+    gpu_ctx.set_march(64, 4)
+    gpu_ctx.render_sky_lut(pw[16:19], 200, 100)
+    assert ulp_diff(gpu_ctx.read_sky_lut(), g["windy_sky"].view(np.float16)).max() <= 2
+    img = gpu_ctx.render_clouds(pw, 45, 21)                         # ragged: 45 x 21
+    ref = oracle.clouds(otex, pw, g["windy_sky"].view(np.float16), rect=(0, 0, 45, 21), primary_steps=64, light_steps=4)
+    ok, info = cloud_close(img, ref)
+    assert ok, info
+    fix = g["windy"].view(np.float16)                                # numpy fixture: rect (8,4,48,24) of the same tile space
+    ok, info = cloud_close(img[4:21, 8:45], fix[:17, :37])
+    assert ok, info
+    gpu_ctx.set_march(128, 6)
+
+
+def test_tile_walk_equals_full_frame_and_is_deterministic(gpu_ctx, oracle):
+    gpu_ctx.render_sky_lut(norm((1, 1, 0)), 200, 100)
+    p = oracle.default_params(256, 128, (1, 1, 0))
+    full = gpu_ctx.render_clouds(p).view(np.uint16)
+    again = gpu_ctx.render_clouds(p).view(np.uint16)
+    assert (full == again).all()                                     # bit-reproducible
+    tiles = np.zeros_like(full)
+    for ty in range(0, 128, 32):                                     # 16-tile temporal split (cloud_sky.gd:36 "Fast(16)")
+        for tx in range(0, 256, 64):
+            q = p.copy(); q[2:4] = (tx, ty)
+            tiles[ty:ty + 32, tx:tx + 64] = gpu_ctx.render_clouds(q, 64, 32).view(np.uint16)
+    assert (tiles == full).all()
+
+
+def test_band_sharding_device_form(pkg, gpu_ctx, oracle):
+    """csky_render_clouds_device with interleaved bands (the N-GPU decomposition) reproduces the full frame."""
+    import torch
+    gpu_ctx.render_sky_lut(norm((1, 1, 0)), 200, 100)
+    W, H = 256, 128
+    p = oracle.default_params(W, H, (1, 1, 0))
+    full = gpu_ctx.render_clouds(p).view(np.uint16)
+    stream = torch.cuda.current_stream().cuda_stream
+    for world in (2, 8):
+        parts = []
+        for r in range(world):
+            b = pkg.tiling.bands_for_rank(H, r, world)
+            loc = torch.zeros((pkg.tiling.max_bands(H, world) * 8, W, 4), dtype=torch.int16, device="cuda")
+            gpu_ctx.render_clouds_device(p, W, b, loc.data_ptr(), W * 8, stream)
+            parts.append(loc)
+        torch.cuda.synchronize()
+        frame = pkg.tiling.interleave(torch.stack(parts, 0), H, world).cpu().numpy().view(np.uint16)
+        assert (frame == full).all(), world
+
+
+def test_early_out_is_bounded(gpu_ctx, oracle):
+    gpu_ctx.render_sky_lut(norm((0, 1, 0)), 200, 100)
+    p = oracle.default_params(256, 128, (0, 1, 0), coverage=0.5)
+    gpu_ctx.set_early_out(0.0)
+    a = gpu_ctx.render_clouds(p).astype(np.float32)
+    gpu_ctx.set_early_out(1e-3)
+    b = gpu_ctx.render_clouds(p).astype(np.float32)
+    gpu_ctx.set_early_out(0.0)
+    d = np.abs(a - b)
+    assert d[..., 3].max() <= 1.5e-3 and d[..., :3].max() <= 1.5e-3 * max(1.0, float(a[..., :3].max()))
+
+
+def test_edge_cases(pkg, gpu_ctx, oracle, otex, o_skies):
+    gpu_ctx.render_sky_lut(norm((0, 1, 0)), 200, 100)
+    # coverage == 0 divides by zero in remap (clouds.glsl:124); defined as density 0, never NaN
+    for cov in (0.0, 1e-6):
+        img = gpu_ctx.render_clouds(oracle.default_params(64, 32, (0, 1, 0), coverage=cov)).astype(np.float32)
+        assert (img == 0).all()
+    # sun below the horizon (cloud_sky.gd:72 default LIGHT_DIRECTION = (0,-1,0)): finite, matches the oracle
+    gpu_ctx.render_sky_lut(norm((0, -1, 0)), 200, 100)
+    p = oracle.default_params(64, 32, (0, -1, 0))
+    sk = oracle.sky_lut(norm((0, -1, 0)), oracle.transmittance_lut())
+    ok, info = cloud_close(gpu_ctx.render_clouds(p), oracle.clouds(otex, p, sk))
+    assert ok, info
+    # 1 x 1 tile, 8 x 8 texture
+    tiny = gpu_ctx.render_clouds(oracle.default_params(8, 8, (0, 1, 0)), 1, 1)
+    assert tiny.shape == (1, 1, 4) and (tiny.astype(np.float32) == 0).all()      # pixel (0,0) is on the horizon
+    # maximum march length accepted by the ABI
+    gpu_ctx.set_march(1024, 6)
+    gpu_ctx.render_sky_lut(norm((0, 1, 0)), 200, 100)
+    p = oracle.default_params(16, 8, (0, 1, 0))
+    ok, info = cloud_close(gpu_ctx.render_clouds(p), oracle.clouds(otex, p, o_skies["zenith"], primary_steps=1024))
+    assert ok, info
+    gpu_ctx.set_march(128, 6)
+
+
+def test_error_behaviour(pkg, noise):
+    ctx = pkg.Context(0)
+    p = np.zeros(28, np.float32); p[0:2] = (16, 8)
+    with pytest.raises(pkg.CloudSkyError) as e:                      # clouds before noise (cloud_sky.gd:379 order)
+        ctx.render_clouds(p)
+    assert e.value.code == pkg._lib.ERR_STATE
+    ctx.set_noise(*noise)
+    with pytest.raises(pkg.CloudSkyError) as e:                      # clouds before any sky LUT
+        ctx.render_clouds(p)
+    assert e.value.code == pkg._lib.ERR_STATE
+    with pytest.raises(pkg.CloudSkyError):
+        ctx.set_march(0, 6)
+    with pytest.raises(pkg.CloudSkyError):
+        ctx.set_march(128, 7)                                        # RANDOM_VECTORS has 6 entries
+    with pytest.raises(pkg.CloudSkyError):
+        ctx.set_variant(10 ** 6)
+    with pytest.raises(pkg.CloudSkyError):
+        pkg.Context(10 ** 6)
+    ctx.close(); ctx.close()                                         # idempotent
+
+
+def test_full_size_c3_properties(gpu_ctx, oracle, otex, o_skies):
+    """BASELINE configs[2] (2048x1024 @ 128x6): size-independent properties + oracle parity on sampled 8x8 tiles."""
+    gpu_ctx.set_march(128, 6)
+    gpu_ctx.render_sky_lut(norm((1, 1, 0)), 200, 100)
+    W, H = 2048, 1024
+    p = oracle.default_params(W, H, (1, 1, 0))
+    img = gpu_ctx.render_clouds(p)
+    st = gpu_ctx.cloud_stats()
+    f = img.astype(np.float32)
+    assert np.isfinite(f).all() and f.min() >= 0 and f[..., 3].max() <= 1
+    assert (f[0] == 0).all() and (f[:, 0] == 0).all()                          # 3 071 horizon pixels are exactly 0
+    assert ((f[..., 3] == 0) == (f[..., :3].sum(-1) == 0)).all()
+    assert st["rays"] == W * H and st["primary_samples"] == (W - 1) * (H - 1) * 128
+    assert 0.3 < f[..., 3].mean() < 0.7
+    assert (gpu_ctx.render_clouds(p).view(np.uint16) == img.view(np.uint16)).all()   # idempotent / deterministic
+    rng = np.random.default_rng(5)
+    for _ in range(24):                                                        # oracle parity on random 8x8 tiles
+        tx, ty = int(rng.integers(0, W // 8)) * 8, int(rng.integers(0, H // 8)) * 8
+        ref = oracle.clouds(otex, p, o_skies["deg45"], rect=(tx, ty, 8, 8))
+        a, b = f[ty:ty + 8, tx:tx + 8], ref.astype(np.float32)
+        assert (np.abs(a - b) <= 2e-3 + 1e-2 * np.abs(b)).mean() >= 0.98, (tx, ty)
+
+
+def test_cloud_sky_host_class_on_gpu(pkg, noise, oracle, otex, o_skies):
+    """The GDScript mirror end to end on the device-buffer path (torch tensors, current stream)."""
+    import torch
+    sky = pkg.CloudSky.from_default_resource(device_id=0, texture_size=(128, 64), noise=noise, clock=lambda: 0.0, device_buffers=True)
+    sky.sun = pkg.cloud_sky.DirectionalLight(direction=(1, 1, 0))
+    tex = sky.update_sky()
+    torch.cuda.synchronize()
+    ref = oracle.clouds(otex, oracle.default_params(128, 64, (1, 1, 0)), o_skies["deg45"])
+    ok, info = cloud_close(tex.cpu().numpy(), ref)
+    assert ok, info
+    sky.close()

@@ -1,0 +1,81 @@
+"""The kernel cores (csrc/cloud_core.h, lut_core.h: the per-lane code the HIP kernels instantiate), compiled for the
+host by tests/hostsim, checked against the oracle on a CPU: kernel maths, texture baking and band addressing.
+This is a unit test of device code, not a render path: libcloudsky itself has no CPU implementation."""
+import ctypes as C
+
+import numpy as np
+
+from conftest import SUNS, cloud_close, norm, ulp_diff
+
+
+def P(a):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+def hs_clouds(hostsim, pkg, noise, params, sky, tile_w, bands, primary=128, light=6, eps=0.0):
+    large, small, weather = noise
+    lc, sc = pkg.assets.build_mips(large, 8), pkg.assets.build_mips(small, 6)
+    rows = bands[0] * bands[3]
+    out = np.zeros((rows, tile_w, 4), np.uint16)
+    ic = C.c_uint64()
+    p = np.ascontiguousarray(params, np.float32)
+    s = np.ascontiguousarray(sky).view(np.uint16)
+    hostsim.hostsim_clouds(P(lc), P(sc), P(weather), P(p), primary, light, C.c_float(eps), P(s), s.shape[1], s.shape[0], tile_w,
+                           bands[0], bands[1], bands[2], bands[3], P(out), C.byref(ic))
+    return out.view(np.float16), ic.value
+
+
+def test_lut_cores_bit_exact(hostsim, o_trans, o_skies):
+    t = np.zeros((64, 256, 4), np.uint16)
+    hostsim.hostsim_transmittance(256, 64, P(t))
+    assert (t == o_trans.view(np.uint16)).all()
+    for k, sun in SUNS.items():
+        s = np.zeros((100, 200, 4), np.uint16)
+        sn = norm(sun)
+        hostsim.hostsim_sky(200, 100, P(sn), P(o_trans.view(np.uint16)), 256, 64, P(s))
+        assert (s == o_skies[k].view(np.uint16)).all(), k
+
+
+def test_cloud_core_matches_oracle(hostsim, pkg, oracle, noise, otex, o_skies):
+    for k, sun in SUNS.items():
+        p = oracle.default_params(64, 32, sun)
+        ref, st = oracle.clouds(otex, p, o_skies[k], return_stats=True)
+        img, ic = hs_clouds(hostsim, pkg, noise, p, o_skies[k], 64, (8, 0, 1, 4))
+        ok, info = cloud_close(img, ref, frac=0.9995, atol=1e-3, rtol=2e-3)
+        assert ok, (k, info)
+        assert ic == st["incloud_samples"], k           # both exact rejects agree with the oracle's t > 0 decisions
+
+
+def test_cloud_core_windy_tile(hostsim, pkg, oracle, noise, otex):
+    import os
+    from conftest import GOLDEN
+    g = np.load(os.path.join(GOLDEN, "clouds_np.npz"))
+    pw, sk = g["windy_params"], g["windy_sky"].view(np.float16)
+    ref = oracle.clouds(otex, pw, sk, rect=(0, 0, 48, 24), primary_steps=64, light_steps=4)
+    img, _ = hs_clouds(hostsim, pkg, noise, pw, sk, 48, (8, 0, 1, 3), primary=64, light=4)
+    ok, info = cloud_close(img, ref, frac=0.9995, atol=1e-3, rtol=2e-3)
+    assert ok, info
+
+
+def test_band_addressing(hostsim, pkg, oracle, noise, o_skies):
+    """csky_bands: rank r of N renders bands r, r+N, ...; the compact outputs interleave back to the full frame."""
+    p = oracle.default_params(32, 48, (1, 1, 0))
+    full, _ = hs_clouds(hostsim, pkg, noise, p, o_skies["deg45"], 32, (8, 0, 1, 6))
+    world = 4
+    parts = []
+    for r in range(world):
+        b = pkg.tiling.bands_for_rank(48, r, world)
+        img, _ = hs_clouds(hostsim, pkg, noise, p, o_skies["deg45"], 32, b)
+        pad = np.zeros((pkg.tiling.max_bands(48, world) * 8, 32, 4), np.float16)
+        pad[: img.shape[0]] = img
+        parts.append(pad)
+    re = pkg.tiling.interleave(np.stack(parts, 0), 48, world)
+    assert (re.view(np.uint16) == full.view(np.uint16)).all()
+
+
+def test_early_out_bounded(hostsim, pkg, oracle, noise, o_skies):
+    p = oracle.default_params(48, 24, (0, 1, 0), coverage=0.5)
+    a, _ = hs_clouds(hostsim, pkg, noise, p, o_skies["zenith"], 48, (8, 0, 1, 3), eps=0.0)
+    b, _ = hs_clouds(hostsim, pkg, noise, p, o_skies["zenith"], 48, (8, 0, 1, 3), eps=1e-3)
+    d = np.abs(a.astype(np.float32) - b.astype(np.float32))
+    assert d[..., 3].max() <= 1.5e-3 and d[..., :3].max() <= 1.5e-3 * max(1.0, float(a.astype(np.float32)[..., :3].max()))
