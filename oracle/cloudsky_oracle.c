@@ -581,6 +581,42 @@ void csko_clouds(const csko_textures *tex, const float params[28], int primary_s
     }
 }
 
+
+/* Same as csko_clouds but over the band set of the product's csky_bands (compact output rows): used by the
+ * cpu_baseline leg of bench.py to time a bounded, evenly spread sample of the frame on all host cores
+ * (OpenMP over (row, 64-column chunk) work items, dynamic schedule). */
+void csko_clouds_bands(const csko_textures *tex, const float params[28], int primary_steps, int light_steps,
+                       const uint16_t *sky_lut, int sw, int sh, int tile_w, int band_rows, int first_band, int band_stride,
+                       int n_bands, uint16_t *out, int nthreads, csko_stats *stats) {
+    cloud_params P; memcpy(&P, params, sizeof(P));
+    cloud_ctx c = {tex, &P, sky_lut, sw, sh, light_steps};
+    uint64_t incloud_total = 0, marched_total = 0;
+    const int rows = n_bands * band_rows, chunks = (tile_w + 63) / 64;
+#ifdef _OPENMP
+    if (nthreads < 1) nthreads = 1;
+#pragma omp parallel for schedule(dynamic, 1) num_threads(nthreads) reduction(+ : incloud_total, marched_total)
+#endif
+    for (int item = 0; item < rows * chunks; item++) {
+        const int lr = item / chunks, ch = item - lr * chunks;
+        const int band = lr / band_rows, rib = lr - band * band_rows;
+        const int gy = (first_band + band * band_stride) * band_rows + rib;
+        const int x1 = (ch * 64 + 64 < tile_w) ? ch * 64 + 64 : tile_w;
+        for (int gx = ch * 64; gx < x1; gx++) {
+            v3 dir = pixel_dir(&P, gx, gy);
+            uint64_t ic = 0; int m = 0;
+            v4 col = sky(&c, dir, primary_steps, &ic, &m);
+            incloud_total += ic; marched_total += (uint64_t)m;
+            uint16_t *o = out + ((size_t)lr * tile_w + gx) * 4;
+            o[0] = csko_f2h(col.x); o[1] = csko_f2h(col.y); o[2] = csko_f2h(col.z); o[3] = csko_f2h(col.w);
+        }
+    }
+    (void)nthreads;
+    if (stats) {
+        stats->rays = (uint64_t)tile_w * (uint64_t)rows; stats->rays_marched = marched_total;
+        stats->primary_samples = marched_total * (uint64_t)primary_steps; stats->incloud_samples = incloud_total;
+    }
+}
+
 /* ------------------------------------------------------------------ probes for structural tests */
 float csko_hash_probe(float px, float py, float pz) { return hash3(muls3(V3(px, py, pz), 10.0f)); }
 void csko_pixel_dir(const float params[28], int px, int py, float dir[3]) {

@@ -68,6 +68,11 @@ void csko_clouds(const csko_textures *tex, const float params[28], int primary_s
                  const uint16_t *sky_lut, int sw, int sh, int gx0, int gy0, int w, int h,
                  uint16_t *out_rgba16f, size_t pitch_bytes, int nthreads, csko_stats *stats);
 
+/* csko_clouds over a band set (same meaning as the product's csky_bands), compact output rows */
+void csko_clouds_bands(const csko_textures *tex, const float params[28], int primary_steps, int light_steps,
+                       const uint16_t *sky_lut, int sw, int sh, int tile_w, int band_rows, int first_band, int band_stride,
+                       int n_bands, uint16_t *out_rgba16f, int nthreads, csko_stats *stats);
+
 /* probes used by the structural tests */
 float csko_hash_probe(float px, float py, float pz);                     /* clouds.glsl:60-64 on pos*10 */
 void csko_pixel_dir(const float params[28], int px, int py, float dir[3]); /* clouds.glsl:260-262        */

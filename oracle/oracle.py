@@ -51,6 +51,8 @@ def lib():
         L.csko_clouds.argtypes = [C.POINTER(Textures), C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_int,
                                   C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_size_t, C.c_int,
                                   C.POINTER(Stats)]
+        L.csko_clouds_bands.argtypes = [C.POINTER(Textures), C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int,
+                                        C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int, C.POINTER(Stats)]
         L.csko_hash_probe.restype = C.c_float
         L.csko_hash_probe.argtypes = [C.c_float] * 3
         L.csko_pixel_dir.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p]
@@ -118,6 +120,19 @@ def clouds(tex, params, sky, rect=None, primary_steps=128, light_steps=6, nthrea
         return img, dict(rays=st.rays, rays_marched=st.rays_marched, primary_samples=st.primary_samples,
                          incloud_samples=st.incloud_samples)
     return img
+
+
+def clouds_bands(tex, params, sky, tile_w, bands, primary_steps=128, light_steps=6, nthreads=1):
+    """Band-set form (bands = (band_rows, first_band, band_stride, n_bands)); returns (float16 [rows, tile_w, 4], stats)."""
+    p = np.ascontiguousarray(params, np.float32)
+    s = np.ascontiguousarray(sky).view(np.uint16)
+    br, first, stride, n = [int(v) for v in bands]
+    out = np.zeros((br * n, tile_w, 4), np.uint16)
+    st = Stats()
+    lib().csko_clouds_bands(C.byref(tex.c), _ptr(p), primary_steps, light_steps, _ptr(s), s.shape[1], s.shape[0], tile_w, br, first,
+                            stride, n, _ptr(out), nthreads, C.byref(st))
+    return out.view(np.float16), dict(rays=st.rays, rays_marched=st.rays_marched, primary_samples=st.primary_samples,
+                                      incloud_samples=st.incloud_samples)
 
 
 def default_params(w, h, sun, coverage=0.2, density=0.05):

@@ -40,7 +40,7 @@ def test_sky_lut(gpu_ctx, o_skies):
         s = gpu_ctx.render_sky_lut(norm(sun), 200, 100)
         d = ulp_diff(s, o_skies[k])
         assert d.max() <= 2 and (d > 0).mean() < 0.05, (k, d.max(), (d > 0).mean())
-        assert ulp_diff(s, g[k].view(np.float16)).max() <= 2
+        assert ulp_diff(s, g[k].view(np.float16)).max() <= 3    # the numpy fixture is itself +-1 ulp from the oracle
         assert (gpu_ctx.read_sky_lut().view(np.uint16) == s.view(np.uint16)).all()
 
 
@@ -90,7 +90,9 @@ def test_windy_offset_tile(gpu_ctx, oracle, otex):
     pw = g["windy_params"].copy()
     gpu_ctx.set_march(64, 4)
     gpu_ctx.render_sky_lut(pw[16:19], 200, 100)
-    assert ulp_diff(gpu_ctx.read_sky_lut(), g["windy_sky"].view(np.float16)).max() <= 2
+    sk_o = oracle.sky_lut(pw[16:19], oracle.transmittance_lut())
+    assert ulp_diff(gpu_ctx.read_sky_lut(), sk_o).max() <= 2                      # stated LUT tolerance, vs the C oracle
+    assert ulp_diff(gpu_ctx.read_sky_lut(), g["windy_sky"].view(np.float16)).max() <= 3   # numpy fixture is itself +-1 from the oracle
     img = gpu_ctx.render_clouds(pw, 45, 21)                         # ragged: 45 x 21
     ref = oracle.clouds(otex, pw, g["windy_sky"].view(np.float16), rect=(0, 0, 45, 21), primary_steps=64, light_steps=4)
     ok, info = cloud_close(img, ref)
