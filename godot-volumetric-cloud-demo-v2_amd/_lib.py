@@ -59,6 +59,7 @@ SYMBOLS = [
     ("csky_get_cloud_stats", C.c_int, [C.c_void_p, C.POINTER(CloudStats)]),
     ("csky_set_variant", C.c_int, [C.c_void_p, C.c_int]),
     ("csky_variant_count", C.c_int, []),
+    ("csky_set_schedule", C.c_int, [C.c_void_p, C.c_int]),
     ("csky_variant_name", C.c_char_p, [C.c_int]),
     ("csky_load_bmp_rgb8", C.c_int, [C.c_char_p, C.POINTER(C.c_int), C.POINTER(C.c_int), C.c_void_p, C.c_size_t]),
     ("csky_strip_to_volume", C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
@@ -141,6 +142,9 @@ class Context:
 
     def set_early_out(self, eps):
         self._chk(self._L.csky_set_early_out(self._h, float(eps)))
+
+    def set_schedule(self, mode):
+        self._chk(self._L.csky_set_schedule(self._h, int(mode)))
 
     def set_variant(self, v):
         self._chk(self._L.csky_set_variant(self._h, int(v)))

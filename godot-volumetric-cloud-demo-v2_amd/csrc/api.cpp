@@ -7,10 +7,13 @@
 #include <cstdio>
 #include <cstring>
 #include <new>
+#include <algorithm>
+#include <cmath>
 #include <vector>
 #include "../../include/cloudsky.h"
 #include "kernels.h"
 #include "bake.h"
+#include "cloud_core.h"
 
 using namespace csky;
 
@@ -31,7 +34,11 @@ struct csky_ctx {
     uint2* d_frame = nullptr; size_t frame_px = 0;  // internal frame for the host-buffer form / timing
     int primary_steps = 128, light_steps = 6;        // clouds.glsl:228, :186
     float early_eps = 0.0f;
-    int variant = 0;
+    int variant = 1;
+    int sched_mode = 0;
+    // workgroup schedule (physical workgroup -> slab), cached per render geometry
+    uint32_t* d_order = nullptr; size_t order_cap = 0; int order_grid = 0;
+    std::vector<uint32_t> h_order; long long order_key[10] = {-1, -1, -1, -1, -1, -1, -1, -1, -1, -1};
     csky_cloud_stats last_stats = {0, 0, 0};
     char err[512] = {0};
 };
@@ -91,6 +98,53 @@ int check_bands(csky_ctx* c, const csky_bands* b, int tile_w) {
     return CSKY_OK;
 }
 
+// Workgroup schedule.  A slab = one 32 x 8 pixel workgroup footprint (4 wavefront tiles).  mode 0 (default): XCD x
+// (= physical workgroup id % 8, observed placement, speed only) gets the slabs whose centre lies in the x-th 45-degree
+// azimuth wedge of the hemi-octahedral map (clouds.glsl:248-256), ordered horizon-first (longest marches first, so
+// they do not form the tail).  mode 1: contiguous eighths of the frame per XCD.  mode 2: natural order.
+int build_schedule(csky_ctx* c, const CloudParams& p, const RenderGeom& g, hipStream_t s) {
+    const int tiles_x = (g.tile_w + 31) >> 5, local_rows = g.n_bands * g.band_rows, slabs = (local_rows + 7) >> 3;
+    const int nblocks = tiles_x * slabs;
+    const long long key[10] = {g.tile_w, g.band_rows, g.first_band, g.band_stride, g.n_bands, (long long)p.texture_size[0], (long long)p.texture_size[1],
+                               (long long)p.update_position[0], (long long)p.update_position[1], c->sched_mode};
+    if (c->d_order && memcmp(key, c->order_key, sizeof key) == 0) return CSKY_OK;
+    std::vector<uint32_t>& ord = c->h_order;
+    if (c->sched_mode == 2) {
+        ord.resize(nblocks);
+        for (int i = 0; i < nblocks; i++) ord[i] = (uint32_t)i;
+    } else if (c->sched_mode == 1) {
+        const int per = (nblocks + 7) >> 3;
+        ord.assign((size_t)per * 8, 0xffffffffu);
+        for (int b = 0; b < per * 8; b++) { const int l = (b & 7) * per + (b >> 3); if (l < nblocks) ord[b] = (uint32_t)l; }
+    } else {
+        std::vector<std::pair<float, uint32_t>> wedge[8];
+        for (int slab = 0; slab < slabs; slab++) for (int bx = 0; bx < tiles_x; bx++) {
+            const int lr = slab * 8 + 4, band = lr / g.band_rows, rib = lr - band * g.band_rows;
+            const float gy = (float)((g.first_band + band * g.band_stride) * g.band_rows + rib) + p.update_position[1];
+            const float gx = (float)(bx * 32 + 16) + p.update_position[0];
+            const float u = gx / p.texture_size[0], v = gy / p.texture_size[1];
+            const float nx = u - v, ny = (u + v) - 1.0f, nz = 1.0f - std::fabs(nx) - std::fabs(ny);
+            int w = (int)std::floor((std::atan2(ny, nx) + 3.14159265f) * (4.0f / 3.14159265f));
+            w = w < 0 ? 0 : (w > 7 ? 7 : w);
+            wedge[w].push_back({nz, (uint32_t)(slab * tiles_x + bx)});
+        }
+        size_t longest = 0;
+        for (auto& w : wedge) { std::stable_sort(w.begin(), w.end(), [](const std::pair<float, uint32_t>& a, const std::pair<float, uint32_t>& b) { return a.first < b.first; }); longest = std::max(longest, w.size()); }
+        ord.assign(longest * 8, 0xffffffffu);
+        for (int x = 0; x < 8; x++) for (size_t i = 0; i < wedge[x].size(); i++) ord[i * 8 + x] = wedge[x][i].second;
+    }
+    if (c->order_cap < ord.size()) {
+        if (c->d_order) { HIPCHK(c, hipStreamSynchronize(s)); (void)hipFree(c->d_order); c->d_order = nullptr; }
+        HIPCHK(c, hipMalloc(reinterpret_cast<void**>(&c->d_order), ord.size() * sizeof(uint32_t)));
+        c->order_cap = ord.size();
+    }
+    HIPCHK(c, hipMemcpyAsync(c->d_order, ord.data(), ord.size() * sizeof(uint32_t), hipMemcpyHostToDevice, s));
+    HIPCHK(c, hipStreamSynchronize(s));   // h_order is pageable; the table is rebuilt only when the geometry changes
+    c->order_grid = (int)ord.size();
+    memcpy(c->order_key, key, sizeof key);
+    return CSKY_OK;
+}
+
 // frame_setup + clouds on stream s into d_out (compact rows).  stats: optional device counters.
 int clouds_dev(csky_ctx* c, const csky_cloud_params* p, int tile_w, const csky_bands* b, uint2* d_out, size_t pitch_bytes, hipStream_t s,
                unsigned long long* d_stats, bool setup) {
@@ -105,7 +159,8 @@ int clouds_dev(csky_ctx* c, const csky_cloud_params* p, int tile_w, const csky_b
     if (setup) HIPCHK(c, launch_frame_setup(cp, c->d_sky_f, c->sw, c->sh, c->primary_steps, c->light_steps, c->early_eps, c->d_fc, s));
     RenderGeom g; g.tile_w = tile_w; g.band_rows = b->band_rows; g.first_band = b->first_band; g.band_stride = b->band_stride; g.n_bands = b->n_bands;
     g.pitch_px = (uint32_t)(pitch_bytes / 8);
-    HIPCHK(c, launch_clouds(c->variant, texset(c), c->d_fc, g, d_out, d_stats, s));
+    if ((rc = build_schedule(c, cp, g, s))) return rc;
+    HIPCHK(c, launch_clouds(c->variant, texset(c), c->d_fc, g, c->d_order, c->order_grid, d_out, d_stats, s));
     return CSKY_OK;
 }
 
@@ -150,7 +205,7 @@ void csky_destroy(csky_ctx* c) {
     if (!c) return;
     (void)hipSetDevice(c->device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
-    void* ptrs[] = {c->d_shape, c->d_detail, c->d_weather, c->d_trans_h, c->d_trans_f, c->d_sky_h, c->d_sky_f, c->d_fc, c->d_stats, c->d_frame};
+    void* ptrs[] = {c->d_shape, c->d_detail, c->d_weather, c->d_trans_h, c->d_trans_f, c->d_sky_h, c->d_sky_f, c->d_fc, c->d_stats, c->d_frame, c->d_order};
     for (void* p : ptrs) if (p) (void)hipFree(p);
     if (c->ev0) (void)hipEventDestroy(c->ev0);
     if (c->ev1) (void)hipEventDestroy(c->ev1);
@@ -171,6 +226,8 @@ int csky_set_noise(csky_ctx* c, const uint8_t* large_rgba8, const uint8_t* small
     bake_shape(lc, shape, c->shape_off);
     bake_detail(sc, detail, c->detail_off);
     bake_weather(weather_rgb8, weather);
+    for (int l = 0; l < SHAPE_LEVELS; l++) if (c->shape_off[l] != shape_level_offset(l)) return fail(c, CSKY_ERR_INVALID, "internal: shape mip offset mismatch");
+    for (int l = 0; l < DETAIL_LEVELS; l++) if (c->detail_off[l] != detail_level_offset(l)) return fail(c, CSKY_ERR_INVALID, "internal: detail mip offset mismatch");
     HIPCHK(c, hipStreamSynchronize(c->stream));
     if ((rc = dev_alloc(c, &c->d_shape, shape.size()))) return rc;
     if ((rc = dev_alloc(c, &c->d_detail, detail.size()))) return rc;
@@ -199,6 +256,11 @@ int csky_set_variant(csky_ctx* c, int variant) {
     if (!c) return fail(nullptr, CSKY_ERR_INVALID, "csky_set_variant: ctx is NULL");
     if (variant < 0 || variant >= cloud_variant_count()) return fail(c, CSKY_ERR_INVALID, "csky_set_variant: unknown variant %d", variant);
     c->variant = variant; return CSKY_OK;
+}
+int csky_set_schedule(csky_ctx* c, int mode) {
+    if (!c) return fail(nullptr, CSKY_ERR_INVALID, "csky_set_schedule: ctx is NULL");
+    if (mode < 0 || mode > 2) return fail(c, CSKY_ERR_INVALID, "csky_set_schedule: mode must be 0 (azimuth wedges, horizon first), 1 (contiguous eighths) or 2 (natural)");
+    c->sched_mode = mode; return CSKY_OK;
 }
 int csky_variant_count(void) { return cloud_variant_count(); }
 const char* csky_variant_name(int v) { return cloud_variant_name(v); }

@@ -172,6 +172,11 @@ CSKY_HD void weather_tap(const uint2* __restrict__ w, float sx, float sy, float&
     wb = lerpf(lerpf(ub(q.y, 0), ub(q.y, 1), ax), lerpf(ub(q.y, 2), ub(q.y, 3), ax), ay) * (1.0f / 255.0f);
 }
 
+// texel offset of mip level l inside the packed chains: sum_{i<l} (N>>i)^3 = (N^3*8 - (N>>l)^3*8) / 7, computed
+// arithmetically so a per-lane level needs no table (api.cpp checks it against the baked offsets)
+CSKY_HD uint32_t shape_level_offset(int l) { return ((1u << 24) - (1u << (24 - 3 * l))) / 7u; }
+CSKY_HD uint32_t detail_level_offset(int l) { return ((1u << 18) - (1u << (18 - 3 * l))) / 7u; }
+
 // REPEAT + LINEAR trilinear tap of the shape volume at integer level `lvl` (clouds.glsl:117).
 // Returns r = n.r and fbm = n.g*0.625 + n.b*0.25 + n.a*0.125 (clouds.glsl:118; exact integer numerators, filtered linearly).
 CSKY_HD void shape_tap(const TexSet& T, int lvl, float sx, float sy, float sz, float& r, float& fbm) {
@@ -182,7 +187,7 @@ CSKY_HD void shape_tap(const TexSet& T, int lvl, float sx, float sy, float sz, f
     const float ax = ux - fx0, ay = uy - fy0, az = uz - fz0;
     const int x0 = ((int)fx0) & m, y0 = ((int)fy0) & m, z0 = ((int)fz0) & m;
     const int y1 = (y0 + 1) & m, z1 = (z0 + 1) & m;
-    const uint2* __restrict__ b = T.shape + T.shape_off[lvl];
+    const uint2* __restrict__ b = T.shape + shape_level_offset(lvl);
     const uint2 t00 = b[(z0 * n + y0) * n + x0], t10 = b[(z0 * n + y1) * n + x0];
     const uint2 t01 = b[(z1 * n + y0) * n + x0], t11 = b[(z1 * n + y1) * n + x0];
     const float r00 = lerpf(ub(t00.x, 0), ub(t00.y, 0), ax), r10 = lerpf(ub(t10.x, 0), ub(t10.y, 0), ax);
@@ -201,7 +206,7 @@ CSKY_HD float detail_tap(const TexSet& T, int lvl, float sx, float sy, float sz)
     const float fx0 = floorf(ux), fy0 = floorf(uy), fz0 = floorf(uz);
     const float ax = ux - fx0, ay = uy - fy0, az = uz - fz0;
     const int x0 = ((int)fx0) & m, y0 = ((int)fy0) & m, z0 = ((int)fz0) & m;
-    const uint4 q = T.detail[T.detail_off[lvl] + (z0 * n + y0) * n + x0];
+    const uint4 q = T.detail[detail_level_offset(lvl) + (z0 * n + y0) * n + x0];
     const float c00 = lerpf(lo16(q.x), hi16(q.x), ax), c10 = lerpf(lo16(q.y), hi16(q.y), ax);
     const float c01 = lerpf(lo16(q.z), hi16(q.z), ax), c11 = lerpf(lo16(q.w), hi16(q.w), ax);
     return lerpf(lerpf(c00, c10, ay), lerpf(c01, c11, ay), az) * (1.0f / (8.0f * 255.0f));
@@ -260,12 +265,32 @@ CSKY_HD float henyey_greenstein(float c, float g) {                         // c
     return 0.0795774715459f * (1.0f - g * g) / powf(1.0f + g * g - 2.0f * g * c, 1.5f);
 }
 
+// clouds.glsl:202-210: shade one in-cloud sample (density t, height fraction hf, step transmittance dt, summed light-march
+// density cd) and composite it front to back into (L, alpha, T).
+CSKY_HD void shade_sample(const FrameConsts& fc, float phase, float t, float hf, float dt, float cd, float& Tr, float& alpha, float& Lr,
+                          float& Lg, float& Lb) {
+    const float lss = (SKY_T_RADIUS - SKY_B_RADIUS) / 64.0f;
+    const float nd = -fc.density;
+    const float beers = fast_exp(nd * cd * lss * 3.0f);                                  // :202
+    const float powder = 1.0f - fast_exp(nd * cd * lss * 3.0f * 2.0f);                   // :203
+    const float bt = 2.0f * beers * powder;                                              // :204
+    const float sm = hf * hf * (3.0f - 2.0f * hf);                                       // smoothstep(0,1,hf), hf already in [0,1]
+    const float ar = fc.gnd_c[0] * (1.0f - sm) + fc.amb_c[0] * sm;                       // :206
+    const float ag = fc.gnd_c[1] * (1.0f - sm) + fc.amb_c[1] * sm;
+    const float ab = fc.gnd_c[2] * (1.0f - sm) + fc.amb_c[2] * sm;
+    alpha += (1.0f - dt) * (1.0f - alpha);                                               // :207
+    const float k = bt * phase;
+    const float rr = (ar + k * fc.sun_c[0]) * t, rg = (ag + k * fc.sun_c[1]) * t, rb = (ab + k * fc.sun_c[2]) * t;  // :208
+    const float w = Tr * fast_rcp(fmaxf(0.0000001f, t));                                 // :209
+    Lr += (rr - rr * dt) * w; Lg += (rg - rg * dt) * w; Lb += (rb - rb * dt) * w;
+    Tr *= dt;                                                                            // :210
+}
+
 struct MarchOut { float r, g, b, a; uint32_t incloud; };
 
 // clouds.glsl:139-215 march() for one ray.
 CSKY_HD MarchOut march(const TexSet& T, const FrameConsts& fc, Ray ray) {
     MarchOut o; o.r = o.g = o.b = o.a = 0.0f; o.incloud = 0;
-    const float lss = (SKY_T_RADIUS - SKY_B_RADIUS) / 64.0f;
     float phase = 0.0f;
     if (ray.above) {
         const float ct = fc.ldir[0] * ray.dx + fc.ldir[1] * ray.dy + fc.ldir[2] * ray.dz;   // :158
@@ -306,19 +331,7 @@ CSKY_HD MarchOut march(const TexSet& T, const FrameConsts& fc, Ray ray) {
                 const float ld = density(T, fc, lx, ly, lz, lhf, lwr, lwb, 3, 5);
                 cd += fast_pow(ld, (1.0f - lhf) * 0.8f + 0.5f);                              // :198 (second pow)
             }
-            const float beers = fast_exp(nd * cd * lss * 3.0f);                              // :202
-            const float powder = 1.0f - fast_exp(nd * cd * lss * 3.0f * 2.0f);               // :203
-            const float bt = 2.0f * beers * powder;                                          // :204
-            const float sm = hf * hf * (3.0f - 2.0f * hf);                                   // smoothstep(0,1,hf), hf already in [0,1]
-            const float ar = fc.gnd_c[0] * (1.0f - sm) + fc.amb_c[0] * sm;                   // :206
-            const float ag = fc.gnd_c[1] * (1.0f - sm) + fc.amb_c[1] * sm;
-            const float ab = fc.gnd_c[2] * (1.0f - sm) + fc.amb_c[2] * sm;
-            alpha += (1.0f - dt) * (1.0f - alpha);                                           // :207
-            const float k = bt * phase;
-            const float rr = (ar + k * fc.sun_c[0]) * t, rg = (ag + k * fc.sun_c[1]) * t, rb = (ab + k * fc.sun_c[2]) * t;  // :208
-            const float w = Tr * fast_rcp(fmaxf(0.0000001f, t));                             // :209
-            Lr += (rr - rr * dt) * w; Lg += (rg - rg * dt) * w; Lb += (rb - rb * dt) * w;
-            Tr *= dt;                                                                        // :210
+            shade_sample(fc, phase, t, hf, dt, cd, Tr, alpha, Lr, Lg, Lb);                       // :202-210
         }
     }
     o.r = Lr; o.g = Lg; o.b = Lb; o.a = sat(alpha);                                          // :213-214

@@ -62,23 +62,116 @@ hipError_t launch_frame_setup(const CloudParams& p, const float4* d_sky, int sw,
     return hipGetLastError();
 }
 
+// ---- wave-cooperative march (variant "coop") ---------------------------------------------------------------
+// The lock-step march above runs the 7-sample light march on all 64 lanes whenever ANY lane of the wave is inside
+// a cloud (measured: lanes are in cloud on 15 % of the steps, waves on ~70 %), so ~4/5 of the light-march VALU
+// work is masked off.  Here the two loops are decoupled:
+//   A. every lane advances its own ray to its NEXT in-cloud sample (or the end of the march);
+//   B. the wave's n pending samples need n*(light_steps+1) independent density evaluations: they are flattened
+//      (e = j*n + k) and dealt out 64 at a time, so every round runs with all lanes busy regardless of which
+//      rays are in cloud.  Sample positions travel through a per-wave LDS slab (no __syncthreads: waves are
+//      independent, LDS ops of one wave complete in order, wavefront-scope fences stop compiler reordering);
+//   C. each owning lane sums its light samples in the reference's order and composites the sample.
+// Per-ray results are the same as the lock-step march up to fp32 summation order (none is changed).
+__device__ __forceinline__ void wave_lds_fence() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+__device__ __forceinline__ MarchOut march_coop(const TexSet& T, const FrameConsts& fc, Ray ray, float* __restrict__ lds_pos /*[3*64]*/,
+                                               float* __restrict__ lds_lt /*[7*64]*/) {
+    MarchOut o; o.r = o.g = o.b = o.a = 0.0f; o.incloud = 0;
+    const int lane = threadIdx.x & 63;
+    const int steps = fc.primary_steps, ls = fc.light_steps, nl = ls + 1;
+    float phase = 0.0f;
+    if (ray.above) {
+        const float ct = fc.ldir[0] * ray.dx + fc.ldir[1] * ray.dy + fc.ldir[2] * ray.dz;
+        phase = fmaxf(fmaxf(henyey_greenstein(ct, 0.6f), henyey_greenstein(ct, fc.hg_g2)), henyey_greenstein(ct, -0.2f));
+    }
+    float Tr = 1.0f, alpha = 0.0f, Lr = 0.0f, Lg = 0.0f, Lb = 0.0f;
+    float px = ray.px, py = ray.py, pz = ray.pz;
+    const float nd = -fc.density;
+    int i = ray.above ? 0 : steps;
+    for (;;) {
+        // ---- A: advance to this lane's next in-cloud sample
+        float t = 0.0f, hf = 0.0f;
+        bool have = false;
+        while (i < steps) {
+            if (fc.early_eps > 0.0f && Tr < fc.early_eps) { i = steps; break; }   // per-lane early-out (bounded error, off by default)
+            i++;
+            advance(px, py, pz, ray.sx, ray.sy, ray.sz);
+            float wsx, wsy, wr, wb;
+            weather_coord(px, pz, fc.wpos_x, fc.wpos_y, wsx, wsy);
+            weather_tap(T.weather, wsx, wsy, wr, wb);
+            hf = height_fraction(length3_exact(px, py, pz));
+            t = density(T, fc, px, py, pz, hf, wr, wb, 0, 0);
+            if (t > 0.0f) { have = true; break; }
+        }
+        const unsigned long long m = __ballot(have);
+        if (m == 0ull) break;                                   // every ray of the tile has finished
+        const int n = __popcll(m);
+        const int idx = (int)__builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));
+        if (have) { lds_pos[idx] = px; lds_pos[64 + idx] = py; lds_pos[128 + idx] = pz; }
+        wave_lds_fence();
+        // ---- B: n*(ls+1) light-march evaluations, 64 per round, all lanes busy
+        const int total = n * nl;
+        const float rn = 1.0f / (float)n;
+        for (int e0 = 0; e0 < total; e0 += 64) {
+            const int e = e0 + lane;
+            if (e < total) {
+                const int j = (int)(((float)e + 0.5f) * rn);    // e = j*n + k, exact for e < 448, n <= 64
+                const int k = e - j * n;
+                float lx = lds_pos[k], ly = lds_pos[64 + k], lz = lds_pos[128 + k];
+                const bool distant = (j == ls);
+                if (distant) {
+                    advance(lx, ly, lz, fc.ldist[0], fc.ldist[1], fc.ldist[2]);                     // clouds.glsl:195
+                } else {
+#pragma unroll
+                    for (int jj = 0; jj < 6; jj++)                                                  // clouds.glsl:187, cumulative in fp32
+                        if (jj <= j) advance(lx, ly, lz, fc.linc[jj][0], fc.linc[jj][1], fc.linc[jj][2]);
+                }
+                const float lhf = height_fraction(length3_exact(lx, ly, lz));
+                float wsx, wsy, lwr, lwb;
+                weather_coord(lx, lz, distant ? 0.0f : fc.wpos_x, distant ? 0.0f : fc.wpos_y, wsx, wsy);   // :197 has no weather_pos
+                weather_tap(T.weather, wsx, wsy, lwr, lwb);
+                const int lod_s = distant ? 3 : (j > 2 ? j - 2 : 0), lod_d = distant ? 5 : j;
+                float d = density(T, fc, lx, ly, lz, lhf, lwr, lwb, lod_s, lod_d);
+                if (distant) d = fast_pow(d, (1.0f - lhf) * 0.8f + 0.5f);                          // :198
+                lds_lt[j * 64 + k] = d;
+            }
+        }
+        wave_lds_fence();
+        // ---- C: composite (owner lanes), light samples summed in the reference's order (:191, :199)
+        if (have) {
+            o.incloud++;
+            float cd = 0.0f;
+            for (int j = 0; j < nl; j++) cd += lds_lt[j * 64 + idx];
+            const float dt = fast_exp(nd * t * ray.ss);
+            shade_sample(fc, phase, t, hf, dt, cd, Tr, alpha, Lr, Lg, Lb);
+        }
+        wave_lds_fence();
+    }
+    o.r = Lr; o.g = Lg; o.b = Lb; o.a = sat(alpha);
+    return o;
+}
+
 // Pixel <-> lane mapping: a 256-thread workgroup = 4 wavefronts = a 32 x 8 pixel slab; each wavefront owns
 // one 8x8 tile (lane = ly*8 + lx) so its 64 rays are angularly adjacent: their texture footprints overlap
 // (L1/TA coalescing) and they enter/leave cloud together (less divergence).  The reference uses the same
 // 8x8 footprint per workgroup (clouds.glsl:5).
-// XCD-aware order: workgroup b runs on XCD b % 8 (observed, speed only); the remap gives every XCD one
-// contiguous eighth of the frame, so the slice of the noise volumes its rays touch stays in ITS 4 MiB L2.
+// Workgroup order: physical workgroup b runs on XCD b % 8 (observed, speed only).  `order` (built on the host,
+// api.cpp::build_schedule) maps b to a slab so that every XCD gets one 45-degree azimuth wedge of the
+// hemisphere -- the same elevation mix (balanced load) and a compact wedge of the noise volumes (its own 4 MiB L2
+// keeps it) -- and walks it horizon-first: horizon slabs are the slowest, so they must not form the tail.
 template <int VARIANT>
-__global__ __launch_bounds__(256) void clouds_kernel(TexSet T, const FrameConsts* __restrict__ fcp, RenderGeom G, uint2* __restrict__ out,
-                                                     unsigned long long* __restrict__ stats) {
+__global__ __launch_bounds__(256) void clouds_kernel(TexSet T, const FrameConsts* __restrict__ fcp, RenderGeom G, const uint32_t* __restrict__ order,
+                                                     uint2* __restrict__ out, unsigned long long* __restrict__ stats) {
     const int tiles_x = (G.tile_w + 31) >> 5;
     const int local_rows = G.n_bands * G.band_rows;
-    const int slabs = (local_rows + 7) >> 3;
-    const int nblocks = tiles_x * slabs;
-    const int per_xcd = (nblocks + 7) >> 3;
-    const int logical = (int)(blockIdx.x & 7) * per_xcd + (int)(blockIdx.x >> 3);
-    if (logical >= nblocks) return;
-    const int slab = logical / tiles_x, bx = logical - slab * tiles_x;
+    const uint32_t logical = order[blockIdx.x];
+    if (logical == 0xffffffffu) return;
+    const int slab = (int)logical / tiles_x, bx = (int)logical - slab * tiles_x;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int gx = bx * 32 + wave * 8 + (lane & 7);
     const int lr = slab * 8 + (lane >> 3);
@@ -89,7 +182,13 @@ __global__ __launch_bounds__(256) void clouds_kernel(TexSet T, const FrameConsts
     const FrameConsts& fc = *fcp;
     Ray ray = ray_setup(fc, valid ? gx : 0, valid ? gy : 0);
     if (!valid) ray.above = false;
-    const MarchOut o = march(T, fc, ray);
+    MarchOut o;
+    if constexpr (VARIANT == 0) {
+        o = march(T, fc, ray);
+    } else {
+        __shared__ float lds[4][10 * 64];
+        o = march_coop(T, fc, ray, &lds[wave][0], &lds[wave][3 * 64]);
+    }
     if (valid) {
         const uint32_t lo = (uint32_t)f2h(o.r) | ((uint32_t)f2h(o.g) << 16), hi = (uint32_t)f2h(o.b) | ((uint32_t)f2h(o.a) << 16);
         out[(size_t)lr * G.pitch_px + gx] = make_uint2(lo, hi);  // imageStore, clouds.glsl:264
@@ -101,18 +200,16 @@ __global__ __launch_bounds__(256) void clouds_kernel(TexSet T, const FrameConsts
     }
 }
 
-static const char* const kVariantNames[] = {"lockstep"};
+static const char* const kVariantNames[] = {"lockstep", "coop"};
 int cloud_variant_count() { return (int)(sizeof(kVariantNames) / sizeof(kVariantNames[0])); }
 const char* cloud_variant_name(int v) { return (v >= 0 && v < cloud_variant_count()) ? kVariantNames[v] : nullptr; }
 
-hipError_t launch_clouds(int variant, const TexSet& t, const FrameConsts* d_fc, const RenderGeom& g, uint2* d_out, unsigned long long* d_stats,
-                         hipStream_t s) {
-    const int tiles_x = (g.tile_w + 31) >> 5, slabs = (g.n_bands * g.band_rows + 7) >> 3;
-    const int nblocks = tiles_x * slabs;
-    if (nblocks <= 0) return hipSuccess;
-    const int grid = ((nblocks + 7) >> 3) << 3;
+hipError_t launch_clouds(int variant, const TexSet& t, const FrameConsts* d_fc, const RenderGeom& g, const uint32_t* d_order, int grid,
+                         uint2* d_out, unsigned long long* d_stats, hipStream_t s) {
+    if (grid <= 0) return hipSuccess;
     switch (variant) {
-        case 0: clouds_kernel<0><<<grid, 256, 0, s>>>(t, d_fc, g, d_out, d_stats); break;
+        case 0: clouds_kernel<0><<<grid, 256, 0, s>>>(t, d_fc, g, d_order, d_out, d_stats); break;
+        case 1: clouds_kernel<1><<<grid, 256, 0, s>>>(t, d_fc, g, d_order, d_out, d_stats); break;
         default: return hipErrorInvalidValue;
     }
     return hipGetLastError();

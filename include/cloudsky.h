@@ -130,9 +130,11 @@ int csky_read_sky_lut(csky_ctx* ctx, uint16_t* out_rgba16f, int* w, int* h);
 int csky_time_clouds(csky_ctx* ctx, const csky_cloud_params* p, int tile_w, const csky_bands* bands, int warmup,
                      int iters, float* mean_ms, csky_cloud_stats* stats);
 int csky_get_cloud_stats(csky_ctx* ctx, csky_cloud_stats* stats); /* tallies of the last stats-enabled launch */
-/* Kernel variant selector for A/B measurement (0 = default).  Unknown ids -> CSKY_ERR_INVALID. */
+/* Kernel variant selector for A/B measurement (default = the fastest measured; csky_variant_name lists them).  Unknown ids -> CSKY_ERR_INVALID. */
 int csky_set_variant(csky_ctx* ctx, int variant);
 int csky_variant_count(void);
+/* Workgroup -> XCD schedule: 0 = azimuth wedges, horizon first (default); 1 = contiguous eighths; 2 = natural order. */
+int csky_set_schedule(csky_ctx* ctx, int mode);
 const char* csky_variant_name(int variant);
 
 /* ---- asset layer (host only; usable without a GPU) ------------------------------------------------

@@ -14,7 +14,8 @@ CONFIGS = {"C2": (512, 256, 64, 4, (0.0, 1.0, 0.0)), "C3": (2048, 1024, 128, 6, 
 ap = argparse.ArgumentParser()
 ap.add_argument("--config", default="C3")
 ap.add_argument("--frames", type=int, default=5)
-ap.add_argument("--variant", type=int, default=0)
+ap.add_argument("--variant", type=int, default=1)
+ap.add_argument("--sched", type=int, default=0)
 ap.add_argument("--early-out", type=float, default=0.0)
 ap.add_argument("--coverage", type=float, default=0.2)
 ap.add_argument("--time", action="store_true", help="print csky_time_clouds mean ms for every variant")
@@ -32,13 +33,16 @@ ctx.render_transmittance(256, 64)
 ctx.render_sky_lut(s, 200, 100, readback=False)
 if a.time:
     L = gvcd_amd.lib()
-    for v in range(L.csky_variant_count()):
-        ctx.set_variant(v)
-        ms, st = ctx.time_clouds(p, W, (8, 0, 1, H // 8), warmup=2, iters=a.frames)
-        print("variant %d %-24s %8.3f ms  %8.1f Mrays/s  incloud %.4f" % (v, L.csky_variant_name(v).decode(), ms, W * H / ms / 1e3,
-                                                                        st["incloud_samples"] / max(1, st["primary_samples"])), flush=True)
+    for sched in (0, 1, 2):
+        ctx.set_schedule(sched)
+        for v in range(L.csky_variant_count()):
+            ctx.set_variant(v)
+            ms, st = ctx.time_clouds(p, W, (8, 0, 1, H // 8), warmup=2, iters=a.frames)
+            print("sched %d variant %d %-12s %8.3f ms  %8.1f Mrays/s  incloud %.4f" % (sched, v, L.csky_variant_name(v).decode(), ms, W * H / ms / 1e3,
+                                                                                    st["incloud_samples"] / max(1, st["primary_samples"])), flush=True)
 else:
     ctx.set_variant(a.variant)
+    ctx.set_schedule(a.sched)
     ms, st = ctx.time_clouds(p, W, (8, 0, 1, H // 8), warmup=1, iters=a.frames)
     print("variant %d: %.3f ms/launch" % (a.variant, ms))
 ctx.close()
