@@ -62,97 +62,128 @@ hipError_t launch_frame_setup(const CloudParams& p, const float4* d_sky, int sw,
     return hipGetLastError();
 }
 
-// ---- wave-cooperative march (variant "coop") ---------------------------------------------------------------
-// The lock-step march above runs the 7-sample light march on all 64 lanes whenever ANY lane of the wave is inside
-// a cloud (measured: lanes are in cloud on 15 % of the steps, waves on ~70 %), so ~4/5 of the light-march VALU
-// work is masked off.  Here the two loops are decoupled:
-//   A. every lane advances its own ray to its NEXT in-cloud sample (or the end of the march);
-//   B. the wave's n pending samples need n*(light_steps+1) independent density evaluations: they are flattened
-//      (e = j*n + k) and dealt out 64 at a time, so every round runs with all lanes busy regardless of which
-//      rays are in cloud.  Sample positions travel through a per-wave LDS slab (no __syncthreads: waves are
-//      independent, LDS ops of one wave complete in order, wavefront-scope fences stop compiler reordering);
-//   C. each owning lane sums its light samples in the reference's order and composites the sample.
-// Per-ray results are the same as the lock-step march up to fp32 summation order (none is changed).
+// ---- wave-cooperative march (variant "queue") --------------------------------------------------------------
+// The lock-step march (cloud_core.h march()) runs the (light_steps+1)-sample light march on all 64 lanes whenever
+// ANY lane of the wavefront is inside a cloud.  Measured on the headline frame: a lane is in cloud on 15 % of its
+// steps, a wavefront on ~70 % of them, so ~4/5 of the light-march VALU work is masked off.  Here the two loops
+// are decoupled through a per-wavefront event queue in LDS:
+//   A. all lanes march their primary samples in lock step (uniform loop, clouds.glsl:172-178); every in-cloud
+//      sample (t > 0, clouds.glsl:184) is appended to the queue (position, t, height fraction) at
+//      slot = running count + mbcnt(ballot);
+//   B. when the queue may overflow (or the march ends) the n queued samples need n*(light_steps+1) independent
+//      density evaluations (clouds.glsl:186-199).  They are flattened as e = j*n + k and dealt out 64 per round,
+//      so every round runs with all lanes busy no matter which rays were in cloud;
+//   C. the queue is replayed step by step: the owning lane sums its light samples in the reference's order and
+//      composites the sample front to back (clouds.glsl:202-210).
+// No __syncthreads: wavefronts are independent; LDS operations of one wavefront complete in issue order and
+// wavefront-scope fences keep the compiler from reordering them.  Per-ray arithmetic and its order are unchanged.
+constexpr int QCAP = 128;                                   // events per wavefront queue
+constexpr int Q_FLOATS = 5 * QCAP + 7 * QCAP + 3 * 128;     // pos(3) t hf | lt[7] | per-step mask lo/hi + base (up to 128 steps per chunk)
+
 __device__ __forceinline__ void wave_lds_fence() {
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
-__device__ __forceinline__ MarchOut march_coop(const TexSet& T, const FrameConsts& fc, Ray ray, float* __restrict__ lds_pos /*[3*64]*/,
-                                               float* __restrict__ lds_lt /*[7*64]*/) {
+__device__ __forceinline__ MarchOut march_queue(const TexSet& T, const FrameConsts& fc, Ray ray, float* __restrict__ q) {
+    float* __restrict__ ev_px = q;
+    float* __restrict__ ev_py = q + QCAP;
+    float* __restrict__ ev_pz = q + 2 * QCAP;
+    float* __restrict__ ev_t = q + 3 * QCAP;
+    float* __restrict__ ev_hf = q + 4 * QCAP;
+    float* __restrict__ ev_lt = q + 5 * QCAP;                               // [7][QCAP]
+    unsigned* __restrict__ st_lo = reinterpret_cast<unsigned*>(q + 12 * QCAP);   // [128]
+    unsigned* __restrict__ st_hi = st_lo + 128;
+    unsigned* __restrict__ st_base = st_hi + 128;
+
     MarchOut o; o.r = o.g = o.b = o.a = 0.0f; o.incloud = 0;
     const int lane = threadIdx.x & 63;
     const int steps = fc.primary_steps, ls = fc.light_steps, nl = ls + 1;
     float phase = 0.0f;
     if (ray.above) {
-        const float ct = fc.ldir[0] * ray.dx + fc.ldir[1] * ray.dy + fc.ldir[2] * ray.dz;
-        phase = fmaxf(fmaxf(henyey_greenstein(ct, 0.6f), henyey_greenstein(ct, fc.hg_g2)), henyey_greenstein(ct, -0.2f));
+        const float ct = fc.ldir[0] * ray.dx + fc.ldir[1] * ray.dy + fc.ldir[2] * ray.dz;                       // clouds.glsl:158
+        phase = fmaxf(fmaxf(henyey_greenstein(ct, 0.6f), henyey_greenstein(ct, fc.hg_g2)), henyey_greenstein(ct, -0.2f));  // :160
     }
     float Tr = 1.0f, alpha = 0.0f, Lr = 0.0f, Lg = 0.0f, Lb = 0.0f;
     float px = ray.px, py = ray.py, pz = ray.pz;
     const float nd = -fc.density;
-    int i = ray.above ? 0 : steps;
-    for (;;) {
-        // ---- A: advance to this lane's next in-cloud sample
+    bool live = ray.above;
+    int count = 0, cs = 0;                                    // queued events / steps-with-events in the current chunk (uniform)
+    if (!__any(live)) return o;
+    for (int i = 0; i < steps; i++) {
+        // ---- A: one primary sample per lane
         float t = 0.0f, hf = 0.0f;
-        bool have = false;
-        while (i < steps) {
-            if (fc.early_eps > 0.0f && Tr < fc.early_eps) { i = steps; break; }   // per-lane early-out (bounded error, off by default)
-            i++;
-            advance(px, py, pz, ray.sx, ray.sy, ray.sz);
+        if (live) {
+            advance(px, py, pz, ray.sx, ray.sy, ray.sz);                                                       // :173
             float wsx, wsy, wr, wb;
             weather_coord(px, pz, fc.wpos_x, fc.wpos_y, wsx, wsy);
-            weather_tap(T.weather, wsx, wsy, wr, wb);
-            hf = height_fraction(length3_exact(px, py, pz));
-            t = density(T, fc, px, py, pz, hf, wr, wb, 0, 0);
-            if (t > 0.0f) { have = true; break; }
+            weather_tap(T.weather, wsx, wsy, wr, wb);                                                          // :174
+            hf = height_fraction(length3_exact(px, py, pz));                                                   // :175
+            t = density(T, fc, px, py, pz, hf, wr, wb, 0, 0);                                                  // :177
         }
+        const bool have = t > 0.0f;                                                                            // :184
         const unsigned long long m = __ballot(have);
-        if (m == 0ull) break;                                   // every ray of the tile has finished
-        const int n = __popcll(m);
-        const int idx = (int)__builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));
-        if (have) { lds_pos[idx] = px; lds_pos[64 + idx] = py; lds_pos[128 + idx] = pz; }
+        if (m != 0ull) {
+            const int slot = count + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));
+            if (have) { ev_px[slot] = px; ev_py[slot] = py; ev_pz[slot] = pz; ev_t[slot] = t; ev_hf[slot] = hf; }
+            if (lane == 0) { st_lo[cs] = (unsigned)m; st_hi[cs] = (unsigned)(m >> 32); st_base[cs] = (unsigned)count; }
+            count += __popcll(m);
+            cs++;
+        }
+        if (count <= QCAP - 64 && i + 1 < steps) continue;
+        if (count == 0) continue;
+        // ---- B: count*(ls+1) light-march evaluations, 64 per round, all lanes busy
         wave_lds_fence();
-        // ---- B: n*(ls+1) light-march evaluations, 64 per round, all lanes busy
-        const int total = n * nl;
-        const float rn = 1.0f / (float)n;
+        const int total = count * nl;
+        const float rn = 1.0f / (float)count;
         for (int e0 = 0; e0 < total; e0 += 64) {
             const int e = e0 + lane;
             if (e < total) {
-                const int j = (int)(((float)e + 0.5f) * rn);    // e = j*n + k, exact for e < 448, n <= 64
-                const int k = e - j * n;
-                float lx = lds_pos[k], ly = lds_pos[64 + k], lz = lds_pos[128 + k];
+                const int j = (int)(((float)e + 0.5f) * rn);          // e = j*count + k (exact: e < 896, count <= 128)
+                const int k = e - j * count;
+                float lx = ev_px[k], ly = ev_py[k], lz = ev_pz[k];
                 const bool distant = (j == ls);
                 if (distant) {
-                    advance(lx, ly, lz, fc.ldist[0], fc.ldist[1], fc.ldist[2]);                     // clouds.glsl:195
+                    advance(lx, ly, lz, fc.ldist[0], fc.ldist[1], fc.ldist[2]);                                // :195
                 } else {
 #pragma unroll
-                    for (int jj = 0; jj < 6; jj++)                                                  // clouds.glsl:187, cumulative in fp32
+                    for (int jj = 0; jj < 6; jj++)                                                             // :187, cumulative in fp32
                         if (jj <= j) advance(lx, ly, lz, fc.linc[jj][0], fc.linc[jj][1], fc.linc[jj][2]);
                 }
-                const float lhf = height_fraction(length3_exact(lx, ly, lz));
+                const float lhf = height_fraction(length3_exact(lx, ly, lz));                                  // :188 / :196
                 float wsx, wsy, lwr, lwb;
-                weather_coord(lx, lz, distant ? 0.0f : fc.wpos_x, distant ? 0.0f : fc.wpos_y, wsx, wsy);   // :197 has no weather_pos
+                weather_coord(lx, lz, distant ? 0.0f : fc.wpos_x, distant ? 0.0f : fc.wpos_y, wsx, wsy);       // :189 / :197 (no weather_pos)
                 weather_tap(T.weather, wsx, wsy, lwr, lwb);
-                const int lod_s = distant ? 3 : (j > 2 ? j - 2 : 0), lod_d = distant ? 5 : j;
-                float d = density(T, fc, lx, ly, lz, lhf, lwr, lwb, lod_s, lod_d);
-                if (distant) d = fast_pow(d, (1.0f - lhf) * 0.8f + 0.5f);                          // :198
-                lds_lt[j * 64 + k] = d;
+                const int lod_s = distant ? 3 : (j > 2 ? j - 2 : 0), lod_d = distant ? 5 : j;                  // textureLod(.., mip-2) / (.., mip)
+                float d = density(T, fc, lx, ly, lz, lhf, lwr, lwb, lod_s, lod_d);                             // :190 / :198
+                if (distant) d = fast_pow(d, (1.0f - lhf) * 0.8f + 0.5f);                                      // :198 second pow
+                ev_lt[j * QCAP + k] = d;
             }
         }
         wave_lds_fence();
-        // ---- C: composite (owner lanes), light samples summed in the reference's order (:191, :199)
-        if (have) {
-            o.incloud++;
-            float cd = 0.0f;
-            for (int j = 0; j < nl; j++) cd += lds_lt[j * 64 + idx];
-            const float dt = fast_exp(nd * t * ray.ss);
-            shade_sample(fc, phase, t, hf, dt, cd, Tr, alpha, Lr, Lg, Lb);
+        // ---- C: replay the chunk in step order; owners composite (:191,:199 sums in the reference's order, :202-210)
+        for (int s = 0; s < cs; s++) {
+            const unsigned lo = st_lo[s], hi = st_hi[s];
+            const bool mine = lane < 32 ? ((lo >> lane) & 1u) : ((hi >> (lane - 32)) & 1u);
+            if (mine) {
+                const int slot = (int)st_base[s] + (int)__builtin_amdgcn_mbcnt_hi(hi, __builtin_amdgcn_mbcnt_lo(lo, 0u));
+                float cd = 0.0f;
+                for (int j = 0; j < nl; j++) cd += ev_lt[j * QCAP + slot];
+                const float et = ev_t[slot], ehf = ev_hf[slot];
+                const float dt = fast_exp(nd * et * ray.ss);                                                   // :178
+                shade_sample(fc, phase, et, ehf, dt, cd, Tr, alpha, Lr, Lg, Lb);
+                o.incloud++;
+            }
         }
         wave_lds_fence();
+        count = 0; cs = 0;
+        if (fc.early_eps > 0.0f) {                                     // build-side early-out (off by default, bounded error)
+            if (Tr < fc.early_eps) live = false;
+            if (!__any(live)) break;
+        }
     }
-    o.r = Lr; o.g = Lg; o.b = Lb; o.a = sat(alpha);
+    o.r = Lr; o.g = Lg; o.b = Lb; o.a = sat(alpha);                                                            // :213-214
     return o;
 }
 
@@ -186,8 +217,8 @@ __global__ __launch_bounds__(256) void clouds_kernel(TexSet T, const FrameConsts
     if constexpr (VARIANT == 0) {
         o = march(T, fc, ray);
     } else {
-        __shared__ float lds[4][10 * 64];
-        o = march_coop(T, fc, ray, &lds[wave][0], &lds[wave][3 * 64]);
+        __shared__ float lds[4][Q_FLOATS];
+        o = march_queue(T, fc, ray, &lds[wave][0]);
     }
     if (valid) {
         const uint32_t lo = (uint32_t)f2h(o.r) | ((uint32_t)f2h(o.g) << 16), hi = (uint32_t)f2h(o.b) | ((uint32_t)f2h(o.a) << 16);
@@ -200,7 +231,7 @@ __global__ __launch_bounds__(256) void clouds_kernel(TexSet T, const FrameConsts
     }
 }
 
-static const char* const kVariantNames[] = {"lockstep", "coop"};
+static const char* const kVariantNames[] = {"lockstep", "queue"};
 int cloud_variant_count() { return (int)(sizeof(kVariantNames) / sizeof(kVariantNames[0])); }
 const char* cloud_variant_name(int v) { return (v >= 0 && v < cloud_variant_count()) ? kVariantNames[v] : nullptr; }
 
