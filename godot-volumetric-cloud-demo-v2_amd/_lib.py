@@ -82,6 +82,12 @@ def lib():
         if not os.path.exists(path):
             raise CloudSkyError(ERR_IO, "%s not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
                                         "(hipcc --offload-arch=gfx950); there is no CPU fallback" % path)
+        try:
+            # torch bundles its own libamdhip64; it must be the FIRST HIP runtime in the process so that libcloudsky's
+            # DT_NEEDED resolves to the same (already loaded) runtime and device pointers / streams can be shared.
+            import torch  # noqa: F401
+        except ImportError:
+            pass
         L = C.CDLL(path)
         for name, res, args in SYMBOLS:
             fn = getattr(L, name)  # AttributeError = ABI mismatch, surfaced loudly

@@ -35,7 +35,7 @@ struct csky_ctx {
     int primary_steps = 128, light_steps = 6;        // clouds.glsl:228, :186
     float early_eps = 0.0f;
     int variant = 1;
-    int sched_mode = 0;
+    int sched_mode = 5;
     // workgroup schedule (physical workgroup -> slab), cached per render geometry
     uint32_t* d_order = nullptr; size_t order_cap = 0; int order_grid = 0;
     std::vector<uint32_t> h_order; long long order_key[10] = {-1, -1, -1, -1, -1, -1, -1, -1, -1, -1};
@@ -98,10 +98,15 @@ int check_bands(csky_ctx* c, const csky_bands* b, int tile_w) {
     return CSKY_OK;
 }
 
-// Workgroup schedule.  A slab = one 32 x 8 pixel workgroup footprint (4 wavefront tiles).  mode 0 (default): XCD x
-// (= physical workgroup id % 8, observed placement, speed only) gets the slabs whose centre lies in the x-th 45-degree
-// azimuth wedge of the hemi-octahedral map (clouds.glsl:248-256), ordered horizon-first (longest marches first, so
-// they do not form the tail).  mode 1: contiguous eighths of the frame per XCD.  mode 2: natural order.
+// Workgroup schedule.  A slab = one 32 x 8 pixel workgroup footprint (4 wavefront tiles); physical workgroup b runs on
+// XCD b % 8 (observed placement, used for speed only).  Modes (measured on the headline frame, queue kernel):
+//   5 (default) slab ROWS dealt round-robin to the XCDs, each XCD walks its rows left to right: every XCD sees the same
+//               mix of elevations (balanced) and concurrently running workgroups are neighbours (shared L1/L2 lines)  3.93 ms
+//   1 contiguous eighths of the frame per XCD (unbalanced: the zenith eighths finish early)                        4.80 ms
+//   2 natural order                                                                                                  4.92 ms
+//   0/3/4 45-degree azimuth wedges per XCD ordered by elevation (horizon first / zenith first / alternating): balanced
+//               but consecutive workgroups are not neighbours                                                   5.3-5.8 ms
+//   6 = 5 with the rows farthest from the zenith row first                                                          4.77 ms
 int build_schedule(csky_ctx* c, const CloudParams& p, const RenderGeom& g, hipStream_t s) {
     const int tiles_x = (g.tile_w + 31) >> 5, local_rows = g.n_bands * g.band_rows, slabs = (local_rows + 7) >> 3;
     const int nblocks = tiles_x * slabs;
@@ -116,6 +121,26 @@ int build_schedule(csky_ctx* c, const CloudParams& p, const RenderGeom& g, hipSt
         const int per = (nblocks + 7) >> 3;
         ord.assign((size_t)per * 8, 0xffffffffu);
         for (int b = 0; b < per * 8; b++) { const int l = (b & 7) * per + (b >> 3); if (l < nblocks) ord[b] = (uint32_t)l; }
+    } else if (c->sched_mode == 5 || c->sched_mode == 6) {
+        // slab rows dealt round-robin to the XCDs (every XCD sees the same mix of elevations); each XCD walks its rows
+        // left to right, so concurrently running workgroups are neighbours.  mode 6 additionally starts with the rows
+        // farthest from the zenith row (longest marches first).
+        std::vector<int> rows(slabs);
+        for (int i = 0; i < slabs; i++) rows[i] = i;
+        if (c->sched_mode == 6) {
+            auto elev = [&](int slab) {
+                const int lr = slab * 8 + 4, band = lr / g.band_rows, rib = lr - band * g.band_rows;
+                const float gy = (float)((g.first_band + band * g.band_stride) * g.band_rows + rib) + p.update_position[1];
+                return std::fabs(gy / p.texture_size[1] - 0.5f);
+            };
+            std::stable_sort(rows.begin(), rows.end(), [&](int a, int b) { return elev(a) > elev(b); });
+        }
+        const int rows_per = (slabs + 7) >> 3;
+        ord.assign((size_t)rows_per * tiles_x * 8, 0xffffffffu);
+        for (int i = 0; i < slabs; i++) {
+            const int x = i & 7, k = i >> 3;
+            for (int bx = 0; bx < tiles_x; bx++) ord[((size_t)k * tiles_x + bx) * 8 + x] = (uint32_t)(rows[i] * tiles_x + bx);
+        }
     } else {
         std::vector<std::pair<float, uint32_t>> wedge[8];
         for (int slab = 0; slab < slabs; slab++) for (int bx = 0; bx < tiles_x; bx++) {
@@ -131,7 +156,16 @@ int build_schedule(csky_ctx* c, const CloudParams& p, const RenderGeom& g, hipSt
         size_t longest = 0;
         for (auto& w : wedge) { std::stable_sort(w.begin(), w.end(), [](const std::pair<float, uint32_t>& a, const std::pair<float, uint32_t>& b) { return a.first < b.first; }); longest = std::max(longest, w.size()); }
         ord.assign(longest * 8, 0xffffffffu);
-        for (int x = 0; x < 8; x++) for (size_t i = 0; i < wedge[x].size(); i++) ord[i * 8 + x] = wedge[x][i].second;
+        for (int x = 0; x < 8; x++) {
+            std::vector<std::pair<float, uint32_t>>& w = wedge[x];
+            const size_t n = w.size();
+            for (size_t i = 0; i < n; i++) {
+                size_t src = i;                                            // mode 0: horizon first
+                if (c->sched_mode == 3) src = n - 1 - i;                   // mode 3: zenith first
+                if (c->sched_mode == 4) src = (i & 1) ? n - 1 - i / 2 : i / 2;   // mode 4: alternate horizon / zenith
+                ord[i * 8 + x] = w[src].second;
+            }
+        }
     }
     if (c->order_cap < ord.size()) {
         if (c->d_order) { HIPCHK(c, hipStreamSynchronize(s)); (void)hipFree(c->d_order); c->d_order = nullptr; }
@@ -259,7 +293,7 @@ int csky_set_variant(csky_ctx* c, int variant) {
 }
 int csky_set_schedule(csky_ctx* c, int mode) {
     if (!c) return fail(nullptr, CSKY_ERR_INVALID, "csky_set_schedule: ctx is NULL");
-    if (mode < 0 || mode > 2) return fail(c, CSKY_ERR_INVALID, "csky_set_schedule: mode must be 0 (azimuth wedges, horizon first), 1 (contiguous eighths) or 2 (natural)");
+    if (mode < 0 || mode > 6) return fail(c, CSKY_ERR_INVALID, "csky_set_schedule: mode must be 0 (azimuth wedges, horizon first), 1 (contiguous eighths), 2 (natural), 3 (wedges, zenith first) or 4 (wedges, alternating)");
     c->sched_mode = mode; return CSKY_OK;
 }
 int csky_variant_count(void) { return cloud_variant_count(); }

@@ -77,8 +77,9 @@ hipError_t launch_frame_setup(const CloudParams& p, const float4* d_sky, int sw,
 //      composites the sample front to back (clouds.glsl:202-210).
 // No __syncthreads: wavefronts are independent; LDS operations of one wavefront complete in issue order and
 // wavefront-scope fences keep the compiler from reordering them.  Per-ray arithmetic and its order are unchanged.
-constexpr int QCAP = 128;                                   // events per wavefront queue
-constexpr int Q_FLOATS = 5 * QCAP + 7 * QCAP + 3 * 128;     // pos(3) t hf | lt[7] | per-step mask lo/hi + base (up to 128 steps per chunk)
+constexpr int QCAP = 96;                                    // events per wavefront queue (a flush is forced above QCAP-64)
+constexpr int QSTEPS = 48;                                  // steps-with-events per chunk (a flush is forced when full)
+constexpr int Q_FLOATS = 5 * QCAP + 7 * QCAP + 3 * QSTEPS;  // pos(3) t hf | lt[7] | per-step mask lo/hi + base  = 5.1 KB per wavefront
 
 __device__ __forceinline__ void wave_lds_fence() {
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -93,9 +94,9 @@ __device__ __forceinline__ MarchOut march_queue(const TexSet& T, const FrameCons
     float* __restrict__ ev_t = q + 3 * QCAP;
     float* __restrict__ ev_hf = q + 4 * QCAP;
     float* __restrict__ ev_lt = q + 5 * QCAP;                               // [7][QCAP]
-    unsigned* __restrict__ st_lo = reinterpret_cast<unsigned*>(q + 12 * QCAP);   // [128]
-    unsigned* __restrict__ st_hi = st_lo + 128;
-    unsigned* __restrict__ st_base = st_hi + 128;
+    unsigned* __restrict__ st_lo = reinterpret_cast<unsigned*>(q + 12 * QCAP);   // [QSTEPS]
+    unsigned* __restrict__ st_hi = st_lo + QSTEPS;
+    unsigned* __restrict__ st_base = st_hi + QSTEPS;
 
     MarchOut o; o.r = o.g = o.b = o.a = 0.0f; o.incloud = 0;
     const int lane = threadIdx.x & 63;
@@ -131,7 +132,7 @@ __device__ __forceinline__ MarchOut march_queue(const TexSet& T, const FrameCons
             count += __popcll(m);
             cs++;
         }
-        if (count <= QCAP - 64 && i + 1 < steps) continue;
+        if (count <= QCAP - 64 && cs < QSTEPS && i + 1 < steps) continue;
         if (count == 0) continue;
         // ---- B: count*(ls+1) light-march evaluations, 64 per round, all lanes busy
         wave_lds_fence();
@@ -140,7 +141,7 @@ __device__ __forceinline__ MarchOut march_queue(const TexSet& T, const FrameCons
         for (int e0 = 0; e0 < total; e0 += 64) {
             const int e = e0 + lane;
             if (e < total) {
-                const int j = (int)(((float)e + 0.5f) * rn);          // e = j*count + k (exact: e < 896, count <= 128)
+                const int j = (int)(((float)e + 0.5f) * rn);          // e = j*count + k (exact: e < 672, count <= 96)
                 const int k = e - j * count;
                 float lx = ev_px[k], ly = ev_py[k], lz = ev_pz[k];
                 const bool distant = (j == ls);

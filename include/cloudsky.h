@@ -133,7 +133,8 @@ int csky_get_cloud_stats(csky_ctx* ctx, csky_cloud_stats* stats); /* tallies of 
 /* Kernel variant selector for A/B measurement (default = the fastest measured; csky_variant_name lists them).  Unknown ids -> CSKY_ERR_INVALID. */
 int csky_set_variant(csky_ctx* ctx, int variant);
 int csky_variant_count(void);
-/* Workgroup -> XCD schedule: 0 = azimuth wedges, horizon first (default); 1 = contiguous eighths; 2 = natural order. */
+/* Workgroup -> XCD schedule (tuning knob, results are identical): 5 = slab rows round-robin over the XCDs (default);
+ * 1 = contiguous eighths; 2 = natural order; 0/3/4 = azimuth wedges; 6 = 5 with horizon rows first. */
 int csky_set_schedule(csky_ctx* ctx, int mode);
 const char* csky_variant_name(int variant);
 

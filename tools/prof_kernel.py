@@ -15,7 +15,7 @@ ap = argparse.ArgumentParser()
 ap.add_argument("--config", default="C3")
 ap.add_argument("--frames", type=int, default=5)
 ap.add_argument("--variant", type=int, default=1)
-ap.add_argument("--sched", type=int, default=0)
+ap.add_argument("--sched", type=int, default=5)
 ap.add_argument("--early-out", type=float, default=0.0)
 ap.add_argument("--coverage", type=float, default=0.2)
 ap.add_argument("--time", action="store_true", help="print csky_time_clouds mean ms for every variant")
@@ -33,7 +33,8 @@ ctx.render_transmittance(256, 64)
 ctx.render_sky_lut(s, 200, 100, readback=False)
 if a.time:
     L = gvcd_amd.lib()
-    for sched in (0, 1, 2):
+    for rep in range(1):
+      for sched in (1, 5, 6):
         ctx.set_schedule(sched)
         for v in range(L.csky_variant_count()):
             ctx.set_variant(v)
