@@ -157,7 +157,7 @@ def main():
         alpha_mean = float(fr[..., 3].float().mean().item())
         finite = bool(torch.isfinite(fr.float()).all().item())
         traffic = None
-        pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+        pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")   # written from the committed rocprofv3 --pmc passes (tools/summarize_prof.py)
         traffic_note = "not collected in this run"
         if os.path.exists(pmc):
             try:
@@ -180,7 +180,7 @@ def main():
                                    "weather.bmp + worlnoise.bmp + generated 128^3 shape noise (seed 1), wind frozen"
                                    % (args.config, W, H, primary, light, sun_n[0], sun_n[1], sun_n[2]),
                        "texture_size": [W, H], "primary_steps": primary, "light_steps": light, "early_out_eps": args.early_out,
-                       "variant": gvcd_amd.lib().csky_variant_name(args.variant or 0).decode(),
+                       "variant": gvcd_amd.lib().csky_variant_name(args.variant if args.variant is not None else 1).decode(),
                        "parallelism": "bands%d" % world, "alpha_mean": alpha_mean, "finite": finite},
             "roofline": {"bound": "hbm", "kernel": "clouds_kernel", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_note": traffic_note,

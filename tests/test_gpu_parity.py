@@ -233,7 +233,8 @@ def test_full_size_c3_properties(gpu_ctx, oracle, otex, o_skies):
     f = img.astype(np.float32)
     assert np.isfinite(f).all() and f.min() >= 0 and f[..., 3].max() <= 1
     assert (f[0] == 0).all() and (f[:, 0] == 0).all()                          # 3 071 horizon pixels are exactly 0
-    assert ((f[..., 3] == 0) == (f[..., :3].sum(-1) == 0)).all()
+    # no radiance without opacity and vice versa (up to fp16 underflow of one of the two: alpha = 1 - T can round to 0)
+    assert f[..., :3].max(-1)[f[..., 3] == 0].max() < 1e-4 and f[..., 3][f[..., :3].sum(-1) == 0].max() < 1e-4
     assert st["rays"] == W * H and st["primary_samples"] == (W - 1) * (H - 1) * 128
     assert 0.3 < f[..., 3].mean() < 0.7
     assert (gpu_ctx.render_clouds(p).view(np.uint16) == img.view(np.uint16)).all()   # idempotent / deterministic

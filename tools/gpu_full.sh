@@ -1,0 +1,7 @@
+#!/bin/bash
+# full GPU validation: parity tests, smoke, bench, kernel-trace + PMC profile of the default kernel
+mkdir -p gpurun_out
+timeout 300 python -m pytest tests -m gpu -q 2>&1 | tail -8 | tee gpurun_out/pytest_gpu.log
+timeout 200 python __graft_entry__.py smoke 2>&1 | tail -3 | tee gpurun_out/smoke.log
+timeout 300 python bench.py 2>gpurun_out/bench_stderr.log | tee gpurun_out/bench.json
+bash tools/profile.sh $1 --config C3 --frames 10
