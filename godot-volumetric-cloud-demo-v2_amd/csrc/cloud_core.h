@@ -41,7 +41,22 @@ struct Ray {
     bool above;           // dir.y > 0 (clouds.glsl:221)
 };
 
-CSKY_HD float length3_exact(float x, float y, float z) { return sqrtf(x * x + y * y + z * z); }
+// Correctly rounded sqrt for NORMAL positive inputs (|p|^2 ~ 3.6e13, ray set-up values): v_sqrt_f32 (1 ulp) plus the
+// residual test of its two neighbours -- the same fix-up LLVM emits for an IEEE sqrtf, minus the denormal pre-scaling
+// that can never trigger here (17 -> 9 VALU).  Bit-identical to the oracle's sqrtf.
+CSKY_HD float sqrt_exact(float x) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    const float s = __builtin_amdgcn_sqrtf(x);
+    const float sd = __uint_as_float(__float_as_uint(s) - 1u), su = __uint_as_float(__float_as_uint(s) + 1u);
+    const float ed = __builtin_fmaf(-sd, s, x), eu = __builtin_fmaf(-su, s, x);
+    float r = (ed <= 0.0f) ? sd : s;
+    r = (eu > 0.0f) ? su : r;
+    return r;
+#else
+    return sqrtf(x);
+#endif
+}
+CSKY_HD float length3_exact(float x, float y, float z) { return sqrt_exact(x * x + y * y + z * z); }
 
 // clouds.glsl:97-105 with pos = camPos = (0, g_radius, 0)
 CSKY_HD float intersect_sphere_cam(float dx, float dy, float dz, float r) {
@@ -167,7 +182,7 @@ CSKY_HD void weather_tap(const uint2* __restrict__ w, float sx, float sy, float&
     const float fx0 = floorf(ux), fy0 = floorf(uy);
     const float ax = ux - fx0, ay = uy - fy0;
     const int x0 = ((int)fx0) & 511, y0 = ((int)fy0) & 511;
-    const uint2 q = w[y0 * 512 + x0];
+    const uint2 q = *reinterpret_cast<const uint2*>(reinterpret_cast<const char*>(w) + ((((uint32_t)y0 << 9) | (uint32_t)x0) << 3));
     wr = lerpf(lerpf(ub(q.x, 0), ub(q.x, 1), ax), lerpf(ub(q.x, 2), ub(q.x, 3), ax), ay) * (1.0f / 255.0f);
     wb = lerpf(lerpf(ub(q.y, 0), ub(q.y, 1), ax), lerpf(ub(q.y, 2), ub(q.y, 3), ax), ay) * (1.0f / 255.0f);
 }
@@ -187,14 +202,17 @@ CSKY_HD void shape_tap(const TexSet& T, int lvl, float sx, float sy, float sz, f
     const float ax = ux - fx0, ay = uy - fy0, az = uz - fz0;
     const int x0 = ((int)fx0) & m, y0 = ((int)fy0) & m, z0 = ((int)fz0) & m;
     const int y1 = (y0 + 1) & m, z1 = (z0 + 1) & m;
-    const uint2* __restrict__ b = T.shape + shape_level_offset(lvl);
-    const uint2 t00 = b[(z0 * n + y0) * n + x0], t10 = b[(z0 * n + y1) * n + x0];
-    const uint2 t01 = b[(z1 * n + y0) * n + x0], t11 = b[(z1 * n + y1) * n + x0];
-    const float r00 = lerpf(ub(t00.x, 0), ub(t00.y, 0), ax), r10 = lerpf(ub(t10.x, 0), ub(t10.y, 0), ax);
-    const float r01 = lerpf(ub(t01.x, 0), ub(t01.y, 0), ax), r11 = lerpf(ub(t11.x, 0), ub(t11.y, 0), ax);
+    const uint32_t un = (uint32_t)n, base = shape_level_offset(lvl) + (uint32_t)x0;       // 32-bit offsets: one VGPR + SGPR base
+    const uint32_t r00 = ((uint32_t)z0 * un + (uint32_t)y0) * un, r10 = ((uint32_t)z0 * un + (uint32_t)y1) * un;
+    const uint32_t r01 = ((uint32_t)z1 * un + (uint32_t)y0) * un, r11 = ((uint32_t)z1 * un + (uint32_t)y1) * un;
+    const char* __restrict__ sb = reinterpret_cast<const char*>(T.shape);
+    const uint2 t00 = *reinterpret_cast<const uint2*>(sb + ((base + r00) << 3)), t10 = *reinterpret_cast<const uint2*>(sb + ((base + r10) << 3));
+    const uint2 t01 = *reinterpret_cast<const uint2*>(sb + ((base + r01) << 3)), t11 = *reinterpret_cast<const uint2*>(sb + ((base + r11) << 3));
+    const float c00 = lerpf(ub(t00.x, 0), ub(t00.y, 0), ax), c10 = lerpf(ub(t10.x, 0), ub(t10.y, 0), ax);
+    const float c01 = lerpf(ub(t01.x, 0), ub(t01.y, 0), ax), c11 = lerpf(ub(t11.x, 0), ub(t11.y, 0), ax);
     const float f00 = lerpf(hi16(t00.x), hi16(t00.y), ax), f10 = lerpf(hi16(t10.x), hi16(t10.y), ax);
     const float f01 = lerpf(hi16(t01.x), hi16(t01.y), ax), f11 = lerpf(hi16(t11.x), hi16(t11.y), ax);
-    r = lerpf(lerpf(r00, r10, ay), lerpf(r01, r11, ay), az) * (1.0f / 255.0f);
+    r = lerpf(lerpf(c00, c10, ay), lerpf(c01, c11, ay), az) * (1.0f / 255.0f);
     fbm = lerpf(lerpf(f00, f10, ay), lerpf(f01, f11, ay), az) * (1.0f / (8.0f * 255.0f));
 }
 
@@ -206,7 +224,8 @@ CSKY_HD float detail_tap(const TexSet& T, int lvl, float sx, float sy, float sz)
     const float fx0 = floorf(ux), fy0 = floorf(uy), fz0 = floorf(uz);
     const float ax = ux - fx0, ay = uy - fy0, az = uz - fz0;
     const int x0 = ((int)fx0) & m, y0 = ((int)fy0) & m, z0 = ((int)fz0) & m;
-    const uint4 q = T.detail[detail_level_offset(lvl) + (z0 * n + y0) * n + x0];
+    const uint32_t un = (uint32_t)n, idx = detail_level_offset(lvl) + ((uint32_t)z0 * un + (uint32_t)y0) * un + (uint32_t)x0;
+    const uint4 q = *reinterpret_cast<const uint4*>(reinterpret_cast<const char*>(T.detail) + (idx << 4));
     const float c00 = lerpf(lo16(q.x), hi16(q.x), ax), c10 = lerpf(lo16(q.y), hi16(q.y), ax);
     const float c01 = lerpf(lo16(q.z), hi16(q.z), ax), c11 = lerpf(lo16(q.w), hi16(q.w), ax);
     return lerpf(lerpf(c00, c10, ay), lerpf(c01, c11, ay), az) * (1.0f / (8.0f * 255.0f));
@@ -218,15 +237,17 @@ CSKY_HD float smoothstep_fast(float e0, float e1, float x) {
     const float t = sat((x - e0) * fast_rcp(e1 - e0));
     return t * t * (3.0f - 2.0f * t);
 }
-// clouds.glsl:82-95
+// clouds.glsl:82-95.  mixGradients() is piecewise linear in the cloud type ct: below 0.5 only stratus (1-2ct) and
+// stratocumulus (2ct) are non-zero, above 0.5 only stratocumulus (2-2ct) and cumulus (2ct-1), so each of the four
+// gradient corners is A + ct*B with (A,B) picked by the branch (8 selects + 4 FMA instead of 3 weights x 4 x 2 FMA).
 CSKY_HD float density_height_gradient(float hf, float ct) {
-    const float stratus = 1.0f - sat(ct * 2.0f);
-    const float stratocu = 1.0f - fabsf(ct - 0.5f) * 2.0f;
-    const float cumulus = sat(ct - 0.5f) * 2.0f;
-    const float gx = 0.02f * stratus + 0.02f * stratocu + 0.01f * cumulus;
-    const float gy = 0.05f * stratus + 0.2f * stratocu + 0.0625f * cumulus;
-    const float gz = 0.09f * stratus + 0.48f * stratocu + 0.78f * cumulus;
-    const float gw = 0.11f * stratus + 0.625f * stratocu + 1.0f * cumulus;
+    const bool hi = ct >= 0.5f;
+    const float c = ct;                                       // ct is a filtered UNORM8 texel: always in [0,1]
+    // ct < 0.5 : STRATUS + ct*2*(STRATOCUMULUS - STRATUS)   ; ct >= 0.5 : (2*STRATOCUMULUS - CUMULUS) + ct*2*(CUMULUS - STRATOCUMULUS)
+    const float gx = (hi ? 0.03f : 0.02f) + c * (hi ? -0.02f : 0.0f);
+    const float gy = (hi ? 0.3375f : 0.05f) + c * (hi ? -0.275f : 0.3f);
+    const float gz = (hi ? 0.18f : 0.09f) + c * (hi ? 0.6f : 0.78f);
+    const float gw = (hi ? 0.25f : 0.11f) + c * (hi ? 0.75f : 1.03f);
     return smoothstep_fast(gx, gy, hf) - smoothstep_fast(gz, gw, hf);
 }
 
