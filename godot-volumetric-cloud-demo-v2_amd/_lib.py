@@ -60,6 +60,7 @@ SYMBOLS = [
     ("csky_set_variant", C.c_int, [C.c_void_p, C.c_int]),
     ("csky_variant_count", C.c_int, []),
     ("csky_set_schedule", C.c_int, [C.c_void_p, C.c_int]),
+    ("csky_set_segments", C.c_int, [C.c_void_p, C.c_int]),
     ("csky_variant_name", C.c_char_p, [C.c_int]),
     ("csky_load_bmp_rgb8", C.c_int, [C.c_char_p, C.POINTER(C.c_int), C.POINTER(C.c_int), C.c_void_p, C.c_size_t]),
     ("csky_strip_to_volume", C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
@@ -151,6 +152,9 @@ class Context:
 
     def set_schedule(self, mode):
         self._chk(self._L.csky_set_schedule(self._h, int(mode)))
+
+    def set_segments(self, n):
+        self._chk(self._L.csky_set_segments(self._h, int(n)))
 
     def set_variant(self, v):
         self._chk(self._L.csky_set_variant(self._h, int(v)))

@@ -36,9 +36,10 @@ struct csky_ctx {
     float early_eps = 0.0f;
     int variant = 1;
     int sched_mode = 5;
+    int segments = 0;                                 // ray segments per ray: 0 = auto, 1, 2, 4
     // workgroup schedule (physical workgroup -> slab), cached per render geometry
     uint32_t* d_order = nullptr; size_t order_cap = 0; int order_grid = 0;
-    std::vector<uint32_t> h_order; long long order_key[10] = {-1, -1, -1, -1, -1, -1, -1, -1, -1, -1};
+    std::vector<uint32_t> h_order; long long order_key[11] = {-1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1};
     csky_cloud_stats last_stats = {0, 0, 0};
     char err[512] = {0};
 };
@@ -107,11 +108,12 @@ int check_bands(csky_ctx* c, const csky_bands* b, int tile_w) {
 //   0/3/4 45-degree azimuth wedges per XCD ordered by elevation (horizon first / zenith first / alternating): balanced
 //               but consecutive workgroups are not neighbours                                                   5.3-5.8 ms
 //   6 = 5 with the rows farthest from the zenith row first                                                          4.77 ms
-int build_schedule(csky_ctx* c, const CloudParams& p, const RenderGeom& g, hipStream_t s) {
-    const int tiles_x = (g.tile_w + 31) >> 5, local_rows = g.n_bands * g.band_rows, slabs = (local_rows + 7) >> 3;
+int build_schedule(csky_ctx* c, const CloudParams& p, const RenderGeom& g, int seg, hipStream_t s) {
+    const int bw = 32 / seg;                          // workgroup footprint = bw x 8 pixels
+    const int tiles_x = (g.tile_w + bw - 1) / bw, local_rows = g.n_bands * g.band_rows, slabs = (local_rows + 7) >> 3;
     const int nblocks = tiles_x * slabs;
-    const long long key[10] = {g.tile_w, g.band_rows, g.first_band, g.band_stride, g.n_bands, (long long)p.texture_size[0], (long long)p.texture_size[1],
-                               (long long)p.update_position[0], (long long)p.update_position[1], c->sched_mode};
+    const long long key[11] = {g.tile_w, g.band_rows, g.first_band, g.band_stride, g.n_bands, (long long)p.texture_size[0], (long long)p.texture_size[1],
+                               (long long)p.update_position[0], (long long)p.update_position[1], c->sched_mode, seg};
     if (c->d_order && memcmp(key, c->order_key, sizeof key) == 0) return CSKY_OK;
     std::vector<uint32_t>& ord = c->h_order;
     if (c->sched_mode == 2) {
@@ -146,7 +148,7 @@ int build_schedule(csky_ctx* c, const CloudParams& p, const RenderGeom& g, hipSt
         for (int slab = 0; slab < slabs; slab++) for (int bx = 0; bx < tiles_x; bx++) {
             const int lr = slab * 8 + 4, band = lr / g.band_rows, rib = lr - band * g.band_rows;
             const float gy = (float)((g.first_band + band * g.band_stride) * g.band_rows + rib) + p.update_position[1];
-            const float gx = (float)(bx * 32 + 16) + p.update_position[0];
+            const float gx = (float)(bx * bw + bw / 2) + p.update_position[0];
             const float u = gx / p.texture_size[0], v = gy / p.texture_size[1];
             const float nx = u - v, ny = (u + v) - 1.0f, nz = 1.0f - std::fabs(nx) - std::fabs(ny);
             int w = (int)std::floor((std::atan2(ny, nx) + 3.14159265f) * (4.0f / 3.14159265f));
@@ -193,8 +195,14 @@ int clouds_dev(csky_ctx* c, const csky_cloud_params* p, int tile_w, const csky_b
     if (setup) HIPCHK(c, launch_frame_setup(cp, c->d_sky_f, c->sw, c->sh, c->primary_steps, c->light_steps, c->early_eps, c->d_fc, s));
     RenderGeom g; g.tile_w = tile_w; g.band_rows = b->band_rows; g.first_band = b->first_band; g.band_stride = b->band_stride; g.n_bands = b->n_bands;
     g.pitch_px = (uint32_t)(pitch_bytes / 8);
-    if ((rc = build_schedule(c, cp, g, s))) return rc;
-    HIPCHK(c, launch_clouds(c->variant, texset(c), c->d_fc, g, c->d_order, c->order_grid, d_out, d_stats, s));
+    // ray segments: more, shorter wavefronts when the launch is too small to fill the chip with whole-ray wavefronts
+    int seg = c->variant == 1 ? c->segments : 1;
+    if (c->variant == 1 && seg == 0) {
+        const long long waves = ((long long)(tile_w + 7) / 8) * (((long long)b->n_bands * b->band_rows + 7) / 8);
+        seg = waves >= 16384 ? 1 : (waves >= 8192 ? 2 : 4);
+    }
+    if ((rc = build_schedule(c, cp, g, seg, s))) return rc;
+    HIPCHK(c, launch_clouds(c->variant, seg, texset(c), c->d_fc, g, c->d_order, c->order_grid, d_out, d_stats, s));
     return CSKY_OK;
 }
 
@@ -295,6 +303,11 @@ int csky_set_schedule(csky_ctx* c, int mode) {
     if (!c) return fail(nullptr, CSKY_ERR_INVALID, "csky_set_schedule: ctx is NULL");
     if (mode < 0 || mode > 6) return fail(c, CSKY_ERR_INVALID, "csky_set_schedule: mode must be 0 (azimuth wedges, horizon first), 1 (contiguous eighths), 2 (natural), 3 (wedges, zenith first) or 4 (wedges, alternating)");
     c->sched_mode = mode; return CSKY_OK;
+}
+int csky_set_segments(csky_ctx* c, int segments) {
+    if (!c) return fail(nullptr, CSKY_ERR_INVALID, "csky_set_segments: ctx is NULL");
+    if (segments != 0 && segments != 1 && segments != 2 && segments != 4) return fail(c, CSKY_ERR_INVALID, "csky_set_segments: 0 (auto), 1, 2 or 4");
+    c->segments = segments; return CSKY_OK;
 }
 int csky_variant_count(void) { return cloud_variant_count(); }
 const char* csky_variant_name(int v) { return cloud_variant_name(v); }

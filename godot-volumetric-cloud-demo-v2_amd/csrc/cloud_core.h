@@ -307,11 +307,11 @@ CSKY_HD void shade_sample(const FrameConsts& fc, float phase, float t, float hf,
     Tr *= dt;                                                                            // :210
 }
 
-struct MarchOut { float r, g, b, a; uint32_t incloud; };
+struct MarchOut { float r, g, b, a, t; uint32_t incloud; };   // L.rgb, alpha, transmittance T, #in-cloud samples
 
 // clouds.glsl:139-215 march() for one ray.
 CSKY_HD MarchOut march(const TexSet& T, const FrameConsts& fc, Ray ray) {
-    MarchOut o; o.r = o.g = o.b = o.a = 0.0f; o.incloud = 0;
+    MarchOut o; o.r = o.g = o.b = o.a = 0.0f; o.t = 1.0f; o.incloud = 0;
     float phase = 0.0f;
     if (ray.above) {
         const float ct = fc.ldir[0] * ray.dx + fc.ldir[1] * ray.dy + fc.ldir[2] * ray.dz;   // :158
@@ -355,7 +355,7 @@ CSKY_HD MarchOut march(const TexSet& T, const FrameConsts& fc, Ray ray) {
             shade_sample(fc, phase, t, hf, dt, cd, Tr, alpha, Lr, Lg, Lb);                       // :202-210
         }
     }
-    o.r = Lr; o.g = Lg; o.b = Lb; o.a = sat(alpha);                                          // :213-214
+    o.r = Lr; o.g = Lg; o.b = Lb; o.a = sat(alpha); o.t = Tr;                                // :213-214
     return o;
 }
 

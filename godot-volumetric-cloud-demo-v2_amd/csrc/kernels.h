@@ -16,8 +16,9 @@ hipError_t launch_frame_setup(const CloudParams& p, const float4* d_sky, int sw,
                               float early_eps, FrameConsts* d_fc, hipStream_t s);
 // clouds.glsl main() over the rows described by `g`.  d_stats (may be null): [0] += in-cloud samples,
 // [1] += rays above the horizon.
-// d_order[grid]: physical workgroup -> slab id (0xffffffff = idle), see api.cpp::build_schedule.
-hipError_t launch_clouds(int variant, const TexSet& t, const FrameConsts* d_fc, const RenderGeom& g, const uint32_t* d_order, int grid,
+// seg = ray segments per ray (1, 2 or 4; variant 1 only): a workgroup covers 4/seg tiles of 8x8 pixels.
+// d_order[grid]: physical workgroup -> workgroup-footprint id (0xffffffff = idle), see api.cpp::build_schedule.
+hipError_t launch_clouds(int variant, int seg, const TexSet& t, const FrameConsts* d_fc, const RenderGeom& g, const uint32_t* d_order, int grid,
                          uint2* d_out, unsigned long long* d_stats, hipStream_t s);
 
 int cloud_variant_count();

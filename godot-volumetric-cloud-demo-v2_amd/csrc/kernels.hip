@@ -87,7 +87,7 @@ __device__ __forceinline__ void wave_lds_fence() {
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
-__device__ __forceinline__ MarchOut march_queue(const TexSet& T, const FrameConsts& fc, Ray ray, float* __restrict__ q) {
+__device__ __forceinline__ MarchOut march_queue(const TexSet& T, const FrameConsts& fc, Ray ray, float* __restrict__ q, int step_begin, int step_end) {
     float* __restrict__ ev_px = q;
     float* __restrict__ ev_py = q + QCAP;
     float* __restrict__ ev_pz = q + 2 * QCAP;
@@ -98,9 +98,9 @@ __device__ __forceinline__ MarchOut march_queue(const TexSet& T, const FrameCons
     unsigned* __restrict__ st_hi = st_lo + QSTEPS;
     unsigned* __restrict__ st_base = st_hi + QSTEPS;
 
-    MarchOut o; o.r = o.g = o.b = o.a = 0.0f; o.incloud = 0;
+    MarchOut o; o.r = o.g = o.b = o.a = 0.0f; o.t = 1.0f; o.incloud = 0;
     const int lane = threadIdx.x & 63;
-    const int steps = fc.primary_steps, ls = fc.light_steps, nl = ls + 1;
+    const int ls = fc.light_steps, nl = ls + 1;
     float phase = 0.0f;
     if (ray.above) {
         const float ct = fc.ldir[0] * ray.dx + fc.ldir[1] * ray.dy + fc.ldir[2] * ray.dz;                       // clouds.glsl:158
@@ -112,7 +112,10 @@ __device__ __forceinline__ MarchOut march_queue(const TexSet& T, const FrameCons
     bool live = ray.above;
     int count = 0, cs = 0;                                    // queued events / steps-with-events in the current chunk (uniform)
     if (!__any(live)) return o;
-    for (int i = 0; i < steps; i++) {
+    // a ray segment starts where the sequential march would be after step_begin steps: replay the fp32 additions
+    // (clouds.glsl:173) so every sample position is bit-identical to the unsegmented march
+    for (int i = 0; i < step_begin; i++) advance(px, py, pz, ray.sx, ray.sy, ray.sz);
+    for (int i = step_begin; i < step_end; i++) {
         // ---- A: one primary sample per lane
         float t = 0.0f, hf = 0.0f;
         if (live) {
@@ -132,7 +135,7 @@ __device__ __forceinline__ MarchOut march_queue(const TexSet& T, const FrameCons
             count += __popcll(m);
             cs++;
         }
-        if (count <= QCAP - 64 && cs < QSTEPS && i + 1 < steps) continue;
+        if (count <= QCAP - 64 && cs < QSTEPS && i + 1 < step_end) continue;
         if (count == 0) continue;
         // ---- B: count*(ls+1) light-march evaluations, 64 per round, all lanes busy
         wave_lds_fence();
@@ -184,28 +187,32 @@ __device__ __forceinline__ MarchOut march_queue(const TexSet& T, const FrameCons
             if (!__any(live)) break;
         }
     }
-    o.r = Lr; o.g = Lg; o.b = Lb; o.a = sat(alpha);                                                            // :213-214
+    o.r = Lr; o.g = Lg; o.b = Lb; o.a = sat(alpha); o.t = Tr;                                                  // :213-214
     return o;
 }
 
-// Pixel <-> lane mapping: a 256-thread workgroup = 4 wavefronts = a 32 x 8 pixel slab; each wavefront owns
-// one 8x8 tile (lane = ly*8 + lx) so its 64 rays are angularly adjacent: their texture footprints overlap
-// (L1/TA coalescing) and they enter/leave cloud together (less divergence).  The reference uses the same
-// 8x8 footprint per workgroup (clouds.glsl:5).
-// Workgroup order: physical workgroup b runs on XCD b % 8 (observed, speed only).  `order` (built on the host,
-// api.cpp::build_schedule) maps b to a slab so that every XCD gets one 45-degree azimuth wedge of the
-// hemisphere -- the same elevation mix (balanced load) and a compact wedge of the noise volumes (its own 4 MiB L2
-// keeps it) -- and walks it horizon-first: horizon slabs are the slowest, so they must not form the tail.
-template <int VARIANT>
+// Pixel <-> lane mapping: a wavefront owns one 8x8-pixel tile (lane = ly*8 + lx), the reference's workgroup footprint
+// (clouds.glsl:5): its 64 rays are angularly adjacent, so their texture footprints overlap (L1/TA coalescing) and
+// they enter/leave cloud together.  A 256-thread workgroup = 4 wavefronts covers 4/SEG tiles side by side:
+//   SEG = 1: 4 tiles (32x8 px), every wavefront marches its rays end to end;
+//   SEG = 2/4: the primary march of each ray is cut into SEG segments marched by SEG wavefronts in parallel and
+//              combined front to back through LDS (L = L0 + T0*L1 + ..., T = prod T_s, 1-alpha = prod (1-alpha_s)):
+//              a wavefront's latency (0.65 ms for 128 steps) is what limits small launches (one GPU's 1/8 frame), and
+//              segments divide it by SEG.  Sample positions stay bit-identical; the compositing sums are re-associated.
+// Workgroup order: physical workgroup b runs on XCD b % 8 (observed, speed only); `order` (api.cpp::build_schedule)
+// maps b to a workgroup footprint.
+template <int VARIANT, int SEG>
 __global__ __launch_bounds__(256) void clouds_kernel(TexSet T, const FrameConsts* __restrict__ fcp, RenderGeom G, const uint32_t* __restrict__ order,
                                                      uint2* __restrict__ out, unsigned long long* __restrict__ stats) {
-    const int tiles_x = (G.tile_w + 31) >> 5;
+    constexpr int BW = 32 / SEG;                               // workgroup footprint width in pixels
+    const int tiles_x = (G.tile_w + BW - 1) / BW;
     const int local_rows = G.n_bands * G.band_rows;
     const uint32_t logical = order[blockIdx.x];
-    if (logical == 0xffffffffu) return;
+    if (logical == 0xffffffffu) return;                        // workgroup-uniform
     const int slab = (int)logical / tiles_x, bx = (int)logical - slab * tiles_x;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const int gx = bx * 32 + wave * 8 + (lane & 7);
+    const int tile = wave / SEG, seg = wave - tile * SEG;
+    const int gx = bx * BW + tile * 8 + (lane & 7);
     const int lr = slab * 8 + (lane >> 3);
     const bool valid = gx < G.tile_w && lr < local_rows;
     const int band = lr / G.band_rows, rib = lr - band * G.band_rows;
@@ -216,17 +223,34 @@ __global__ __launch_bounds__(256) void clouds_kernel(TexSet T, const FrameConsts
     if (!valid) ray.above = false;
     MarchOut o;
     if constexpr (VARIANT == 0) {
+        static_assert(SEG == 1, "the lock-step reference variant marches whole rays");
         o = march(T, fc, ray);
     } else {
         __shared__ float lds[4][Q_FLOATS];
-        o = march_queue(T, fc, ray, &lds[wave][0]);
+        const int s0 = (fc.primary_steps * seg) / SEG, s1 = (fc.primary_steps * (seg + 1)) / SEG;
+        o = march_queue(T, fc, ray, &lds[wave][0], s0, s1);
+        if constexpr (SEG > 1) {
+            __shared__ float comb[4][5][64];
+            comb[wave][0][lane] = o.r; comb[wave][1][lane] = o.g; comb[wave][2][lane] = o.b; comb[wave][3][lane] = o.t; comb[wave][4][lane] = o.a;
+            __syncthreads();
+            if (seg == 0) {
+                float Tr = o.t, na = 1.0f - o.a;
+#pragma unroll
+                for (int s = 1; s < SEG; s++) {
+                    const int w = tile * SEG + s;
+                    o.r += Tr * comb[w][0][lane]; o.g += Tr * comb[w][1][lane]; o.b += Tr * comb[w][2][lane];
+                    Tr *= comb[w][3][lane]; na *= 1.0f - comb[w][4][lane];
+                }
+                o.a = sat(1.0f - na); o.t = Tr;
+            }
+        }
     }
-    if (valid) {
+    if (valid && seg == 0) {
         const uint32_t lo = (uint32_t)f2h(o.r) | ((uint32_t)f2h(o.g) << 16), hi = (uint32_t)f2h(o.b) | ((uint32_t)f2h(o.a) << 16);
         out[(size_t)lr * G.pitch_px + gx] = make_uint2(lo, hi);  // imageStore, clouds.glsl:264
     }
     if (stats) {
-        unsigned ic = o.incloud, ab = ray.above ? 1u : 0u;
+        unsigned ic = o.incloud, ab = (ray.above && seg == 0) ? 1u : 0u;
         for (int off = 32; off > 0; off >>= 1) { ic += __shfl_down(ic, off); ab += __shfl_down(ab, off); }
         if (lane == 0) { atomicAdd(&stats[0], (unsigned long long)ic); atomicAdd(&stats[1], (unsigned long long)ab); }
     }
@@ -236,14 +260,14 @@ static const char* const kVariantNames[] = {"lockstep", "queue"};
 int cloud_variant_count() { return (int)(sizeof(kVariantNames) / sizeof(kVariantNames[0])); }
 const char* cloud_variant_name(int v) { return (v >= 0 && v < cloud_variant_count()) ? kVariantNames[v] : nullptr; }
 
-hipError_t launch_clouds(int variant, const TexSet& t, const FrameConsts* d_fc, const RenderGeom& g, const uint32_t* d_order, int grid,
+hipError_t launch_clouds(int variant, int seg, const TexSet& t, const FrameConsts* d_fc, const RenderGeom& g, const uint32_t* d_order, int grid,
                          uint2* d_out, unsigned long long* d_stats, hipStream_t s) {
     if (grid <= 0) return hipSuccess;
-    switch (variant) {
-        case 0: clouds_kernel<0><<<grid, 256, 0, s>>>(t, d_fc, g, d_order, d_out, d_stats); break;
-        case 1: clouds_kernel<1><<<grid, 256, 0, s>>>(t, d_fc, g, d_order, d_out, d_stats); break;
-        default: return hipErrorInvalidValue;
-    }
+    if (variant == 0 && seg == 1) clouds_kernel<0, 1><<<grid, 256, 0, s>>>(t, d_fc, g, d_order, d_out, d_stats);
+    else if (variant == 1 && seg == 1) clouds_kernel<1, 1><<<grid, 256, 0, s>>>(t, d_fc, g, d_order, d_out, d_stats);
+    else if (variant == 1 && seg == 2) clouds_kernel<1, 2><<<grid, 256, 0, s>>>(t, d_fc, g, d_order, d_out, d_stats);
+    else if (variant == 1 && seg == 4) clouds_kernel<1, 4><<<grid, 256, 0, s>>>(t, d_fc, g, d_order, d_out, d_stats);
+    else return hipErrorInvalidValue;
     return hipGetLastError();
 }
 

@@ -136,6 +136,10 @@ int csky_variant_count(void);
 /* Workgroup -> XCD schedule (tuning knob, results are identical): 5 = slab rows round-robin over the XCDs (default);
  * 1 = contiguous eighths; 2 = natural order; 0/3/4 = azimuth wedges; 6 = 5 with horizon rows first. */
 int csky_set_schedule(csky_ctx* ctx, int mode);
+/* Ray segments: the primary march of every ray is cut into `segments` pieces marched by different wavefronts of one
+ * workgroup and composited front to back (T and L are associative).  0 = auto (1 for large launches, 2/4 when the
+ * launch has too few rays to fill the chip, e.g. one GPU's share of a frame split 8 ways), 1, 2 or 4. */
+int csky_set_segments(csky_ctx* ctx, int segments);
 const char* csky_variant_name(int variant);
 
 /* ---- asset layer (host only; usable without a GPU) ------------------------------------------------

@@ -85,6 +85,16 @@ def test_variants_and_schedules_agree(gpu_ctx, oracle):
     assert ok, info
     assert imgs[0][1] == imgs[1][1]
     gpu_ctx.set_variant(1); gpu_ctx.set_schedule(5)
+    # ray segments (1, 2, 4 wavefronts per ray): identical sample positions and in-cloud counts, re-associated compositing
+    for seg in (1, 2, 4):
+        gpu_ctx.set_segments(seg)
+        for sch in (5, 2):
+            gpu_ctx.set_schedule(sch)
+            img = gpu_ctx.render_clouds(p)
+            ok, info = cloud_close(img, imgs[1][0], frac=0.9999, atol=5e-4, rtol=2e-3)
+            assert ok, (seg, info)
+            assert gpu_ctx.cloud_stats() == imgs[1][1], seg
+    gpu_ctx.set_segments(0); gpu_ctx.set_schedule(5)
 
 
 def test_clouds_vs_numpy_fixture(gpu_ctx, oracle):
@@ -107,6 +117,21 @@ def test_config_c2_512x256_64x4_zenith(gpu_ctx, oracle, otex, o_skies):
     ok, info = cloud_close(img, ref)
     assert ok, info
     gpu_ctx.set_march(128, 6)
+
+
+@pytest.mark.parametrize("seg", [2, 4])
+def test_segments_vs_oracle_ragged(gpu_ctx, oracle, otex, o_skies, seg):
+    """Segmented march on a ragged tile (45 x 21, 64 and 100 primary steps: not divisible by the segment count)."""
+    gpu_ctx.set_segments(seg)
+    gpu_ctx.render_sky_lut(norm((1, 1, 0)), 200, 100)
+    for steps in (64, 100):
+        gpu_ctx.set_march(steps, 6)
+        p = oracle.default_params(90, 42, (1, 1, 0))
+        img = gpu_ctx.render_clouds(p, 45, 21)
+        ref = oracle.clouds(otex, p, o_skies["deg45"], rect=(0, 0, 45, 21), primary_steps=steps)
+        ok, info = cloud_close(img, ref)
+        assert ok, (steps, info)
+    gpu_ctx.set_march(128, 6); gpu_ctx.set_segments(0)
 
 
 def test_windy_offset_tile(gpu_ctx, oracle, otex):

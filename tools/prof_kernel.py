@@ -33,14 +33,13 @@ ctx.render_transmittance(256, 64)
 ctx.render_sky_lut(s, 200, 100, readback=False)
 if a.time:
     L = gvcd_amd.lib()
-    for rep in range(1):
-      for sched in (1, 5, 6):
-        ctx.set_schedule(sched)
-        for v in range(L.csky_variant_count()):
-            ctx.set_variant(v)
-            ms, st = ctx.time_clouds(p, W, (8, 0, 1, H // 8), warmup=2, iters=a.frames)
-            print("sched %d variant %d %-12s %8.3f ms  %8.1f Mrays/s  incloud %.4f" % (sched, v, L.csky_variant_name(v).decode(), ms, W * H / ms / 1e3,
-                                                                                    st["incloud_samples"] / max(1, st["primary_samples"])), flush=True)
+    ctx.set_schedule(a.sched)
+    for nb, label in ((1, "full frame"), (8, "1/8 frame (rank 0 of 8)")):
+        bands = (8, 0, nb, H // 8 // nb)
+        for v, seg in ((0, 1), (1, 1), (1, 2), (1, 4), (1, 0)):
+            ctx.set_variant(v); ctx.set_segments(seg)
+            ms, st = ctx.time_clouds(p, W, bands, warmup=2, iters=a.frames)
+            print("%-26s variant %d %-9s seg %d %8.3f ms  %8.1f Mrays/s" % (label, v, L.csky_variant_name(v).decode(), seg, ms, W * H / nb / ms / 1e3), flush=True)
 else:
     ctx.set_variant(a.variant)
     ctx.set_schedule(a.sched)
