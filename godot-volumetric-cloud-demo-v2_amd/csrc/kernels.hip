@@ -148,12 +148,18 @@ __device__ __forceinline__ MarchOut march_queue(const TexSet& T, const FrameCons
                 const int k = e - j * count;
                 float lx = ev_px[k], ly = ev_py[k], lz = ev_pz[k];
                 const bool distant = (j == ls);
+                // cone sample j: lp = p + sum_{i<=j} (ldir + RANDOM_VECTORS[i]*i)*lss, added one by one in fp32 like :187.
+                // e grows with the lane, so j is non-decreasing across the wavefront: the additions up to the first lane's j
+                // are wave-uniform (plain adds under a scalar branch), only the few beyond it need per-lane predication.
+                const int j_lo = __builtin_amdgcn_readfirstlane(j);
                 if (distant) {
                     advance(lx, ly, lz, fc.ldist[0], fc.ldist[1], fc.ldist[2]);                                // :195
                 } else {
 #pragma unroll
-                    for (int jj = 0; jj < 6; jj++)                                                             // :187, cumulative in fp32
-                        if (jj <= j) advance(lx, ly, lz, fc.linc[jj][0], fc.linc[jj][1], fc.linc[jj][2]);
+                    for (int jj = 0; jj < 6; jj++) {
+                        if (jj <= j_lo) advance(lx, ly, lz, fc.linc[jj][0], fc.linc[jj][1], fc.linc[jj][2]);
+                        else if (jj <= j) advance(lx, ly, lz, fc.linc[jj][0], fc.linc[jj][1], fc.linc[jj][2]);
+                    }
                 }
                 const float lhf = height_fraction(length3_exact(lx, ly, lz));                                  // :188 / :196
                 float wsx, wsy, lwr, lwb;

@@ -33,13 +33,12 @@ ctx.render_transmittance(256, 64)
 ctx.render_sky_lut(s, 200, 100, readback=False)
 if a.time:
     L = gvcd_amd.lib()
-    ctx.set_schedule(a.sched)
-    for nb, label in ((1, "full frame"), (8, "1/8 frame (rank 0 of 8)")):
-        bands = (8, 0, nb, H // 8 // nb)
-        for v, seg in ((0, 1), (1, 1), (1, 2), (1, 4), (1, 0)):
-            ctx.set_variant(v); ctx.set_segments(seg)
+    for v in (0, 1):
+        ctx.set_variant(v)
+        for nb in (1, 8):
+            bands = (8, 0, nb, H // 8 // nb)
             ms, st = ctx.time_clouds(p, W, bands, warmup=2, iters=a.frames)
-            print("%-26s variant %d %-9s seg %d %8.3f ms  %8.1f Mrays/s" % (label, v, L.csky_variant_name(v).decode(), seg, ms, W * H / nb / ms / 1e3), flush=True)
+            print("variant %d %-9s 1/%d frame: %.3f ms  %.1f Mrays/s" % (v, L.csky_variant_name(v).decode(), nb, ms, W * H / nb / ms / 1e3), flush=True)
 else:
     ctx.set_variant(a.variant)
     ctx.set_schedule(a.sched)

@@ -23,6 +23,14 @@ __global__ __launch_bounds__(256) void k(float* out, int iters, float seed) {
         if constexpr (KIND == 7) { REP8(asm volatile("v_mul_f32 %0, %0, %4\n v_mul_f32 %1, %1, %4\n v_mul_f32 %2, %2, %4\n v_mul_f32 %3, %3, %4\n v_add_f32 %0, %0, %4\n v_add_f32 %1, %1, %4\n v_add_f32 %2, %2, %4\n v_add_f32 %3, %3, %4" : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3) : "v"(a4));) }
         if constexpr (KIND == 8) { REP8(asm volatile("v_mad_u64_u32 %0, vcc, %2, %3, %0\n v_mad_u64_u32 %1, vcc, %2, %3, %1\n v_mad_u64_u32 %0, vcc, %2, %3, %0\n v_mad_u64_u32 %1, vcc, %2, %3, %1\n v_mad_u64_u32 %0, vcc, %2, %3, %0\n v_mad_u64_u32 %1, vcc, %2, %3, %1\n v_mad_u64_u32 %0, vcc, %2, %3, %0\n v_mad_u64_u32 %1, vcc, %2, %3, %1" : "+v"(*(unsigned long long*)&a0), "+v"(*(unsigned long long*)&a2) : "v"(u0), "v"(u1) : "vcc");) }
         if constexpr (KIND == 9) { REP8(asm volatile("v_exp_f32 %0, %0\n v_log_f32 %1, %1\n v_sqrt_f32 %2, %2\n v_exp_f32 %3, %3\n v_log_f32 %0, %0\n v_sqrt_f32 %1, %1\n v_exp_f32 %2, %2\n v_log_f32 %3, %3" : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3));) }
+        if constexpr (KIND == 11) { REP8(asm volatile("v_cndmask_b32_e64 %0, %0, %4, s[20:21]\n v_cndmask_b32_e64 %1, %1, %4, s[20:21]\n v_cndmask_b32_e64 %2, %2, %4, s[20:21]\n v_cndmask_b32_e64 %3, %3, %4, s[20:21]\n v_cndmask_b32_e64 %0, %0, %4, s[20:21]\n v_cndmask_b32_e64 %1, %1, %4, s[20:21]\n v_cndmask_b32_e64 %2, %2, %4, s[20:21]\n v_cndmask_b32_e64 %3, %3, %4, s[20:21]" : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3) : "v"(a4) : "s20", "s21");) }
+        if constexpr (KIND == 12) { REP8(asm volatile("v_cmp_gt_f32 vcc, %0, %4\n v_cndmask_b32 %1, %1, %4, vcc\n v_cmp_gt_f32 vcc, %2, %4\n v_cndmask_b32 %3, %3, %4, vcc\n v_cmp_gt_f32 vcc, %0, %4\n v_cndmask_b32 %1, %1, %4, vcc\n v_cmp_gt_f32 vcc, %2, %4\n v_cndmask_b32 %3, %3, %4, vcc" : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3) : "v"(a4) : "vcc");) }
+        if constexpr (KIND == 13) { REP8(asm volatile("v_cndmask_b32 %0, %4, %5, vcc\n v_cndmask_b32 %1, %4, %5, vcc\n v_cndmask_b32 %2, %4, %5, vcc\n v_cndmask_b32 %3, %4, %5, vcc\n v_cndmask_b32 %0, %4, %5, vcc\n v_cndmask_b32 %1, %4, %5, vcc\n v_cndmask_b32 %2, %4, %5, vcc\n v_cndmask_b32 %3, %4, %5, vcc" : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3) : "v"(a4), "v"(a5) : );) }
+        if constexpr (KIND == 14) { REP8(asm volatile("v_pk_add_f32 %0, %0, %2\n v_pk_mul_f32 %1, %1, %2\n v_pk_add_f32 %0, %0, %2\n v_pk_mul_f32 %1, %1, %2\n v_pk_add_f32 %0, %0, %2\n v_pk_mul_f32 %1, %1, %2\n v_pk_add_f32 %0, %0, %2\n v_pk_mul_f32 %1, %1, %2" : "+v"(*(double*)&a0), "+v"(*(double*)&a2) : "v"(*(double*)&a4));) }
+        if constexpr (KIND == 15) { REP8(asm volatile("v_fmac_f32 %0, %4, %5\n v_fmac_f32 %1, %4, %5\n v_fmac_f32 %2, %4, %5\n v_fmac_f32 %3, %4, %5\n v_fmac_f32 %0, %4, %5\n v_fmac_f32 %1, %4, %5\n v_fmac_f32 %2, %4, %5\n v_fmac_f32 %3, %4, %5" : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3) : "v"(a4), "v"(a5));) }
+        if constexpr (KIND == 16) { REP8(asm volatile("v_mul_f32 %0, %0, %4 clamp\n v_floor_f32 %1, %1\n v_sub_f32 %2, %2, %4\n v_mul_f32 %3, %3, %4 clamp\n v_floor_f32 %0, %0\n v_sub_f32 %1, %1, %4\n v_mul_f32 %2, %2, %4 clamp\n v_floor_f32 %3, %3" : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3) : "v"(a4));) }
+        if constexpr (KIND == 17) { REP8(asm volatile("v_cmp_gt_f32 vcc, %0, %4\n v_cndmask_b32 %1, %1, %4, vcc\n v_cndmask_b32 %2, %2, %4, vcc\n v_cndmask_b32 %3, %3, %4, vcc\n v_cndmask_b32 %1, %1, %5, vcc\n v_cndmask_b32 %2, %2, %5, vcc\n v_cndmask_b32 %3, %3, %5, vcc\n v_cndmask_b32 %1, %1, %4, vcc" : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3) : "v"(a4), "v"(a5) : "vcc");) }
+        if constexpr (KIND == 18) { REP8(asm volatile("v_cmp_gt_f32 s[20:21], %0, %4\n v_cndmask_b32_e64 %1, %1, %4, s[20:21]\n v_cndmask_b32_e64 %2, %2, %4, s[20:21]\n v_cndmask_b32_e64 %3, %3, %4, s[20:21]\n v_cndmask_b32_e64 %1, %1, %5, s[20:21]\n v_cndmask_b32_e64 %2, %2, %5, s[20:21]\n v_cndmask_b32_e64 %3, %3, %5, s[20:21]\n v_cndmask_b32_e64 %1, %1, %4, s[20:21]" : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3) : "v"(a4), "v"(a5) : "s20", "s21");) }
         if constexpr (KIND == 10) { REP8(asm volatile("v_floor_f32 %0, %0\n v_cvt_i32_f32 %1, %1\n v_cvt_f32_i32 %2, %2\n v_floor_f32 %3, %3\n v_and_b32 %0, %0, %4\n v_lshlrev_b32 %1, 3, %1\n v_max_f32 %2, %2, %4\n v_min_f32 %3, %3, %4" : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3) : "v"(a4));) }
     }
     if (a0 + a1 + a2 + a3 + a4 + a5 + a6 + a7 + (float)(u0 + u1 + u2 + u3) == 12345.678f) out[threadIdx.x] = a0;
@@ -48,6 +56,9 @@ int main() {
     float* d; CHK(hipMalloc(&d, 4096));
     run<0>("v_fma_f32", d, 64); run<7>("v_mul/add_f32", d, 64); run<3>("v_pk_fma_f32", d, 64); run<1>("v_add_u32", d, 64);
     run<2>("v_cvt_f32_ubyteN", d, 64); run<5>("v_cndmask_b32", d, 64); run<6>("v_sub_u32_sdwa", d, 64); run<10>("floor/cvt/and/shl/min/max", d, 64);
+    run<11>("v_cndmask_b32_e64 sgpr mask", d, 64); run<12>("v_cmp + v_cndmask vcc", d, 64); run<13>("v_cndmask vcc (no dep)", d, 64);
+    run<17>("v_cmp vcc + 7 v_cndmask vcc", d, 64); run<18>("v_cmp sgpr + 7 v_cndmask e64", d, 64);
+    run<14>("v_pk_add/mul_f32", d, 64); run<15>("v_fmac_f32", d, 64); run<16>("mul clamp/floor/sub", d, 64);
     run<4>("v_rcp_f32", d, 64); run<9>("v_exp/log/sqrt_f32", d, 64); run<8>("v_mad_u64_u32", d, 64);
     return 0;
 }
