@@ -208,7 +208,7 @@ __device__ __forceinline__ MarchOut march_queue(const TexSet& T, const FrameCons
 // Workgroup order: physical workgroup b runs on XCD b % 8 (observed, speed only); `order` (api.cpp::build_schedule)
 // maps b to a workgroup footprint.
 template <int VARIANT, int SEG>
-__global__ __launch_bounds__(256) void clouds_kernel(TexSet T, const FrameConsts* __restrict__ fcp, RenderGeom G, const uint32_t* __restrict__ order,
+__global__ __launch_bounds__(256, 7) void clouds_kernel(TexSet T, const FrameConsts* __restrict__ fcp, RenderGeom G, const uint32_t* __restrict__ order,
                                                      uint2* __restrict__ out, unsigned long long* __restrict__ stats) {
     constexpr int BW = 32 / SEG;                               // workgroup footprint width in pixels
     const int tiles_x = (G.tile_w + BW - 1) / BW;
