@@ -33,6 +33,11 @@ class Bands(C.Structure):
     _fields_ = [("band_rows", C.c_int), ("first_band", C.c_int), ("band_stride", C.c_int), ("n_bands", C.c_int)]
 
 
+class CompositeParams(C.Structure):
+    _fields_ = [("out_w", C.c_int), ("out_h", C.c_int), ("cloud_w", C.c_int), ("cloud_h", C.c_int), ("sky_w", C.c_int), ("sky_h", C.c_int),
+                ("blend_amount", C.c_float), ("sun_disk_scale", C.c_float), ("light_direction", C.c_float * 3)]
+
+
 class CloudStats(C.Structure):
     _fields_ = [("rays", C.c_uint64), ("primary_samples", C.c_uint64), ("incloud_samples", C.c_uint64)]
 
@@ -55,6 +60,7 @@ SYMBOLS = [
     ("csky_sync", C.c_int, [C.c_void_p]),
     ("csky_read_transmittance", C.c_int, [C.c_void_p, C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     ("csky_read_sky_lut", C.c_int, [C.c_void_p, C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
+    ("csky_composite_sky", C.c_int, [C.c_void_p, C.POINTER(CompositeParams), C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     ("csky_time_clouds", C.c_int, [C.c_void_p, C.POINTER(CloudParams), C.c_int, C.POINTER(Bands), C.c_int, C.c_int, C.POINTER(C.c_float), C.POINTER(CloudStats)]),
     ("csky_get_cloud_stats", C.c_int, [C.c_void_p, C.POINTER(CloudStats)]),
     ("csky_set_variant", C.c_int, [C.c_void_p, C.c_int]),
@@ -211,6 +217,16 @@ class Context:
         self._chk(self._L.csky_read_sky_lut(self._h, None, C.byref(w), C.byref(h)))
         out = np.zeros((h.value, w.value, 4), np.uint16)
         self._chk(self._L.csky_read_sky_lut(self._h, _ptr(out), C.byref(w), C.byref(h)))
+        return out.view(np.float16)
+
+    def composite_sky(self, cloud_from, cloud_to, sky_from, sky_to, light_dir, blend_amount=0.0, sun_disk_scale=2.0, out_w=2048, out_h=1024):
+        """clouds.gdshader sky() on an equirectangular panorama; inputs float16 [h, w, 4] host arrays."""
+        a = [np.ascontiguousarray(x).view(np.uint16) for x in (cloud_from, cloud_to, sky_from, sky_to)]
+        p = CompositeParams(out_w, out_h, a[0].shape[1], a[0].shape[0], a[2].shape[1], a[2].shape[0], float(blend_amount), float(sun_disk_scale))
+        for k in range(3):
+            p.light_direction[k] = float(light_dir[k])
+        out = np.zeros((out_h, out_w, 4), np.uint16)
+        self._chk(self._L.csky_composite_sky(self._h, C.byref(p), _ptr(a[0]), _ptr(a[1]), _ptr(a[2]), _ptr(a[3]), _ptr(out)))
         return out.view(np.float16)
 
     # ---- measurement

@@ -221,6 +221,18 @@ class CloudSky:
         self.cleanup()
         self.ctx.close()
 
+    def sky_panorama(self, out_w=2048, out_h=1024):
+        """What clouds_material.tres + clouds.gdshader draw: the two blend textures cross-faded by blend_amount over the
+        atmosphere with the sun disk, evaluated on an equirectangular panorama (csky_composite_sky).  float16 [h, w, 4]."""
+        def host(t):
+            return t.cpu().numpy() if hasattr(t, "cpu") else t
+        bf, bt = host(self.textures[self.texture_to_blend_from]), host(self.textures[self.texture_to_blend_to])
+        sky = self.sky_lut.image
+        back = self.sky_lut.back_texture
+        sf = back[0] if back[0] is not None else sky          # sky_blend_from/to_texture (cloud_sky.gd:147-148)
+        st = back[1] if back[1] is not None else sky
+        return self.ctx.composite_sky(bf, bt, sf, st, self.frame_data.LIGHT_DIRECTION, self.blend_amount, self.sun_disk_scale, out_w, out_h)
+
     # ---- render thread ------------------------------------------------------------------------------------
     def _stream(self):
         if not self.device_buffers:

@@ -420,6 +420,35 @@ int csky_time_clouds(csky_ctx* c, const csky_cloud_params* p, int tile_w, const 
     return CSKY_OK;
 }
 
+int csky_composite_sky(csky_ctx* c, const csky_composite_params* p, const uint16_t* cloud_from, const uint16_t* cloud_to, const uint16_t* sky_from,
+                       const uint16_t* sky_to, uint16_t* out) {
+    if (!c) return fail(nullptr, CSKY_ERR_INVALID, "csky_composite_sky: ctx is NULL");
+    if (!p || !cloud_from || !cloud_to || !sky_from || !sky_to || !out) return fail(c, CSKY_ERR_INVALID, "csky_composite_sky: NULL argument");
+    if (p->out_w < 1 || p->out_h < 1 || p->cloud_w < 1 || p->cloud_h < 1 || p->sky_w < 1 || p->sky_h < 1 || p->out_w > 16384 || p->out_h > 16384)
+        return fail(c, CSKY_ERR_INVALID, "csky_composite_sky: bad image size");
+    int rc; if ((rc = bind(c))) return rc;
+    if (!c->have_trans && (rc = render_trans_dev(c, 256, 64, c->stream))) return rc;       // source_transmittance, clouds_material.tres
+    const size_t cb = (size_t)p->cloud_w * p->cloud_h * 8, sb = (size_t)p->sky_w * p->sky_h * 8, ob = (size_t)p->out_w * p->out_h * 8;
+    uint8_t* d = nullptr;
+    HIPCHK(c, hipMalloc(reinterpret_cast<void**>(&d), 2 * cb + 2 * sb + ob));
+    hipError_t e = hipSuccess;
+    auto up = [&](size_t off, const void* src, size_t n) { if (e == hipSuccess) e = hipMemcpyAsync(d + off, src, n, hipMemcpyHostToDevice, c->stream); };
+    up(0, cloud_from, cb); up(cb, cloud_to, cb); up(2 * cb, sky_from, sb); up(2 * cb + sb, sky_to, sb);
+    CompositeArgs a;
+    a.cloud_from = reinterpret_cast<const uint16_t*>(d); a.cloud_to = reinterpret_cast<const uint16_t*>(d + cb); a.cw = p->cloud_w; a.ch = p->cloud_h;
+    a.sky_from = reinterpret_cast<const uint16_t*>(d + 2 * cb); a.sky_to = reinterpret_cast<const uint16_t*>(d + 2 * cb + sb); a.sw = p->sky_w; a.sh = p->sky_h;
+    a.trans = c->d_trans_f; a.tw = c->tw; a.th = c->th;
+    a.blend_amount = p->blend_amount; a.sun_disk_scale = p->sun_disk_scale;
+    a.sun[0] = p->light_direction[0]; a.sun[1] = p->light_direction[1]; a.sun[2] = p->light_direction[2];
+    a.out_w = p->out_w; a.out_h = p->out_h;
+    if (e == hipSuccess) e = launch_composite(a, reinterpret_cast<uint2*>(d + 2 * cb + 2 * sb), c->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(out, d + 2 * cb + 2 * sb, ob, hipMemcpyDeviceToHost, c->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+    (void)hipFree(d);
+    if (e != hipSuccess) return fail(c, CSKY_ERR_HIP, "csky_composite_sky: %s", hipGetErrorString(e));
+    return CSKY_OK;
+}
+
 int csky_get_cloud_stats(csky_ctx* c, csky_cloud_stats* stats) {
     if (!c || !stats) return fail(c, CSKY_ERR_INVALID, "csky_get_cloud_stats: NULL argument");
     *stats = c->last_stats; return CSKY_OK;

@@ -2,6 +2,7 @@
 #pragma once
 #include <hip/hip_runtime_api.h>
 #include "csky_common.h"
+#include "composite_core.h"
 
 namespace csky {
 
@@ -20,6 +21,9 @@ hipError_t launch_frame_setup(const CloudParams& p, const float4* d_sky, int sw,
 // d_order[grid]: physical workgroup -> workgroup-footprint id (0xffffffff = idle), see api.cpp::build_schedule.
 hipError_t launch_clouds(int variant, int seg, const TexSet& t, const FrameConsts* d_fc, const RenderGeom& g, const uint32_t* d_order, int grid,
                          uint2* d_out, unsigned long long* d_stats, hipStream_t s);
+
+// clouds.gdshader sky() on an equirectangular panorama (all pointers in `a` are device pointers)
+hipError_t launch_composite(const CompositeArgs& a, uint2* d_out, hipStream_t s);
 
 int cloud_variant_count();
 const char* cloud_variant_name(int v);

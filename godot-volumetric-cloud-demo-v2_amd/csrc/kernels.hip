@@ -10,6 +10,7 @@
 #include "kernels.h"
 #include "cloud_core.h"
 #include "lut_core.h"
+#include "composite_core.h"
 
 namespace csky {
 
@@ -44,6 +45,19 @@ hipError_t launch_sky_lut(int w, int h, const float sun[3], const float4* d_tran
                           hipStream_t s) {
     Sun3 sv; sv.v[0] = sun[0]; sv.v[1] = sun[1]; sv.v[2] = sun[2];
     sky_lut_kernel<<<dim3((w + 7) / 8, (h + 7) / 8), 64, 0, s>>>(w, h, sv, d_trans, tw, th, d_half, d_float);
+    return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------------ compositor
+// clouds.gdshader sky() on an equirectangular panorama, one pixel per lane
+__global__ __launch_bounds__(256) void composite_kernel(CompositeArgs A, uint2* __restrict__ out) {
+    const int i = blockIdx.x * 32 + (threadIdx.x & 31), j = blockIdx.y * 8 + (threadIdx.x >> 5);
+    if (i >= A.out_w || j >= A.out_h) return;
+    const C3 c = composite_pixel(A, i, j);
+    out[(size_t)j * A.out_w + i] = make_uint2((uint32_t)f2h(c.x) | ((uint32_t)f2h(c.y) << 16), (uint32_t)f2h(c.z) | ((uint32_t)f2h(1.0f) << 16));
+}
+hipError_t launch_composite(const CompositeArgs& a, uint2* d_out, hipStream_t s) {
+    composite_kernel<<<dim3((a.out_w + 31) / 32, (a.out_h + 7) / 8), 256, 0, s>>>(a, d_out);
     return hipGetLastError();
 }
 

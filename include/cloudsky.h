@@ -123,6 +123,23 @@ int csky_sync(csky_ctx* ctx); /* wait for the context's own stream */
 int csky_read_transmittance(csky_ctx* ctx, uint16_t* out_rgba16f, int* w, int* h);
 int csky_read_sky_lut(csky_ctx* ctx, uint16_t* out_rgba16f, int* w, int* h);
 
+/* ---- sky compositor ("next" row: the consumer of the path) -----------------------------------------
+ * clouds.gdshader:105-116 `sky()` with its helpers (:15-103): samples the two cloud textures through the inverse
+ * hemi-octahedral map, cross-fades them by blend_amount, adds the atmosphere (two sky LUTs / 50) and the sun disk +
+ * bloom attenuated by the transmittance LUT, fades to the atmosphere at the horizon.  Godot evaluates it per screen
+ * pixel (EYEDIR); this entry point evaluates it for an equirectangular panorama (u -> azimuth, v -> elevation, y up).
+ * cloud_from/to = blend_from_texture/blend_to_texture, sky_from/to = sky_blend_from/to_texture (clouds_material.tres),
+ * all RGBA16F host buffers; source_transmittance is the context's LUT.  light_direction = LIGHT0_DIRECTION. */
+typedef struct {
+    int out_w, out_h;
+    int cloud_w, cloud_h, sky_w, sky_h;
+    float blend_amount;       /* clouds.gdshader:12, cloud_sky.gd:152 */
+    float sun_disk_scale;     /* clouds.gdshader:13, clouds_sky.tres: 2.0 */
+    float light_direction[3];
+} csky_composite_params;
+int csky_composite_sky(csky_ctx* ctx, const csky_composite_params* p, const uint16_t* cloud_from, const uint16_t* cloud_to,
+                       const uint16_t* sky_from, const uint16_t* sky_to, uint16_t* out_rgba16f);
+
 /* ---- measurement ---------------------------------------------------------------------------------
  * Times `iters` back-to-back launches of the cloud kernel alone with HIP events on the context's stream
  * (after `warmup` untimed launches) and returns the mean per-launch milliseconds.  Also fills the

@@ -617,6 +617,115 @@ void csko_clouds_bands(const csko_textures *tex, const float params[28], int pri
     }
 }
 
+/* ==================================================================================== clouds.gdshader (G:line)
+ * "Next" row 1: the raster sky() pass that composites the cloud texture over the atmosphere.  EYEDIR is
+ * supplied by Godot per screen pixel; this restatement evaluates sky() for the pixels of an equirectangular panorama:
+ * u = (i+0.5)/W -> azimuth (2u-1)*pi, v = (j+0.5)/H -> elevation (0.5-v)*pi, EYEDIR = (cos e cos a, sin e, cos e sin a)
+ * (build-side mapping, y up like Godot).  G_PI is the Godot shading language's built-in PI (full precision). */
+#define G_PI 3.14159265358979323846f
+static v4 tap16_clamp(const uint16_t *t, int w, int h, float sx, float sy) { return sample_rgba16f_clamp(t, w, h, sx, sy); }
+
+/* G:22-32 vec3_to_oct */
+static void vec3_to_oct(v3 e, float *ox, float *oy) {
+    float d = fabsf(e.x) + fabsf(e.y) + fabsf(e.z);
+    e = divs3(e, d);
+    if (!(e.z >= 0.0f)) { float a, b; oct_wrap(e.x, e.y, &a, &b); e.x = a; e.y = b; }
+    float ny = e.y * 0.5f + 0.5f;
+    float nx = e.x * 0.5f + ny;
+    ny = e.x * -0.5f + ny;
+    *ox = nx; *oy = ny;
+}
+typedef struct { const uint16_t *cf, *ct; int cw, ch; const uint16_t *sf, *st; int sw, sh; const uint16_t *tr; int tw, th;
+                 float blend, sun_disk_scale; v3 sun; } comp_ctx;
+/* G:34-45 */
+static v3 g_getValFromSkyLUT(const comp_ctx *c, v3 rayDir) {
+    float phi = atan2f(rayDir.z, rayDir.x);
+    float theta = asinf(rayDir.y);
+    float ux = (phi / G_PI * 0.5f + 0.5f);
+    float uy = sqrtf(fabsf(theta) / (G_PI * 0.5f)) * signf(theta) * 0.5f + 0.5f;
+    v4 a = tap16_clamp(c->sf, c->sw, c->sh, ux, uy), b = tap16_clamp(c->st, c->sw, c->sh, ux, uy);
+    v3 m = mix3(V3(a.x, a.y, a.z), V3(b.x, b.y, b.z), c->blend);
+    return divs3(m, 50.0f);
+}
+/* G:48-59 */
+static v3 sunWithBloom(const comp_ctx *c, v3 rayDir, v3 sunDir) {
+    float sunSolidAngle = c->sun_disk_scale * 0.53f * G_PI / 180.0f;
+    float minSunCosTheta = cosf(sunSolidAngle);
+    float cosTheta = dot3(rayDir, sunDir);
+    if (cosTheta >= minSunCosTheta) return V3(1.0f, 1.0f, 1.0f);
+    float offset = minSunCosTheta - cosTheta;
+    float gaussianBloom = expf(-offset * 50000.0f) * 0.5f;
+    float invBloom = 1.0f / (0.02f + offset * 300.0f) * 0.01f;
+    float s = gaussianBloom + invBloom;
+    return V3(s, s, s);
+}
+/* G:61-70 */
+static float rayIntersectSphere(v3 ro, v3 rd, float rad) {
+    float b = dot3(ro, rd);
+    float c = dot3(ro, ro) - rad * rad;
+    if (c > 0.0f && b > 0.0f) return -1.0f;
+    float discr = b * b - c;
+    if (discr < 0.0f) return -1.0f;
+    if (discr > b * b) return (-b + sqrtf(discr));
+    return -b - sqrtf(discr);
+}
+#define groundRadiusMM 6.360f        /* G:72 */
+#define atmosphereRadiusMM 6.460f    /* G:73 */
+/* G:77-85 (tLUTRes == bufferRes, G:75,101) */
+static v3 getValFromTLUT(const comp_ctx *c, v3 pos, v3 sunDir) {
+    float height = length3(pos);
+    v3 up = divs3(pos, height);
+    float sunCosZenithAngle = dot3(up, sunDir);
+    float ux = 256.0f * clampf(0.5f + 0.5f * sunCosZenithAngle, 0.0f, 1.0f);
+    float uy = 64.0f * fmaxf(0.0f, fminf(1.0f, (height - groundRadiusMM) / (atmosphereRadiusMM - groundRadiusMM)));
+    ux /= 256.0f; uy /= 64.0f;
+    v4 t = tap16_clamp(c->tr, c->tw, c->th, ux, uy);
+    return V3(t.x, t.y, t.z);
+}
+static float smoothstep1(float e0, float e1, float x) { return smoothstepf(e0, e1, x); }
+/* G:87-103 */
+static v3 get_atmo(const comp_ctx *c, v3 dir) {
+    v3 col = g_getValFromSkyLUT(c, dir);
+    v3 sunLum = sunWithBloom(c, dir, c->sun);
+    sunLum = V3(smoothstep1(0.002f, 1.0f, sunLum.x), smoothstep1(0.002f, 1.0f, sunLum.y), smoothstep1(0.002f, 1.0f, sunLum.z));
+    const v3 viewPos = V3(0.0f, groundRadiusMM + 0.0002f, 0.0f);                /* G:74 */
+    if (length3(sunLum) > 0.0f) {
+        if (rayIntersectSphere(viewPos, dir, groundRadiusMM) >= 0.0f) sunLum = muls3(sunLum, 0.0f);
+        else sunLum = mul3(sunLum, getValFromTLUT(c, viewPos, c->sun));
+    }
+    return add3(col, sunLum);
+}
+/* G:105-116 sky() for one EYEDIR */
+static v3 sky_composite(const comp_ctx *c, v3 EYEDIR) {
+    v3 norm = EYEDIR;
+    norm.y = fmaxf(0.0f, norm.y);
+    norm = normalize3(norm);
+    float ox, oy;
+    vec3_to_oct(V3(norm.x, norm.z, norm.y), &ox, &oy);                           /* G:110 norm.xz = vec3_to_oct(norm.xzy) */
+    v4 bf = tap16_clamp(c->cf, c->cw, c->ch, ox, oy), bt = tap16_clamp(c->ct, c->cw, c->ch, ox, oy);
+    v4 clouds = V4(mixf(bf.x, bt.x, c->blend), mixf(bf.y, bt.y, c->blend), mixf(bf.z, bt.z, c->blend), mixf(bf.w, bt.w, c->blend));
+    v3 background = get_atmo(c, EYEDIR);
+    v3 COLOR = add3(muls3(background, 1.0f - clouds.w), V3(clouds.x, clouds.y, clouds.z));
+    float k = smoothstep1(0.6f, 1.0f, 1.0f - EYEDIR.y);
+    v3 a = V3(clampf(COLOR.x, 0.0f, 100.0f), clampf(COLOR.y, 0.0f, 100.0f), clampf(COLOR.z, 0.0f, 100.0f));
+    v3 b = V3(clampf(background.x, 0.0f, 100.0f), clampf(background.y, 0.0f, 100.0f), clampf(background.z, 0.0f, 100.0f));
+    return mix3(a, b, k);
+}
+void csko_composite(int out_w, int out_h, const uint16_t *cloud_from, const uint16_t *cloud_to, int cw, int ch, const uint16_t *sky_from,
+                    const uint16_t *sky_to, int sw, int sh, const uint16_t *trans, int tw, int th, float blend_amount,
+                    float sun_disk_scale, const float light_dir[3], uint16_t *out_rgba16f) {
+    comp_ctx c = {cloud_from, cloud_to, cw, ch, sky_from, sky_to, sw, sh, trans, tw, th, blend_amount, sun_disk_scale,
+                  V3(light_dir[0], light_dir[1], light_dir[2])};
+    for (int j = 0; j < out_h; j++) for (int i = 0; i < out_w; i++) {
+        float u = ((float)i + 0.5f) / (float)out_w, v = ((float)j + 0.5f) / (float)out_h;
+        float az = (u * 2.0f - 1.0f) * G_PI, el = (0.5f - v) * G_PI;
+        v3 eye = V3(cosf(el) * cosf(az), sinf(el), cosf(el) * sinf(az));
+        v3 col = sky_composite(&c, eye);
+        uint16_t *o = out_rgba16f + ((size_t)j * out_w + i) * 4;
+        o[0] = csko_f2h(col.x); o[1] = csko_f2h(col.y); o[2] = csko_f2h(col.z); o[3] = csko_f2h(1.0f);
+    }
+}
+
 /* ------------------------------------------------------------------ probes for structural tests */
 float csko_hash_probe(float px, float py, float pz) { return hash3(muls3(V3(px, py, pz), 10.0f)); }
 void csko_pixel_dir(const float params[28], int px, int py, float dir[3]) {

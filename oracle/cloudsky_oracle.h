@@ -73,6 +73,12 @@ void csko_clouds_bands(const csko_textures *tex, const float params[28], int pri
                        const uint16_t *sky_lut, int sw, int sh, int tile_w, int band_rows, int first_band, int band_stride,
                        int n_bands, uint16_t *out_rgba16f, int nthreads, csko_stats *stats);
 
+/* clouds.gdshader:105-116 sky() evaluated on an equirectangular panorama (build-side EYEDIR mapping, see the .c file).
+ * cloud_from/to: RGBA16F cloud textures (cw x ch); sky_from/to: RGBA16F sky LUTs; trans: transmittance LUT. */
+void csko_composite(int out_w, int out_h, const uint16_t *cloud_from, const uint16_t *cloud_to, int cw, int ch, const uint16_t *sky_from,
+                    const uint16_t *sky_to, int sw, int sh, const uint16_t *trans, int tw, int th, float blend_amount,
+                    float sun_disk_scale, const float light_dir[3], uint16_t *out_rgba16f);
+
 /* probes used by the structural tests */
 float csko_hash_probe(float px, float py, float pz);                     /* clouds.glsl:60-64 on pos*10 */
 void csko_pixel_dir(const float params[28], int px, int py, float dir[3]); /* clouds.glsl:260-262        */

@@ -53,6 +53,8 @@ def lib():
                                   C.POINTER(Stats)]
         L.csko_clouds_bands.argtypes = [C.POINTER(Textures), C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int,
                                         C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int, C.POINTER(Stats)]
+        L.csko_composite.argtypes = [C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_int,
+                                     C.c_void_p, C.c_int, C.c_int, C.c_float, C.c_float, C.c_void_p, C.c_void_p]
         L.csko_hash_probe.restype = C.c_float
         L.csko_hash_probe.argtypes = [C.c_float] * 3
         L.csko_pixel_dir.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p]
@@ -133,6 +135,16 @@ def clouds_bands(tex, params, sky, tile_w, bands, primary_steps=128, light_steps
                             stride, n, _ptr(out), nthreads, C.byref(st))
     return out.view(np.float16), dict(rays=st.rays, rays_marched=st.rays_marched, primary_samples=st.primary_samples,
                                       incloud_samples=st.incloud_samples)
+
+
+def composite(cloud_from, cloud_to, sky_from, sky_to, trans, light_dir, blend_amount=0.0, sun_disk_scale=2.0, out_w=256, out_h=128):
+    """clouds.gdshader sky() on an equirectangular panorama; all inputs float16 [h, w, 4]; returns float16 [out_h, out_w, 4]."""
+    a = [np.ascontiguousarray(x).view(np.uint16) for x in (cloud_from, cloud_to, sky_from, sky_to, trans)]
+    ld = np.asarray(light_dir, np.float32)
+    out = np.zeros((out_h, out_w, 4), np.uint16)
+    lib().csko_composite(out_w, out_h, _ptr(a[0]), _ptr(a[1]), a[0].shape[1], a[0].shape[0], _ptr(a[2]), _ptr(a[3]), a[2].shape[1],
+                         a[2].shape[0], _ptr(a[4]), a[4].shape[1], a[4].shape[0], blend_amount, sun_disk_scale, _ptr(ld), _ptr(out))
+    return out.view(np.float16)
 
 
 def default_params(w, h, sun, coverage=0.2, density=0.05):

@@ -8,6 +8,7 @@
 #include "../../godot-volumetric-cloud-demo-v2_amd/csrc/cloud_core.h"
 #include "../../godot-volumetric-cloud-demo-v2_amd/csrc/lut_core.h"
 #include "../../godot-volumetric-cloud-demo-v2_amd/csrc/bake.h"
+#include "../../godot-volumetric-cloud-demo-v2_amd/csrc/composite_core.h"
 
 using namespace csky;
 
@@ -64,6 +65,19 @@ void hostsim_clouds(const uint8_t* large_chain, const uint8_t* small_chain, cons
         }
     }
     if (incloud) *incloud = ic;
+}
+
+void hostsim_composite(int out_w, int out_h, const uint16_t* cf, const uint16_t* ct, int cw, int ch, const uint16_t* sf, const uint16_t* st, int sw, int sh,
+                       const uint16_t* trans_h, int tw, int th, float blend, float sun_disk_scale, const float sun[3], uint16_t* out_h_) {
+    std::vector<float4> tf = widen(trans_h, tw, th);
+    CompositeArgs A;
+    A.cloud_from = cf; A.cloud_to = ct; A.cw = cw; A.ch = ch; A.sky_from = sf; A.sky_to = st; A.sw = sw; A.sh = sh; A.trans = tf.data(); A.tw = tw; A.th = th;
+    A.blend_amount = blend; A.sun_disk_scale = sun_disk_scale; A.sun[0] = sun[0]; A.sun[1] = sun[1]; A.sun[2] = sun[2]; A.out_w = out_w; A.out_h = out_h;
+    for (int j = 0; j < out_h; j++) for (int i = 0; i < out_w; i++) {
+        C3 c = composite_pixel(A, i, j);
+        uint16_t* o = out_h_ + ((size_t)j * out_w + i) * 4;
+        o[0] = f2h(c.x); o[1] = f2h(c.y); o[2] = f2h(c.z); o[3] = f2h(1.0f);
+    }
 }
 
 size_t csky_mip_offset(int n, int level, int ch) {  // same definition as assets.cpp (this tool does not link libcloudsky)

@@ -1,0 +1,77 @@
+"""Sky compositor (clouds.gdshader): oracle structure, host-compiled kernel core vs oracle (CPU), and
+the HIP kernel through the C ABI vs the oracle (-m gpu)."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from conftest import norm, ulp_diff
+
+
+def P(a):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+@pytest.fixture(scope="module")
+def scene(oracle, otex, o_trans):
+    sun = norm((-0.6, 0.35, 0.3))
+    sk = oracle.sky_lut(sun, o_trans)
+    sk2 = oracle.sky_lut(norm((-0.6, 0.30, 0.3)), o_trans)
+    cl = oracle.clouds(otex, oracle.default_params(128, 64, sun), sk)
+    cl2 = oracle.clouds(otex, oracle.default_params(128, 64, sun, coverage=0.3), sk)
+    return dict(sun=sun, sky=sk, sky2=sk2, cl=cl, cl2=cl2, tr=o_trans)
+
+
+def test_oracle_compositor_structure(oracle, scene):
+    s = scene
+    img = oracle.composite(s["cl"], s["cl2"], s["sky"], s["sky2"], s["tr"], s["sun"], 0.25, 2.0, 128, 64).astype(np.float32)
+    assert np.isfinite(img).all() and (img[..., 3] == 1).all() and img[..., :3].min() >= 0 and img[..., :3].max() <= 100
+    # below the horizon (EYEDIR.y <= 0) the fade factor is 1: the pixel is the atmosphere alone, clouds do not matter
+    empty = np.zeros_like(s["cl"])
+    a = oracle.composite(s["cl"], s["cl"], s["sky"], s["sky"], s["tr"], s["sun"], 0.0, 2.0, 128, 64)
+    b = oracle.composite(empty, empty, s["sky"], s["sky"], s["tr"], s["sun"], 0.0, 2.0, 128, 64)
+    assert (a.view(np.uint16)[32:] == b.view(np.uint16)[32:]).all()
+    assert (a.view(np.uint16)[:20] != b.view(np.uint16)[:20]).any()          # ... and they do above it
+    # blend_amount 0 / 1 select the from / to textures (G:113, G:43)
+    f = oracle.composite(s["cl"], s["cl2"], s["sky"], s["sky2"], s["tr"], s["sun"], 0.0, 2.0, 64, 32)
+    t = oracle.composite(s["cl2"], s["cl"], s["sky2"], s["sky"], s["tr"], s["sun"], 1.0, 2.0, 64, 32)
+    assert (f.view(np.uint16) == t.view(np.uint16)).all()
+    # clear sky: the sun disk pixel is atmosphere + 1 * transmittance.rgb towards the sun (G:51, G:99)
+    big = oracle.composite(empty, empty, s["sky"], s["sky"], s["tr"], s["sun"], 0.0, 2.0, 1024, 512).astype(np.float32)
+    sun = s["sun"].astype(np.float64)
+    az, el = np.arctan2(sun[2], sun[0]), np.arcsin(sun[1])
+    i, j = int((az / np.pi + 1) / 2 * 1024), int((0.5 - el / np.pi) * 512)
+    disk, near = big[j, i, :3], big[j, i + 40, :3]
+    assert (disk > near + 0.3).all()
+
+
+def test_compositor_core_matches_oracle(hostsim, oracle, scene):
+    s = scene
+    ref = oracle.composite(s["cl"], s["cl2"], s["sky"], s["sky2"], s["tr"], s["sun"], 0.25, 2.0, 192, 96)
+    out = np.zeros((96, 192, 4), np.uint16)
+    u = lambda a: np.ascontiguousarray(a).view(np.uint16)
+    hostsim.hostsim_composite(192, 96, P(u(s["cl"])), P(u(s["cl2"])), 128, 64, P(u(s["sky"])), P(u(s["sky2"])), 200, 100, P(u(s["tr"])), 256, 64,
+                              C.c_float(0.25), C.c_float(2.0), P(s["sun"]), P(out))
+    d = ulp_diff(out.view(np.float16), ref)
+    assert d.max() <= 1 and (d > 0).mean() < 0.01
+
+
+@pytest.mark.gpu
+def test_compositor_gpu_vs_oracle(gpu_ctx, oracle, scene):
+    s = scene
+    gpu_ctx.render_transmittance(256, 64)
+    for blend, w, h in ((0.25, 192, 96), (0.90625, 333, 111)):           # clouds_material.tres blend_amount; ragged size
+        ref = oracle.composite(s["cl"], s["cl2"], s["sky"], s["sky2"], s["tr"], s["sun"], blend, 2.0, w, h)
+        img = gpu_ctx.composite_sky(s["cl"], s["cl2"], s["sky"], s["sky2"], s["sun"], blend, 2.0, w, h)
+        d = ulp_diff(img, ref)
+        assert d.max() <= 2 and (d > 0).mean() < 0.02, (d.max(), (d > 0).mean())
+
+
+@pytest.mark.gpu
+def test_host_class_panorama(pkg, noise):
+    sky = pkg.CloudSky.from_default_resource(device_id=0, texture_size=(128, 64), noise=noise, clock=lambda: 0.0)
+    sky.sun = pkg.cloud_sky.DirectionalLight(direction=(-0.6, 0.35, 0.3))
+    sky.update_sky()
+    pano = sky.sky_panorama(256, 128).astype(np.float32)
+    assert pano.shape == (128, 256, 4) and np.isfinite(pano).all() and pano[..., :3].max() > 0.05
+    sky.close()
