@@ -71,6 +71,7 @@ SYMBOLS = [
     ("csky_load_bmp_rgb8", C.c_int, [C.c_char_p, C.POINTER(C.c_int), C.POINTER(C.c_int), C.c_void_p, C.c_size_t]),
     ("csky_strip_to_volume", C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
     ("csky_generate_shape_noise", C.c_int, [C.c_uint32, C.c_int, C.c_void_p]),
+    ("csky_generate_shape_noise_device", C.c_int, [C.c_void_p, C.c_uint32, C.c_int, C.c_void_p]),
     ("csky_mip_offset", C.c_size_t, [C.c_int, C.c_int, C.c_int]),
     ("csky_build_mips", C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int]),
     ("csky_assets_last_error", C.c_char_p, []),
@@ -228,6 +229,12 @@ class Context:
         out = np.zeros((out_h, out_w, 4), np.uint16)
         self._chk(self._L.csky_composite_sky(self._h, C.byref(p), _ptr(a[0]), _ptr(a[1]), _ptr(a[2]), _ptr(a[3]), _ptr(out)))
         return out.view(np.float16)
+
+    def generate_shape_noise(self, seed=1, n=128):
+        """GPU bake of the stand-in shape volume: uint8 [n, n, n, 4], byte-identical to assets.generate_shape_noise."""
+        vol = np.zeros((n, n, n, 4), np.uint8)
+        self._chk(self._L.csky_generate_shape_noise_device(self._h, seed, n, _ptr(vol)))
+        return vol
 
     # ---- measurement
     def time_clouds(self, params, tile_w, bands, warmup=2, iters=10):

@@ -449,6 +449,21 @@ int csky_composite_sky(csky_ctx* c, const csky_composite_params* p, const uint16
     return CSKY_OK;
 }
 
+int csky_generate_shape_noise_device(csky_ctx* c, uint32_t seed, int n, uint8_t* out_rgba8) {
+    if (!c) return fail(nullptr, CSKY_ERR_INVALID, "csky_generate_shape_noise_device: ctx is NULL");
+    if (!out_rgba8 || n < 8 || n > 512 || (n & (n - 1))) return fail(c, CSKY_ERR_INVALID, "csky_generate_shape_noise_device: n must be a power of two in [8, 512]");
+    int rc; if ((rc = bind(c))) return rc;
+    const size_t bytes = (size_t)n * n * n * 4;
+    uint32_t* d = nullptr;
+    HIPCHK(c, hipMalloc(reinterpret_cast<void**>(&d), bytes));
+    hipError_t e = launch_shape_noise(seed, n, d, c->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(out_rgba8, d, bytes, hipMemcpyDeviceToHost, c->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+    (void)hipFree(d);
+    if (e != hipSuccess) return fail(c, CSKY_ERR_HIP, "csky_generate_shape_noise_device: %s", hipGetErrorString(e));
+    return CSKY_OK;
+}
+
 int csky_get_cloud_stats(csky_ctx* c, csky_cloud_stats* stats) {
     if (!c || !stats) return fail(c, CSKY_ERR_INVALID, "csky_get_cloud_stats: NULL argument");
     *stats = c->last_stats; return CSKY_OK;

@@ -25,6 +25,9 @@ hipError_t launch_clouds(int variant, int seg, const TexSet& t, const FrameConst
 // clouds.gdshader sky() on an equirectangular panorama (all pointers in `a` are device pointers)
 hipError_t launch_composite(const CompositeArgs& a, uint2* d_out, hipStream_t s);
 
+// stand-in shape noise bake: n^3 RGBA8 voxels (little-endian u32 = r | g<<8 | b<<16 | a<<24)
+hipError_t launch_shape_noise(uint32_t seed, int n, uint32_t* d_out, hipStream_t s);
+
 int cloud_variant_count();
 const char* cloud_variant_name(int v);
 

@@ -11,6 +11,7 @@
 #include "cloud_core.h"
 #include "lut_core.h"
 #include "composite_core.h"
+#include "noise_core.h"
 
 namespace csky {
 
@@ -45,6 +46,22 @@ hipError_t launch_sky_lut(int w, int h, const float sun[3], const float4* d_tran
                           hipStream_t s) {
     Sun3 sv; sv.v[0] = sun[0]; sv.v[1] = sun[1]; sv.v[2] = sun[2];
     sky_lut_kernel<<<dim3((w + 7) / 8, (h + 7) / 8), 64, 0, s>>>(w, h, sv, d_trans, tw, th, d_half, d_float);
+    return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------------ shape-noise bake
+// The stand-in 128^3 RGBA shape volume, one voxel per lane (bit-identical to the host generator: noise_core.h).
+__global__ __launch_bounds__(256) void shape_noise_kernel(uint32_t seed, int n, uint32_t* __restrict__ out) {
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= (size_t)n * n * n) return;
+    const int x = (int)(i % n), y = (int)((i / n) % n), z = (int)(i / ((size_t)n * n));
+    uint8_t o[4];
+    shape_voxel(seed, n, x, y, z, o);
+    out[i] = (uint32_t)o[0] | ((uint32_t)o[1] << 8) | ((uint32_t)o[2] << 16) | ((uint32_t)o[3] << 24);
+}
+hipError_t launch_shape_noise(uint32_t seed, int n, uint32_t* d_out, hipStream_t s) {
+    const size_t total = (size_t)n * n * n;
+    shape_noise_kernel<<<(unsigned)((total + 255) / 256), 256, 0, s>>>(seed, n, d_out);
     return hipGetLastError();
 }
 

@@ -1,0 +1,92 @@
+// noise_core.h -- the deterministic stand-in generator for the missing cloud_sky/perlworlnoise.tga (128^3 RGBA shape
+// noise, perlworlnoise.tga.import:24-27), host+device.  Used by assets.cpp (csky_generate_shape_noise, threads) and by
+// kernels.hip (shape_noise_kernel; SURVEY §8f row 2 and README.md:30 TODO 3 "generate the noise on the GPU").
+#pragma once
+#include "csky_common.h"
+
+namespace csky {
+#pragma clang fp contract(off)
+
+CSKY_HD uint32_t hash_u32(uint32_t x) {  // lowbias32 finaliser
+    x ^= x >> 16; x *= 0x7feb352dU; x ^= x >> 15; x *= 0x846ca68bU; x ^= x >> 16; return x;
+}
+CSKY_HD uint32_t hash_cell(int x, int y, int z, uint32_t salt) {
+    return hash_u32((uint32_t)x * 0x8da6b343U ^ hash_u32((uint32_t)y * 0xd8163841U ^ hash_u32((uint32_t)z * 0xcb1ab31fU ^ salt)));
+}
+CSKY_HD float u01(uint32_t h) { return (float)(h >> 8) * (1.0f / 16777216.0f); }  // exact: 24-bit / 2^24
+CSKY_HD int nwrap(int i, int n) { int m = i % n; return m < 0 ? m + n : m; }
+
+// Inverted tileable Worley (cellular) noise: 1 - distance to the nearest feature point, period `freq` cells.
+CSKY_HD float worley(float x, float y, float z, int freq, uint32_t salt) {
+    float px = x * (float)freq, py = y * (float)freq, pz = z * (float)freq;
+    int cx = (int)floorf(px), cy = (int)floorf(py), cz = (int)floorf(pz);
+    float best = 1e9f;
+    for (int dz = -1; dz <= 1; dz++) for (int dy = -1; dy <= 1; dy++) for (int dx = -1; dx <= 1; dx++) {
+        int gx = cx + dx, gy = cy + dy, gz = cz + dz;
+        uint32_t h = hash_cell(nwrap(gx, freq), nwrap(gy, freq), nwrap(gz, freq), salt);
+        float fx = (float)gx + u01(h), fy = (float)gy + u01(hash_u32(h + 0x9e3779b9U)), fz = (float)gz + u01(hash_u32(h + 0x3c6ef372U));
+        float ex = fx - px, ey = fy - py, ez = fz - pz;
+        float d2 = ex * ex + ey * ey + ez * ez;
+        if (d2 < best) best = d2;
+    }
+    float d = sqrtf(best);
+    float v = 1.0f - d;
+    return v < 0.0f ? 0.0f : v;
+}
+CSKY_HD float worley_fbm(float x, float y, float z, int freq, uint32_t salt) {
+    return worley(x, y, z, freq, salt) * 0.625f + worley(x, y, z, freq * 2, salt + 1) * 0.25f + worley(x, y, z, freq * 4, salt + 2) * 0.125f;
+}
+
+// Tileable gradient (Perlin) noise, 12 edge gradients, quintic fade; result roughly in [-1,1].
+CSKY_HD float grad(uint32_t h, float x, float y, float z) {
+    switch (h % 12U) {
+        case 0: return x + y;  case 1: return -x + y; case 2: return x - y;  case 3: return -x - y;
+        case 4: return x + z;  case 5: return -x + z; case 6: return x - z;  case 7: return -x - z;
+        case 8: return y + z;  case 9: return -y + z; case 10: return y - z; default: return -y - z;
+    }
+}
+CSKY_HD float fade(float t) { return t * t * t * (t * (t * 6.0f - 15.0f) + 10.0f); }
+CSKY_HD float nlerp(float a, float b, float t) { return a + (b - a) * t; }
+CSKY_HD float perlin(float x, float y, float z, int freq, uint32_t salt) {
+    float px = x * (float)freq, py = y * (float)freq, pz = z * (float)freq;
+    int ix = (int)floorf(px), iy = (int)floorf(py), iz = (int)floorf(pz);
+    float fx = px - (float)ix, fy = py - (float)iy, fz = pz - (float)iz;
+    float u = fade(fx), v = fade(fy), w = fade(fz);
+    float c[2][2][2];
+    for (int dz = 0; dz < 2; dz++) for (int dy = 0; dy < 2; dy++) for (int dx = 0; dx < 2; dx++)
+        c[dz][dy][dx] = grad(hash_cell(nwrap(ix + dx, freq), nwrap(iy + dy, freq), nwrap(iz + dz, freq), salt), fx - (float)dx, fy - (float)dy, fz - (float)dz);
+    return nlerp(nlerp(nlerp(c[0][0][0], c[0][0][1], u), nlerp(c[0][1][0], c[0][1][1], u), v),
+                 nlerp(nlerp(c[1][0][0], c[1][0][1], u), nlerp(c[1][1][0], c[1][1][1], u), v), w);
+}
+CSKY_HD float perlin_fbm(float x, float y, float z, int freq, int octaves, uint32_t salt) {
+    float amp = 1.0f, sum = 0.0f, norm = 0.0f;
+    for (int o = 0; o < octaves; o++) {
+        sum += amp * perlin(x, y, z, freq << o, salt + 17U * (uint32_t)o);
+        norm += amp; amp *= 0.5f;
+    }
+    return sum / norm;
+}
+CSKY_HD float remapf(float v, float omin, float omax, float nmin, float nmax) { return nmin + ((v - omin) / (omax - omin)) * (nmax - nmin); }
+CSKY_HD float clamp01(float v) { return v < 0.0f ? 0.0f : (v > 1.0f ? 1.0f : v); }
+CSKY_HD uint8_t unorm8(float v) { return (uint8_t)(int)(clamp01(v) * 255.0f + 0.5f); }
+
+// One voxel of the stand-in shape volume (R = Perlin-Worley, G/B/A = Worley fBm octaves).  Integer hashing + IEEE
+// +,-,*,/,sqrt only, FP contraction off: bit-identical on the host and on the GPU.
+CSKY_HD void shape_voxel(uint32_t seed, int n, int x, int y, int z, uint8_t o[4]) {
+    const float inv = 1.0f / (float)n;
+    const float u = ((float)x + 0.5f) * inv, v = ((float)y + 0.5f) * inv, w = ((float)z + 0.5f) * inv;
+    // G/B/A: inverted Worley fBm at rising base frequency (Schneider / "Nubis" layout)
+    const float g = worley_fbm(u, v, w, 4, seed * 101U + 11U);
+    const float b = worley_fbm(u, v, w, 8, seed * 101U + 23U);
+    const float a = worley_fbm(u, v, w, 16, seed * 101U + 37U);
+    // R: low-frequency Perlin fBm dilated by the first Worley fBm ("Perlin-Worley"), then a fixed contrast curve
+    // calibrated so that the default coverage (0.2) gives mean alpha in 0.3-0.6 (the original asset is
+    // missing so this is a calibration, not a reconstruction).
+    const float pf = perlin_fbm(u, v, w, 4, 5, seed * 101U + 53U);        // ~[-0.6, 0.6]
+    const float p01 = clamp01(pf * 0.9f + 0.5f);
+    const float pw = remapf(p01, 0.0f, 1.0f, g * 0.55f, 1.0f);            // dilate towards the worley cells
+    const float r = clamp01((pw - 0.38f) * 1.75f + 0.32f);
+    o[0] = unorm8(r); o[1] = unorm8(g); o[2] = unorm8(b); o[3] = unorm8(a);
+}
+
+}  // namespace csky

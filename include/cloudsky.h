@@ -166,6 +166,8 @@ const char* csky_variant_name(int variant);
 int csky_load_bmp_rgb8(const char* path, int* w, int* h, uint8_t* out_rgb8, size_t out_capacity);
 int csky_strip_to_volume(const uint8_t* strip, int n, int ch, uint8_t* vol);
 int csky_generate_shape_noise(uint32_t seed, int n, uint8_t* out_rgba8);
+/* The same generator as a HIP kernel (one voxel per lane): byte-identical output, ~1 ms for 128^3 (README.md:30 TODO 3). */
+int csky_generate_shape_noise_device(csky_ctx* ctx, uint32_t seed, int n, uint8_t* out_rgba8);
 size_t csky_mip_offset(int n, int level, int ch);
 int csky_build_mips(uint8_t* vol, int n, int ch, int levels);
 const char* csky_assets_last_error(void);
