@@ -282,3 +282,11 @@ def test_cloud_sky_host_class_on_gpu(pkg, noise, oracle, otex, o_skies):
     ok, info = cloud_close(tex.cpu().numpy(), ref)
     assert ok, info
     sky.close()
+
+
+def test_gpu_shape_noise_bake_is_byte_identical(pkg, gpu_ctx, noise):
+    """the stand-in 128^3 shape volume baked by a HIP kernel equals the host generator byte for byte."""
+    assert (gpu_ctx.generate_shape_noise(1, 128) == noise[0]).all()
+    assert (gpu_ctx.generate_shape_noise(7, 32) == pkg.assets.generate_shape_noise(7, 32)).all()
+    with pytest.raises(pkg.CloudSkyError):
+        gpu_ctx.generate_shape_noise(1, 12)
