@@ -66,6 +66,7 @@ SYMBOLS = [
     ("csky_set_variant", C.c_int, [C.c_void_p, C.c_int]),
     ("csky_variant_count", C.c_int, []),
     ("csky_set_schedule", C.c_int, [C.c_void_p, C.c_int]),
+    ("csky_set_height_window", C.c_int, [C.c_void_p, C.c_int]),
     ("csky_set_segments", C.c_int, [C.c_void_p, C.c_int]),
     ("csky_variant_name", C.c_char_p, [C.c_int]),
     ("csky_load_bmp_rgb8", C.c_int, [C.c_char_p, C.POINTER(C.c_int), C.POINTER(C.c_int), C.c_void_p, C.c_size_t]),
@@ -159,6 +160,9 @@ class Context:
 
     def set_schedule(self, mode):
         self._chk(self._L.csky_set_schedule(self._h, int(mode)))
+
+    def set_height_window(self, enabled):
+        self._chk(self._L.csky_set_height_window(self._h, int(bool(enabled))))
 
     def set_segments(self, n):
         self._chk(self._L.csky_set_segments(self._h, int(n)))

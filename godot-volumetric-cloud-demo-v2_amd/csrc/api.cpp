@@ -26,6 +26,8 @@ struct csky_ctx {
     // noise set (cloud_sky.gd:298-341)
     uint2* d_shape = nullptr; uint4* d_detail = nullptr; uint2* d_weather = nullptr; bool have_noise = false;
     uint32_t shape_off[SHAPE_LEVELS] = {}, detail_off[DETAIL_LEVELS] = {};
+    double w_rmin = 0.0, w_rmax = 1.0, w_bmax = 1.0;   // range of the weather map's cloud-type / coverage channels
+    float win_cov = -1e30f, win_lo = -1.0f, win_hi = 2.0f; bool use_window = true;
     // LUTs: RGBA16F image + float4 copy of the rounded values
     uint16_t* d_trans_h = nullptr; float4* d_trans_f = nullptr; int tw = 0, th = 0; bool have_trans = false;
     uint16_t* d_sky_h = nullptr; float4* d_sky_f = nullptr; int sw = 0, sh = 0; bool have_sky = false;
@@ -192,7 +194,14 @@ int clouds_dev(csky_ctx* c, const csky_cloud_params* p, int tile_w, const csky_b
     if (pitch_bytes % 8 || pitch_bytes < (size_t)tile_w * 8) return fail(c, CSKY_ERR_INVALID, "render_clouds: row pitch must be a multiple of 8 and >= tile_w*8");
     if (b->n_bands == 0) return CSKY_OK;
     CloudParams cp; memcpy(&cp, p, sizeof cp);
-    if (setup) HIPCHK(c, launch_frame_setup(cp, c->d_sky_f, c->sw, c->sh, c->primary_steps, c->light_steps, c->early_eps, c->d_fc, s));
+    if (setup) {
+        if (c->win_cov != cp.cloud_coverage) {          // height window of the exact reject (bake.h), cached per coverage value
+            height_window((double)cp.cloud_coverage, c->w_rmin, c->w_rmax, c->w_bmax, c->win_lo, c->win_hi);
+            c->win_cov = cp.cloud_coverage;
+        }
+        const float lo = c->use_window ? c->win_lo : -1.0f, hi = c->use_window ? c->win_hi : 2.0f;
+        HIPCHK(c, launch_frame_setup(cp, c->d_sky_f, c->sw, c->sh, c->primary_steps, c->light_steps, c->early_eps, lo, hi, c->d_fc, s));
+    }
     RenderGeom g; g.tile_w = tile_w; g.band_rows = b->band_rows; g.first_band = b->first_band; g.band_stride = b->band_stride; g.n_bands = b->n_bands;
     g.pitch_px = (uint32_t)(pitch_bytes / 8);
     // ray segments: more, shorter wavefronts when the launch is too small to fill the chip with whole-ray wavefronts
@@ -268,6 +277,11 @@ int csky_set_noise(csky_ctx* c, const uint8_t* large_rgba8, const uint8_t* small
     bake_shape(lc, shape, c->shape_off);
     bake_detail(sc, detail, c->detail_off);
     bake_weather(weather_rgb8, weather);
+    {   // channel ranges of the weather map for the height-window reject
+        int rmin = 255, rmax = 0, bmax = 0;
+        for (size_t i = 0; i < (size_t)WEATHER_N * WEATHER_N; i++) { const int r = weather_rgb8[3 * i], b = weather_rgb8[3 * i + 2]; rmin = r < rmin ? r : rmin; rmax = r > rmax ? r : rmax; bmax = b > bmax ? b : bmax; }
+        c->w_rmin = rmin / 255.0; c->w_rmax = rmax / 255.0; c->w_bmax = bmax / 255.0; c->win_cov = -1e30f;
+    }
     for (int l = 0; l < SHAPE_LEVELS; l++) if (c->shape_off[l] != shape_level_offset(l)) return fail(c, CSKY_ERR_INVALID, "internal: shape mip offset mismatch");
     for (int l = 0; l < DETAIL_LEVELS; l++) if (c->detail_off[l] != detail_level_offset(l)) return fail(c, CSKY_ERR_INVALID, "internal: detail mip offset mismatch");
     HIPCHK(c, hipStreamSynchronize(c->stream));
@@ -308,6 +322,10 @@ int csky_set_segments(csky_ctx* c, int segments) {
     if (!c) return fail(nullptr, CSKY_ERR_INVALID, "csky_set_segments: ctx is NULL");
     if (segments != 0 && segments != 1 && segments != 2 && segments != 4) return fail(c, CSKY_ERR_INVALID, "csky_set_segments: 0 (auto), 1, 2 or 4");
     c->segments = segments; return CSKY_OK;
+}
+int csky_set_height_window(csky_ctx* c, int enabled) {
+    if (!c) return fail(nullptr, CSKY_ERR_INVALID, "csky_set_height_window: ctx is NULL");
+    c->use_window = enabled != 0; return CSKY_OK;
 }
 int csky_variant_count(void) { return cloud_variant_count(); }
 const char* csky_variant_name(int v) { return cloud_variant_name(v); }

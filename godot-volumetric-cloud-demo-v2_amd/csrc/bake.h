@@ -1,6 +1,7 @@
 // bake.h -- host-side conversion of the 8-bit mip chains into the device texture layouts of csky_common.h.
 // Internal to libcloudsky (api.cpp); also included by the host-compiled kernel-core unit test (tests/hostsim).
 #pragma once
+#include <cmath>
 #include <vector>
 #include "csky_common.h"
 #include "../../include/cloudsky.h"
@@ -54,4 +55,41 @@ inline void bake_weather(const uint8_t* rgb, std::vector<uint2>& out) {
         out[(size_t)y * n + x] = q;
     }
 }
+
+// Height-fraction window outside which density() (clouds.glsl:109-137) is provably 0 for the WHOLE bound weather map.
+// density() needs g > 1 - coverage*weather.b (clouds.glsl:121-125) with g = smoothstep(gx,gy,hf) - smoothstep(gz,gw,hf)
+// (:92-95).  Both smoothsteps lie in [0,1] and are non-decreasing in hf, so for any cloud type ct
+//      g <= S1(hf,ct) = smoothstep(gx,gy,hf)            and            g <= 1 - S2(hf,ct) = 1 - smoothstep(gz,gw,hf).
+// With tau = 1 - coverage*max(weather.b) the smallest threshold anywhere on the map: every sample with
+// max_ct S1(hf,ct) <= tau (below the cloud body) or max_ct (1 - S2(hf,ct)) <= tau (above it) fails reject (1) of density().
+// The maxima run over the map's cloud-type range [rmin,rmax] (bilinear filtering stays inside the texel range) on a
+// 4096-point grid; 0.03 of slack in g covers the grid spacing and fp32 rounding by two orders of magnitude, and the
+// window is widened by 5e-4 in hf (the fp32 height-fraction quantum is 2e-4).  lo = -1 / hi = 2 disable the reject.
+inline void height_window(double coverage, double rmin, double rmax, double bmax, float& lo, float& hi) {
+    lo = -1.0f; hi = 2.0f;
+    if (!(coverage <= 1.0) || !(bmax <= 1.0) || !(rmin >= 0.0) || !(rmax <= 1.0)) return;   // wc could exceed 1: keep the plain path
+    const double tm = (1.0 - coverage * bmax) - 0.03;
+    if (!(tm > 0.0)) return;
+    auto sat = [](double x) { return x < 0.0 ? 0.0 : (x > 1.0 ? 1.0 : x); };
+    auto smooth = [&](double e0, double e1, double x) { const double t = sat((x - e0) / (e1 - e0)); return t * t * (3.0 - 2.0 * t); };
+    auto bound = [&](double h, bool upper) {              // max over ct of S1 (lower side) or 1 - S2 (upper side)
+        double best = 0.0;
+        const int N = 4096;
+        for (int i = 0; i <= N; i++) {
+            const double ct = rmin + (rmax - rmin) * (double)i / N;
+            const double st = 1.0 - sat(ct * 2.0), sc = 1.0 - std::fabs(ct - 0.5) * 2.0, cu = sat(ct - 0.5) * 2.0;   // clouds.glsl:86-88
+            const double gx = 0.02 * st + 0.02 * sc + 0.01 * cu, gy = 0.05 * st + 0.2 * sc + 0.0625 * cu;
+            const double gz = 0.09 * st + 0.48 * sc + 0.78 * cu, gw = 0.11 * st + 0.625 * sc + 1.0 * cu;
+            const double v = upper ? 1.0 - smooth(gz, gw, h) : smooth(gx, gy, h);
+            if (v > best) best = v;
+        }
+        return best;
+    };
+    if (bound(1.0, false) <= tm) { lo = 2.0f; hi = 2.0f; return; }        // nothing can ever pass: reject everything
+    double a = 0.0, b = 1.0;                                             // largest h with S1max(h) <= tm (S1max non-decreasing)
+    if (bound(0.0, false) <= tm) { for (int it = 0; it < 40; it++) { const double m = 0.5 * (a + b); if (bound(m, false) <= tm) a = m; else b = m; } lo = (float)(a - 5e-4); }
+    a = 0.0; b = 1.0;                                                    // smallest h with (1 - S2)max(h) <= tm (non-increasing)
+    if (bound(1.0, true) <= tm) { for (int it = 0; it < 40; it++) { const double m = 0.5 * (a + b); if (bound(m, true) <= tm) b = m; else a = m; } hi = (float)(b + 5e-4); }
+}
+
 }  // namespace csky

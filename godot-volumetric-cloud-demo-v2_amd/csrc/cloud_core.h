@@ -134,7 +134,7 @@ CSKY_HD void sky_lut_tap(const float4* sky, int w, int h, float sx, float sy, fl
 }
 
 CSKY_HD void frame_setup(const CloudParams& P, const float4* sky, int sky_w, int sky_h, int primary_steps, int light_steps,
-                         float early_eps, FrameConsts& fc) {
+                         float early_eps, float hf_lo, float hf_hi, FrameConsts& fc) {
     const float RV[6][3] = {{0.38051305f, 0.92453449f, -0.02111345f}, {-0.50625799f, -0.03590792f, -0.86163418f},
                             {-0.32509218f, -0.94557439f, 0.01428793f}, {0.09026238f, -0.27376545f, 0.95755165f},
                             {0.28128598f, 0.42443639f, -0.86065785f}, {-0.16852403f, 0.14748697f, 0.97460106f}};  // clouds.glsl:140
@@ -165,6 +165,7 @@ CSKY_HD void frame_setup(const CloudParams& P, const float4* sky, int sky_w, int
     fc.density = P.density; fc.coverage = P.cloud_coverage;
     fc.primary_steps = primary_steps; fc.light_steps = light_steps; fc.steps_f = (float)primary_steps;
     fc.early_eps = early_eps;
+    fc.hf_lo = hf_lo; fc.hf_hi = hf_hi;
 }
 
 // =================================================================================================
@@ -282,6 +283,20 @@ CSKY_HD float density(const TexSet& T, const FrameConsts& fc, float px, float py
     return fast_pow(sat(base), (1.0f - hf) * 0.8f + 0.5f);                  // :136
 }
 
+// One density sample of the march: weather tap (clouds.glsl:174/:189/:197) + density() (:109-137), behind a third
+// EXACT reject: outside the height window (fc.hf_lo, fc.hf_hi) the height gradient cannot exceed 1 - coverage*weather.b
+// for ANY texel of the bound weather map (bake.h height_window: g <= smoothstep(gx,gy,hf) below the cloud body and
+// g <= 1 - smoothstep(gz,gw,hf) above it, maximised over the map's cloud-type range), so reject (1) would fire anyway:
+// the weather tap and the gradient are skipped.  Samples above/below the cloud body cost ~20 VALU instead of ~100.
+CSKY_HD float sample_density(const TexSet& T, const FrameConsts& fc, float px, float py, float pz, float hf, float wx, float wy,
+                             int lod_shape, int lod_detail) {
+    if (!(hf > fc.hf_lo && hf < fc.hf_hi)) return 0.0f;
+    float wsx, wsy, wr, wb;
+    weather_coord(px, pz, wx, wy, wsx, wsy);
+    weather_tap(T.weather, wsx, wsy, wr, wb);
+    return density(T, fc, px, py, pz, hf, wr, wb, lod_shape, lod_detail);
+}
+
 CSKY_HD float henyey_greenstein(float c, float g) {                         // clouds.glsl:72-75 (once per ray: accurate powf)
     return 0.0795774715459f * (1.0f - g * g) / powf(1.0f + g * g - 2.0f * g * c, 1.5f);
 }
@@ -325,11 +340,8 @@ CSKY_HD MarchOut march(const TexSet& T, const FrameConsts& fc, Ray ray) {
         if (fc.early_eps > 0.0f && CSKY_WAVE_ALL(!ray.above || Tr < fc.early_eps)) break;    // build-side early-out
         if (!ray.above) continue;
         advance(px, py, pz, ray.sx, ray.sy, ray.sz);                                         // :173
-        float wsx, wsy, wr, wb;
-        weather_coord(px, pz, fc.wpos_x, fc.wpos_y, wsx, wsy);
-        weather_tap(T.weather, wsx, wsy, wr, wb);                                            // :174
         const float hf = height_fraction(length3_exact(px, py, pz));                         // :175
-        const float t = density(T, fc, px, py, pz, hf, wr, wb, 0, 0);                        // :177
+        const float t = sample_density(T, fc, px, py, pz, hf, fc.wpos_x, fc.wpos_y, 0, 0);   // :174,:177
         if (t > 0.0f) {                                                                      // :184
             o.incloud++;
             const float dt = fast_exp(nd * t * ray.ss);                                      // :178
@@ -337,19 +349,13 @@ CSKY_HD MarchOut march(const TexSet& T, const FrameConsts& fc, Ray ray) {
             for (int j = 0; j < ls; j++) {                                                   // :186
                 advance(lx, ly, lz, fc.linc[j][0], fc.linc[j][1], fc.linc[j][2]);            // :187
                 const float lhf = height_fraction(length3_exact(lx, ly, lz));                // :188
-                float lwr, lwb;
-                weather_coord(lx, lz, fc.wpos_x, fc.wpos_y, wsx, wsy);
-                weather_tap(T.weather, wsx, wsy, lwr, lwb);                                  // :189
-                cd += density(T, fc, lx, ly, lz, lhf, lwr, lwb, j > 2 ? j - 2 : 0, j);       // :190-191 (LOD mip-2 clamps at 0)
+                cd += sample_density(T, fc, lx, ly, lz, lhf, fc.wpos_x, fc.wpos_y, j > 2 ? j - 2 : 0, j);   // :189-191 (LOD mip-2 clamps at 0)
             }
             {   // distant sample, :195-199
                 lx = px; ly = py; lz = pz;
                 advance(lx, ly, lz, fc.ldist[0], fc.ldist[1], fc.ldist[2]);
                 const float lhf = height_fraction(length3_exact(lx, ly, lz));
-                float lwr, lwb;
-                weather_coord(lx, lz, 0.0f, 0.0f, wsx, wsy);                                 // :197 has no weather_pos
-                weather_tap(T.weather, wsx, wsy, lwr, lwb);
-                const float ld = density(T, fc, lx, ly, lz, lhf, lwr, lwb, 3, 5);
+                const float ld = sample_density(T, fc, lx, ly, lz, lhf, 0.0f, 0.0f, 3, 5);   // :197 has no weather_pos
                 cd += fast_pow(ld, (1.0f - lhf) * 0.8f + 0.5f);                              // :198 (second pow)
             }
             shade_sample(fc, phase, t, hf, dt, cd, Tr, alpha, Lr, Lg, Lb);                       // :202-210

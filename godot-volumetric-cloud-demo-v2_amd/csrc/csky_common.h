@@ -62,6 +62,7 @@ struct FrameConsts {
     int primary_steps, light_steps;   // clouds.glsl:228 (128), :186 (6)
     float steps_f;
     float early_eps;                  // wave early-out threshold on T (0 = off; not in the reference)
+    float hf_lo, hf_hi;               // height-fraction window outside which density() is provably 0 (bake.h height_window)
 };
 
 // Which rows a launch renders (cloudsky.h csky_bands) + output addressing.

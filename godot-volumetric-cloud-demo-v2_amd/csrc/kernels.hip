@@ -80,16 +80,16 @@ hipError_t launch_composite(const CompositeArgs& a, uint2* d_out, hipStream_t s)
 
 // ------------------------------------------------------------------------------------------------ clouds
 __global__ __launch_bounds__(64) void frame_setup_kernel(CloudParams p, const float4* __restrict__ sky, int sw, int sh, int primary_steps,
-                                                         int light_steps, float early_eps, FrameConsts* __restrict__ out) {
+                                                         int light_steps, float early_eps, float hf_lo, float hf_hi, FrameConsts* __restrict__ out) {
     if (threadIdx.x == 0 && blockIdx.x == 0) {
         FrameConsts fc;
-        frame_setup(p, sky, sw, sh, primary_steps, light_steps, early_eps, fc);
+        frame_setup(p, sky, sw, sh, primary_steps, light_steps, early_eps, hf_lo, hf_hi, fc);
         *out = fc;
     }
 }
 hipError_t launch_frame_setup(const CloudParams& p, const float4* d_sky, int sw, int sh, int primary_steps, int light_steps, float early_eps,
-                              FrameConsts* d_fc, hipStream_t s) {
-    frame_setup_kernel<<<1, 64, 0, s>>>(p, d_sky, sw, sh, primary_steps, light_steps, early_eps, d_fc);
+                              float hf_lo, float hf_hi, FrameConsts* d_fc, hipStream_t s) {
+    frame_setup_kernel<<<1, 64, 0, s>>>(p, d_sky, sw, sh, primary_steps, light_steps, early_eps, hf_lo, hf_hi, d_fc);
     return hipGetLastError();
 }
 
@@ -151,11 +151,8 @@ __device__ __forceinline__ MarchOut march_queue(const TexSet& T, const FrameCons
         float t = 0.0f, hf = 0.0f;
         if (live) {
             advance(px, py, pz, ray.sx, ray.sy, ray.sz);                                                       // :173
-            float wsx, wsy, wr, wb;
-            weather_coord(px, pz, fc.wpos_x, fc.wpos_y, wsx, wsy);
-            weather_tap(T.weather, wsx, wsy, wr, wb);                                                          // :174
             hf = height_fraction(length3_exact(px, py, pz));                                                   // :175
-            t = density(T, fc, px, py, pz, hf, wr, wb, 0, 0);                                                  // :177
+            t = sample_density(T, fc, px, py, pz, hf, fc.wpos_x, fc.wpos_y, 0, 0);                             // :174, :177
         }
         const bool have = t > 0.0f;                                                                            // :184
         const unsigned long long m = __ballot(have);
@@ -193,11 +190,8 @@ __device__ __forceinline__ MarchOut march_queue(const TexSet& T, const FrameCons
                     }
                 }
                 const float lhf = height_fraction(length3_exact(lx, ly, lz));                                  // :188 / :196
-                float wsx, wsy, lwr, lwb;
-                weather_coord(lx, lz, distant ? 0.0f : fc.wpos_x, distant ? 0.0f : fc.wpos_y, wsx, wsy);       // :189 / :197 (no weather_pos)
-                weather_tap(T.weather, wsx, wsy, lwr, lwb);
                 const int lod_s = distant ? 3 : (j > 2 ? j - 2 : 0), lod_d = distant ? 5 : j;                  // textureLod(.., mip-2) / (.., mip)
-                float d = density(T, fc, lx, ly, lz, lhf, lwr, lwb, lod_s, lod_d);                             // :190 / :198
+                float d = sample_density(T, fc, lx, ly, lz, lhf, distant ? 0.0f : fc.wpos_x, distant ? 0.0f : fc.wpos_y, lod_s, lod_d);  // :189-190 / :197-198
                 if (distant) d = fast_pow(d, (1.0f - lhf) * 0.8f + 0.5f);                                      // :198 second pow
                 ev_lt[j * QCAP + k] = d;
             }

@@ -149,6 +149,9 @@ int csky_time_clouds(csky_ctx* ctx, const csky_cloud_params* p, int tile_w, cons
 int csky_get_cloud_stats(csky_ctx* ctx, csky_cloud_stats* stats); /* tallies of the last stats-enabled launch */
 /* Kernel variant selector for A/B measurement (default = the fastest measured; csky_variant_name lists them).  Unknown ids -> CSKY_ERR_INVALID. */
 int csky_set_variant(csky_ctx* ctx, int variant);
+/* Exact height-window reject (density() provably 0 above/below the cloud body for the bound weather map): on by default;
+ * 0 disables it (A/B measurement, identical results). */
+int csky_set_height_window(csky_ctx* ctx, int enabled);
 int csky_variant_count(void);
 /* Workgroup -> XCD schedule (tuning knob, results are identical): 5 = slab rows round-robin over the XCDs (default);
  * 1 = contiguous eighths; 2 = natural order; 0/3/4 = azimuth wedges; 6 = 5 with horizon rows first. */

@@ -40,7 +40,7 @@ void hostsim_sky(int w, int h, const float sun[3], const uint16_t* trans_h, int 
 // mip chains (level 0 first) -> baked layouts -> march every pixel of the band set, like clouds_kernel does.
 void hostsim_clouds(const uint8_t* large_chain, const uint8_t* small_chain, const uint8_t* weather_rgb8, const float params[28],
                     int primary_steps, int light_steps, float early_eps, const uint16_t* sky_h, int sw, int sh, int tile_w,
-                    int band_rows, int first_band, int band_stride, int n_bands, uint16_t* out_h, uint64_t* incloud) {
+                    int band_rows, int first_band, int band_stride, int n_bands, uint16_t* out_h, uint64_t* incloud, int use_window, float* window_out) {
     std::vector<uint8_t> lc(large_chain, large_chain + csky_mip_offset(SHAPE_N, SHAPE_LEVELS, 4));
     std::vector<uint8_t> sc(small_chain, small_chain + csky_mip_offset(DETAIL_N, DETAIL_LEVELS, 3));
     std::vector<uint2> shape, weather; std::vector<uint4> detail;
@@ -50,7 +50,14 @@ void hostsim_clouds(const uint8_t* large_chain, const uint8_t* small_chain, cons
     T.shape = shape.data(); T.detail = detail.data(); T.weather = weather.data(); T.sky = sky.data(); T.sky_w = sw; T.sky_h = sh;
     CloudParams P; memcpy(&P, params, sizeof P);
     FrameConsts fc;
-    frame_setup(P, sky.data(), sw, sh, primary_steps, light_steps, early_eps, fc);
+    float hlo = -1.0f, hhi = 2.0f;
+    if (use_window) {
+        int rmin = 255, rmax = 0, bmax = 0;
+        for (size_t i = 0; i < (size_t)WEATHER_N * WEATHER_N; i++) { const int r = weather_rgb8[3 * i], b = weather_rgb8[3 * i + 2]; rmin = r < rmin ? r : rmin; rmax = r > rmax ? r : rmax; bmax = b > bmax ? b : bmax; }
+        height_window((double)P.cloud_coverage, rmin / 255.0, rmax / 255.0, bmax / 255.0, hlo, hhi);
+    }
+    if (window_out) { window_out[0] = hlo; window_out[1] = hhi; }
+    frame_setup(P, sky.data(), sw, sh, primary_steps, light_steps, early_eps, hlo, hhi, fc);
     uint64_t ic = 0;
     const int rows = n_bands * band_rows;
     for (int lr = 0; lr < rows; lr++) {

@@ -284,6 +284,19 @@ def test_cloud_sky_host_class_on_gpu(pkg, noise, oracle, otex, o_skies):
     sky.close()
 
 
+def test_height_window_reject_is_exact_on_gpu(gpu_ctx, oracle):
+    """csky_set_height_window(0/1): identical frames and in-cloud counts (the reject only skips provably-zero samples)."""
+    gpu_ctx.render_sky_lut(norm((1, 1, 0)), 200, 100)
+    for cov in (0.1, 0.2, 0.6, 1.0):
+        p = oracle.default_params(256, 128, (1, 1, 0), coverage=cov)
+        gpu_ctx.set_height_window(True)
+        a = gpu_ctx.render_clouds(p).view(np.uint16); sa = gpu_ctx.cloud_stats()
+        gpu_ctx.set_height_window(False)
+        b = gpu_ctx.render_clouds(p).view(np.uint16); sb = gpu_ctx.cloud_stats()
+        gpu_ctx.set_height_window(True)
+        assert (a == b).all() and sa == sb, cov
+
+
 def test_gpu_shape_noise_bake_is_byte_identical(pkg, gpu_ctx, noise):
     """the stand-in 128^3 shape volume baked by a HIP kernel equals the host generator byte for byte."""
     assert (gpu_ctx.generate_shape_noise(1, 128) == noise[0]).all()

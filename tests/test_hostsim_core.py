@@ -12,16 +12,19 @@ def P(a):
     return a.ctypes.data_as(C.c_void_p)
 
 
-def hs_clouds(hostsim, pkg, noise, params, sky, tile_w, bands, primary=128, light=6, eps=0.0):
+def hs_clouds(hostsim, pkg, noise, params, sky, tile_w, bands, primary=128, light=6, eps=0.0, window=True, ret_window=False):
     large, small, weather = noise
     lc, sc = pkg.assets.build_mips(large, 8), pkg.assets.build_mips(small, 6)
     rows = bands[0] * bands[3]
     out = np.zeros((rows, tile_w, 4), np.uint16)
     ic = C.c_uint64()
+    win = np.zeros(2, np.float32)
     p = np.ascontiguousarray(params, np.float32)
     s = np.ascontiguousarray(sky).view(np.uint16)
     hostsim.hostsim_clouds(P(lc), P(sc), P(weather), P(p), primary, light, C.c_float(eps), P(s), s.shape[1], s.shape[0], tile_w,
-                           bands[0], bands[1], bands[2], bands[3], P(out), C.byref(ic))
+                           bands[0], bands[1], bands[2], bands[3], P(out), C.byref(ic), int(window), P(win))
+    if ret_window:
+        return out.view(np.float16), ic.value, win
     return out.view(np.float16), ic.value
 
 
@@ -79,3 +82,19 @@ def test_early_out_bounded(hostsim, pkg, oracle, noise, o_skies):
     b, _ = hs_clouds(hostsim, pkg, noise, p, o_skies["zenith"], 48, (8, 0, 1, 3), eps=1e-3)
     d = np.abs(a.astype(np.float32) - b.astype(np.float32))
     assert d[..., 3].max() <= 1.5e-3 and d[..., :3].max() <= 1.5e-3 * max(1.0, float(a.astype(np.float32)[..., :3].max()))
+
+
+def test_height_window_reject_is_exact(hostsim, pkg, oracle, noise, o_skies):
+    """The height-window reject (bake.h height_window) must never change a pixel: with and without it the kernel core
+    renders bit-identical images and in-cloud counts, for several coverages; and the window is non-trivial at the default."""
+    for cov in (0.05, 0.2, 0.5, 0.95, 1.0, 1.5, 0.0, -0.5):
+        p = oracle.default_params(48, 24, (1, 1, 0), coverage=cov)
+        a, ia, win = hs_clouds(hostsim, pkg, noise, p, o_skies["deg45"], 48, (8, 0, 1, 3), window=True, ret_window=True)
+        b, ib = hs_clouds(hostsim, pkg, noise, p, o_skies["deg45"], 48, (8, 0, 1, 3), window=False)
+        assert (a.view(np.uint16) == b.view(np.uint16)).all() and ia == ib, cov
+        if cov == 0.2:
+            assert 0.03 < win[0] < 0.2 and 0.6 < win[1] < 0.95, win        # default map: clouds only between ~6 % and ~80 % height
+        if cov > 1.0:
+            assert win[0] == -1.0 and win[1] == 2.0                        # coverage*weather.b may exceed 1: shortcut disabled
+        if cov <= 0.0:
+            assert ia == 0
