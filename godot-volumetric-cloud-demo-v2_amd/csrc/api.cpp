@@ -24,7 +24,7 @@ struct csky_ctx {
     hipStream_t stream = nullptr;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     // noise set (cloud_sky.gd:298-341)
-    uint2* d_shape = nullptr; uint4* d_detail = nullptr; uint2* d_weather = nullptr; bool have_noise = false;
+    uint2* d_shape = nullptr; uint4* d_detail = nullptr; uint4* d_weather = nullptr; bool have_noise = false;
     uint32_t shape_off[SHAPE_LEVELS] = {}, detail_off[DETAIL_LEVELS] = {};
     double w_rmin = 0.0, w_rmax = 1.0, w_bmax = 1.0;   // range of the weather map's cloud-type / coverage channels
     float win_cov = -1e30f, win_lo = -1.0f, win_hi = 2.0f; bool use_window = true;
@@ -273,7 +273,7 @@ int csky_set_noise(csky_ctx* c, const uint8_t* large_rgba8, const uint8_t* small
     memcpy(sc.data(), small_rgb8, (size_t)DETAIL_N * DETAIL_N * DETAIL_N * 3);
     csky_build_mips(lc.data(), SHAPE_N, 4, SHAPE_LEVELS);      // mipmaps/generate=true, perlworlnoise.tga.import:24
     csky_build_mips(sc.data(), DETAIL_N, 3, DETAIL_LEVELS);    // worlnoise.bmp.import:24
-    std::vector<uint2> shape, weather; std::vector<uint4> detail;
+    std::vector<uint2> shape; std::vector<uint4> detail, weather;
     bake_shape(lc, shape, c->shape_off);
     bake_detail(sc, detail, c->detail_off);
     bake_weather(weather_rgb8, weather);
@@ -290,7 +290,7 @@ int csky_set_noise(csky_ctx* c, const uint8_t* large_rgba8, const uint8_t* small
     if ((rc = dev_alloc(c, &c->d_weather, weather.size()))) return rc;
     HIPCHK(c, hipMemcpy(c->d_shape, shape.data(), shape.size() * sizeof(uint2), hipMemcpyHostToDevice));
     HIPCHK(c, hipMemcpy(c->d_detail, detail.data(), detail.size() * sizeof(uint4), hipMemcpyHostToDevice));
-    HIPCHK(c, hipMemcpy(c->d_weather, weather.data(), weather.size() * sizeof(uint2), hipMemcpyHostToDevice));
+    HIPCHK(c, hipMemcpy(c->d_weather, weather.data(), weather.size() * sizeof(uint4), hipMemcpyHostToDevice));
     c->have_noise = true;
     return CSKY_OK;
 }

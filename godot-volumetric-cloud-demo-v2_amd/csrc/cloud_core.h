@@ -173,19 +173,31 @@ CSKY_HD void frame_setup(const CloudParams& P, const float4* sky, int sky_w, int
 // =================================================================================================
 #pragma clang fp contract(fast)
 
-CSKY_HD float ub(uint32_t v, int k) { return (float)((v >> (8 * k)) & 0xffu); }   // -> v_cvt_f32_ubyteK
-CSKY_HD float lo16(uint32_t v) { return (float)(v & 0xffffu); }
-CSKY_HD float hi16(uint32_t v) { return (float)(v >> 16); }
+// lo + f*(hi - lo) for a pair of fp16 texel values packed in one dword (lo = bits 0-15, hi = bits 16-31), evaluated in
+// fp32 as fma(hi, f, fma(lo, -f, lo)).  On gfx950 this is two v_fma_mix_f32 (the f16 -> f32 widening is free inside the
+// FMA: 2 x 4.4 cycles instead of cvt + cvt + sub + fma = 17 cycles for byte texels; tools/ubench/valu_rates.hip).
+// Texel values are small integers (<= 2040), exact in fp16, so nothing is lost by the storage format.
+CSKY_HD float lerp_h(uint32_t p, float f) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    float t, r;
+    asm("v_fma_mix_f32 %0, %1, -%2, %1 op_sel:[0,0,0] op_sel_hi:[1,0,1]" : "=v"(t) : "v"(p), "v"(f));
+    asm("v_fma_mix_f32 %0, %1, %2, %3 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(r) : "v"(p), "v"(f), "v"(t));
+    return r;
+#else
+    const float lo = h2f((uint16_t)(p & 0xffffu)), hi = h2f((uint16_t)(p >> 16));
+    return fmaf(hi, f, fmaf(lo, -f, lo));
+#endif
+}
 
 // REPEAT + LINEAR bilinear tap of the quad-packed weather map (clouds.glsl:174).  Returns r (cloud type), b (coverage).
-CSKY_HD void weather_tap(const uint2* __restrict__ w, float sx, float sy, float& wr, float& wb) {
+CSKY_HD void weather_tap(const uint4* __restrict__ w, float sx, float sy, float& wr, float& wb) {
     const float ux = sx * 512.0f - 0.5f, uy = sy * 512.0f - 0.5f;
     const float fx0 = floorf(ux), fy0 = floorf(uy);
     const float ax = ux - fx0, ay = uy - fy0;
     const int x0 = ((int)fx0) & 511, y0 = ((int)fy0) & 511;
-    const uint2 q = *reinterpret_cast<const uint2*>(reinterpret_cast<const char*>(w) + ((((uint32_t)y0 << 9) | (uint32_t)x0) << 3));
-    wr = lerpf(lerpf(ub(q.x, 0), ub(q.x, 1), ax), lerpf(ub(q.x, 2), ub(q.x, 3), ax), ay) * (1.0f / 255.0f);
-    wb = lerpf(lerpf(ub(q.y, 0), ub(q.y, 1), ax), lerpf(ub(q.y, 2), ub(q.y, 3), ax), ay) * (1.0f / 255.0f);
+    const uint4 q = *reinterpret_cast<const uint4*>(reinterpret_cast<const char*>(w) + ((((uint32_t)y0 << 9) | (uint32_t)x0) << 4));
+    wr = lerpf(lerp_h(q.x, ax), lerp_h(q.y, ax), ay) * (1.0f / 255.0f);
+    wb = lerpf(lerp_h(q.z, ax), lerp_h(q.w, ax), ay) * (1.0f / 255.0f);
 }
 
 // texel offset of mip level l inside the packed chains: sum_{i<l} (N>>i)^3 = (N^3*8 - (N>>l)^3*8) / 7, computed
@@ -209,12 +221,8 @@ CSKY_HD void shape_tap(const TexSet& T, int lvl, float sx, float sy, float sz, f
     const char* __restrict__ sb = reinterpret_cast<const char*>(T.shape);
     const uint2 t00 = *reinterpret_cast<const uint2*>(sb + ((base + r00) << 3)), t10 = *reinterpret_cast<const uint2*>(sb + ((base + r10) << 3));
     const uint2 t01 = *reinterpret_cast<const uint2*>(sb + ((base + r01) << 3)), t11 = *reinterpret_cast<const uint2*>(sb + ((base + r11) << 3));
-    const float c00 = lerpf(ub(t00.x, 0), ub(t00.y, 0), ax), c10 = lerpf(ub(t10.x, 0), ub(t10.y, 0), ax);
-    const float c01 = lerpf(ub(t01.x, 0), ub(t01.y, 0), ax), c11 = lerpf(ub(t11.x, 0), ub(t11.y, 0), ax);
-    const float f00 = lerpf(hi16(t00.x), hi16(t00.y), ax), f10 = lerpf(hi16(t10.x), hi16(t10.y), ax);
-    const float f01 = lerpf(hi16(t01.x), hi16(t01.y), ax), f11 = lerpf(hi16(t11.x), hi16(t11.y), ax);
-    r = lerpf(lerpf(c00, c10, ay), lerpf(c01, c11, ay), az) * (1.0f / 255.0f);
-    fbm = lerpf(lerpf(f00, f10, ay), lerpf(f01, f11, ay), az) * (1.0f / (8.0f * 255.0f));
+    r = lerpf(lerpf(lerp_h(t00.x, ax), lerp_h(t10.x, ax), ay), lerpf(lerp_h(t01.x, ax), lerp_h(t11.x, ax), ay), az) * (1.0f / 255.0f);
+    fbm = lerpf(lerpf(lerp_h(t00.y, ax), lerp_h(t10.y, ax), ay), lerpf(lerp_h(t01.y, ax), lerp_h(t11.y, ax), ay), az) * (1.0f / (8.0f * 255.0f));
 }
 
 // REPEAT + LINEAR trilinear tap of the oct-packed detail volume (clouds.glsl:132-133): returns hfbm.
@@ -227,9 +235,7 @@ CSKY_HD float detail_tap(const TexSet& T, int lvl, float sx, float sy, float sz)
     const int x0 = ((int)fx0) & m, y0 = ((int)fy0) & m, z0 = ((int)fz0) & m;
     const uint32_t un = (uint32_t)n, idx = detail_level_offset(lvl) + ((uint32_t)z0 * un + (uint32_t)y0) * un + (uint32_t)x0;
     const uint4 q = *reinterpret_cast<const uint4*>(reinterpret_cast<const char*>(T.detail) + (idx << 4));
-    const float c00 = lerpf(lo16(q.x), hi16(q.x), ax), c10 = lerpf(lo16(q.y), hi16(q.y), ax);
-    const float c01 = lerpf(lo16(q.z), hi16(q.z), ax), c11 = lerpf(lo16(q.w), hi16(q.w), ax);
-    return lerpf(lerpf(c00, c10, ay), lerpf(c01, c11, ay), az) * (1.0f / (8.0f * 255.0f));
+    return lerpf(lerpf(lerp_h(q.x, ax), lerp_h(q.y, ax), ay), lerpf(lerp_h(q.z, ax), lerp_h(q.w, ax), ay), az) * (1.0f / (8.0f * 255.0f));
 }
 
 CSKY_HD float height_fraction(float r) { return sat((r - SKY_B_RADIUS) * (1.0f / (SKY_T_RADIUS - SKY_B_RADIUS))); }  // clouds.glsl:77-80

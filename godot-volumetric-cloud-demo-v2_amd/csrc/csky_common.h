@@ -29,17 +29,19 @@ constexpr int SHAPE_N = 128, SHAPE_LEVELS = 8;   // perlworlnoise.tga.import:24-
 constexpr int DETAIL_N = 32, DETAIL_LEVELS = 6;  // worlnoise.bmp.import:24-27 (32 slices, mips on)
 constexpr int WEATHER_N = 512;                   // weather.bmp.import:25 (no mips)
 
-// ---- device texture layouts (baked by api.cpp::bake_*) ----------------------------
-// shape  : per texel u32  = r | (5g+2b+a) << 16     (fbm numerator, exact: fbm = num / (8*255))
-//          stored x-pair-packed: uint2{texel(x), texel(x+1 mod N)} -> 4 x 8-byte loads per trilinear tap
-// detail : per texel oct-packed 8 x u16 numerators (5r+2g+b) of the 2x2x2 neighbourhood (wrapped),
-//          order bit0 = +x, bit1 = +y, bit2 = +z -> ONE 16-byte load per trilinear tap
-// weather: per texel quad-packed bytes {r00,r10,r01,r11, b00,b10,b01,b11} of the 2x2 neighbourhood
-//          (wrapped) -> ONE 8-byte load per bilinear tap (G is never read: clouds.glsl:121,123)
+// ---- device texture layouts (baked by bake.h) ----------------------------------------
+// Texel values are stored as fp16 (small integers, exact) so that v_fma_mix_f32 widens them for free inside the
+// filtering FMAs; every dword holds the x-neighbour pair {lo = texel(x), hi = texel(x+1 mod N)}.
+// shape  : per texel uint2 {r pair, fbm-numerator pair}, numerator = 5g+2b+a (fbm = num / (8*255), clouds.glsl:118)
+//          -> 4 x 8-byte loads per trilinear tap
+// detail : per texel uint4 = the 2x2x2 neighbourhood's numerators 5r+2g+b (clouds.glsl:133): {y0z0, y1z0, y0z1, y1z1} pairs
+//          -> ONE 16-byte load per trilinear tap
+// weather: per texel uint4 = the 2x2 neighbourhood {r(y0), r(y1), b(y0), b(y1)} pairs (G is never read: clouds.glsl:121,123)
+//          -> ONE 16-byte load per bilinear tap
 struct TexSet {
     const uint2* shape;     // all levels, level l at shape_off[l] (in texels)
     const uint4* detail;    // all levels, level l at detail_off[l]
-    const uint2* weather;   // 512*512
+    const uint4* weather;   // 512*512
     const float4* sky;      // sky LUT, fp16-rounded values widened to float, sky_w x sky_h
     int sky_w, sky_h;
     uint32_t shape_off[SHAPE_LEVELS];

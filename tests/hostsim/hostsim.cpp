@@ -43,7 +43,7 @@ void hostsim_clouds(const uint8_t* large_chain, const uint8_t* small_chain, cons
                     int band_rows, int first_band, int band_stride, int n_bands, uint16_t* out_h, uint64_t* incloud, int use_window, float* window_out) {
     std::vector<uint8_t> lc(large_chain, large_chain + csky_mip_offset(SHAPE_N, SHAPE_LEVELS, 4));
     std::vector<uint8_t> sc(small_chain, small_chain + csky_mip_offset(DETAIL_N, DETAIL_LEVELS, 3));
-    std::vector<uint2> shape, weather; std::vector<uint4> detail;
+    std::vector<uint2> shape; std::vector<uint4> detail, weather;
     TexSet T;
     bake_shape(lc, shape, T.shape_off); bake_detail(sc, detail, T.detail_off); bake_weather(weather_rgb8, weather);
     std::vector<float4> sky = widen(sky_h, sw, sh);

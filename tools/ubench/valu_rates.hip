@@ -31,6 +31,8 @@ __global__ __launch_bounds__(256) void k(float* out, int iters, float seed) {
         if constexpr (KIND == 16) { REP8(asm volatile("v_mul_f32 %0, %0, %4 clamp\n v_floor_f32 %1, %1\n v_sub_f32 %2, %2, %4\n v_mul_f32 %3, %3, %4 clamp\n v_floor_f32 %0, %0\n v_sub_f32 %1, %1, %4\n v_mul_f32 %2, %2, %4 clamp\n v_floor_f32 %3, %3" : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3) : "v"(a4));) }
         if constexpr (KIND == 17) { REP8(asm volatile("v_cmp_gt_f32 vcc, %0, %4\n v_cndmask_b32 %1, %1, %4, vcc\n v_cndmask_b32 %2, %2, %4, vcc\n v_cndmask_b32 %3, %3, %4, vcc\n v_cndmask_b32 %1, %1, %5, vcc\n v_cndmask_b32 %2, %2, %5, vcc\n v_cndmask_b32 %3, %3, %5, vcc\n v_cndmask_b32 %1, %1, %4, vcc" : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3) : "v"(a4), "v"(a5) : "vcc");) }
         if constexpr (KIND == 18) { REP8(asm volatile("v_cmp_gt_f32 s[20:21], %0, %4\n v_cndmask_b32_e64 %1, %1, %4, s[20:21]\n v_cndmask_b32_e64 %2, %2, %4, s[20:21]\n v_cndmask_b32_e64 %3, %3, %4, s[20:21]\n v_cndmask_b32_e64 %1, %1, %5, s[20:21]\n v_cndmask_b32_e64 %2, %2, %5, s[20:21]\n v_cndmask_b32_e64 %3, %3, %5, s[20:21]\n v_cndmask_b32_e64 %1, %1, %4, s[20:21]" : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3) : "v"(a4), "v"(a5) : "s20", "s21");) }
+        if constexpr (KIND == 19) { REP8(asm volatile("v_fma_mix_f32 %0, %4, %5, %0 op_sel:[0,0,0] op_sel_hi:[1,0,0]\n v_fma_mix_f32 %1, %4, %5, %1 op_sel:[1,0,0] op_sel_hi:[1,0,0]\n v_fma_mix_f32 %2, %4, %5, %2 op_sel:[0,0,0] op_sel_hi:[1,0,0]\n v_fma_mix_f32 %3, %4, %5, %3 op_sel:[1,0,0] op_sel_hi:[1,0,0]\n v_fma_mix_f32 %0, %4, %5, %0 op_sel:[0,0,0] op_sel_hi:[1,0,0]\n v_fma_mix_f32 %1, %4, %5, %1 op_sel:[1,0,0] op_sel_hi:[1,0,0]\n v_fma_mix_f32 %2, %4, %5, %2 op_sel:[0,0,0] op_sel_hi:[1,0,0]\n v_fma_mix_f32 %3, %4, %5, %3 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3) : "v"(u0), "v"(a5));) }
+        if constexpr (KIND == 20) { REP8(asm volatile("v_cvt_f32_f16 %0, %4\n v_cvt_f32_f16_sdwa %1, %4 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1\n v_cvt_f32_f16 %2, %5\n v_cvt_f32_f16_sdwa %3, %5 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1\n v_cvt_f32_f16 %0, %4\n v_cvt_f32_f16_sdwa %1, %4 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1\n v_cvt_f32_f16 %2, %5\n v_cvt_f32_f16_sdwa %3, %5 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1" : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3) : "v"(u0), "v"(u1));) }
         if constexpr (KIND == 10) { REP8(asm volatile("v_floor_f32 %0, %0\n v_cvt_i32_f32 %1, %1\n v_cvt_f32_i32 %2, %2\n v_floor_f32 %3, %3\n v_and_b32 %0, %0, %4\n v_lshlrev_b32 %1, 3, %1\n v_max_f32 %2, %2, %4\n v_min_f32 %3, %3, %4" : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3) : "v"(a4));) }
     }
     if (a0 + a1 + a2 + a3 + a4 + a5 + a6 + a7 + (float)(u0 + u1 + u2 + u3) == 12345.678f) out[threadIdx.x] = a0;
@@ -58,6 +60,7 @@ int main() {
     run<2>("v_cvt_f32_ubyteN", d, 64); run<5>("v_cndmask_b32", d, 64); run<6>("v_sub_u32_sdwa", d, 64); run<10>("floor/cvt/and/shl/min/max", d, 64);
     run<11>("v_cndmask_b32_e64 sgpr mask", d, 64); run<12>("v_cmp + v_cndmask vcc", d, 64); run<13>("v_cndmask vcc (no dep)", d, 64);
     run<17>("v_cmp vcc + 7 v_cndmask vcc", d, 64); run<18>("v_cmp sgpr + 7 v_cndmask e64", d, 64);
+    run<19>("v_fma_mix_f32 (f16 src)", d, 64); run<20>("v_cvt_f32_f16 (+sdwa)", d, 64);
     run<14>("v_pk_add/mul_f32", d, 64); run<15>("v_fmac_f32", d, 64); run<16>("mul clamp/floor/sub", d, 64);
     run<4>("v_rcp_f32", d, 64); run<9>("v_exp/log/sqrt_f32", d, 64); run<8>("v_mad_u64_u32", d, 64);
     return 0;
