@@ -180,8 +180,8 @@ CSKY_HD void frame_setup(const CloudParams& P, const float4* sky, int sky_w, int
 CSKY_HD float lerp_h(uint32_t p, float f) {
 #if defined(__HIP_DEVICE_COMPILE__)
     float t, r;
-    asm("v_fma_mix_f32 %0, %1, -%2, %1 op_sel:[0,0,0] op_sel_hi:[1,0,1]" : "=v"(t) : "v"(p), "v"(f));
-    asm("v_fma_mix_f32 %0, %1, %2, %3 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(r) : "v"(p), "v"(f), "v"(t));
+    asm volatile("v_fma_mix_f32 %0, %1, -%2, %1 op_sel:[0,0,0] op_sel_hi:[1,0,1]" : "=v"(t) : "v"(p), "v"(f));
+    asm volatile("v_fma_mix_f32 %0, %1, %2, %3 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(r) : "v"(p), "v"(f), "v"(t));
     return r;
 #else
     const float lo = h2f((uint16_t)(p & 0xffffu)), hi = h2f((uint16_t)(p >> 16));
@@ -204,6 +204,14 @@ CSKY_HD void weather_tap(const uint4* __restrict__ w, float sx, float sy, float&
 // arithmetically so a per-lane level needs no table (api.cpp checks it against the baked offsets)
 CSKY_HD uint32_t shape_level_offset(int l) { return ((1u << 24) - (1u << (24 - 3 * l))) / 7u; }
 CSKY_HD uint32_t detail_level_offset(int l) { return ((1u << 18) - (1u << (18 - 3 * l))) / 7u; }
+// floor + fraction of a texel coordinate
+struct TexCoord { int i; float f; };
+CSKY_HD TexCoord split_coord(float u) {
+    TexCoord c;
+    const float fl = floorf(u);
+    c.i = (int)fl; c.f = u - fl;
+    return c;
+}
 
 // REPEAT + LINEAR trilinear tap of the shape volume at integer level `lvl` (clouds.glsl:117).
 // Returns r = n.r and fbm = n.g*0.625 + n.b*0.25 + n.a*0.125 (clouds.glsl:118; exact integer numerators, filtered linearly).
@@ -215,9 +223,9 @@ CSKY_HD void shape_tap(const TexSet& T, int lvl, float sx, float sy, float sz, f
     const float ax = ux - fx0, ay = uy - fy0, az = uz - fz0;
     const int x0 = ((int)fx0) & m, y0 = ((int)fy0) & m, z0 = ((int)fz0) & m;
     const int y1 = (y0 + 1) & m, z1 = (z0 + 1) & m;
-    const uint32_t un = (uint32_t)n, base = shape_level_offset(lvl) + (uint32_t)x0;       // 32-bit offsets: one VGPR + SGPR base
-    const uint32_t r00 = ((uint32_t)z0 * un + (uint32_t)y0) * un, r10 = ((uint32_t)z0 * un + (uint32_t)y1) * un;
-    const uint32_t r01 = ((uint32_t)z1 * un + (uint32_t)y0) * un, r11 = ((uint32_t)z1 * un + (uint32_t)y1) * un;
+    const uint32_t sh = (uint32_t)(7 - lvl), base = shape_level_offset(lvl) + (uint32_t)x0;   // n = 1 << sh: shifts, not v_mul_lo_u32 (quarter rate)
+    const uint32_t r00 = ((((uint32_t)z0 << sh) | (uint32_t)y0) << sh), r10 = ((((uint32_t)z0 << sh) | (uint32_t)y1) << sh);
+    const uint32_t r01 = ((((uint32_t)z1 << sh) | (uint32_t)y0) << sh), r11 = ((((uint32_t)z1 << sh) | (uint32_t)y1) << sh);
     const char* __restrict__ sb = reinterpret_cast<const char*>(T.shape);
     const uint2 t00 = *reinterpret_cast<const uint2*>(sb + ((base + r00) << 3)), t10 = *reinterpret_cast<const uint2*>(sb + ((base + r10) << 3));
     const uint2 t01 = *reinterpret_cast<const uint2*>(sb + ((base + r01) << 3)), t11 = *reinterpret_cast<const uint2*>(sb + ((base + r11) << 3));
@@ -233,7 +241,7 @@ CSKY_HD float detail_tap(const TexSet& T, int lvl, float sx, float sy, float sz)
     const float fx0 = floorf(ux), fy0 = floorf(uy), fz0 = floorf(uz);
     const float ax = ux - fx0, ay = uy - fy0, az = uz - fz0;
     const int x0 = ((int)fx0) & m, y0 = ((int)fy0) & m, z0 = ((int)fz0) & m;
-    const uint32_t un = (uint32_t)n, idx = detail_level_offset(lvl) + ((uint32_t)z0 * un + (uint32_t)y0) * un + (uint32_t)x0;
+    const uint32_t sh = (uint32_t)(5 - lvl), idx = detail_level_offset(lvl) + ((((((uint32_t)z0 << sh) | (uint32_t)y0) << sh)) | (uint32_t)x0);
     const uint4 q = *reinterpret_cast<const uint4*>(reinterpret_cast<const char*>(T.detail) + (idx << 4));
     return lerpf(lerpf(lerp_h(q.x, ax), lerp_h(q.y, ax), ay), lerpf(lerp_h(q.z, ax), lerp_h(q.w, ax), ay), az) * (1.0f / (8.0f * 255.0f));
 }
