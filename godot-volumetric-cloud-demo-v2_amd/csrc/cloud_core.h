@@ -285,13 +285,14 @@ CSKY_HD float density(const TexSet& T, const FrameConsts& fc, float px, float py
     shape_tap(T, lod_shape, sx, sy, sz, nr, fbm);                           // :117-118
     const float omf = 1.0f - fbm;
     float base = (nr + omf) * fast_rcp(1.0f + omf);                         // :122 remap(n.r, -(1-fbm), 1, 0, 1)
-    base = (base * g - omw) * fast_rcp(1.0f - omw);                         // :124
-    base *= wc;                                                             // :125
+    // :124-125: remap(base*g, 1-wc, 1, 0, 1) * wc = (base*g - omw) / (1 - omw) * wc.  In fp32 1 - omw = 1 - (1 - wc) equals wc up to
+    // one rounding of 1 - wc, i.e. the factor wc / (1 - omw) is 1 + O(6e-8 / wc): dropped (same sign, relative change < 1e-6)
+    base = base * g - omw;
     if (!(base > 0.0f)) return 0.0f;                                        // exact reject (2)
     detail_coord(fc, qx, qy, qz, sx, sy, sz);                               // :128-129
     float hfbm = detail_tap(T, lod_detail, sx, sy, sz);                     // :132-133
     const float k = sat(hf * 4.0f);
-    hfbm = hfbm * (1.0f - k) + (1.0f - hfbm) * k;                           // :134
+    hfbm = hfbm + k * (1.0f - 2.0f * hfbm);                                 // :134 mix(hfbm, 1-hfbm, k)
     const float hm = hfbm * 0.4f * hf;
     base = (base - hm) * fast_rcp(1.0f - hm);                               // :135
     return fast_pow(sat(base), (1.0f - hf) * 0.8f + 0.5f);                  // :136
