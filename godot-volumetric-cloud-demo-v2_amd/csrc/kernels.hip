@@ -27,15 +27,37 @@ __global__ __launch_bounds__(64) void transmittance_kernel(int w, int h, uint16_
 }
 
 struct Sun3 { float v[3]; };
-__global__ __launch_bounds__(64) void sky_lut_kernel(int w, int h, Sun3 sun, const float4* __restrict__ trans, int tw, int th,
+// sky-lut.glsl: one texel per HALF wavefront: lanes 0..29 evaluate the 30 in-scattering steps in parallel (each step is
+// ~600 VALU with 20 LUT loads and 12 transcendentals and independent of the others), park source term + transmittance
+// in LDS, then lane 0 of the half replays the front-to-back accumulation in the reference's order (bit-identical to the
+// one-lane-per-texel form, 4x shorter critical path: this kernel sits on the critical path of every frame).
+__global__ __launch_bounds__(256) void sky_lut_kernel(int w, int h, Sun3 sun, const float4* __restrict__ trans, int tw, int th,
                                                      uint16_t* __restrict__ out_h, float4* __restrict__ out_f) {
-    const int px = blockIdx.x * 8 + (threadIdx.x & 7), py = blockIdx.y * 8 + (threadIdx.x >> 3);  // dispatch 25x13, sky_lut.gd:140
-    if (px >= w || py >= h) return;  // rows 100..103 of the reference dispatch are discarded image stores (S:281)
-    const F4 c = sky_texel(px, py, (float)w, (float)h, sun.v, trans, tw, th);
-    const uint16_t hx = f2h(c.x), hy = f2h(c.y), hz = f2h(c.z), hw = f2h(c.w);
-    const size_t i = (size_t)py * w + px;
-    reinterpret_cast<uint2*>(out_h)[i] = make_uint2((uint32_t)hx | ((uint32_t)hy << 16), (uint32_t)hz | ((uint32_t)hw << 16));
-    out_f[i] = make_float4(h2f(hx), h2f(hy), h2f(hz), h2f(hw));
+    __shared__ float steps[8][IN_SCATTERING_STEPS][8];
+    const int half = threadIdx.x >> 5, sub = threadIdx.x & 31;
+    const int texel = blockIdx.x * 8 + half;                      // rows 100..103 of the reference dispatch are discarded stores (S:281)
+    const bool live = texel < w * h;
+    const int px = live ? texel % w : 0, py = live ? texel / w : 0;
+    const SkyRay r = sky_ray(px, py, (float)w, (float)h, sun.v);
+    if (sub < IN_SCATTERING_STEPS) {
+        const SkyStep s = sky_step(r, sub, trans, tw, th);
+        float* d = steps[half][sub];
+        d[0] = s.S_int.x; d[1] = s.S_int.y; d[2] = s.S_int.z; d[3] = s.S_int.w;
+        d[4] = s.step_tr.x; d[5] = s.step_tr.y; d[6] = s.step_tr.z; d[7] = s.step_tr.w;
+    }
+    __syncthreads();
+    if (sub == 0 && live) {
+        F4 L = f4(0, 0, 0, 0), Tr = f4(1, 1, 1, 1);
+        for (int i = 0; i < IN_SCATTERING_STEPS; ++i) {
+            const float* d = steps[half][i];
+            SkyStep s; s.S_int = f4(d[0], d[1], d[2], d[3]); s.step_tr = f4(d[4], d[5], d[6], d[7]);
+            sky_accumulate(L, Tr, s);
+        }
+        const F4 c = sky_output(L);
+        const uint16_t hx = f2h(c.x), hy = f2h(c.y), hz = f2h(c.z), hw = f2h(c.w);
+        reinterpret_cast<uint2*>(out_h)[texel] = make_uint2((uint32_t)hx | ((uint32_t)hy << 16), (uint32_t)hz | ((uint32_t)hw << 16));
+        out_f[texel] = make_float4(h2f(hx), h2f(hy), h2f(hz), h2f(hw));
+    }
 }
 
 hipError_t launch_transmittance(int w, int h, uint16_t* d_half, float4* d_float, hipStream_t s) {
@@ -45,7 +67,7 @@ hipError_t launch_transmittance(int w, int h, uint16_t* d_half, float4* d_float,
 hipError_t launch_sky_lut(int w, int h, const float sun[3], const float4* d_trans, int tw, int th, uint16_t* d_half, float4* d_float,
                           hipStream_t s) {
     Sun3 sv; sv.v[0] = sun[0]; sv.v[1] = sun[1]; sv.v[2] = sun[2];
-    sky_lut_kernel<<<dim3((w + 7) / 8, (h + 7) / 8), 64, 0, s>>>(w, h, sv, d_trans, tw, th, d_half, d_float);
+    sky_lut_kernel<<<(w * h + 7) / 8, 256, 0, s>>>(w, h, sv, d_trans, tw, th, d_half, d_float);
     return hipGetLastError();
 }
 

@@ -87,57 +87,75 @@ CSKY_HD F4 transmittance_from_lut(const float4* t, int tw, int th, float cos_the
     return lut_tap_clamp(t, tw, th, sat(cos_theta * 0.5f + 0.5f), sat(normalized_altitude));
 }
 
-// S:278-315 main() for texel (px,py); sun = params.sun_direction (S:16).  Returns linear sRGB, alpha 1.
-CSKY_HD F4 sky_texel(int px, int py, float w, float h, const float sun[3], const float4* trans, int tw, int th) {
-    const float uvx = (float)px / w, uvy = (float)py / h;
-    const float azimuth = (float)(2.0 * LUT_PI) * uvx;
-    const float l = uvy * 2.0f - 1.0f;
-    const float elev = l * l * signf(l) * (float)LUT_PI * 0.5f;
-    const float rdx = cosf(elev) * cosf(azimuth), rdy = cosf(elev) * sinf(azimuth), rdz = sinf(elev);
-    const float oz = 6371.5f;                                                        // S:61-62
-    const float atmos_dist = ray_sphere_intersection(0, 0, oz, rdx, rdy, rdz, ATMOSPHERE_RADIUS);
-    const float ground_dist = ray_sphere_intersection(0, 0, oz, rdx, rdy, rdz, EARTH_RADIUS);
-    const float t_d = (ground_dist < 0.0f) ? atmos_dist : ground_dist;               // S:303-309
-    // compute_inscattering, S:219-276
-    const float sdx = -sun[0], sdy = -sun[2], sdz = sun[1];                          // S:221-223
-    const float cos_theta = (-rdx) * sdx + (-rdy) * sdy + (-rdz) * sdz;              // S:224
-    const float molecular_phase = (float)((3.0 / 16.0) * (1.0 / LUT_PI)) * (1.0f + cos_theta * cos_theta);  // S:114-117
-    const float den = (float)(1.0 + 0.8 * 0.8) + (float)(2.0 * 0.8) * cos_theta;     // S:124
-    const float aerosol_phase = (float)(0.25 * (1.0 / LUT_PI)) * (1.0f - (float)(0.8 * 0.8)) / (den * sqrtf(den));  // S:125
-    const float dt = t_d / (float)IN_SCATTERING_STEPS;
-    F4 L = f4(0, 0, 0, 0), Tr = f4(1, 1, 1, 1);
+// sky-lut.glsl main() (S:278-315) + compute_inscattering (S:219-276), split so that the 30 in-scattering steps of one
+// texel can be evaluated by 30 lanes in parallel: every step's source term and transmittance are independent of the
+// others; only the front-to-back accumulation (S:271-272) is sequential, and it is replayed in the reference's order.
+struct SkyRay { float rdx, rdy, rdz, oz, dt, sdx, sdy, sdz, molecular_phase, aerosol_phase; };
+struct SkyStep { F4 S_int, step_tr; };
+
+CSKY_HD SkyRay sky_ray(int px, int py, float w, float h, const float sun[3]) {
+    SkyRay r;
+    const float uvx = (float)px / w, uvy = (float)py / h;                             // S:284
+    const float azimuth = (float)(2.0 * LUT_PI) * uvx;                                // S:286
+    const float l = uvy * 2.0f - 1.0f;                                                // S:290
+    const float elev = l * l * signf(l) * (float)LUT_PI * 0.5f;                       // S:291
+    r.rdx = cosf(elev) * cosf(azimuth); r.rdy = cosf(elev) * sinf(azimuth); r.rdz = sinf(elev);   // S:293-295
+    r.oz = 6371.5f;                                                                   // S:61-62
+    const float atmos_dist = ray_sphere_intersection(0, 0, r.oz, r.rdx, r.rdy, r.rdz, ATMOSPHERE_RADIUS);
+    const float ground_dist = ray_sphere_intersection(0, 0, r.oz, r.rdx, r.rdy, r.rdz, EARTH_RADIUS);
+    const float t_d = (ground_dist < 0.0f) ? atmos_dist : ground_dist;                // S:303-309
+    r.sdx = -sun[0]; r.sdy = -sun[2]; r.sdz = sun[1];                                 // S:221-223
+    const float cos_theta = (-r.rdx) * r.sdx + (-r.rdy) * r.sdy + (-r.rdz) * r.sdz;   // S:224
+    r.molecular_phase = (float)((3.0 / 16.0) * (1.0 / LUT_PI)) * (1.0f + cos_theta * cos_theta);  // S:114-117
+    const float den = (float)(1.0 + 0.8 * 0.8) + (float)(2.0 * 0.8) * cos_theta;      // S:124
+    r.aerosol_phase = (float)(0.25 * (1.0 / LUT_PI)) * (1.0f - (float)(0.8 * 0.8)) / (den * sqrtf(den));  // S:125
+    r.dt = t_d / (float)IN_SCATTERING_STEPS;                                          // S:229
+    return r;
+}
+
+// one iteration of the loop at S:234-273, up to (not including) the accumulation
+CSKY_HD SkyStep sky_step(const SkyRay& r, int i, const float4* trans, int tw, int th) {
+    const float dt = r.dt;
+    const float t = ((float)i + 0.5f) * dt;
+    const float x = 0.0f + r.rdx * t, y = 0.0f + r.rdy * t, z = r.oz + r.rdz * t;
+    const float dist = sqrtf(x * x + y * y + z * z);
+    const float zx = x / dist, zy = y / dist, zz = z / dist;
+    const float altitude = dist - EARTH_RADIUS;
+    const float nalt = altitude / ATMOSPHERE_THICKNESS;
+    const float sct = zx * r.sdx + zy * r.sdy + zz * r.sdz;                          // S:243
+    const Coeffs cf = atmosphere_collision_coefficients(altitude);
+    const F4 t_sun = transmittance_from_lut(trans, tw, th, sct, nalt);               // S:254
+    // get_multiple_scattering, S:144-164
+    const float omega = (float)(2.0 * LUT_PI) * (1.0f - sqrtf(dist * dist - EARTH_RADIUS * EARTH_RADIUS) / dist);
+    const F4 T_to_ground = transmittance_from_lut(trans, tw, th, sct, 0.0f);
+    const F4 T_g2s = transmittance_from_lut(trans, tw, th, 1.0f, 0.0f) / transmittance_from_lut(trans, tw, th, 1.0f, nalt);
+    const float ks = (float)(0.25 * (1.0 / LUT_PI)) * omega * (float)(0.3 / LUT_PI);
+    const F4 L_ground = f4(ks, ks, ks, ks) * T_to_ground * T_g2s * sct;
+    const float fm = 1.0f / (1.0f + 5.0f * expf(-17.92f * sct));
+    const F4 L_ms = f4((float)(0.02 * 0.217), (float)(0.02 * 0.347), (float)(0.02 * 0.594), (float)(0.02 * 1.0)) * fm;
+    const F4 ms = L_ms + L_ground;
     const F4 irr = f4(1.679f, 1.828f, 1.986f, 1.307f);                               // S:67
-    for (int i = 0; i < IN_SCATTERING_STEPS; ++i) {
-        const float t = ((float)i + 0.5f) * dt;
-        const float x = 0.0f + rdx * t, y = 0.0f + rdy * t, z = oz + rdz * t;
-        const float dist = sqrtf(x * x + y * y + z * z);
-        const float zx = x / dist, zy = y / dist, zz = z / dist;
-        const float altitude = dist - EARTH_RADIUS;
-        const float nalt = altitude / ATMOSPHERE_THICKNESS;
-        const float sct = zx * sdx + zy * sdy + zz * sdz;                            // S:243
-        const Coeffs cf = atmosphere_collision_coefficients(altitude);
-        const F4 t_sun = transmittance_from_lut(trans, tw, th, sct, nalt);           // S:254
-        // get_multiple_scattering, S:144-164
-        const float omega = (float)(2.0 * LUT_PI) * (1.0f - sqrtf(dist * dist - EARTH_RADIUS * EARTH_RADIUS) / dist);
-        const F4 T_to_ground = transmittance_from_lut(trans, tw, th, sct, 0.0f);
-        const F4 T_g2s = transmittance_from_lut(trans, tw, th, 1.0f, 0.0f) / transmittance_from_lut(trans, tw, th, 1.0f, nalt);
-        const float ks = (float)(0.25 * (1.0 / LUT_PI)) * omega * (float)(0.3 / LUT_PI);
-        const F4 L_ground = f4(ks, ks, ks, ks) * T_to_ground * T_g2s * sct;
-        const float fm = 1.0f / (1.0f + 5.0f * expf(-17.92f * sct));
-        const F4 L_ms = f4((float)(0.02 * 0.217), (float)(0.02 * 0.347), (float)(0.02 * 0.594), (float)(0.02 * 1.0)) * fm;
-        const F4 ms = L_ms + L_ground;
-        const F4 S = irr * (cf.molecular_scattering * (t_sun * molecular_phase + ms) + cf.aerosol_scattering * (t_sun * aerosol_phase + ms));  // S:261-263
-        const F4 step_tr = exp4(cf.extinction * (-dt));                              // S:265
-        const F4 ext_c = f4(fmaxf(cf.extinction.x, 1e-7f), fmaxf(cf.extinction.y, 1e-7f), fmaxf(cf.extinction.z, 1e-7f), fmaxf(cf.extinction.w, 1e-7f));
-        const F4 S_int = (S - S * step_tr) / ext_c;                                  // S:270
-        L = L + Tr * S_int;
-        Tr = Tr * step_tr;
-    }
-    // S:207-217: mat4x3 M (column-major, 4 columns of 3)
+    const F4 S = irr * (cf.molecular_scattering * (t_sun * r.molecular_phase + ms) + cf.aerosol_scattering * (t_sun * r.aerosol_phase + ms));  // S:261-263
+    SkyStep o;
+    o.step_tr = exp4(cf.extinction * (-dt));                                         // S:265
+    const F4 ext_c = f4(fmaxf(cf.extinction.x, 1e-7f), fmaxf(cf.extinction.y, 1e-7f), fmaxf(cf.extinction.z, 1e-7f), fmaxf(cf.extinction.w, 1e-7f));
+    o.S_int = (S - S * o.step_tr) / ext_c;                                           // S:270
+    return o;
+}
+CSKY_HD void sky_accumulate(F4& L, F4& Tr, const SkyStep& s) { L = L + Tr * s.S_int; Tr = Tr * s.step_tr; }   // S:271-272
+// S:207-217: mat4x3 M (column-major, 4 columns of 3), S:313
+CSKY_HD F4 sky_output(const F4& L) {
     const float r = 137.672389239975f * L.x + 32.549094028629234f * L.y + -38.91428392614275f * L.z + 8.572844237945445f * L.w;
     const float g = -8.632904716299537f * L.x + 91.29801417199785f * L.y + 34.31665471469816f * L.z + -11.103384660054624f * L.w;
     const float b = -1.7181567391931372f * L.x + -12.005406444382531f * L.y + 29.89044807197628f * L.z + 117.47585277566478f * L.w;
     return f4(r, g, b, 1.0f);
+}
+// the whole texel on one lane (host-compiled unit test; the kernel spreads the steps over lanes)
+CSKY_HD F4 sky_texel(int px, int py, float w, float h, const float sun[3], const float4* trans, int tw, int th) {
+    const SkyRay r = sky_ray(px, py, w, h, sun);
+    F4 L = f4(0, 0, 0, 0), Tr = f4(1, 1, 1, 1);
+    for (int i = 0; i < IN_SCATTERING_STEPS; ++i) sky_accumulate(L, Tr, sky_step(r, i, trans, tw, th));
+    return sky_output(L);
 }
 
 }  // namespace csky
