@@ -153,7 +153,8 @@ int csky_set_variant(csky_ctx* ctx, int variant);
  * 0 disables it (A/B measurement, identical results). */
 int csky_set_height_window(csky_ctx* ctx, int enabled);
 int csky_variant_count(void);
-/* Workgroup -> XCD schedule (tuning knob, results are identical): 5 = slab rows round-robin over the XCDs (default);
+/* Workgroup -> XCD schedule (tuning knob, results are identical): -1 = auto (default: 5 for large launches, 2 for small);
+ * 5 = slab rows round-robin over the XCDs;
  * 1 = contiguous eighths; 2 = natural order; 0/3/4 = azimuth wedges; 6 = 5 with horizon rows first. */
 int csky_set_schedule(csky_ctx* ctx, int mode);
 /* Ray segments: the primary march of every ray is cut into `segments` pieces marched by different wavefronts of one

@@ -84,7 +84,7 @@ def test_variants_and_schedules_agree(gpu_ctx, oracle):
     ok, info = cloud_close(imgs[1][0], imgs[0][0], frac=0.9999, atol=5e-4, rtol=2e-3)
     assert ok, info
     assert imgs[0][1] == imgs[1][1]
-    gpu_ctx.set_variant(1); gpu_ctx.set_schedule(5)
+    gpu_ctx.set_variant(1); gpu_ctx.set_schedule(-1)
     # ray segments (1, 2, 4 wavefronts per ray): identical sample positions and in-cloud counts, re-associated compositing
     for seg in (1, 2, 4):
         gpu_ctx.set_segments(seg)
@@ -94,7 +94,7 @@ def test_variants_and_schedules_agree(gpu_ctx, oracle):
             ok, info = cloud_close(img, imgs[1][0], frac=0.9999, atol=5e-4, rtol=2e-3)
             assert ok, (seg, info)
             assert gpu_ctx.cloud_stats() == imgs[1][1], seg
-    gpu_ctx.set_segments(0); gpu_ctx.set_schedule(5)
+    gpu_ctx.set_segments(0); gpu_ctx.set_schedule(-1)
 
 
 def test_clouds_vs_numpy_fixture(gpu_ctx, oracle):

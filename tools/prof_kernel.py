@@ -15,7 +15,7 @@ ap = argparse.ArgumentParser()
 ap.add_argument("--config", default="C3")
 ap.add_argument("--frames", type=int, default=5)
 ap.add_argument("--variant", type=int, default=1)
-ap.add_argument("--sched", type=int, default=5)
+ap.add_argument("--sched", type=int, default=-1)
 ap.add_argument("--early-out", type=float, default=0.0)
 ap.add_argument("--coverage", type=float, default=0.2)
 ap.add_argument("--time", action="store_true", help="print csky_time_clouds mean ms for every variant")
