@@ -89,13 +89,21 @@ def main():
         raise SystemExit("bench.py: --gpus %d but WORLD_SIZE=%d (launch N>1 with torch.distributed.run)" % (args.gpus, world))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py: no GPU visible; the cloud path has no CPU fallback")
+    # CSKY_BENCH_ONE_GPU_DEBUG=1: every rank renders on cuda:0 and the gather goes through gloo on host copies.  It exists
+    # only to exercise the N > 1 code path (band split, gather, interleave) on a single-GPU box; its number is meaningless.
+    debug_one_gpu = os.environ.get("CSKY_BENCH_ONE_GPU_DEBUG") == "1"
+    if debug_one_gpu:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     dist = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if debug_one_gpu:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
     W, H, primary, light, sun = CONFIGS[args.config]
     params, sun_n = default_params(W, H, sun)
@@ -114,16 +122,24 @@ def main():
     mb = tiling.max_bands(H, world)
     local = torch.zeros((mb * tiling.BAND_ROWS, W, 4), dtype=torch.int16, device=dev)
     local_b = local.view(torch.uint8)   # collectives move raw bytes (RCCL has no int16 type)
-    parts = [torch.empty_like(local_b) for _ in range(world)] if (world > 1 and rank == 0) else None
+    # rank 0 gathers straight into one [world, rows, W, 4] tensor (no per-frame stack/copy before the band interleave)
+    gathered = torch.empty((world,) + tuple(local.shape), dtype=torch.int16, device=dev) if (world > 1 and rank == 0) else None
+    parts = [gathered[i].view(torch.uint8) for i in range(world)] if gathered is not None else None
     frame = [None]
 
     def step():
         ctx.render_sky_lut_device(sun_n, 200, 100, stream)                               # sky_lut.gd:122-148
         ctx.render_clouds_device(params, W, bands, local.data_ptr(), W * 8, stream)      # cloud_sky.gd:234-248
-        if world > 1:
+        if world > 1 and debug_one_gpu:
+            host = local_b.cpu()
+            hparts = [torch.empty_like(host) for _ in range(world)] if rank == 0 else None
+            dist.gather(host, gather_list=hparts, dst=0)
+            if rank == 0:
+                frame[0] = tiling.interleave(torch.stack(hparts, 0).view(torch.int16).to(dev), H, world)
+        elif world > 1:
             dist.gather(local_b, gather_list=parts, dst=0)
             if rank == 0:
-                frame[0] = tiling.interleave(torch.stack(parts, 0).view(torch.int16), H, world)
+                frame[0] = tiling.interleave(gathered, H, world)
         else:
             frame[0] = local
 
@@ -140,7 +156,7 @@ def main():
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if debug_one_gpu else dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
@@ -156,6 +172,17 @@ def main():
         fr = frame[0].view(torch.float16)
         alpha_mean = float(fr[..., 3].float().mean().item())
         finite = bool(torch.isfinite(fr.float()).all().item())
+        if debug_one_gpu and world > 1:   # the gathered frame must equal a single-context full-frame render
+            full = torch.zeros((H, W, 4), dtype=torch.int16, device=dev)
+            ctx.render_clouds_device(params, W, (H, 0, 1, 1), full.data_ptr(), W * 8, stream)
+            torch.cuda.synchronize()
+            a, b = full.view(torch.float16).float(), frame[0].view(torch.float16).float()
+            err = (a - b).abs()
+            ok = float((err <= 5e-4 + 2e-3 * a.abs()).float().mean().item())
+            print("debug: gathered %d-rank frame vs single-rank frame: max|d| = %.3g, within 1 fp16 ulp-ish: %.6f "
+                  "(segmented small launches re-associate the compositing sums)" % (world, float(err.max().item()), ok), file=sys.stderr, flush=True)
+            if ok < 0.9999:
+                raise SystemExit("bench.py: multi-rank frame differs from the single-rank frame")
         traffic = None
         pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")   # written from the committed rocprofv3 --pmc passes (tools/summarize_prof.py)
         traffic_note = "not collected in this run"

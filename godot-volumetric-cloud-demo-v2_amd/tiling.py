@@ -54,8 +54,8 @@ def render_sharded(render_bands, height, width, rank, world, dist=None, device=N
     # the collective moves raw bytes: neither RCCL nor gloo has a 16-bit integer type, uint8 works on both
     lb = local.view(torch.uint8)
     if rank == 0:
-        parts = [torch.empty_like(lb) for _ in range(world)]
-        dist.gather(lb, gather_list=parts, dst=0)
-        return interleave(torch.stack(parts, 0).view(local.dtype), height, world, band_rows)
+        gathered = torch.empty((world,) + tuple(local.shape), dtype=local.dtype, device=local.device)
+        dist.gather(lb, gather_list=[gathered[i].view(torch.uint8) for i in range(world)], dst=0)
+        return interleave(gathered, height, world, band_rows)
     dist.gather(lb, gather_list=None, dst=0)
     return None
