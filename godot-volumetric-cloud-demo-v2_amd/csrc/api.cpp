@@ -111,7 +111,7 @@ int check_bands(csky_ctx* c, const csky_bands* b, int tile_w) {
 //               but consecutive workgroups are not neighbours                                                   5.3-5.8 ms
 //   6 = 5 with the rows farthest from the zenith row first                                                          4.77 ms
 int build_schedule(csky_ctx* c, const CloudParams& p, const RenderGeom& g, int seg, int mode, hipStream_t s) {
-    const int bw = 32 / seg;                          // workgroup footprint = bw x 8 pixels
+    const int bw = seg == 5 ? 8 : 32 / seg;           // workgroup footprint = bw x 8 pixels (seg 5 = 4 interleaved segments: one tile)
     const int tiles_x = (g.tile_w + bw - 1) / bw, local_rows = g.n_bands * g.band_rows, slabs = (local_rows + 7) >> 3;
     const int nblocks = tiles_x * slabs;
     const long long key[11] = {g.tile_w, g.band_rows, g.first_band, g.band_stride, g.n_bands, (long long)p.texture_size[0], (long long)p.texture_size[1],
@@ -205,13 +205,16 @@ int clouds_dev(csky_ctx* c, const csky_cloud_params* p, int tile_w, const csky_b
     RenderGeom g; g.tile_w = tile_w; g.band_rows = b->band_rows; g.first_band = b->first_band; g.band_stride = b->band_stride; g.n_bands = b->n_bands;
     g.pitch_px = (uint32_t)(pitch_bytes / 8);
     // ray segments: more, shorter wavefronts when the launch is too small to fill the chip with whole-ray wavefronts
-    // Small launches (one GPU's share of a frame split 4-8 ways) cannot fill the chip with whole-ray wavefronts: cut rays into
-    // segments and deal workgroups to the XCDs one by one (measured on the 1/8 frame: 0.88 ms -> 0.80 ms); large launches
-    // keep whole rays and row-wise XCD locality (3.2 ms vs 4.3 ms with segments, 3.2 ms vs 4.2 ms with natural order).
+    // Launch-size policy (measured, tools/crossover.py, kernel ms at 256 / 1024 / 4096 / 8192 / 32768 tiles of 8x8 rays):
+    //   whole rays, slab rows per XCD (seg 1, sched 5)      0.68  0.75  0.86  1.23  3.13   <- throughput: large launches
+    //   4 step-range segments, natural order (seg 4, 2)     0.29  0.39  0.79  1.28  4.56   <- one GPU's 1/8 .. 1/4 of a frame
+    //   4 interleaved segments, natural order (seg 5, 2)    0.18  0.34  0.87  1.67  6.44   <- latency: the reference's 96x96 tiles
+    // A lone wavefront is bound by its chain of dependent gathers (~0.5 us per primary step, ~1.7 us per light-march round),
+    // so small launches want more, shorter wavefronts; large launches want the fewest instructions.
     const long long waves = ((long long)(tile_w + 7) / 8) * (((long long)b->n_bands * b->band_rows + 7) / 8);
     int seg = c->variant == 1 ? c->segments : 1;
-    if (c->variant == 1 && seg == 0) seg = waves >= 16384 ? 1 : (waves >= 8192 ? 2 : 4);
-    const int mode = c->sched_mode >= 0 ? c->sched_mode : (waves >= 8192 ? 5 : 2);
+    if (c->variant == 1 && seg == 0) seg = waves >= 6144 ? 1 : (waves >= 1536 ? 4 : 5);
+    const int mode = c->sched_mode >= 0 ? c->sched_mode : (waves >= 6144 ? 5 : 2);
     if ((rc = build_schedule(c, cp, g, seg, mode, s))) return rc;
     HIPCHK(c, launch_clouds(c->variant, seg, texset(c), c->d_fc, g, c->d_order, c->order_grid, d_out, d_stats, s));
     return CSKY_OK;
@@ -322,7 +325,7 @@ int csky_set_schedule(csky_ctx* c, int mode) {
 }
 int csky_set_segments(csky_ctx* c, int segments) {
     if (!c) return fail(nullptr, CSKY_ERR_INVALID, "csky_set_segments: ctx is NULL");
-    if (segments != 0 && segments != 1 && segments != 2 && segments != 4) return fail(c, CSKY_ERR_INVALID, "csky_set_segments: 0 (auto), 1, 2 or 4");
+    if (segments != 0 && segments != 1 && segments != 2 && segments != 4 && segments != 5) return fail(c, CSKY_ERR_INVALID, "csky_set_segments: 0 (auto), 1, 2, 4 (step ranges) or 5 (4 interleaved)");
     c->segments = segments; return CSKY_OK;
 }
 int csky_set_height_window(csky_ctx* c, int enabled) {

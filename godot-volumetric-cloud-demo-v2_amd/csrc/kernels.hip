@@ -244,6 +244,172 @@ __device__ __forceinline__ MarchOut march_queue(const TexSet& T, const FrameCons
     return o;
 }
 
+// ---- interleaved ray segments (small launches) ------------------------------------------------------------------
+// One workgroup = ONE 8x8 tile; wavefront w marches the primary samples i = 4m + w of every ray of the tile.  In-cloud
+// samples cluster in a few step ranges of a ray, so splitting a ray by step RANGE leaves one wavefront with most of the
+// light march; dealing the steps out round-robin gives all four SIMDs of the CU a quarter of the tile's light march
+// (the heaviest tile of the headline frame has 4.2x the mean in-cloud samples and is the critical path of a launch that
+// holds only a few wavefronts per SIMD: one GPU's share of a frame split 8 ways).
+// Front-to-back compositing needs T_i = prod_{k<i} dt_k across ALL wavefronts' samples: per chunk of 32 steps every
+// wavefront publishes the step transmittances dt of its samples (1 for samples outside cloud), 16 lanes per wavefront
+// scan them into exclusive prefix products, and each wavefront then shades its own samples with L_w += T_i * (...).
+// The partial L_w are summed in wavefront order and alpha = 1 - T_end (clouds.glsl:207 is the same product).  Sample
+// positions and densities are bit-identical to the sequential march; only the compositing sums are re-associated.
+constexpr int IL_CHUNK = 32, IL_OWN = IL_CHUNK / 4, IL_BATCH = 96;
+constexpr int IL_WAVE_FLOATS = 5 * IL_OWN * 64 + (IL_OWN * 64) / 2 + 7 * IL_BATCH;     // dense px,py,pz,t,hf | idx (u16) | lt
+constexpr int IL_BLOCK_FLOATS = 4 * IL_WAVE_FLOATS + 2 * IL_CHUNK * 64 + 4 * 4 * 64;     // + D, P planes + combine
+
+__device__ __forceinline__ void march_interleaved(const TexSet& T, const FrameConsts& fc, const Ray& ray, float* __restrict__ smem, int wave, int lane,
+                                                  float& out_r, float& out_g, float& out_b, float& out_a, unsigned& incloud) {
+    float* __restrict__ wq = smem + wave * IL_WAVE_FLOATS;
+    float* __restrict__ d_px = wq;                              // [IL_OWN][64]; reused for cd after the light march
+    float* __restrict__ d_py = wq + IL_OWN * 64;
+    float* __restrict__ d_pz = wq + 2 * IL_OWN * 64;
+    float* __restrict__ d_t = wq + 3 * IL_OWN * 64;
+    float* __restrict__ d_hf = wq + 4 * IL_OWN * 64;
+    unsigned short* __restrict__ ev_idx = reinterpret_cast<unsigned short*>(wq + 5 * IL_OWN * 64);   // [IL_OWN*64]
+    float* __restrict__ lt = wq + 5 * IL_OWN * 64 + (IL_OWN * 64) / 2;                                  // [7][IL_BATCH]
+    float* __restrict__ D = smem + 4 * IL_WAVE_FLOATS;          // [IL_CHUNK][64] step transmittance of every sample of the chunk
+    float* __restrict__ P = D + IL_CHUNK * 64;                  // [IL_CHUNK][64] exclusive prefix products
+    float* __restrict__ comb = P + IL_CHUNK * 64;               // [4][4][64]
+
+    const int steps = fc.primary_steps, ls = fc.light_steps, nl = ls + 1;
+    const float nd = -fc.density;
+    float phase = 0.0f;
+    if (ray.above) {
+        const float ct = fc.ldir[0] * ray.dx + fc.ldir[1] * ray.dy + fc.ldir[2] * ray.dz;
+        phase = fmaxf(fmaxf(henyey_greenstein(ct, 0.6f), henyey_greenstein(ct, fc.hg_g2)), henyey_greenstein(ct, -0.2f));
+    }
+    float Lr = 0.0f, Lg = 0.0f, Lb = 0.0f;
+    float px = ray.px, py = ray.py, pz = ray.pz;
+    int replay = wave + 1;                                      // additions of dir*ss needed to reach this wavefront's next sample
+    float carry = 1.0f;                                         // scan lanes (lane < 16): T of ray 16*wave + lane after the chunks so far
+    incloud = 0;
+    const int nchunks = (steps + IL_CHUNK - 1) / IL_CHUNK;
+    for (int c = 0; c < nchunks; c++) {
+        // ---- A: this wavefront's 8 samples of the chunk
+        int count = 0;
+        for (int q = 0; q < IL_OWN; q++) {
+            const int i = c * IL_CHUNK + 4 * q + wave;
+            float t = 0.0f, hf = 0.0f;
+            if (ray.above && i < steps) {
+                for (int a = 0; a < replay; a++) advance(px, py, pz, ray.sx, ray.sy, ray.sz);     // clouds.glsl:173, one add per step
+                hf = height_fraction(length3_exact(px, py, pz));
+                t = sample_density(T, fc, px, py, pz, hf, fc.wpos_x, fc.wpos_y, 0, 0);
+            }
+            replay = 4;
+            const bool have = t > 0.0f;
+            d_t[q * 64 + lane] = t;
+            D[(4 * q + wave) * 64 + lane] = have ? fast_exp(nd * t * ray.ss) : 1.0f;               // clouds.glsl:178
+            const unsigned long long m = __ballot(have);
+            if (m != 0ull) {
+                const int slot = count + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));
+                if (have) { ev_idx[slot] = (unsigned short)(q * 64 + lane); d_px[q * 64 + lane] = px; d_py[q * 64 + lane] = py; d_pz[q * 64 + lane] = pz; d_hf[q * 64 + lane] = hf; }
+                count += __popcll(m);
+            }
+        }
+        wave_lds_fence();
+        // ---- B: light march of the chunk's events, IL_BATCH events at a time, 64 evaluations per round
+        for (int b0 = 0; b0 < count; b0 += IL_BATCH) {
+            const int nb = (count - b0) < IL_BATCH ? (count - b0) : IL_BATCH;
+            const int total = nb * nl;
+            const float rn = 1.0f / (float)nb;
+            for (int e0 = 0; e0 < total; e0 += 64) {
+                const int e = e0 + lane;
+                if (e < total) {
+                    const int j = (int)(((float)e + 0.5f) * rn);
+                    const int k = e - j * nb;
+                    const int id = ev_idx[b0 + k];
+                    float lx = d_px[id], ly = d_py[id], lz = d_pz[id];
+                    const bool distant = (j == ls);
+                    const int j_lo = __builtin_amdgcn_readfirstlane(j);
+                    if (distant) {
+                        advance(lx, ly, lz, fc.ldist[0], fc.ldist[1], fc.ldist[2]);
+                    } else {
+#pragma unroll
+                        for (int jj = 0; jj < 6; jj++) {
+                            if (jj <= j_lo) advance(lx, ly, lz, fc.linc[jj][0], fc.linc[jj][1], fc.linc[jj][2]);
+                            else if (jj <= j) advance(lx, ly, lz, fc.linc[jj][0], fc.linc[jj][1], fc.linc[jj][2]);
+                        }
+                    }
+                    const float lhf = height_fraction(length3_exact(lx, ly, lz));
+                    const int lod_s = distant ? 3 : (j > 2 ? j - 2 : 0), lod_d = distant ? 5 : j;
+                    float d = sample_density(T, fc, lx, ly, lz, lhf, distant ? 0.0f : fc.wpos_x, distant ? 0.0f : fc.wpos_y, lod_s, lod_d);
+                    if (distant) d = fast_pow(d, (1.0f - lhf) * 0.8f + 0.5f);
+                    lt[j * IL_BATCH + k] = d;
+                }
+            }
+            wave_lds_fence();
+            for (int k = lane; k < nb; k += 64) {               // cd of each event, summed in the reference's order (:191, :199)
+                float cd = 0.0f;
+                for (int j = 0; j < nl; j++) cd += lt[j * IL_BATCH + k];
+                d_px[ev_idx[b0 + k]] = cd;                      // the position is consumed: its x slot now holds cd
+            }
+            wave_lds_fence();
+        }
+        __syncthreads();
+        // ---- scan: exclusive prefix products of the chunk's step transmittances, 16 rays per wavefront
+        if (lane < 16) {
+            const int r = wave * 16 + lane;
+            float Tp = carry;
+            for (int s = 0; s < IL_CHUNK; s++) { P[s * 64 + r] = Tp; Tp *= D[s * 64 + r]; }
+            carry = Tp;
+        }
+        __syncthreads();
+        // ---- C: shade this wavefront's in-cloud samples (clouds.glsl:202-209) with T_i from the scan
+        for (int q = 0; q < IL_OWN; q++) {
+            const float t = d_t[q * 64 + lane];
+            if (t > 0.0f) {
+                const float hf = d_hf[q * 64 + lane], cd = d_px[q * 64 + lane];
+                const float dt = D[(4 * q + wave) * 64 + lane];
+                float Tr = P[(4 * q + wave) * 64 + lane], alpha_unused = 0.0f;
+                shade_sample(fc, phase, t, hf, dt, cd, Tr, alpha_unused, Lr, Lg, Lb);
+                incloud++;
+            }
+        }
+        __syncthreads();                                        // D/P/dense buffers are rewritten by the next chunk
+    }
+    // ---- combine: L = sum of the wavefronts' partial sums (wavefront order), alpha = 1 - T_end
+    comb[(wave * 4 + 0) * 64 + lane] = Lr; comb[(wave * 4 + 1) * 64 + lane] = Lg; comb[(wave * 4 + 2) * 64 + lane] = Lb;
+    if (lane < 16) comb[(0 * 4 + 3) * 64 + wave * 16 + lane] = carry;
+    __syncthreads();
+    out_r = comb[(0 * 4 + 0) * 64 + lane]; out_g = comb[(0 * 4 + 1) * 64 + lane]; out_b = comb[(0 * 4 + 2) * 64 + lane];
+#pragma unroll
+    for (int w = 1; w < 4; w++) { out_r += comb[(w * 4 + 0) * 64 + lane]; out_g += comb[(w * 4 + 1) * 64 + lane]; out_b += comb[(w * 4 + 2) * 64 + lane]; }
+    out_a = sat(1.0f - comb[(0 * 4 + 3) * 64 + lane]);
+}
+
+template <int DUMMY>
+__global__ __launch_bounds__(256) void clouds_kernel_interleaved(TexSet T, const FrameConsts* __restrict__ fcp, RenderGeom G, const uint32_t* __restrict__ order,
+                                                                 uint2* __restrict__ out, unsigned long long* __restrict__ stats) {
+    extern __shared__ __attribute__((aligned(16))) float il_smem[];
+    const int tiles_x = (G.tile_w + 7) >> 3;
+    const int local_rows = G.n_bands * G.band_rows;
+    const uint32_t logical = order[blockIdx.x];
+    if (logical == 0xffffffffu) return;
+    const int slab = (int)logical / tiles_x, bx = (int)logical - slab * tiles_x;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int gx = bx * 8 + (lane & 7);
+    const int lr = slab * 8 + (lane >> 3);
+    const bool valid = gx < G.tile_w && lr < local_rows;
+    const int band = lr / G.band_rows, rib = lr - band * G.band_rows;
+    const int gy = (G.first_band + band * G.band_stride) * G.band_rows + rib;
+    const FrameConsts& fc = *fcp;
+    Ray ray = ray_setup(fc, valid ? gx : 0, valid ? gy : 0);
+    if (!valid) ray.above = false;
+    float r, g, b, a; unsigned ic;
+    march_interleaved(T, fc, ray, il_smem, wave, lane, r, g, b, a, ic);
+    if (valid && wave == 0) {
+        const uint32_t lo = (uint32_t)f2h(r) | ((uint32_t)f2h(g) << 16), hi = (uint32_t)f2h(b) | ((uint32_t)f2h(a) << 16);
+        out[(size_t)lr * G.pitch_px + gx] = make_uint2(lo, hi);
+    }
+    if (stats) {
+        unsigned ab = (ray.above && wave == 0) ? 1u : 0u;
+        for (int off = 32; off > 0; off >>= 1) { ic += __shfl_down(ic, off); ab += __shfl_down(ab, off); }
+        if (lane == 0) { atomicAdd(&stats[0], (unsigned long long)ic); atomicAdd(&stats[1], (unsigned long long)ab); }
+    }
+}
+
 // Pixel <-> lane mapping: a wavefront owns one 8x8-pixel tile (lane = ly*8 + lx), the reference's workgroup footprint
 // (clouds.glsl:5): its 64 rays are angularly adjacent, so their texture footprints overlap (L1/TA coalescing) and
 // they enter/leave cloud together.  A 256-thread workgroup = 4 wavefronts covers 4/SEG tiles side by side:
@@ -320,6 +486,16 @@ hipError_t launch_clouds(int variant, int seg, const TexSet& t, const FrameConst
     else if (variant == 1 && seg == 1) clouds_kernel<1, 1><<<grid, 256, 0, s>>>(t, d_fc, g, d_order, d_out, d_stats);
     else if (variant == 1 && seg == 2) clouds_kernel<1, 2><<<grid, 256, 0, s>>>(t, d_fc, g, d_order, d_out, d_stats);
     else if (variant == 1 && seg == 4) clouds_kernel<1, 4><<<grid, 256, 0, s>>>(t, d_fc, g, d_order, d_out, d_stats);
+    else if (variant == 1 && seg == 5) {                      // 5 = 4 interleaved segments, one tile per workgroup, 76 KB of LDS
+        static bool attr_set = false;
+        if (!attr_set) {
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&clouds_kernel_interleaved<0>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                               (int)(IL_BLOCK_FLOATS * sizeof(float)));
+            if (e != hipSuccess) return e;
+            attr_set = true;
+        }
+        clouds_kernel_interleaved<0><<<grid, 256, IL_BLOCK_FLOATS * sizeof(float), s>>>(t, d_fc, g, d_order, d_out, d_stats);
+    }
     else return hipErrorInvalidValue;
     return hipGetLastError();
 }

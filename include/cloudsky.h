@@ -158,8 +158,9 @@ int csky_variant_count(void);
  * 1 = contiguous eighths; 2 = natural order; 0/3/4 = azimuth wedges; 6 = 5 with horizon rows first. */
 int csky_set_schedule(csky_ctx* ctx, int mode);
 /* Ray segments: the primary march of every ray is cut into `segments` pieces marched by different wavefronts of one
- * workgroup and composited front to back (T and L are associative).  0 = auto (1 for large launches, 2/4 when the
- * launch has too few rays to fill the chip, e.g. one GPU's share of a frame split 8 ways), 1, 2 or 4. */
+ * workgroup and composited front to back (T and L are associative).  0 = auto (whole rays for large launches, 4 step
+ * ranges for one GPU's share of a split frame, 4 interleaved step sets for tile-sized launches such as the reference's
+ * 96x96 temporal tiles), 1, 2, 4 (step ranges) or 5 (4 interleaved). */
 int csky_set_segments(csky_ctx* ctx, int segments);
 const char* csky_variant_name(int variant);
 

@@ -86,7 +86,7 @@ def test_variants_and_schedules_agree(gpu_ctx, oracle):
     assert imgs[0][1] == imgs[1][1]
     gpu_ctx.set_variant(1); gpu_ctx.set_schedule(-1)
     # ray segments (1, 2, 4 wavefronts per ray): identical sample positions and in-cloud counts, re-associated compositing
-    for seg in (1, 2, 4):
+    for seg in (1, 2, 4, 5):
         gpu_ctx.set_segments(seg)
         for sch in (5, 2):
             gpu_ctx.set_schedule(sch)
@@ -119,7 +119,7 @@ def test_config_c2_512x256_64x4_zenith(gpu_ctx, oracle, otex, o_skies):
     gpu_ctx.set_march(128, 6)
 
 
-@pytest.mark.parametrize("seg", [2, 4])
+@pytest.mark.parametrize("seg", [2, 4, 5])
 def test_segments_vs_oracle_ragged(gpu_ctx, oracle, otex, o_skies, seg):
     """Segmented march on a ragged tile (45 x 21, 64 and 100 primary steps: not divisible by the segment count)."""
     gpu_ctx.set_segments(seg)

@@ -33,12 +33,17 @@ ctx.render_transmittance(256, 64)
 ctx.render_sky_lut(s, 200, 100, readback=False)
 if a.time:
     L = gvcd_amd.lib()
-    for v in (0, 1):
-        ctx.set_variant(v)
-        for nb in (1, 8):
-            bands = (8, 0, nb, H // 8 // nb)
-            ms, st = ctx.time_clouds(p, W, bands, warmup=2, iters=a.frames)
-            print("variant %d %-9s 1/%d frame: %.3f ms  %.1f Mrays/s" % (v, L.csky_variant_name(v).decode(), nb, ms, W * H / nb / ms / 1e3), flush=True)
+    ctx.set_variant(1)
+    for nb in (1, 2, 4, 8):
+        bands = (8, 0, nb, H // 8 // nb)
+        row = []
+        for seg in (0, 1, 4, 5):
+            ctx.set_segments(seg)
+            for sched in ((-1,) if seg == 0 else (5, 2)):
+                ctx.set_schedule(sched)
+                ms, st = ctx.time_clouds(p, W, bands, warmup=2, iters=a.frames)
+                row.append("g%d/s%d %.3f" % (seg, sched, ms))
+        print("1/%d frame: %s" % (nb, "  ".join(row)), flush=True)
 else:
     ctx.set_variant(a.variant)
     ctx.set_schedule(a.sched)
