@@ -70,6 +70,7 @@ SYMBOLS = [
     ("csky_set_segments", C.c_int, [C.c_void_p, C.c_int]),
     ("csky_variant_name", C.c_char_p, [C.c_int]),
     ("csky_load_bmp_rgb8", C.c_int, [C.c_char_p, C.POINTER(C.c_int), C.POINTER(C.c_int), C.c_void_p, C.c_size_t]),
+    ("csky_load_tga_rgba8", C.c_int, [C.c_char_p, C.POINTER(C.c_int), C.POINTER(C.c_int), C.c_void_p, C.c_size_t]),
     ("csky_strip_to_volume", C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
     ("csky_generate_shape_noise", C.c_int, [C.c_uint32, C.c_int, C.c_void_p]),
     ("csky_generate_shape_noise_device", C.c_int, [C.c_void_p, C.c_uint32, C.c_int, C.c_void_p]),

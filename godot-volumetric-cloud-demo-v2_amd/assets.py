@@ -28,6 +28,23 @@ def load_bmp_rgb8(path):
     return out
 
 
+def load_tga_rgba8(path):
+    L = _lib.lib()
+    w, h = C.c_int(), C.c_int()
+    _chk(L.csky_load_tga_rgba8(path.encode(), C.byref(w), C.byref(h), None, 0))
+    out = np.zeros((h.value, w.value, 4), np.uint8)
+    _chk(L.csky_load_tga_rgba8(path.encode(), C.byref(w), C.byref(h), out.ctypes.data_as(C.c_void_p), out.nbytes))
+    return out
+
+
+def load_shape_noise_tga(path, n=128):
+    """The reference's own shape volume, if available: perlworlnoise.tga = n horizontal slices of n x n (perlworlnoise.tga.import:26-27)."""
+    img = load_tga_rgba8(path)
+    if img.shape[0] != n or img.shape[1] != n * n:
+        raise ValueError("expected a %d x %d strip, got %d x %d" % (n * n, n, img.shape[1], img.shape[0]))
+    return strip_to_volume(img, n)
+
+
 def strip_to_volume(strip, n):
     """Godot 3-D import, slices/horizontal=n, vertical=1: voxel (x,y,z) = strip[y][n*z + x] -> [z,y,x,ch]."""
     strip = np.ascontiguousarray(strip, np.uint8)

@@ -91,7 +91,6 @@ int render_trans_dev(csky_ctx* c, int w, int h, hipStream_t s) {
 TexSet texset(const csky_ctx* c) {
     TexSet t;
     t.shape = c->d_shape; t.detail = c->d_detail; t.weather = c->d_weather; t.sky = c->d_sky_f; t.sky_w = c->sw; t.sky_h = c->sh;
-    memcpy(t.shape_off, c->shape_off, sizeof t.shape_off); memcpy(t.detail_off, c->detail_off, sizeof t.detail_off);
     return t;
 }
 

@@ -96,6 +96,51 @@ int csky_load_bmp_rgb8(const char* path, int* w, int* h, uint8_t* out, size_t ou
     return CSKY_OK;
 }
 
+// Truevision TGA (types 2 = uncompressed and 10 = RLE true colour, 24 or 32 bpp, either origin) -> tightly packed RGBA8,
+// top row first: the container of the reference's shape noise cloud_sky/perlworlnoise.tga (16384 x 128, 128 slices;
+// missing from the reference checkout but loadable here when a user has it).
+int csky_load_tga_rgba8(const char* path, int* w, int* h, uint8_t* out, size_t out_capacity) {
+    FILE* f = fopen(path, "rb");
+    if (!f) { snprintf(g_asset_err, sizeof g_asset_err, "load_tga: cannot open %s", path); return CSKY_ERR_IO; }
+    uint8_t hd[18];
+    if (fread(hd, 1, 18, f) != 18) { fclose(f); snprintf(g_asset_err, sizeof g_asset_err, "load_tga: %s is truncated", path); return CSKY_ERR_IO; }
+    const int id_len = hd[0], cmap_type = hd[1], type = hd[2], W = hd[12] | (hd[13] << 8), H = hd[14] | (hd[15] << 8), bpp = hd[16];
+    const bool top_down = (hd[17] & 0x20) != 0, right_left = (hd[17] & 0x10) != 0;
+    if (cmap_type != 0 || (type != 2 && type != 10) || (bpp != 24 && bpp != 32) || W <= 0 || H <= 0 || right_left) {
+        fclose(f); snprintf(g_asset_err, sizeof g_asset_err, "load_tga: only true-colour 24/32-bpp TGA (type 2/10) supported (%s)", path); return CSKY_ERR_IO;
+    }
+    if (w) *w = W; if (h) *h = H;
+    if (!out) { fclose(f); return CSKY_OK; }                       // size query
+    if (out_capacity < (size_t)W * H * 4) { fclose(f); snprintf(g_asset_err, sizeof g_asset_err, "load_tga: output buffer too small"); return CSKY_ERR_INVALID; }
+    fseek(f, 18 + id_len, SEEK_SET);
+    const int bytes = bpp / 8;
+    const size_t npx = (size_t)W * H;
+    size_t i = 0;
+    uint8_t px[4] = {0, 0, 0, 255};
+    auto put = [&](size_t idx) {
+        const size_t row = idx / W, col = idx % W;
+        uint8_t* o = out + ((top_down ? row : (size_t)H - 1 - row) * W + col) * 4;
+        o[0] = px[2]; o[1] = px[1]; o[2] = px[0]; o[3] = bytes == 4 ? px[3] : 255;      // BGRA -> RGBA
+    };
+    bool ok = true;
+    if (type == 2) {
+        for (; i < npx && ok; i++) { ok = fread(px, 1, bytes, f) == (size_t)bytes; if (ok) put(i); }
+    } else {
+        while (i < npx && ok) {
+            int c = fgetc(f);
+            if (c == EOF) { ok = false; break; }
+            const size_t run = (size_t)(c & 0x7f) + 1;
+            if (i + run > npx) { ok = false; break; }
+            if (c & 0x80) { ok = fread(px, 1, bytes, f) == (size_t)bytes; for (size_t k = 0; k < run && ok; k++) put(i + k); }
+            else for (size_t k = 0; k < run && ok; k++) { ok = fread(px, 1, bytes, f) == (size_t)bytes; if (ok) put(i + k); }
+            i += run;
+        }
+    }
+    fclose(f);
+    if (!ok) { snprintf(g_asset_err, sizeof g_asset_err, "load_tga: %s is truncated or corrupt", path); return CSKY_ERR_IO; }
+    return CSKY_OK;
+}
+
 // Godot 3-D texture import with slices/horizontal = n, slices/vertical = 1 (worlnoise.bmp.import:26-27,
 // perlworlnoise.tga.import:26-27): the strip image is (n*n) x n; voxel (x,y,z) = strip[row y][col n*z + x].
 int csky_strip_to_volume(const uint8_t* strip, int n, int ch, uint8_t* vol) {

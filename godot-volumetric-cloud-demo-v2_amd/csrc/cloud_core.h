@@ -204,15 +204,6 @@ CSKY_HD void weather_tap(const uint4* __restrict__ w, float sx, float sy, float&
 // arithmetically so a per-lane level needs no table (api.cpp checks it against the baked offsets)
 CSKY_HD uint32_t shape_level_offset(int l) { return ((1u << 24) - (1u << (24 - 3 * l))) / 7u; }
 CSKY_HD uint32_t detail_level_offset(int l) { return ((1u << 18) - (1u << (18 - 3 * l))) / 7u; }
-// floor + fraction of a texel coordinate
-struct TexCoord { int i; float f; };
-CSKY_HD TexCoord split_coord(float u) {
-    TexCoord c;
-    const float fl = floorf(u);
-    c.i = (int)fl; c.f = u - fl;
-    return c;
-}
-
 // REPEAT + LINEAR trilinear tap of the shape volume at integer level `lvl` (clouds.glsl:117).
 // Returns r = n.r and fbm = n.g*0.625 + n.b*0.25 + n.a*0.125 (clouds.glsl:118; exact integer numerators, filtered linearly).
 CSKY_HD void shape_tap(const TexSet& T, int lvl, float sx, float sy, float sz, float& r, float& fbm) {

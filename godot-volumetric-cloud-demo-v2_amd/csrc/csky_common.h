@@ -39,13 +39,11 @@ constexpr int WEATHER_N = 512;                   // weather.bmp.import:25 (no mi
 // weather: per texel uint4 = the 2x2 neighbourhood {r(y0), r(y1), b(y0), b(y1)} pairs (G is never read: clouds.glsl:121,123)
 //          -> ONE 16-byte load per bilinear tap
 struct TexSet {
-    const uint2* shape;     // all levels, level l at shape_off[l] (in texels)
-    const uint4* detail;    // all levels, level l at detail_off[l]
+    const uint2* shape;     // all mip levels back to back; level l starts at shape_level_offset(l) texels (cloud_core.h)
+    const uint4* detail;    // all mip levels back to back; level l starts at detail_level_offset(l)
     const uint4* weather;   // 512*512
     const float4* sky;      // sky LUT, fp16-rounded values widened to float, sky_w x sky_h
     int sky_w, sky_h;
-    uint32_t shape_off[SHAPE_LEVELS];
-    uint32_t detail_off[DETAIL_LEVELS];
 };
 
 // Ray-invariant per-frame constants, computed once per frame by frame_setup() (clouds.glsl:143-170).

@@ -169,6 +169,8 @@ const char* csky_variant_name(int variant);
  * perlworlnoise.tga.import).  perlworlnoise.tga is missing from the reference checkout, hence the
  * deterministic generator. */
 int csky_load_bmp_rgb8(const char* path, int* w, int* h, uint8_t* out_rgb8, size_t out_capacity);
+/* Truevision TGA, true colour 24/32 bpp, uncompressed or RLE (the container of cloud_sky/perlworlnoise.tga) -> RGBA8. */
+int csky_load_tga_rgba8(const char* path, int* w, int* h, uint8_t* out_rgba8, size_t out_capacity);
 int csky_strip_to_volume(const uint8_t* strip, int n, int ch, uint8_t* vol);
 int csky_generate_shape_noise(uint32_t seed, int n, uint8_t* out_rgba8);
 /* The same generator as a HIP kernel (one voxel per lane): byte-identical output, ~1 ms for 128^3 (README.md:30 TODO 3). */

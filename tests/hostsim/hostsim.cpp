@@ -45,7 +45,8 @@ void hostsim_clouds(const uint8_t* large_chain, const uint8_t* small_chain, cons
     std::vector<uint8_t> sc(small_chain, small_chain + csky_mip_offset(DETAIL_N, DETAIL_LEVELS, 3));
     std::vector<uint2> shape; std::vector<uint4> detail, weather;
     TexSet T;
-    bake_shape(lc, shape, T.shape_off); bake_detail(sc, detail, T.detail_off); bake_weather(weather_rgb8, weather);
+    uint32_t shape_off[SHAPE_LEVELS], detail_off[DETAIL_LEVELS];
+    bake_shape(lc, shape, shape_off); bake_detail(sc, detail, detail_off); bake_weather(weather_rgb8, weather);
     std::vector<float4> sky = widen(sky_h, sw, sh);
     T.shape = shape.data(); T.detail = detail.data(); T.weather = weather.data(); T.sky = sky.data(); T.sky_w = sw; T.sky_h = sh;
     CloudParams P; memcpy(&P, params, sizeof P);

@@ -72,3 +72,35 @@ def test_mips_match_oracle_and_numpy(pkg, oracle, noise):
         flat = np.concatenate([l.reshape(-1) for l in chain[:lv]])
         assert (prod == flat).all()
     assert prod[-3:].tolist() == NR.mip_chain(small)[5].reshape(-1).tolist()   # LOD 5 = 1x1x1 mean texel
+
+
+def test_tga_loader_matches_pil(pkg, tmp_path):
+    """TGA types 2 and 10, 24 and 32 bpp, both origins (the container of cloud_sky/perlworlnoise.tga)."""
+    from PIL import Image
+    rng = np.random.default_rng(4)
+    img = rng.integers(0, 256, (16, 64, 4), dtype=np.uint8)
+    img[4:9, 10:40] = img[4, 10]                                    # runs, so RLE packets of both kinds appear
+    for mode, rle in (("RGBA", False), ("RGBA", True), ("RGB", False), ("RGB", True)):
+        p = str(tmp_path / ("t_%s_%d.tga" % (mode, rle)))
+        im = Image.fromarray(img if mode == "RGBA" else img[..., :3], mode)
+        im.save(p, compression="tga_rle" if rle else None)
+        got = pkg.assets.load_tga_rgba8(p)
+        ref = np.array(Image.open(p).convert("RGBA"))
+        assert (got == ref).all(), (mode, rle)
+    # top-left origin flag
+    p = str(tmp_path / "top.tga")
+    Image.fromarray(img, "RGBA").save(p, orientation=1)
+    assert (pkg.assets.load_tga_rgba8(p) == np.array(Image.open(p).convert("RGBA"))).all()
+    # a 3-D strip: 8 slices of 8x8 -> volume layout of perlworlnoise.tga.import:26-27
+    strip = rng.integers(0, 256, (8, 64, 4), dtype=np.uint8)
+    p = str(tmp_path / "strip.tga")
+    Image.fromarray(strip, "RGBA").save(p)
+    vol = pkg.assets.load_shape_noise_tga(p, 8)
+    assert (vol[3, 5, 2] == strip[5, 8 * 3 + 2]).all()
+    import pytest
+    with pytest.raises(pkg.CloudSkyError):
+        pkg.assets.load_tga_rgba8(str(tmp_path / "missing.tga"))
+    bad = tmp_path / "bad.tga"
+    bad.write_bytes(bytes(18))
+    with pytest.raises(pkg.CloudSkyError):
+        pkg.assets.load_tga_rgba8(str(bad))

@@ -303,3 +303,18 @@ def test_gpu_shape_noise_bake_is_byte_identical(pkg, gpu_ctx, noise):
     assert (gpu_ctx.generate_shape_noise(7, 32) == pkg.assets.generate_shape_noise(7, 32)).all()
     with pytest.raises(pkg.CloudSkyError):
         gpu_ctx.generate_shape_noise(1, 12)
+
+
+def test_sun_sweep_time_of_day(gpu_ctx, oracle, otex, o_trans):
+    """BASELINE configs[4] in miniature: sun = (cos th, sin th, 0) swept from 2 to 178 degrees, sky LUT recomputed per frame,
+    every frame checked against the oracle (low suns stress the HG lobe g = 0.4 - 1.4*ldir.y and the horizon LUT texels)."""
+    gpu_ctx.set_march(128, 6)
+    for th in np.linspace(2.0, 178.0, 7):
+        sun = norm((np.cos(np.radians(th)), np.sin(np.radians(th)), 0.0))
+        sk = gpu_ctx.render_sky_lut(sun, 200, 100)
+        sk_o = oracle.sky_lut(sun, o_trans)
+        d = ulp_diff(sk, sk_o)
+        assert d.max() <= 4 and (d <= 1).mean() >= 0.995, (th, d.max())
+        p = oracle.default_params(128, 64, sun)
+        ok, info = cloud_close(gpu_ctx.render_clouds(p), oracle.clouds(otex, p, sk_o))
+        assert ok, (th, info)
