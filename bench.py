@@ -120,37 +120,60 @@ def main():
     stream = torch.cuda.current_stream().cuda_stream
     bands = tiling.bands_for_rank(H, rank, world)
     mb = tiling.max_bands(H, world)
-    local = torch.zeros((mb * tiling.BAND_ROWS, W, 4), dtype=torch.int16, device=dev)
-    local_b = local.view(torch.uint8)   # collectives move raw bytes (RCCL has no int16 type)
-    # rank 0 gathers straight into one [world, rows, W, 4] tensor (no per-frame stack/copy before the band interleave)
-    gathered = torch.empty((world,) + tuple(local.shape), dtype=torch.int16, device=dev) if (world > 1 and rank == 0) else None
-    parts = [gathered[i].view(torch.uint8) for i in range(world)] if gathered is not None else None
+    # N > 1: frames are independent, so the gather of frame k (RCCL, its own stream) overlaps the march of frame k+1:
+    # two band buffers per rank, two gather targets on rank 0 (async_op gather; wait() only orders the compute stream behind
+    # that one collective).  CSKY_BENCH_SYNC_GATHER=1 falls back to gather-then-render.
+    overlap = world > 1 and os.environ.get("CSKY_BENCH_SYNC_GATHER") != "1"
+    nbuf = 2 if overlap else 1
+    local = [torch.zeros((mb * tiling.BAND_ROWS, W, 4), dtype=torch.int16, device=dev) for _ in range(nbuf)]
+    local_b = [t.view(torch.uint8) for t in local]   # collectives move raw bytes (RCCL has no int16 type)
+    gdev = "cpu" if debug_one_gpu else dev
+    gathered = [torch.empty((world,) + tuple(local[0].shape), dtype=torch.int16, device=gdev) for _ in range(nbuf)] if (world > 1 and rank == 0) else None
+    parts = [[g[i].view(torch.uint8) for i in range(world)] for g in gathered] if gathered is not None else [None] * nbuf
+    pending = [None] * nbuf
     frame = [None]
+    counter = [0]
+
+    def finish(o):
+        """Frame in buffer set o has been gathered: order the compute stream behind it and assemble the frame on rank 0."""
+        pending[o].wait()
+        pending[o] = None
+        if rank == 0:
+            frame[0] = tiling.interleave(gathered[o].to(dev) if debug_one_gpu else gathered[o], H, world)
 
     def step():
-        ctx.render_sky_lut_device(sun_n, 200, 100, stream)                               # sky_lut.gd:122-148
-        ctx.render_clouds_device(params, W, bands, local.data_ptr(), W * 8, stream)      # cloud_sky.gd:234-248
-        if world > 1 and debug_one_gpu:
-            host = local_b.cpu()
-            hparts = [torch.empty_like(host) for _ in range(world)] if rank == 0 else None
-            dist.gather(host, gather_list=hparts, dst=0)
-            if rank == 0:
-                frame[0] = tiling.interleave(torch.stack(hparts, 0).view(torch.int16).to(dev), H, world)
-        elif world > 1:
-            dist.gather(local_b, gather_list=parts, dst=0)
-            if rank == 0:
-                frame[0] = tiling.interleave(gathered, H, world)
+        k = counter[0]
+        counter[0] += 1
+        bset = k % nbuf
+        ctx.render_sky_lut_device(sun_n, 200, 100, stream)                                     # sky_lut.gd:122-148
+        ctx.render_clouds_device(params, W, bands, local[bset].data_ptr(), W * 8, stream)      # cloud_sky.gd:234-248
+        if world == 1:
+            frame[0] = local[0]
+            return
+        src = local_b[bset].cpu() if debug_one_gpu else local_b[bset]
+        pending[bset] = dist.gather(src, gather_list=parts[bset], dst=0, async_op=True)
+        if overlap:
+            o = 1 - bset
+            if pending[o] is not None:
+                finish(o)                  # frame k-1: its gather ran while frame k was marching
         else:
-            frame[0] = local
+            finish(bset)
+
+    def drain():
+        for o in range(nbuf):
+            if pending[o] is not None:
+                finish(o)
 
     for _ in range(args.warmup):
         step()
+    drain()
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
+    drain()
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
@@ -174,6 +197,7 @@ def main():
         finite = bool(torch.isfinite(fr.float()).all().item())
         if debug_one_gpu and world > 1:   # the gathered frame must equal a single-context full-frame render
             full = torch.zeros((H, W, 4), dtype=torch.int16, device=dev)
+            ctx.set_segments(1)
             ctx.render_clouds_device(params, W, (H, 0, 1, 1), full.data_ptr(), W * 8, stream)
             torch.cuda.synchronize()
             a, b = full.view(torch.float16).float(), frame[0].view(torch.float16).float()
@@ -208,7 +232,7 @@ def main():
                                    % (args.config, W, H, primary, light, sun_n[0], sun_n[1], sun_n[2]),
                        "texture_size": [W, H], "primary_steps": primary, "light_steps": light, "early_out_eps": args.early_out,
                        "variant": gvcd_amd.lib().csky_variant_name(args.variant if args.variant is not None else 1).decode(),
-                       "parallelism": "bands%d" % world, "alpha_mean": alpha_mean, "finite": finite},
+                       "parallelism": "bands%d%s" % (world, "+overlapped-gather" if overlap else ""), "alpha_mean": alpha_mean, "finite": finite},
             "roofline": {"bound": "hbm", "kernel": "clouds_kernel", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_note": traffic_note,
                          "kernel_ms": k_ms, "rays_per_launch": rays_launch,
