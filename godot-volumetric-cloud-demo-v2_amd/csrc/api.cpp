@@ -26,6 +26,7 @@ struct csky_ctx {
     // noise set (cloud_sky.gd:298-341)
     uint2* d_shape = nullptr; uint4* d_detail = nullptr; uint4* d_weather = nullptr; bool have_noise = false;
     uint32_t shape_off[SHAPE_LEVELS] = {}, detail_off[DETAIL_LEVELS] = {};
+    float detail_lod5 = 0.0f;
     double w_rmin = 0.0, w_rmax = 1.0, w_bmax = 1.0;   // range of the weather map's cloud-type / coverage channels
     float win_cov = -1e30f, win_lo = -1.0f, win_hi = 2.0f; bool use_window = true;
     // LUTs: RGBA16F image + float4 copy of the rounded values
@@ -90,7 +91,7 @@ int render_trans_dev(csky_ctx* c, int w, int h, hipStream_t s) {
 
 TexSet texset(const csky_ctx* c) {
     TexSet t;
-    t.shape = c->d_shape; t.detail = c->d_detail; t.weather = c->d_weather; t.sky = c->d_sky_f; t.sky_w = c->sw; t.sky_h = c->sh;
+    t.shape = c->d_shape; t.detail = c->d_detail; t.weather = c->d_weather; t.sky = c->d_sky_f; t.sky_w = c->sw; t.sky_h = c->sh; t.detail_lod5 = c->detail_lod5;
     return t;
 }
 
@@ -281,6 +282,7 @@ int csky_set_noise(csky_ctx* c, const uint8_t* large_rgba8, const uint8_t* small
     bake_shape(lc, shape, c->shape_off);
     bake_detail(sc, detail, c->detail_off);
     bake_weather(weather_rgb8, weather);
+    { const uint8_t* t5 = sc.data() + csky_mip_offset(DETAIL_N, 5, 3); c->detail_lod5 = (float)(5 * t5[0] + 2 * t5[1] + t5[2]) * (1.0f / (8.0f * 255.0f)); }
     {   // channel ranges of the weather map for the height-window reject
         int rmin = 255, rmax = 0, bmax = 0;
         for (size_t i = 0; i < (size_t)WEATHER_N * WEATHER_N; i++) { const int r = weather_rgb8[3 * i], b = weather_rgb8[3 * i + 2]; rmin = r < rmin ? r : rmin; rmax = r > rmax ? r : rmax; bmax = b > bmax ? b : bmax; }

@@ -226,6 +226,9 @@ CSKY_HD void shape_tap(const TexSet& T, int lvl, float sx, float sy, float sz, f
 
 // REPEAT + LINEAR trilinear tap of the oct-packed detail volume (clouds.glsl:132-133): returns hfbm.
 CSKY_HD float detail_tap(const TexSet& T, int lvl, float sx, float sy, float sz) {
+    // LOD 5 is 1x1x1: with REPEAT all eight corners are that one texel and a + (a - a)*f = a exactly (what the reference's
+    // sampler returns), so light samples j = 5 and the distant sample (clouds.glsl:190,198: textureLod(.., 5.0)) need no tap
+    if (lvl == 5) return T.detail_lod5;
     const int n = DETAIL_N >> lvl, m = n - 1;
     const float fn = (float)n;
     const float ux = sx * fn - 0.5f, uy = sy * fn - 0.5f, uz = sz * fn - 0.5f;

@@ -44,6 +44,7 @@ struct TexSet {
     const uint4* weather;   // 512*512
     const float4* sky;      // sky LUT, fp16-rounded values widened to float, sky_w x sky_h
     int sky_w, sky_h;
+    float detail_lod5;      // the single texel of detail LOD 5 (1x1x1) as hfbm = (5r+2g+b)/(8*255): the filtered value of EVERY tap at that level
 };
 
 // Ray-invariant per-frame constants, computed once per frame by frame_setup() (clouds.glsl:143-170).

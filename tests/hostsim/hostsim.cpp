@@ -49,6 +49,7 @@ void hostsim_clouds(const uint8_t* large_chain, const uint8_t* small_chain, cons
     bake_shape(lc, shape, shape_off); bake_detail(sc, detail, detail_off); bake_weather(weather_rgb8, weather);
     std::vector<float4> sky = widen(sky_h, sw, sh);
     T.shape = shape.data(); T.detail = detail.data(); T.weather = weather.data(); T.sky = sky.data(); T.sky_w = sw; T.sky_h = sh;
+    { const uint8_t* t5 = sc.data() + csky_mip_offset(DETAIL_N, 5, 3); T.detail_lod5 = (float)(5 * t5[0] + 2 * t5[1] + t5[2]) * (1.0f / (8.0f * 255.0f)); }
     CloudParams P; memcpy(&P, params, sizeof P);
     FrameConsts fc;
     float hlo = -1.0f, hhi = 2.0f;

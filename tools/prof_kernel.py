@@ -34,10 +34,10 @@ ctx.render_sky_lut(s, 200, 100, readback=False)
 if a.time:
     L = gvcd_amd.lib()
     ctx.set_variant(1)
-    for nb in (1, 2, 4, 8):
+    for nb in (1, 8):
         bands = (8, 0, nb, H // 8 // nb)
         row = []
-        for seg in (0, 1, 4, 5):
+        for seg in (0,):
             ctx.set_segments(seg)
             for sched in ((-1,) if seg == 0 else (5, 2)):
                 ctx.set_schedule(sched)
