@@ -24,7 +24,7 @@ struct csky_ctx {
     hipStream_t stream = nullptr;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     // noise set (cloud_sky.gd:298-341)
-    uint2* d_shape = nullptr; uint4* d_detail = nullptr; uint4* d_weather = nullptr; bool have_noise = false;
+    uint2* d_shape = nullptr; uint4* d_detail = nullptr; uint4* d_weather = nullptr; uint16_t* d_detail_h = nullptr; bool have_noise = false;
     uint32_t shape_off[SHAPE_LEVELS] = {}, detail_off[DETAIL_LEVELS] = {};
     float detail_lod5 = 0.0f;
     double w_rmin = 0.0, w_rmax = 1.0, w_bmax = 1.0;   // range of the weather map's cloud-type / coverage channels
@@ -91,7 +91,7 @@ int render_trans_dev(csky_ctx* c, int w, int h, hipStream_t s) {
 
 TexSet texset(const csky_ctx* c) {
     TexSet t;
-    t.shape = c->d_shape; t.detail = c->d_detail; t.weather = c->d_weather; t.sky = c->d_sky_f; t.sky_w = c->sw; t.sky_h = c->sh; t.detail_lod5 = c->detail_lod5;
+    t.shape = c->d_shape; t.detail = c->d_detail; t.weather = c->d_weather; t.sky = c->d_sky_f; t.sky_w = c->sw; t.sky_h = c->sh; t.detail_lod5 = c->detail_lod5; t.detail_h = c->d_detail_h; t.detail_lds = nullptr;
     return t;
 }
 
@@ -111,7 +111,7 @@ int check_bands(csky_ctx* c, const csky_bands* b, int tile_w) {
 //               but consecutive workgroups are not neighbours                                                   5.3-5.8 ms
 //   6 = 5 with the rows farthest from the zenith row first                                                          4.77 ms
 int build_schedule(csky_ctx* c, const CloudParams& p, const RenderGeom& g, int seg, int mode, hipStream_t s) {
-    const int bw = seg == 5 ? 8 : 32 / seg;           // workgroup footprint = bw x 8 pixels (seg 5 = 4 interleaved segments: one tile)
+    const int bw = seg == 5 ? 8 : (seg == 16 ? 128 : 32 / seg);   // seg 16 = the 16-wavefront "lds" variant: a 128 x 8 pixel strip           // workgroup footprint = bw x 8 pixels (seg 5 = 4 interleaved segments: one tile)
     const int tiles_x = (g.tile_w + bw - 1) / bw, local_rows = g.n_bands * g.band_rows, slabs = (local_rows + 7) >> 3;
     const int nblocks = tiles_x * slabs;
     const long long key[11] = {g.tile_w, g.band_rows, g.first_band, g.band_stride, g.n_bands, (long long)p.texture_size[0], (long long)p.texture_size[1],
@@ -214,6 +214,7 @@ int clouds_dev(csky_ctx* c, const csky_cloud_params* p, int tile_w, const csky_b
     const long long waves = ((long long)(tile_w + 7) / 8) * (((long long)b->n_bands * b->band_rows + 7) / 8);
     int seg = c->variant == 1 ? c->segments : 1;
     if (c->variant == 1 && seg == 0) seg = waves >= 6144 ? 1 : (waves >= 1536 ? 4 : 5);
+    if (c->variant == 2) seg = 16;
     const int mode = c->sched_mode >= 0 ? c->sched_mode : (waves >= 6144 ? 5 : 2);
     if ((rc = build_schedule(c, cp, g, seg, mode, s))) return rc;
     HIPCHK(c, launch_clouds(c->variant, seg, texset(c), c->d_fc, g, c->d_order, c->order_grid, d_out, d_stats, s));
@@ -261,7 +262,7 @@ void csky_destroy(csky_ctx* c) {
     if (!c) return;
     (void)hipSetDevice(c->device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
-    void* ptrs[] = {c->d_shape, c->d_detail, c->d_weather, c->d_trans_h, c->d_trans_f, c->d_sky_h, c->d_sky_f, c->d_fc, c->d_stats, c->d_frame, c->d_order};
+    void* ptrs[] = {c->d_shape, c->d_detail, c->d_weather, c->d_trans_h, c->d_trans_f, c->d_sky_h, c->d_sky_f, c->d_fc, c->d_stats, c->d_frame, c->d_order, c->d_detail_h};
     for (void* p : ptrs) if (p) (void)hipFree(p);
     if (c->ev0) (void)hipEventDestroy(c->ev0);
     if (c->ev1) (void)hipEventDestroy(c->ev1);
@@ -282,6 +283,9 @@ int csky_set_noise(csky_ctx* c, const uint8_t* large_rgba8, const uint8_t* small
     bake_shape(lc, shape, c->shape_off);
     bake_detail(sc, detail, c->detail_off);
     bake_weather(weather_rgb8, weather);
+    std::vector<uint16_t> detail_h;
+    bake_detail_unpacked(sc, detail_h);
+    if (detail_h.size() != (size_t)DETAIL_CHAIN_TEXELS) return fail(c, CSKY_ERR_INVALID, "internal: detail chain size");
     { const uint8_t* t5 = sc.data() + csky_mip_offset(DETAIL_N, 5, 3); c->detail_lod5 = (float)(5 * t5[0] + 2 * t5[1] + t5[2]) * (1.0f / (8.0f * 255.0f)); }
     {   // channel ranges of the weather map for the height-window reject
         int rmin = 255, rmax = 0, bmax = 0;
@@ -294,6 +298,8 @@ int csky_set_noise(csky_ctx* c, const uint8_t* large_rgba8, const uint8_t* small
     if ((rc = dev_alloc(c, &c->d_shape, shape.size()))) return rc;
     if ((rc = dev_alloc(c, &c->d_detail, detail.size()))) return rc;
     if ((rc = dev_alloc(c, &c->d_weather, weather.size()))) return rc;
+    if ((rc = dev_alloc(c, &c->d_detail_h, detail_h.size() + 8))) return rc;
+    HIPCHK(c, hipMemcpy(c->d_detail_h, detail_h.data(), detail_h.size() * sizeof(uint16_t), hipMemcpyHostToDevice));
     HIPCHK(c, hipMemcpy(c->d_shape, shape.data(), shape.size() * sizeof(uint2), hipMemcpyHostToDevice));
     HIPCHK(c, hipMemcpy(c->d_detail, detail.data(), detail.size() * sizeof(uint4), hipMemcpyHostToDevice));
     HIPCHK(c, hipMemcpy(c->d_weather, weather.data(), weather.size() * sizeof(uint4), hipMemcpyHostToDevice));

@@ -46,6 +46,15 @@ inline void bake_detail(const std::vector<uint8_t>& chain, std::vector<uint4>& o
         }
     }
 }
+// unpacked fp16 numerators of the whole detail chain (the source of the LDS copy of the "lds" kernel variant)
+inline void bake_detail_unpacked(const std::vector<uint8_t>& chain, std::vector<uint16_t>& out) {
+    out.clear();
+    for (int l = 0; l < DETAIL_LEVELS; l++) {
+        const size_t n = DETAIL_N >> l;
+        const uint8_t* src = chain.data() + csky_mip_offset(DETAIL_N, l, 3);
+        for (size_t i = 0; i < n * n * n; i++) out.push_back(f2h((float)(5 * src[3 * i] + 2 * src[3 * i + 1] + src[3 * i + 2])));
+    }
+}
 inline void bake_weather(const uint8_t* rgb, std::vector<uint4>& out) {
     const int n = WEATHER_N;
     out.resize((size_t)n * n);

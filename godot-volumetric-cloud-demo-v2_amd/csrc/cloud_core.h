@@ -235,6 +235,18 @@ CSKY_HD float detail_tap(const TexSet& T, int lvl, float sx, float sy, float sz)
     const float fx0 = floorf(ux), fy0 = floorf(uy), fz0 = floorf(uz);
     const float ax = ux - fx0, ay = uy - fy0, az = uz - fz0;
     const int x0 = ((int)fx0) & m, y0 = ((int)fy0) & m, z0 = ((int)fz0) & m;
+    if (T.detail_lds) {
+        // "lds" variant (north star: noise bricks staged in LDS): the whole detail chain sits in LDS as unpacked fp16 texels, so
+        // a tap is eight 2-byte LDS reads assembled into the same x-neighbour pairs the global layout stores pre-packed
+        const int x1 = (x0 + 1) & m, y1 = (y0 + 1) & m, z1 = (z0 + 1) & m;
+        const uint32_t sh2 = (uint32_t)(5 - lvl);
+        const uint16_t* __restrict__ d = T.detail_lds + detail_level_offset(lvl);
+        const uint32_t r00 = (((uint32_t)z0 << sh2) | (uint32_t)y0) << sh2, r10 = (((uint32_t)z0 << sh2) | (uint32_t)y1) << sh2;
+        const uint32_t r01 = (((uint32_t)z1 << sh2) | (uint32_t)y0) << sh2, r11 = (((uint32_t)z1 << sh2) | (uint32_t)y1) << sh2;
+        const uint32_t p00 = (uint32_t)d[r00 + x0] | ((uint32_t)d[r00 + x1] << 16), p10 = (uint32_t)d[r10 + x0] | ((uint32_t)d[r10 + x1] << 16);
+        const uint32_t p01 = (uint32_t)d[r01 + x0] | ((uint32_t)d[r01 + x1] << 16), p11 = (uint32_t)d[r11 + x0] | ((uint32_t)d[r11 + x1] << 16);
+        return lerpf(lerpf(lerp_h(p00, ax), lerp_h(p10, ax), ay), lerpf(lerp_h(p01, ax), lerp_h(p11, ax), ay), az) * (1.0f / (8.0f * 255.0f));
+    }
     const uint32_t sh = (uint32_t)(5 - lvl), idx = detail_level_offset(lvl) + ((((((uint32_t)z0 << sh) | (uint32_t)y0) << sh)) | (uint32_t)x0);
     const uint4 q = *reinterpret_cast<const uint4*>(reinterpret_cast<const char*>(T.detail) + (idx << 4));
     return lerpf(lerpf(lerp_h(q.x, ax), lerp_h(q.y, ax), ay), lerpf(lerp_h(q.z, ax), lerp_h(q.w, ax), ay), az) * (1.0f / (8.0f * 255.0f));

@@ -28,6 +28,7 @@ constexpr float CLOUD_PI = 3.141592f;  // truncated literal of clouds.glsl:47, k
 constexpr int SHAPE_N = 128, SHAPE_LEVELS = 8;   // perlworlnoise.tga.import:24-27 (128 slices, mips on)
 constexpr int DETAIL_N = 32, DETAIL_LEVELS = 6;  // worlnoise.bmp.import:24-27 (32 slices, mips on)
 constexpr int WEATHER_N = 512;                   // weather.bmp.import:25 (no mips)
+constexpr int DETAIL_CHAIN_TEXELS = 32768 + 4096 + 512 + 64 + 8 + 1;   // all six levels of the 32^3 detail volume
 
 // ---- device texture layouts (baked by bake.h) ----------------------------------------
 // Texel values are stored as fp16 (small integers, exact) so that v_fma_mix_f32 widens them for free inside the
@@ -44,6 +45,8 @@ struct TexSet {
     const uint4* weather;   // 512*512
     const float4* sky;      // sky LUT, fp16-rounded values widened to float, sky_w x sky_h
     int sky_w, sky_h;
+    const uint16_t* detail_h;     // global: unpacked fp16 numerators of the detail chain (source of the LDS copy), 37 449 texels
+    const uint16_t* detail_lds;   // LDS copy of detail_h inside the "lds" kernel variant, else nullptr
     float detail_lod5;      // the single texel of detail LOD 5 (1x1x1) as hfbm = (5r+2g+b)/(8*255): the filtered value of EVERY tap at that level
 };
 

@@ -410,6 +410,52 @@ __global__ __launch_bounds__(256) void clouds_kernel_interleaved(TexSet T, const
     }
 }
 
+// ---- "lds" variant: the detail noise volume staged in LDS (north star) ---------------------------------------------
+// A 1024-thread workgroup (16 wavefronts = a 128 x 8 pixel strip) copies the whole 32^3 detail mip chain (37 449 fp16
+// numerators, 73 KB) into LDS once and every wavefront runs the queue march with its detail taps served from LDS.  LDS:
+// 73 KB + 16 x 5.1 KB of event queues = 155 KB, i.e. ONE workgroup per CU (4 wavefronts per SIMD).  Kept as a measured
+// alternative; the default keeps the detail volume oct-packed in L2 (one 16-byte gather per tap).
+template <int DUMMY>
+__global__ __launch_bounds__(1024) void clouds_kernel_lds(TexSet T, const FrameConsts* __restrict__ fcp, RenderGeom G, const uint32_t* __restrict__ order,
+                                                          uint2* __restrict__ out, unsigned long long* __restrict__ stats) {
+    extern __shared__ __attribute__((aligned(16))) float lds_all[];
+    uint16_t* detail_s = reinterpret_cast<uint16_t*>(lds_all);
+    constexpr int DETAIL_FLOATS = (DETAIL_CHAIN_TEXELS + 7) / 8 * 4;            // rounded up to 16 bytes
+    float* queues = lds_all + DETAIL_FLOATS;
+    {   // stage the detail chain: 16-byte copies, all 1024 threads
+        const uint4* __restrict__ src = reinterpret_cast<const uint4*>(T.detail_h);
+        uint4* dst = reinterpret_cast<uint4*>(lds_all);
+        for (int i = threadIdx.x; i < DETAIL_FLOATS / 4; i += 1024) dst[i] = src[i];
+    }
+    __syncthreads();
+    const uint32_t logical = order[blockIdx.x];
+    if (logical == 0xffffffffu) return;
+    const int tiles_x = (G.tile_w + 127) >> 7;
+    const int local_rows = G.n_bands * G.band_rows;
+    const int slab = (int)logical / tiles_x, bx = (int)logical - slab * tiles_x;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int gx = bx * 128 + wave * 8 + (lane & 7);
+    const int lr = slab * 8 + (lane >> 3);
+    const bool valid = gx < G.tile_w && lr < local_rows;
+    const int band = lr / G.band_rows, rib = lr - band * G.band_rows;
+    const int gy = (G.first_band + band * G.band_stride) * G.band_rows + rib;
+    const FrameConsts& fc = *fcp;
+    Ray ray = ray_setup(fc, valid ? gx : 0, valid ? gy : 0);
+    if (!valid) ray.above = false;
+    TexSet Tl = T;
+    Tl.detail_lds = detail_s;
+    const MarchOut o = march_queue(Tl, fc, ray, queues + wave * Q_FLOATS, 0, fc.primary_steps);
+    if (valid) {
+        const uint32_t lo = (uint32_t)f2h(o.r) | ((uint32_t)f2h(o.g) << 16), hi = (uint32_t)f2h(o.b) | ((uint32_t)f2h(o.a) << 16);
+        out[(size_t)lr * G.pitch_px + gx] = make_uint2(lo, hi);
+    }
+    if (stats) {
+        unsigned ic = o.incloud, ab = ray.above ? 1u : 0u;
+        for (int off = 32; off > 0; off >>= 1) { ic += __shfl_down(ic, off); ab += __shfl_down(ab, off); }
+        if (lane == 0) { atomicAdd(&stats[0], (unsigned long long)ic); atomicAdd(&stats[1], (unsigned long long)ab); }
+    }
+}
+
 // Pixel <-> lane mapping: a wavefront owns one 8x8-pixel tile (lane = ly*8 + lx), the reference's workgroup footprint
 // (clouds.glsl:5): its 64 rays are angularly adjacent, so their texture footprints overlap (L1/TA coalescing) and
 // they enter/leave cloud together.  A 256-thread workgroup = 4 wavefronts covers 4/SEG tiles side by side:
@@ -475,7 +521,7 @@ __global__ __launch_bounds__(256, 7) void clouds_kernel(TexSet T, const FrameCon
     }
 }
 
-static const char* const kVariantNames[] = {"lockstep", "queue"};
+static const char* const kVariantNames[] = {"lockstep", "queue", "queue-lds"};
 int cloud_variant_count() { return (int)(sizeof(kVariantNames) / sizeof(kVariantNames[0])); }
 const char* cloud_variant_name(int v) { return (v >= 0 && v < cloud_variant_count()) ? kVariantNames[v] : nullptr; }
 
@@ -495,6 +541,16 @@ hipError_t launch_clouds(int variant, int seg, const TexSet& t, const FrameConst
             attr_set = true;
         }
         clouds_kernel_interleaved<0><<<grid, 256, IL_BLOCK_FLOATS * sizeof(float), s>>>(t, d_fc, g, d_order, d_out, d_stats);
+    }
+    else if (variant == 2) {                                  // detail noise staged in LDS, 16 wavefronts per workgroup
+        constexpr size_t bytes = ((DETAIL_CHAIN_TEXELS + 7) / 8 * 4 + 16 * Q_FLOATS) * sizeof(float);
+        static bool attr_set = false;
+        if (!attr_set) {
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&clouds_kernel_lds<0>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+            if (e != hipSuccess) return e;
+            attr_set = true;
+        }
+        clouds_kernel_lds<0><<<grid, 1024, bytes, s>>>(t, d_fc, g, d_order, d_out, d_stats);
     }
     else return hipErrorInvalidValue;
     return hipGetLastError();

@@ -40,7 +40,7 @@ void hostsim_sky(int w, int h, const float sun[3], const uint16_t* trans_h, int 
 // mip chains (level 0 first) -> baked layouts -> march every pixel of the band set, like clouds_kernel does.
 void hostsim_clouds(const uint8_t* large_chain, const uint8_t* small_chain, const uint8_t* weather_rgb8, const float params[28],
                     int primary_steps, int light_steps, float early_eps, const uint16_t* sky_h, int sw, int sh, int tile_w,
-                    int band_rows, int first_band, int band_stride, int n_bands, uint16_t* out_h, uint64_t* incloud, int use_window, float* window_out) {
+                    int band_rows, int first_band, int band_stride, int n_bands, uint16_t* out_h, uint64_t* incloud, int use_window, float* window_out, int use_lds_path) {
     std::vector<uint8_t> lc(large_chain, large_chain + csky_mip_offset(SHAPE_N, SHAPE_LEVELS, 4));
     std::vector<uint8_t> sc(small_chain, small_chain + csky_mip_offset(DETAIL_N, DETAIL_LEVELS, 3));
     std::vector<uint2> shape; std::vector<uint4> detail, weather;
@@ -49,6 +49,9 @@ void hostsim_clouds(const uint8_t* large_chain, const uint8_t* small_chain, cons
     bake_shape(lc, shape, shape_off); bake_detail(sc, detail, detail_off); bake_weather(weather_rgb8, weather);
     std::vector<float4> sky = widen(sky_h, sw, sh);
     T.shape = shape.data(); T.detail = detail.data(); T.weather = weather.data(); T.sky = sky.data(); T.sky_w = sw; T.sky_h = sh;
+    std::vector<uint16_t> detail_h;
+    bake_detail_unpacked(sc, detail_h);
+    T.detail_h = detail_h.data(); T.detail_lds = use_lds_path ? detail_h.data() : nullptr;
     { const uint8_t* t5 = sc.data() + csky_mip_offset(DETAIL_N, 5, 3); T.detail_lod5 = (float)(5 * t5[0] + 2 * t5[1] + t5[2]) * (1.0f / (8.0f * 255.0f)); }
     CloudParams P; memcpy(&P, params, sizeof P);
     FrameConsts fc;

@@ -44,7 +44,7 @@ def test_sky_lut(gpu_ctx, o_skies):
         assert (gpu_ctx.read_sky_lut().view(np.uint16) == s.view(np.uint16)).all()
 
 
-@pytest.mark.parametrize("variant", [0, 1])
+@pytest.mark.parametrize("variant", [0, 1, 2])
 @pytest.mark.parametrize("sun_name", list(SUNS))
 def test_clouds_vs_oracle_default_config(gpu_ctx, oracle, otex, o_skies, sun_name, variant):
     sun = SUNS[sun_name]
@@ -84,6 +84,13 @@ def test_variants_and_schedules_agree(gpu_ctx, oracle):
     ok, info = cloud_close(imgs[1][0], imgs[0][0], frac=0.9999, atol=5e-4, rtol=2e-3)
     assert ok, info
     assert imgs[0][1] == imgs[1][1]
+    # the "queue-lds" variant (detail noise staged in LDS) runs the same march: identical counts, frames equal to rounding
+    gpu_ctx.set_variant(2)
+    for sch in (-1, 2):
+        gpu_ctx.set_schedule(sch)
+        img = gpu_ctx.render_clouds(p)
+        ok, info = cloud_close(img, imgs[1][0], frac=0.9999, atol=5e-4, rtol=2e-3)
+        assert ok and gpu_ctx.cloud_stats() == imgs[1][1], (sch, info)
     gpu_ctx.set_variant(1); gpu_ctx.set_schedule(-1)
     # ray segments (1, 2, 4 wavefronts per ray): identical sample positions and in-cloud counts, re-associated compositing
     for seg in (1, 2, 4, 5):

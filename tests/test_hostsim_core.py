@@ -12,7 +12,7 @@ def P(a):
     return a.ctypes.data_as(C.c_void_p)
 
 
-def hs_clouds(hostsim, pkg, noise, params, sky, tile_w, bands, primary=128, light=6, eps=0.0, window=True, ret_window=False):
+def hs_clouds(hostsim, pkg, noise, params, sky, tile_w, bands, primary=128, light=6, eps=0.0, window=True, ret_window=False, lds_path=False):
     large, small, weather = noise
     lc, sc = pkg.assets.build_mips(large, 8), pkg.assets.build_mips(small, 6)
     rows = bands[0] * bands[3]
@@ -22,7 +22,7 @@ def hs_clouds(hostsim, pkg, noise, params, sky, tile_w, bands, primary=128, ligh
     p = np.ascontiguousarray(params, np.float32)
     s = np.ascontiguousarray(sky).view(np.uint16)
     hostsim.hostsim_clouds(P(lc), P(sc), P(weather), P(p), primary, light, C.c_float(eps), P(s), s.shape[1], s.shape[0], tile_w,
-                           bands[0], bands[1], bands[2], bands[3], P(out), C.byref(ic), int(window), P(win))
+                           bands[0], bands[1], bands[2], bands[3], P(out), C.byref(ic), int(window), P(win), int(lds_path))
     if ret_window:
         return out.view(np.float16), ic.value, win
     return out.view(np.float16), ic.value
@@ -98,3 +98,11 @@ def test_height_window_reject_is_exact(hostsim, pkg, oracle, noise, o_skies):
             assert win[0] == -1.0 and win[1] == 2.0                        # coverage*weather.b may exceed 1: shortcut disabled
         if cov <= 0.0:
             assert ia == 0
+
+
+def test_lds_detail_tap_path_is_identical(hostsim, pkg, oracle, noise, o_skies):
+    """The detail tap of the "lds" kernel variant (eight unpacked fp16 reads) returns exactly what the oct-packed gather returns."""
+    p = oracle.default_params(48, 24, (1, 1, 0))
+    a, ia = hs_clouds(hostsim, pkg, noise, p, o_skies["deg45"], 48, (8, 0, 1, 3))
+    b, ib = hs_clouds(hostsim, pkg, noise, p, o_skies["deg45"], 48, (8, 0, 1, 3), lds_path=True)
+    assert (a.view(np.uint16) == b.view(np.uint16)).all() and ia == ib

@@ -33,17 +33,11 @@ ctx.render_transmittance(256, 64)
 ctx.render_sky_lut(s, 200, 100, readback=False)
 if a.time:
     L = gvcd_amd.lib()
-    ctx.set_variant(1)
-    for nb in (1, 8):
-        bands = (8, 0, nb, H // 8 // nb)
-        row = []
-        for seg in (0,):
-            ctx.set_segments(seg)
-            for sched in ((-1,) if seg == 0 else (5, 2)):
-                ctx.set_schedule(sched)
-                ms, st = ctx.time_clouds(p, W, bands, warmup=2, iters=a.frames)
-                row.append("g%d/s%d %.3f" % (seg, sched, ms))
-        print("1/%d frame: %s" % (nb, "  ".join(row)), flush=True)
+    for v in range(L.csky_variant_count()):
+        ctx.set_variant(v)
+        for nb in (1, 8):
+            ms, st = ctx.time_clouds(p, W, (8, 0, nb, H // 8 // nb), warmup=2, iters=a.frames)
+            print("variant %d %-10s 1/%d frame: %.3f ms" % (v, L.csky_variant_name(v).decode(), nb, ms), flush=True)
 else:
     ctx.set_variant(a.variant)
     ctx.set_schedule(a.sched)
