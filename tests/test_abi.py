@@ -61,3 +61,15 @@ def test_product_does_not_reference_oracle():
             if f.endswith((".py", ".cpp", ".hip", ".h")):
                 src = open(os.path.join(dp, f)).read()
                 assert "from oracle" not in src and "import oracle" not in src and "cskoracle" not in src and "csko_" not in src, f
+
+
+def test_header_is_plain_c_and_links(pkg, tmp_path):
+    """include/cloudsky.h compiles as C99 and a plain C program links against libcloudsky.so (no C++/torch types in the ABI)."""
+    import subprocess
+    exe = str(tmp_path / "c_abi_check")
+    lib_dir = os.path.dirname(pkg.library_path())
+    subprocess.check_call(["gcc", "-std=c99", "-Wall", "-Werror", "-pedantic", "-I", os.path.join(ROOT, "include"),
+                           os.path.join(ROOT, "tests", "c_abi_check.c"), "-o", exe, "-L", lib_dir, "-l:libcloudsky.so",
+                           "-Wl,-rpath," + lib_dir, "-Wl,-rpath,/opt/rocm/lib"])
+    out = subprocess.run([exe], capture_output=True, text=True)
+    assert out.returncode == 0 and "c abi ok" in out.stdout, (out.returncode, out.stdout, out.stderr)

@@ -325,3 +325,20 @@ def test_sun_sweep_time_of_day(gpu_ctx, oracle, otex, o_trans):
         p = oracle.default_params(128, 64, sun)
         ok, info = cloud_close(gpu_ctx.render_clouds(p), oracle.clouds(otex, p, sk_o))
         assert ok, (th, info)
+
+
+def test_texture_size_limits(gpu_ctx, oracle, otex, o_skies):
+    """cloud_sky.gd:44 @export_range(32, 8192, 32): the smallest texture against the oracle, the largest through its invariants."""
+    gpu_ctx.set_march(128, 6)
+    gpu_ctx.render_sky_lut(norm((1, 1, 0)), 200, 100)
+    p = oracle.default_params(32, 32, (1, 1, 0))
+    ok, info = cloud_close(gpu_ctx.render_clouds(p), oracle.clouds(otex, p, o_skies["deg45"]))
+    assert ok, info
+    W = H = 8192
+    p = oracle.default_params(W, H, (1, 1, 0))
+    band = gpu_ctx.render_clouds(p, W, 64).astype(np.float32)          # the first 64 rows of the 8192^2 frame (horizon side)
+    assert np.isfinite(band).all() and (band[0] == 0).all() and (band[:, 0] == 0).all() and band[..., 3].max() <= 1
+    q = p.copy(); q[2:4] = (4096 - 32, 4096 - 32)                      # a 64x64 tile around the zenith pixel
+    tile = gpu_ctx.render_clouds(q, 64, 64)
+    ok, info = cloud_close(tile, oracle.clouds(otex, q, o_skies["deg45"], rect=(0, 0, 64, 64)))
+    assert ok, info
