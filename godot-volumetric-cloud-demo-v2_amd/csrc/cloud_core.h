@@ -189,12 +189,24 @@ CSKY_HD float lerp_h(uint32_t p, float f) {
 #endif
 }
 
+// Texel coordinate -> (floor as int, fraction).  gfx950 has v_cvt_flr_i32_f32 (float -> int with floor rounding) and
+// v_fract_f32, so the pair costs 2 instructions instead of floor + cvt + sub; u - floor(u) is exact in fp32 and v_fract returns
+// the same value (it only clamps the one-in-2^25 case u = -tiny to 1 - 2^-24 instead of 1.0).
+CSKY_HD void split_coord(float u, int& i, float& f) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    asm("v_cvt_flr_i32_f32 %0, %1" : "=v"(i) : "v"(u));
+    f = __builtin_amdgcn_fractf(u);
+#else
+    const float fl = floorf(u);
+    i = (int)fl; f = u - fl;
+#endif
+}
+
 // REPEAT + LINEAR bilinear tap of the quad-packed weather map (clouds.glsl:174).  Returns r (cloud type), b (coverage).
 CSKY_HD void weather_tap(const uint4* __restrict__ w, float sx, float sy, float& wr, float& wb) {
-    const float ux = sx * 512.0f - 0.5f, uy = sy * 512.0f - 0.5f;
-    const float fx0 = floorf(ux), fy0 = floorf(uy);
-    const float ax = ux - fx0, ay = uy - fy0;
-    const int x0 = ((int)fx0) & 511, y0 = ((int)fy0) & 511;
+    int ix, iy; float ax, ay;
+    split_coord(sx * 512.0f - 0.5f, ix, ax); split_coord(sy * 512.0f - 0.5f, iy, ay);
+    const int x0 = ix & 511, y0 = iy & 511;
     const uint4 q = *reinterpret_cast<const uint4*>(reinterpret_cast<const char*>(w) + ((((uint32_t)y0 << 9) | (uint32_t)x0) << 4));
     wr = lerpf(lerp_h(q.x, ax), lerp_h(q.y, ax), ay) * (1.0f / 255.0f);
     wb = lerpf(lerp_h(q.z, ax), lerp_h(q.w, ax), ay) * (1.0f / 255.0f);
@@ -209,10 +221,9 @@ CSKY_HD uint32_t detail_level_offset(int l) { return ((1u << 18) - (1u << (18 - 
 CSKY_HD void shape_tap(const TexSet& T, int lvl, float sx, float sy, float sz, float& r, float& fbm) {
     const int n = SHAPE_N >> lvl, m = n - 1;
     const float fn = (float)n;
-    const float ux = sx * fn - 0.5f, uy = sy * fn - 0.5f, uz = sz * fn - 0.5f;
-    const float fx0 = floorf(ux), fy0 = floorf(uy), fz0 = floorf(uz);
-    const float ax = ux - fx0, ay = uy - fy0, az = uz - fz0;
-    const int x0 = ((int)fx0) & m, y0 = ((int)fy0) & m, z0 = ((int)fz0) & m;
+    int ix, iy, iz; float ax, ay, az;
+    split_coord(sx * fn - 0.5f, ix, ax); split_coord(sy * fn - 0.5f, iy, ay); split_coord(sz * fn - 0.5f, iz, az);
+    const int x0 = ix & m, y0 = iy & m, z0 = iz & m;
     const int y1 = (y0 + 1) & m, z1 = (z0 + 1) & m;
     const uint32_t sh = (uint32_t)(7 - lvl), base = shape_level_offset(lvl) + (uint32_t)x0;   // n = 1 << sh: shifts, not v_mul_lo_u32 (quarter rate)
     const uint32_t r00 = ((((uint32_t)z0 << sh) | (uint32_t)y0) << sh), r10 = ((((uint32_t)z0 << sh) | (uint32_t)y1) << sh);
@@ -231,10 +242,9 @@ CSKY_HD float detail_tap(const TexSet& T, int lvl, float sx, float sy, float sz)
     if (lvl == 5) return T.detail_lod5;
     const int n = DETAIL_N >> lvl, m = n - 1;
     const float fn = (float)n;
-    const float ux = sx * fn - 0.5f, uy = sy * fn - 0.5f, uz = sz * fn - 0.5f;
-    const float fx0 = floorf(ux), fy0 = floorf(uy), fz0 = floorf(uz);
-    const float ax = ux - fx0, ay = uy - fy0, az = uz - fz0;
-    const int x0 = ((int)fx0) & m, y0 = ((int)fy0) & m, z0 = ((int)fz0) & m;
+    int ix, iy, iz; float ax, ay, az;
+    split_coord(sx * fn - 0.5f, ix, ax); split_coord(sy * fn - 0.5f, iy, ay); split_coord(sz * fn - 0.5f, iz, az);
+    const int x0 = ix & m, y0 = iy & m, z0 = iz & m;
     if (T.detail_lds) {
         // "lds" variant (north star: noise bricks staged in LDS): the whole detail chain sits in LDS as unpacked fp16 texels, so
         // a tap is eight 2-byte LDS reads assembled into the same x-neighbour pairs the global layout stores pre-packed
