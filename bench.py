@@ -31,6 +31,8 @@ CONFIGS = {
     "C2": (512, 256, 64, 4, (0.0, 1.0, 0.0)),
     "C3": (2048, 1024, 128, 6, (1.0, 1.0, 0.0)),
     "C5frame": (4096, 2048, 128, 6, (1.0, 1.0, 0.0)),
+    # BASELINE configs[4]: 64-frame animated sun sweep, sun = (cos th, sin th, 0), th = 2..178 degrees, sky LUT recomputed per frame
+    "C5": (4096, 2048, 128, 6, "sweep"),
 }
 BYTES_PER_SAMPLE = 80        # weather bilinear (4 texels) + shape trilinear (8) + detail trilinear (8), RGBA8
 HBM_PEAK_GBS = 8000.0        # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
@@ -107,6 +109,11 @@ def main():
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
     W, H, primary, light, sun = CONFIGS[args.config]
+    sweep = None
+    if isinstance(sun, str):
+        th = np.radians(np.linspace(2.0, 178.0, 64))
+        sweep = [default_params(W, H, (np.cos(t), np.sin(t), 0.0)) for t in th]      # one push-constant block + sun per frame
+        sun = (np.cos(th[16]), np.sin(th[16]), 0.0)                                    # representative frame for the kernel-only timing
     params, sun_n = default_params(W, H, sun)
     large, small, weather = gvcd_amd.assets.load_default_noise()
 
@@ -146,8 +153,9 @@ def main():
         k = counter[0]
         counter[0] += 1
         bset = k % nbuf
-        ctx.render_sky_lut_device(sun_n, 200, 100, stream)                                     # sky_lut.gd:122-148
-        ctx.render_clouds_device(params, W, bands, local[bset].data_ptr(), W * 8, stream)      # cloud_sky.gd:234-248
+        fp, fs = (params, sun_n) if sweep is None else sweep[k % len(sweep)]
+        ctx.render_sky_lut_device(fs, 200, 100, stream)                                        # sky_lut.gd:122-148
+        ctx.render_clouds_device(fp, W, bands, local[bset].data_ptr(), W * 8, stream)         # cloud_sky.gd:234-248
         if world == 1:
             frame[0] = local[0]
             return
