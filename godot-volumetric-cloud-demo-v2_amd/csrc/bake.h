@@ -8,7 +8,8 @@
 
 namespace csky {
 // ---- texture baking (layouts documented in csky_common.h) ----
-inline uint32_t hpair(uint32_t lo, uint32_t hi) { return (uint32_t)f2h((float)lo) | ((uint32_t)f2h((float)hi) << 16); }   // exact: values <= 2040
+// {texel(x), texel(x+1) - texel(x)} as two fp16 (exact: |values| <= 2040), the operand pair of lerp_h() in cloud_core.h
+inline uint32_t hpair(uint32_t lo, uint32_t hi) { return (uint32_t)f2h((float)lo) | ((uint32_t)f2h((float)((int)hi - (int)lo)) << 16); }
 
 inline void bake_shape(const std::vector<uint8_t>& chain, std::vector<uint2>& out, uint32_t off[SHAPE_LEVELS]) {
     size_t total = 0;

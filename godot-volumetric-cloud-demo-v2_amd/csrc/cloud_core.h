@@ -173,18 +173,29 @@ CSKY_HD void frame_setup(const CloudParams& P, const float4* sky, int sky_w, int
 // =================================================================================================
 #pragma clang fp contract(fast)
 
-// lo + f*(hi - lo) for a pair of fp16 texel values packed in one dword (lo = bits 0-15, hi = bits 16-31), evaluated in
-// fp32 as fma(hi, f, fma(lo, -f, lo)).  On gfx950 this is two v_fma_mix_f32 (the f16 -> f32 widening is free inside the
-// FMA: 2 x 4.4 cycles instead of cvt + cvt + sub + fma = 17 cycles for byte texels; tools/ubench/valu_rates.hip).
-// Texel values are small integers (<= 2040), exact in fp16, so nothing is lost by the storage format.
+// a + f*d for an fp16 pair packed in one dword: lo = texel(x) = a, hi = texel(x+1) - texel(x) = d (the x-neighbour DIFFERENCE is
+// stored, not the neighbour: an integer in [-2040, 2040], exact in fp16).  On gfx950 this is ONE v_fma_mix_f32: the f16 -> f32
+// widening is free inside the FMA (4.4 cycles; byte texels needed cvt + cvt + sub + fma = 17, tools/ubench/valu_rates.hip), and
+// it is literally the reference sampler's a + (b - a)*f with an exact (b - a).
 CSKY_HD float lerp_h(uint32_t p, float f) {
 #if defined(__HIP_DEVICE_COMPILE__)
-    float t, r;
-    asm volatile("v_fma_mix_f32 %0, %1, -%2, %1 op_sel:[0,0,0] op_sel_hi:[1,0,1]" : "=v"(t) : "v"(p), "v"(f));
-    asm volatile("v_fma_mix_f32 %0, %1, %2, %3 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(r) : "v"(p), "v"(f), "v"(t));
+    float r;
+    asm volatile("v_fma_mix_f32 %0, %1, %2, %1 op_sel:[1,0,0] op_sel_hi:[1,0,1]" : "=v"(r) : "v"(p), "v"(f));
     return r;
 #else
-    const float lo = h2f((uint16_t)(p & 0xffffu)), hi = h2f((uint16_t)(p >> 16));
+    const float a = h2f((uint16_t)(p & 0xffffu)), d = h2f((uint16_t)(p >> 16));
+    return fmaf(d, f, a);
+#endif
+}
+// the same for two separately stored fp16 texels a, b (LDS variant: the neighbours are not pre-differenced)
+CSKY_HD float lerp_h2(uint32_t a_lo_b_hi, float f) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    float t, r;
+    asm volatile("v_fma_mix_f32 %0, %1, -%2, %1 op_sel:[0,0,0] op_sel_hi:[1,0,1]" : "=v"(t) : "v"(a_lo_b_hi), "v"(f));
+    asm volatile("v_fma_mix_f32 %0, %1, %2, %3 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(r) : "v"(a_lo_b_hi), "v"(f), "v"(t));
+    return r;
+#else
+    const float lo = h2f((uint16_t)(a_lo_b_hi & 0xffffu)), hi = h2f((uint16_t)(a_lo_b_hi >> 16));
     return fmaf(hi, f, fmaf(lo, -f, lo));
 #endif
 }
@@ -255,7 +266,7 @@ CSKY_HD float detail_tap(const TexSet& T, int lvl, float sx, float sy, float sz)
         const uint32_t r01 = (((uint32_t)z1 << sh2) | (uint32_t)y0) << sh2, r11 = (((uint32_t)z1 << sh2) | (uint32_t)y1) << sh2;
         const uint32_t p00 = (uint32_t)d[r00 + x0] | ((uint32_t)d[r00 + x1] << 16), p10 = (uint32_t)d[r10 + x0] | ((uint32_t)d[r10 + x1] << 16);
         const uint32_t p01 = (uint32_t)d[r01 + x0] | ((uint32_t)d[r01 + x1] << 16), p11 = (uint32_t)d[r11 + x0] | ((uint32_t)d[r11 + x1] << 16);
-        return lerpf(lerpf(lerp_h(p00, ax), lerp_h(p10, ax), ay), lerpf(lerp_h(p01, ax), lerp_h(p11, ax), ay), az) * (1.0f / (8.0f * 255.0f));
+        return lerpf(lerpf(lerp_h2(p00, ax), lerp_h2(p10, ax), ay), lerpf(lerp_h2(p01, ax), lerp_h2(p11, ax), ay), az) * (1.0f / (8.0f * 255.0f));
     }
     const uint32_t sh = (uint32_t)(5 - lvl), idx = detail_level_offset(lvl) + ((((((uint32_t)z0 << sh) | (uint32_t)y0) << sh)) | (uint32_t)x0);
     const uint4 q = *reinterpret_cast<const uint4*>(reinterpret_cast<const char*>(T.detail) + (idx << 4));

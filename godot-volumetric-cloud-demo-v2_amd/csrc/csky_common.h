@@ -32,7 +32,7 @@ constexpr int DETAIL_CHAIN_TEXELS = 32768 + 4096 + 512 + 64 + 8 + 1;   // all si
 
 // ---- device texture layouts (baked by bake.h) ----------------------------------------
 // Texel values are stored as fp16 (small integers, exact) so that v_fma_mix_f32 widens them for free inside the
-// filtering FMAs; every dword holds the x-neighbour pair {lo = texel(x), hi = texel(x+1 mod N)}.
+// filtering FMAs; every dword holds {lo = texel(x), hi = texel(x+1 mod N) - texel(x)}: the x-lerp is one FMA, a + f*d.
 // shape  : per texel uint2 {r pair, fbm-numerator pair}, numerator = 5g+2b+a (fbm = num / (8*255), clouds.glsl:118)
 //          -> 4 x 8-byte loads per trilinear tap
 // detail : per texel uint4 = the 2x2x2 neighbourhood's numerators 5r+2g+b (clouds.glsl:133): {y0z0, y1z0, y0z1, y1z1} pairs
