@@ -395,6 +395,7 @@ __global__ __launch_bounds__(256) void clouds_kernel_interleaved(TexSet T, const
     const int band = lr / G.band_rows, rib = lr - band * G.band_rows;
     const int gy = (G.first_band + band * G.band_stride) * G.band_rows + rib;
     const FrameConsts& fc = *fcp;
+    T.detail_lds = nullptr;
     Ray ray = ray_setup(fc, valid ? gx : 0, valid ? gy : 0);
     if (!valid) ray.above = false;
     float r, g, b, a; unsigned ic;
@@ -484,6 +485,7 @@ __global__ __launch_bounds__(256, 7) void clouds_kernel(TexSet T, const FrameCon
     const int gy = (G.first_band + band * G.band_stride) * G.band_rows + rib;
 
     const FrameConsts& fc = *fcp;
+    T.detail_lds = nullptr;                                    // compile-time constant here: the LDS tap path folds away
     Ray ray = ray_setup(fc, valid ? gx : 0, valid ? gy : 0);
     if (!valid) ray.above = false;
     MarchOut o;
