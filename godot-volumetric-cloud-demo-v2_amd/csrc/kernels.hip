@@ -535,23 +535,16 @@ hipError_t launch_clouds(int variant, int seg, const TexSet& t, const FrameConst
     else if (variant == 1 && seg == 2) clouds_kernel<1, 2><<<grid, 256, 0, s>>>(t, d_fc, g, d_order, d_out, d_stats);
     else if (variant == 1 && seg == 4) clouds_kernel<1, 4><<<grid, 256, 0, s>>>(t, d_fc, g, d_order, d_out, d_stats);
     else if (variant == 1 && seg == 5) {                      // 5 = 4 interleaved segments, one tile per workgroup, 76 KB of LDS
-        static bool attr_set = false;
-        if (!attr_set) {
-            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&clouds_kernel_interleaved<0>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                               (int)(IL_BLOCK_FLOATS * sizeof(float)));
-            if (e != hipSuccess) return e;
-            attr_set = true;
-        }
+        // > 64 KB of dynamic LDS needs the opt-in attribute; it is per device, so set it on every launch (cheap, idempotent)
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&clouds_kernel_interleaved<0>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                           (int)(IL_BLOCK_FLOATS * sizeof(float)));
+        if (e != hipSuccess) return e;
         clouds_kernel_interleaved<0><<<grid, 256, IL_BLOCK_FLOATS * sizeof(float), s>>>(t, d_fc, g, d_order, d_out, d_stats);
     }
     else if (variant == 2) {                                  // detail noise staged in LDS, 16 wavefronts per workgroup
         constexpr size_t bytes = ((DETAIL_CHAIN_TEXELS + 7) / 8 * 4 + 16 * Q_FLOATS) * sizeof(float);
-        static bool attr_set = false;
-        if (!attr_set) {
-            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&clouds_kernel_lds<0>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
-            if (e != hipSuccess) return e;
-            attr_set = true;
-        }
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&clouds_kernel_lds<0>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+        if (e != hipSuccess) return e;
         clouds_kernel_lds<0><<<grid, 1024, bytes, s>>>(t, d_fc, g, d_order, d_out, d_stats);
     }
     else return hipErrorInvalidValue;
