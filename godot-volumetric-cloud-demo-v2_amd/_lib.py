@@ -50,6 +50,7 @@ SYMBOLS = [
     ("csky_destroy", None, [C.c_void_p]),
     ("csky_last_error", C.c_char_p, [C.c_void_p]),
     ("csky_set_noise", C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    ("csky_noise_inexact_coeffs", C.c_int, [C.c_void_p, C.POINTER(C.c_uint64)]),
     ("csky_set_march", C.c_int, [C.c_void_p, C.c_int, C.c_int]),
     ("csky_set_early_out", C.c_int, [C.c_void_p, C.c_float]),
     ("csky_render_transmittance", C.c_int, [C.c_void_p, C.POINTER(TransParams), C.c_void_p]),
@@ -81,7 +82,8 @@ SYMBOLS = [
 
 
 def library_path():
-    return os.path.join(_HERE, "libcloudsky.so")
+    # CSKY_LIBRARY: explicit path of an alternative build (A/B timing of kernel experiments); default = the in-tree build
+    return os.environ.get("CSKY_LIBRARY") or os.path.join(_HERE, "libcloudsky.so")
 
 
 def lib():
@@ -152,6 +154,12 @@ class Context:
         if a.size != 128 ** 3 * 4 or b.size != 32 ** 3 * 3 or c.size != 512 * 512 * 3:
             raise ValueError("set_noise: expected 128^3 RGBA8, 32^3 RGB8, 512^2 RGB8")
         self._chk(self._L.csky_set_noise(self._h, _ptr(a), _ptr(b), _ptr(c)))
+
+    def noise_inexact_coeffs(self):
+        """Finite-difference coefficients of the bound textures that fp16 could not hold exactly (0 for natural noise)."""
+        n = C.c_uint64()
+        self._chk(self._L.csky_noise_inexact_coeffs(self._h, C.byref(n)))
+        return n.value
 
     def set_march(self, primary_steps=128, light_steps=6):
         self._chk(self._L.csky_set_march(self._h, primary_steps, light_steps))

@@ -24,7 +24,7 @@ struct csky_ctx {
     hipStream_t stream = nullptr;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     // noise set (cloud_sky.gd:298-341)
-    uint2* d_shape = nullptr; uint4* d_detail = nullptr; uint4* d_weather = nullptr; uint16_t* d_detail_h = nullptr; bool have_noise = false;
+    ShapeTexel* d_shape = nullptr; unsigned long long inexact_coeffs = 0; uint4* d_detail = nullptr; uint4* d_weather = nullptr; uint16_t* d_detail_h = nullptr; bool have_noise = false;
     uint32_t shape_off[SHAPE_LEVELS] = {}, detail_off[DETAIL_LEVELS] = {};
     float detail_lod5 = 0.0f;
     double w_rmin = 0.0, w_rmax = 1.0, w_bmax = 1.0;   // range of the weather map's cloud-type / coverage channels
@@ -279,10 +279,11 @@ int csky_set_noise(csky_ctx* c, const uint8_t* large_rgba8, const uint8_t* small
     memcpy(sc.data(), small_rgb8, (size_t)DETAIL_N * DETAIL_N * DETAIL_N * 3);
     csky_build_mips(lc.data(), SHAPE_N, 4, SHAPE_LEVELS);      // mipmaps/generate=true, perlworlnoise.tga.import:24
     csky_build_mips(sc.data(), DETAIL_N, 3, DETAIL_LEVELS);    // worlnoise.bmp.import:24
-    std::vector<uint2> shape; std::vector<uint4> detail, weather;
-    bake_shape(lc, shape, c->shape_off);
-    bake_detail(sc, detail, c->detail_off);
-    bake_weather(weather_rgb8, weather);
+    std::vector<ShapeTexel> shape; std::vector<uint4> detail, weather;
+    c->inexact_coeffs = 0;
+    bake_shape(lc, shape, c->shape_off, &c->inexact_coeffs);
+    bake_detail(sc, detail, c->detail_off, &c->inexact_coeffs);
+    bake_weather(weather_rgb8, weather, &c->inexact_coeffs);
     std::vector<uint16_t> detail_h;
     bake_detail_unpacked(sc, detail_h);
     if (detail_h.size() != (size_t)DETAIL_CHAIN_TEXELS) return fail(c, CSKY_ERR_INVALID, "internal: detail chain size");
@@ -300,10 +301,17 @@ int csky_set_noise(csky_ctx* c, const uint8_t* large_rgba8, const uint8_t* small
     if ((rc = dev_alloc(c, &c->d_weather, weather.size()))) return rc;
     if ((rc = dev_alloc(c, &c->d_detail_h, detail_h.size() + 8))) return rc;
     HIPCHK(c, hipMemcpy(c->d_detail_h, detail_h.data(), detail_h.size() * sizeof(uint16_t), hipMemcpyHostToDevice));
-    HIPCHK(c, hipMemcpy(c->d_shape, shape.data(), shape.size() * sizeof(uint2), hipMemcpyHostToDevice));
+    HIPCHK(c, hipMemcpy(c->d_shape, shape.data(), shape.size() * sizeof(ShapeTexel), hipMemcpyHostToDevice));
     HIPCHK(c, hipMemcpy(c->d_detail, detail.data(), detail.size() * sizeof(uint4), hipMemcpyHostToDevice));
     HIPCHK(c, hipMemcpy(c->d_weather, weather.data(), weather.size() * sizeof(uint4), hipMemcpyHostToDevice));
     c->have_noise = true;
+    return CSKY_OK;
+}
+
+int csky_noise_inexact_coeffs(csky_ctx* c, uint64_t* n) {
+    if (!c || !n) return CSKY_ERR_INVALID;
+    if (!c->have_noise) return fail(c, CSKY_ERR_STATE, "csky_noise_inexact_coeffs: csky_set_noise has not been called");
+    *n = (uint64_t)c->inexact_coeffs;
     return CSKY_OK;
 }
 

@@ -219,8 +219,8 @@ CSKY_HD void weather_tap(const uint4* __restrict__ w, float sx, float sy, float&
     split_coord(sx * 512.0f - 0.5f, ix, ax); split_coord(sy * 512.0f - 0.5f, iy, ay);
     const int x0 = ix & 511, y0 = iy & 511;
     const uint4 q = *reinterpret_cast<const uint4*>(reinterpret_cast<const char*>(w) + ((((uint32_t)y0 << 9) | (uint32_t)x0) << 4));
-    wr = lerpf(lerp_h(q.x, ax), lerp_h(q.y, ax), ay) * (1.0f / 255.0f);
-    wb = lerpf(lerp_h(q.z, ax), lerp_h(q.w, ax), ay) * (1.0f / 255.0f);
+    wr = fmaf(ay, lerp_h(q.y, ax), lerp_h(q.x, ax)) * (1.0f / 255.0f);      // polynomial cell: (c0 + c1 fx) + fy (c2 + c3 fx)
+    wb = fmaf(ay, lerp_h(q.w, ax), lerp_h(q.z, ax)) * (1.0f / 255.0f);
 }
 
 // texel offset of mip level l inside the packed chains: sum_{i<l} (N>>i)^3 = (N^3*8 - (N>>l)^3*8) / 7, computed
@@ -235,15 +235,29 @@ CSKY_HD void shape_tap(const TexSet& T, int lvl, float sx, float sy, float sz, f
     int ix, iy, iz; float ax, ay, az;
     split_coord(sx * fn - 0.5f, ix, ax); split_coord(sy * fn - 0.5f, iy, ay); split_coord(sz * fn - 0.5f, iz, az);
     const int x0 = ix & m, y0 = iy & m, z0 = iz & m;
-    const int y1 = (y0 + 1) & m, z1 = (z0 + 1) & m;
     const uint32_t sh = (uint32_t)(7 - lvl), base = shape_level_offset(lvl) + (uint32_t)x0;   // n = 1 << sh: shifts, not v_mul_lo_u32 (quarter rate)
+    const char* __restrict__ sb = reinterpret_cast<const char*>(T.shape);
+#if CSKY_SHAPE_POLY == 1
+    const int y1 = (y0 + 1) & m, z1 = (z0 + 1) & m;
     const uint32_t r00 = ((((uint32_t)z0 << sh) | (uint32_t)y0) << sh), r10 = ((((uint32_t)z0 << sh) | (uint32_t)y1) << sh);
     const uint32_t r01 = ((((uint32_t)z1 << sh) | (uint32_t)y0) << sh), r11 = ((((uint32_t)z1 << sh) | (uint32_t)y1) << sh);
-    const char* __restrict__ sb = reinterpret_cast<const char*>(T.shape);
     const uint2 t00 = *reinterpret_cast<const uint2*>(sb + ((base + r00) << 3)), t10 = *reinterpret_cast<const uint2*>(sb + ((base + r10) << 3));
     const uint2 t01 = *reinterpret_cast<const uint2*>(sb + ((base + r01) << 3)), t11 = *reinterpret_cast<const uint2*>(sb + ((base + r11) << 3));
     r = lerpf(lerpf(lerp_h(t00.x, ax), lerp_h(t10.x, ax), ay), lerpf(lerp_h(t01.x, ax), lerp_h(t11.x, ax), ay), az) * (1.0f / 255.0f);
     fbm = lerpf(lerpf(lerp_h(t00.y, ax), lerp_h(t10.y, ax), ay), lerpf(lerp_h(t01.y, ax), lerp_h(t11.y, ax), ay), az) * (1.0f / (8.0f * 255.0f));
+#elif CSKY_SHAPE_POLY == 2
+    const int z1 = (z0 + 1) & m;
+    const uint32_t r0 = ((((uint32_t)z0 << sh) | (uint32_t)y0) << sh), r1 = ((((uint32_t)z1 << sh) | (uint32_t)y0) << sh);
+    const uint4 t0 = *reinterpret_cast<const uint4*>(sb + ((base + r0) << 4)), t1 = *reinterpret_cast<const uint4*>(sb + ((base + r1) << 4));
+    r = lerpf(fmaf(ay, lerp_h(t0.y, ax), lerp_h(t0.x, ax)), fmaf(ay, lerp_h(t1.y, ax), lerp_h(t1.x, ax)), az) * (1.0f / 255.0f);
+    fbm = lerpf(fmaf(ay, lerp_h(t0.w, ax), lerp_h(t0.z, ax)), fmaf(ay, lerp_h(t1.w, ax), lerp_h(t1.z, ax)), az) * (1.0f / (8.0f * 255.0f));
+#else
+    const uint32_t r0 = ((((uint32_t)z0 << sh) | (uint32_t)y0) << sh);
+    const uint4* __restrict__ t = reinterpret_cast<const uint4*>(sb + ((base + r0) << 5));
+    const uint4 tr = t[0], tf = t[1];
+    r = fmaf(az, fmaf(ay, lerp_h(tr.w, ax), lerp_h(tr.z, ax)), fmaf(ay, lerp_h(tr.y, ax), lerp_h(tr.x, ax))) * (1.0f / 255.0f);
+    fbm = fmaf(az, fmaf(ay, lerp_h(tf.w, ax), lerp_h(tf.z, ax)), fmaf(ay, lerp_h(tf.y, ax), lerp_h(tf.x, ax))) * (1.0f / (8.0f * 255.0f));
+#endif
 }
 
 // REPEAT + LINEAR trilinear tap of the oct-packed detail volume (clouds.glsl:132-133): returns hfbm.
@@ -270,7 +284,7 @@ CSKY_HD float detail_tap(const TexSet& T, int lvl, float sx, float sy, float sz)
     }
     const uint32_t sh = (uint32_t)(5 - lvl), idx = detail_level_offset(lvl) + ((((((uint32_t)z0 << sh) | (uint32_t)y0) << sh)) | (uint32_t)x0);
     const uint4 q = *reinterpret_cast<const uint4*>(reinterpret_cast<const char*>(T.detail) + (idx << 4));
-    return lerpf(lerpf(lerp_h(q.x, ax), lerp_h(q.y, ax), ay), lerpf(lerp_h(q.z, ax), lerp_h(q.w, ax), ay), az) * (1.0f / (8.0f * 255.0f));
+    return fmaf(az, fmaf(ay, lerp_h(q.w, ax), lerp_h(q.z, ax)), fmaf(ay, lerp_h(q.y, ax), lerp_h(q.x, ax))) * (1.0f / (8.0f * 255.0f));   // polynomial cell
 }
 
 CSKY_HD float height_fraction(float r) { return sat((r - SKY_B_RADIUS) * (1.0f / (SKY_T_RADIUS - SKY_B_RADIUS))); }  // clouds.glsl:77-80

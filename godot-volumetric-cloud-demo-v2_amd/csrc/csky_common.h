@@ -32,15 +32,33 @@ constexpr int DETAIL_CHAIN_TEXELS = 32768 + 4096 + 512 + 64 + 8 + 1;   // all si
 
 // ---- device texture layouts (baked by bake.h) ----------------------------------------
 // Texel values are stored as fp16 (small integers, exact) so that v_fma_mix_f32 widens them for free inside the
-// filtering FMAs; every dword holds {lo = texel(x), hi = texel(x+1 mod N) - texel(x)}: the x-lerp is one FMA, a + f*d.
-// shape  : per texel uint2 {r pair, fbm-numerator pair}, numerator = 5g+2b+a (fbm = num / (8*255), clouds.glsl:118)
-//          -> 4 x 8-byte loads per trilinear tap
-// detail : per texel uint4 = the 2x2x2 neighbourhood's numerators 5r+2g+b (clouds.glsl:133): {y0z0, y1z0, y0z1, y1z1} pairs
-//          -> ONE 16-byte load per trilinear tap
-// weather: per texel uint4 = the 2x2 neighbourhood {r(y0), r(y1), b(y0), b(y1)} pairs (G is never read: clouds.glsl:121,123)
-//          -> ONE 16-byte load per bilinear tap
+// filtering FMAs.  Each texel stores the coefficients of the bi-/trilinear interpolant of the cell that STARTS at it
+// ("polynomial cell"): with corner values v000..v111 (index = x,y,z bit) and fractions (fx,fy,fz)
+//      v(fx,fy,fz) = (c0 + c1 fx) + fy (c2 + c3 fx) + fz [ (c4 + c5 fx) + fy (c6 + c7 fx) ]
+//      c0 = v000, c1 = d_x, c2 = d_y, c3 = d_xy, c4 = d_z, c5 = d_xz, c6 = d_yz, c7 = d_xyz   (finite differences)
+// which is the reference sampler's nested a + (b - a) f expanded once on the host.  Every dword is an fp16 pair
+// {c_even, c_odd}: one v_fma_mix_f32 gives (c_even + c_odd fx), so a trilinear tap is 4 + 2 + 1 = 7 FMAs (nested lerps
+// on x-pairs: 10) and a bilinear one 2 + 1 = 3 (4).  Differences are integers; fp16 holds integers up to 2048 exactly
+// and the bake COUNTS coefficients that do not fit (csky_noise_inexact_coeffs(); 0 for every shipped texture, a
+// synthetic checkerboard can exceed it and then carries a relative 2^-11 error on that coefficient).
+// weather: per texel uint4 {r: c0c1, c2c3, b: c0c1, c2c3} (G is never read: clouds.glsl:121,123) -> ONE 16-byte load / tap
+// detail : per texel uint4 {c0c1, c2c3, c4c5, c6c7} of the hfbm numerator 5r+2g+b (clouds.glsl:133)    -> ONE 16-byte load / tap
+// shape  : CSKY_SHAPE_POLY selects the cell rank for {r, fbm numerator 5g+2b+a (clouds.glsl:118)}:
+//          1: uint2 {r c0c1, f c0c1}: 8 B/texel, 4 x 8-byte loads / tap (x cells; y and z lerped in the kernel)
+//          2: uint4 {r c0c1, r c2c3, f c0c1, f c2c3}: 16 B/texel, 2 x 16-byte loads / tap (xy cells; z lerped in the kernel)
+//          3: 2 x uint4 {r c0..c7}{f c0..c7}: 32 B/texel, 2 x 16-byte loads from ONE address / tap (xyz cells)
+#ifndef CSKY_SHAPE_POLY
+#define CSKY_SHAPE_POLY 3   // measured on MI355X, C3 frame: rank 1 2.89 ms, rank 2 2.56 ms, rank 3 2.52 ms (profiles/r01/texture_cell_rank_ab.txt)
+#endif
+#if CSKY_SHAPE_POLY == 1
+typedef uint2 ShapeTexel;
+#elif CSKY_SHAPE_POLY == 2
+typedef uint4 ShapeTexel;
+#else
+struct ShapeTexel { uint4 r, f; };
+#endif
 struct TexSet {
-    const uint2* shape;     // all mip levels back to back; level l starts at shape_level_offset(l) texels (cloud_core.h)
+    const ShapeTexel* shape;   // all mip levels back to back; level l starts at shape_level_offset(l) texels (cloud_core.h)
     const uint4* detail;    // all mip levels back to back; level l starts at detail_level_offset(l)
     const uint4* weather;   // 512*512
     const float4* sky;      // sky LUT, fp16-rounded values widened to float, sky_w x sky_h

@@ -88,6 +88,10 @@ const char* csky_last_error(const csky_ctx* ctx); /* ctx may be NULL: last creat
  * weather_rgb8: 512x512 RGB8, row 0 = top row of the bitmap                  (weather.bmp)
  * Level-0 data only; the library builds the mip chains (2x2x2 box) and its device layouts. */
 int csky_set_noise(csky_ctx* ctx, const uint8_t* large_rgba8, const uint8_t* small_rgb8, const uint8_t* weather_rgb8);
+/* The device layouts store finite differences of neighbouring texels as fp16 (exact for integers up to 2048).  Returns how
+ * many coefficients of the textures bound by the last csky_set_noise did NOT fit exactly (0 for natural noise; only
+ * adversarial checkerboards of extreme values exceed the range and then carry a relative 2^-11 error on that term). */
+int csky_noise_inexact_coeffs(csky_ctx* ctx, uint64_t* count);
 /* clouds.glsl:228 (128 primary steps) and clouds.glsl:186 (6 light steps) are literals in the reference;
  * this generalises them (BASELINE config 2 is 64 x 4).  light_steps in [0,6], primary_steps in [1,1024]. */
 int csky_set_march(csky_ctx* ctx, int primary_steps, int light_steps);

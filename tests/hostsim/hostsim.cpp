@@ -38,12 +38,24 @@ void hostsim_sky(int w, int h, const float sun[3], const uint16_t* trans_h, int 
 }
 
 // mip chains (level 0 first) -> baked layouts -> march every pixel of the band set, like clouds_kernel does.
+// number of fp16-inexact polynomial-cell coefficients of a texture set (bake.h), and the shape cell rank this build uses
+unsigned long long hostsim_inexact_coeffs(const uint8_t* large_chain, const uint8_t* small_chain, const uint8_t* weather_rgb8) {
+    std::vector<uint8_t> lc(large_chain, large_chain + csky_mip_offset(SHAPE_N, SHAPE_LEVELS, 4));
+    std::vector<uint8_t> sc(small_chain, small_chain + csky_mip_offset(DETAIL_N, DETAIL_LEVELS, 3));
+    std::vector<ShapeTexel> shape; std::vector<uint4> detail, weather;
+    uint32_t so[SHAPE_LEVELS], dof[DETAIL_LEVELS];
+    unsigned long long n = 0;
+    bake_shape(lc, shape, so, &n); bake_detail(sc, detail, dof, &n); bake_weather(weather_rgb8, weather, &n);
+    return n;
+}
+int hostsim_shape_poly() { return CSKY_SHAPE_POLY; }
+
 void hostsim_clouds(const uint8_t* large_chain, const uint8_t* small_chain, const uint8_t* weather_rgb8, const float params[28],
                     int primary_steps, int light_steps, float early_eps, const uint16_t* sky_h, int sw, int sh, int tile_w,
                     int band_rows, int first_band, int band_stride, int n_bands, uint16_t* out_h, uint64_t* incloud, int use_window, float* window_out, int use_lds_path) {
     std::vector<uint8_t> lc(large_chain, large_chain + csky_mip_offset(SHAPE_N, SHAPE_LEVELS, 4));
     std::vector<uint8_t> sc(small_chain, small_chain + csky_mip_offset(DETAIL_N, DETAIL_LEVELS, 3));
-    std::vector<uint2> shape; std::vector<uint4> detail, weather;
+    std::vector<ShapeTexel> shape; std::vector<uint4> detail, weather;
     TexSet T;
     uint32_t shape_off[SHAPE_LEVELS], detail_off[DETAIL_LEVELS];
     bake_shape(lc, shape, shape_off); bake_detail(sc, detail, detail_off); bake_weather(weather_rgb8, weather);

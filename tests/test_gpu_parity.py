@@ -342,3 +342,34 @@ def test_texture_size_limits(gpu_ctx, oracle, otex, o_skies):
     tile = gpu_ctx.render_clouds(q, 64, 64)
     ok, info = cloud_close(tile, oracle.clouds(otex, q, o_skies["deg45"], rect=(0, 0, 64, 64)))
     assert ok, info
+
+
+def test_polynomial_cell_coefficients_exact_for_shipped_noise(gpu_ctx):
+    assert gpu_ctx.noise_inexact_coeffs() == 0
+
+
+def test_white_noise_textures(pkg, oracle, o_trans):
+    """Adversarial inputs: white-noise volumes and weather map (largest texel-to-texel differences; some finite differences
+    leave the exact fp16 range and the library reports how many).  Same tolerance as every other cloud parity test."""
+    rng = np.random.default_rng(11)
+    noise = (rng.integers(0, 256, (128, 128, 128, 4), dtype=np.uint8), rng.integers(0, 256, (32, 32, 32, 3), dtype=np.uint8),
+             rng.integers(0, 256, (512, 512, 3), dtype=np.uint8))
+    otex = oracle.OracleTextures(*noise)
+    sun = norm((1, 1, 0))
+    sk = oracle.sky_lut(sun, o_trans)
+    ctx = pkg.Context(0)
+    try:
+        ctx.set_noise(*noise)
+        assert ctx.noise_inexact_coeffs() > 0
+        ctx.render_transmittance(256, 64)
+        ctx.render_sky_lut(sun, 200, 100)
+        for cov in (0.2, 0.6):
+            p = oracle.default_params(128, 64, (1, 1, 0), coverage=cov)
+            ref, st = oracle.clouds(otex, p, sk, return_stats=True)
+            img = ctx.render_clouds(p)
+            ok, info = cloud_close(img, ref)
+            assert ok, (cov, info)
+            got = int(ctx.cloud_stats()["incloud_samples"])
+            assert got > 0 and abs(got - st["incloud_samples"]) <= 1e-3 * st["incloud_samples"] + 1, cov
+    finally:
+        ctx.close()

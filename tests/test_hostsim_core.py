@@ -107,3 +107,43 @@ def test_lds_detail_tap_path_matches(hostsim, pkg, oracle, noise, o_skies):
     a, ia = hs_clouds(hostsim, pkg, noise, p, o_skies["deg45"], 48, (8, 0, 1, 3))
     b, ib = hs_clouds(hostsim, pkg, noise, p, o_skies["deg45"], 48, (8, 0, 1, 3), lds_path=True)
     assert ia == ib and ulp_diff(a, b).max() <= 1
+
+
+def test_shape_cell_ranks_and_exact_coefficients(hostsim, pkg, oracle, noise, otex, o_skies):
+    """The polynomial-cell layouts (csky_common.h): every rank of the shape cell (x / xy / xyz) reproduces the oracle, and all
+    finite-difference coefficients of the shipped textures are exact in fp16."""
+    import os
+    from conftest import ROOT
+    large, small, weather = noise
+    lc, sc = pkg.assets.build_mips(large, 8), pkg.assets.build_mips(small, 6)
+    p = oracle.default_params(64, 32, SUNS["deg45"])
+    ref, st = oracle.clouds(otex, p, o_skies["deg45"], return_stats=True)
+    for rank, name in ((3, "libhostsim.so"), (1, "libhostsim_p1.so"), (2, "libhostsim_p2.so")):
+        hs = C.CDLL(os.path.join(ROOT, "tests", "hostsim", name))
+        assert hs.hostsim_shape_poly() == rank
+        hs.hostsim_inexact_coeffs.restype = C.c_uint64
+        assert hs.hostsim_inexact_coeffs(P(lc), P(sc), P(weather)) == 0, rank
+        img, ic = hs_clouds(hs, pkg, noise, p, o_skies["deg45"], 64, (8, 0, 1, 4))
+        ok, info = cloud_close(img, ref, frac=0.9995, atol=1e-3, rtol=2e-3)
+        assert ok, (rank, info)
+        assert ic == st["incloud_samples"], rank
+    # white noise does leave the exact range (second differences of the fbm numerator beyond 2048), and the bake says so
+    rnd = np.random.default_rng(5).integers(0, 256, (128, 128, 128, 4), dtype=np.uint8)
+    assert hs.hostsim_inexact_coeffs(P(pkg.assets.build_mips(rnd, 8)), P(sc), P(weather)) > 0
+
+
+def test_white_noise_textures(hostsim, pkg, oracle, o_trans):
+    """Adversarial inputs: white-noise volumes and weather map (largest possible texel-to-texel differences, some finite
+    differences beyond the exact fp16 range).  The filtered result still matches the oracle and every t > 0 decision agrees."""
+    rng = np.random.default_rng(11)
+    noise = (rng.integers(0, 256, (128, 128, 128, 4), dtype=np.uint8), rng.integers(0, 256, (32, 32, 32, 3), dtype=np.uint8),
+             rng.integers(0, 256, (512, 512, 3), dtype=np.uint8))
+    otex = oracle.OracleTextures(*noise)
+    sk = oracle.sky_lut(norm((1, 1, 0)), o_trans)
+    for cov in (0.2, 0.6):
+        p = oracle.default_params(64, 32, (1, 1, 0), coverage=cov)
+        ref, st = oracle.clouds(otex, p, sk, return_stats=True)
+        img, ic = hs_clouds(hostsim, pkg, noise, p, sk, 64, (8, 0, 1, 4))
+        ok, info = cloud_close(img, ref, frac=0.9995, atol=1e-3, rtol=2e-3)
+        assert ok, (cov, info)
+        assert ic == st["incloud_samples"] and ic > 0, cov
