@@ -257,7 +257,7 @@ def main():
                                    "weather.bmp + worlnoise.bmp + generated 128^3 shape noise (seed 1), wind frozen"
                                    % (args.config, W, H, primary, light, sun_n[0], sun_n[1], sun_n[2]),
                        "texture_size": [W, H], "primary_steps": primary, "light_steps": light, "early_out_eps": args.early_out, "with_early_out": early,
-                       "variant": gvcd_amd.lib().csky_variant_name(args.variant if args.variant is not None else 1).decode(),
+                       "variant": gvcd_amd.lib().csky_variant_name(args.variant if args.variant is not None else gvcd_amd._lib.DEFAULT_VARIANT).decode(),
                        "parallelism": "bands%d%s" % (world, "+overlapped-gather" if overlap else ""), "alpha_mean": alpha_mean, "finite": finite},
             "roofline": {"bound": "hbm", "kernel": "clouds_kernel", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_note": traffic_note,

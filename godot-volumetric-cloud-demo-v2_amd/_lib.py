@@ -81,6 +81,9 @@ SYMBOLS = [
 ]
 
 
+DEFAULT_VARIANT = 3   # include/cloudsky.h CSKY_DEFAULT_VARIANT ("compact"); set_variant(-1) selects it
+
+
 def library_path():
     # CSKY_LIBRARY: explicit path of an alternative build (A/B timing of kernel experiments); default = the in-tree build
     return os.environ.get("CSKY_LIBRARY") or os.path.join(_HERE, "libcloudsky.so")

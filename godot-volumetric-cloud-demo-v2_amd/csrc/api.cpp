@@ -37,7 +37,7 @@ struct csky_ctx {
     uint2* d_frame = nullptr; size_t frame_px = 0;  // internal frame for the host-buffer form / timing
     int primary_steps = 128, light_steps = 6;        // clouds.glsl:228, :186
     float early_eps = 0.0f;
-    int variant = 1;
+    int variant = CSKY_DEFAULT_VARIANT;
     int sched_mode = -1;                              // -1 = auto (5 for large launches, 2 for small ones)
     int segments = 0;                                 // ray segments per ray: 0 = auto, 1, 2, 4
     // workgroup schedule (physical workgroup -> slab), cached per render geometry
@@ -204,18 +204,21 @@ int clouds_dev(csky_ctx* c, const csky_cloud_params* p, int tile_w, const csky_b
     }
     RenderGeom g; g.tile_w = tile_w; g.band_rows = b->band_rows; g.first_band = b->first_band; g.band_stride = b->band_stride; g.n_bands = b->n_bands;
     g.pitch_px = (uint32_t)(pitch_bytes / 8);
-    // ray segments: more, shorter wavefronts when the launch is too small to fill the chip with whole-ray wavefronts
-    // Launch-size policy (measured, tools/crossover.py, kernel ms at 256 / 1024 / 4096 / 8192 / 32768 tiles of 8x8 rays):
-    //   whole rays, slab rows per XCD (seg 1, sched 5)      0.68  0.75  0.86  1.23  3.13   <- throughput: large launches
-    //   4 step-range segments, natural order (seg 4, 2)     0.29  0.39  0.79  1.28  4.56   <- one GPU's 1/8 .. 1/4 of a frame
-    //   4 interleaved segments, natural order (seg 5, 2)    0.18  0.34  0.87  1.67  6.44   <- latency: the reference's 96x96 tiles
-    // A lone wavefront is bound by its chain of dependent gathers (~0.5 us per primary step, ~1.7 us per light-march round),
-    // so small launches want more, shorter wavefronts; large launches want the fewest instructions.
+    // ray segments: more, shorter wavefronts when the launch is too small to fill the chip with whole-ray wavefronts.
+    // Launch-size policy (measured, tools/crossover.py, "compact" variant, kernel ms at 256 / 1024 / 4096 / 8192 / 16384 / 32768
+    // tiles of 8x8 rays = 1/128 .. 1/1 of the headline frame):
+    //   whole rays, slab rows per XCD (seg 1, sched 5)      0.50  0.55  0.58  0.94  1.36  2.20   <- throughput: large launches
+    //   4 step-range segments, natural order (seg 4, 2)     0.22  0.28  0.50  0.81  1.48  2.81   <- one GPU's 1/8 .. 1/4 of a frame
+    //   4 interleaved segments, natural order (seg 5, 2)    0.16  0.30  0.80  1.52  2.96  5.77   <- latency: the reference's 96x96 tiles
+    // A lone wavefront is bound by its chain of dependent gathers, so small launches want more, shorter wavefronts; large
+    // launches want the fewest instructions.  (The "queue" variant crosses over earlier: 6144 / 1536 wavefronts.)
     const long long waves = ((long long)(tile_w + 7) / 8) * (((long long)b->n_bands * b->band_rows + 7) / 8);
-    int seg = c->variant == 1 ? c->segments : 1;
-    if (c->variant == 1 && seg == 0) seg = waves >= 6144 ? 1 : (waves >= 1536 ? 4 : 5);
+    const bool queued = c->variant == 1 || c->variant == 3;
+    const long long big = c->variant == 3 ? 12288 : 6144, small = c->variant == 3 ? 768 : 1536;
+    int seg = queued ? c->segments : 1;
+    if (queued && seg == 0) seg = waves >= big ? 1 : (waves >= small ? 4 : 5);
     if (c->variant == 2) seg = 16;
-    const int mode = c->sched_mode >= 0 ? c->sched_mode : (waves >= 6144 ? 5 : 2);
+    const int mode = c->sched_mode >= 0 ? c->sched_mode : (waves >= big ? 5 : 2);
     if ((rc = build_schedule(c, cp, g, seg, mode, s))) return rc;
     HIPCHK(c, launch_clouds(c->variant, seg, texset(c), c->d_fc, g, c->d_order, c->order_grid, d_out, d_stats, s));
     return CSKY_OK;
@@ -330,8 +333,8 @@ int csky_set_early_out(csky_ctx* c, float eps) {
 
 int csky_set_variant(csky_ctx* c, int variant) {
     if (!c) return fail(nullptr, CSKY_ERR_INVALID, "csky_set_variant: ctx is NULL");
-    if (variant < 0 || variant >= cloud_variant_count()) return fail(c, CSKY_ERR_INVALID, "csky_set_variant: unknown variant %d", variant);
-    c->variant = variant; return CSKY_OK;
+    if (variant < -1 || variant >= cloud_variant_count()) return fail(c, CSKY_ERR_INVALID, "csky_set_variant: unknown variant %d", variant);
+    c->variant = variant < 0 ? CSKY_DEFAULT_VARIANT : variant; return CSKY_OK;
 }
 int csky_set_schedule(csky_ctx* c, int mode) {
     if (!c) return fail(nullptr, CSKY_ERR_INVALID, "csky_set_schedule: ctx is NULL");

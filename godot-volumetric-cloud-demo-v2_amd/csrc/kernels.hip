@@ -244,6 +244,133 @@ __device__ __forceinline__ MarchOut march_queue(const TexSet& T, const FrameCons
     return o;
 }
 
+// ---- compacted light march (variant "compact") ------------------------------------------------------------------
+// Same decoupling as march_queue, but a flush always takes EXACTLY 64 queued samples, one per lane (k = lane): every lane
+// then runs the reference's whole light march (clouds.glsl:186-199) for its sample in registers.  The loop index j is
+// wave-uniform, so the LOD, the mip extent and offsets, the cone increment and the distant-sample special case are scalar
+// (SALU / immediates) instead of per-lane VALU selects, the cone position is carried in registers (3 adds per sample instead
+// of re-adding j+1 increments under predication), and the per-sample densities are summed in place (no lt[7][QCAP] array).
+// Samples beyond the 64th stay queued (moved to the front) together with the part of the last step that owns them; only
+// the final flush of a ray segment runs with idle lanes.
+constexpr int CQ_CAP = 128;                                  // a flush is taken as soon as 64 samples are queued: count <= 63 + 64
+constexpr int CQ_STEPS = 66;                                 // steps-with-events between flushes: <= 1 carried + 64 (>= 1 event each)
+constexpr int CQ_FLOATS = 5 * CQ_CAP + 64 + 3 * CQ_STEPS;    // pos(3) t hf | cd | per-step mask lo/hi + base = 3.6 KB per wavefront
+
+__device__ __forceinline__ MarchOut march_compact(const TexSet& T, const FrameConsts& fc, Ray ray, float* __restrict__ q, int step_begin, int step_end) {
+    float* __restrict__ ev_px = q;
+    float* __restrict__ ev_py = q + CQ_CAP;
+    float* __restrict__ ev_pz = q + 2 * CQ_CAP;
+    float* __restrict__ ev_t = q + 3 * CQ_CAP;
+    float* __restrict__ ev_hf = q + 4 * CQ_CAP;
+    float* __restrict__ ev_cd = q + 5 * CQ_CAP;                                  // [64]
+    unsigned* __restrict__ st_lo = reinterpret_cast<unsigned*>(q + 5 * CQ_CAP + 64);   // [CQ_STEPS]
+    unsigned* __restrict__ st_hi = st_lo + CQ_STEPS;
+    unsigned* __restrict__ st_base = st_hi + CQ_STEPS;
+
+    MarchOut o; o.r = o.g = o.b = o.a = 0.0f; o.t = 1.0f; o.incloud = 0;
+    const int lane = threadIdx.x & 63;
+    const int ls = fc.light_steps;
+    float phase = 0.0f;
+    if (ray.above) {
+        const float ct = fc.ldir[0] * ray.dx + fc.ldir[1] * ray.dy + fc.ldir[2] * ray.dz;                       // clouds.glsl:158
+        phase = fmaxf(fmaxf(henyey_greenstein(ct, 0.6f), henyey_greenstein(ct, fc.hg_g2)), henyey_greenstein(ct, -0.2f));  // :160
+    }
+    float Tr = 1.0f, alpha = 0.0f, Lr = 0.0f, Lg = 0.0f, Lb = 0.0f;
+    float px = ray.px, py = ray.py, pz = ray.pz;
+    const float nd = -fc.density;
+    bool live = ray.above;
+    int count = 0, cs = 0;                                    // queued samples / steps owning them (uniform)
+    if (!__any(live)) return o;
+    for (int i = 0; i < step_begin; i++) advance(px, py, pz, ray.sx, ray.sy, ray.sz);   // segment start: replay the fp32 additions (:173)
+    for (int i = step_begin;;) {
+        // ---- A: one primary sample per lane (none once the segment is exhausted and only carried samples remain)
+        if (i < step_end) {
+            float t = 0.0f, hf = 0.0f;
+            if (live) {
+                advance(px, py, pz, ray.sx, ray.sy, ray.sz);                                                   // :173
+                hf = height_fraction(length3_exact(px, py, pz));                                               // :175
+                t = sample_density(T, fc, px, py, pz, hf, fc.wpos_x, fc.wpos_y, 0, 0);                         // :174, :177
+            }
+            const bool have = t > 0.0f;                                                                        // :184
+            const unsigned long long m = __ballot(have);
+            if (m != 0ull) {
+                const int slot = count + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));
+                if (have) { ev_px[slot] = px; ev_py[slot] = py; ev_pz[slot] = pz; ev_t[slot] = t; ev_hf[slot] = hf; }
+                if (lane == 0) { st_lo[cs] = (unsigned)m; st_hi[cs] = (unsigned)(m >> 32); st_base[cs] = (unsigned)count; }
+                count += __popcll(m);
+                cs++;
+            }
+            i++;
+        }
+        const bool last = i >= step_end;
+        if (count == 0) { if (last) break; continue; }
+        if (count < 64 && !last) continue;
+        // ---- B: the light march of the first n = min(count, 64) queued samples, one per lane
+        wave_lds_fence();
+        const int n = count < 64 ? count : 64;
+        if (lane < n) {
+            const float ex = ev_px[lane], ey = ev_py[lane], ez = ev_pz[lane];
+            float lx = ex, ly = ey, lz = ez, cd = 0.0f;
+#if CSKY_EXP_UNROLL
+#pragma unroll
+#else
+#pragma unroll 1
+#endif
+            for (int j = 0; j < 6; j++) {                                                                      // :186 (light_steps <= 6)
+                if (j >= ls) break;
+                advance(lx, ly, lz, fc.linc[j][0], fc.linc[j][1], fc.linc[j][2]);                              // :187
+                const float lhf = height_fraction(length3_exact(lx, ly, lz));                                  // :188
+                cd += sample_density(T, fc, lx, ly, lz, lhf, fc.wpos_x, fc.wpos_y, j > 2 ? j - 2 : 0, j);      // :189-191
+            }
+            {   // distant sample, :195-199
+                lx = ex; ly = ey; lz = ez;
+                advance(lx, ly, lz, fc.ldist[0], fc.ldist[1], fc.ldist[2]);
+                const float lhf = height_fraction(length3_exact(lx, ly, lz));
+                const float ld = sample_density(T, fc, lx, ly, lz, lhf, 0.0f, 0.0f, 3, 5);                     // :197 has no weather_pos
+                cd += fast_pow(ld, (1.0f - lhf) * 0.8f + 0.5f);                                                // :198 (second pow)
+            }
+            ev_cd[lane] = cd;
+        }
+        wave_lds_fence();
+        // ---- C: replay the steps in order; owners of evaluated samples (slot < n) composite (:202-210)
+        unsigned long long carry = 0ull;                     // lanes of the last step whose sample is still queued
+        for (int s = 0; s < cs; s++) {
+            const unsigned lo = st_lo[s], hi = st_hi[s];
+            const bool mine = lane < 32 ? ((lo >> lane) & 1u) : ((hi >> (lane - 32)) & 1u);
+            const int slot = (int)st_base[s] + (int)__builtin_amdgcn_mbcnt_hi(hi, __builtin_amdgcn_mbcnt_lo(lo, 0u));
+            if (mine && slot < n) {
+                const float cd = ev_cd[slot];
+                const float et = ev_t[slot], ehf = ev_hf[slot];
+                const float dt = fast_exp(nd * et * ray.ss);                                                   // :178
+                shade_sample(fc, phase, et, ehf, dt, cd, Tr, alpha, Lr, Lg, Lb);
+                o.incloud++;
+            }
+            if (s == cs - 1) carry = __ballot(mine && slot >= n);
+        }
+        wave_lds_fence();
+        // ---- keep what was not evaluated: samples n..count-1 move to the front, the last step keeps its unevaluated lanes
+        const int rem = count - n;
+        if (rem > 0) {
+            float a0 = 0.0f, a1 = 0.0f, a2 = 0.0f, a3 = 0.0f, a4 = 0.0f;
+            if (lane < rem) { a0 = ev_px[n + lane]; a1 = ev_py[n + lane]; a2 = ev_pz[n + lane]; a3 = ev_t[n + lane]; a4 = ev_hf[n + lane]; }
+            wave_lds_fence();
+            if (lane < rem) { ev_px[lane] = a0; ev_py[lane] = a1; ev_pz[lane] = a2; ev_t[lane] = a3; ev_hf[lane] = a4; }
+            if (lane == 0) { st_lo[0] = (unsigned)carry; st_hi[0] = (unsigned)(carry >> 32); st_base[0] = 0u; }
+            wave_lds_fence();
+            count = rem; cs = 1;
+        } else {
+            count = 0; cs = 0;
+        }
+        if (fc.early_eps > 0.0f) {                                     // build-side early-out (off by default, bounded error)
+            if (Tr < fc.early_eps) live = false;
+            if (!__any(live)) break;
+        }
+        if (last && count == 0) break;                               // carried samples get one more (partial) flush
+    }
+    o.r = Lr; o.g = Lg; o.b = Lb; o.a = sat(alpha); o.t = Tr;                                                  // :213-214
+    return o;
+}
+
 // ---- interleaved ray segments (small launches) ------------------------------------------------------------------
 // One workgroup = ONE 8x8 tile; wavefront w marches the primary samples i = 4m + w of every ray of the tile.  In-cloud
 // samples cluster in a few step ranges of a ray, so splitting a ray by step RANGE leaves one wavefront with most of the
@@ -467,8 +594,14 @@ __global__ __launch_bounds__(1024) void clouds_kernel_lds(TexSet T, const FrameC
 //              segments divide it by SEG.  Sample positions stay bit-identical; the compositing sums are re-associated.
 // Workgroup order: physical workgroup b runs on XCD b % 8 (observed, speed only); `order` (api.cpp::build_schedule)
 // maps b to a workgroup footprint.
+#ifndef CSKY_EXP_WAVES
+#define CSKY_EXP_WAVES 8   // waves/SIMD asked of the "compact" variant (62 VGPRs, 3.6 KB LDS per wavefront): 8 measured 1.5 % faster than 7
+#endif
+#ifndef CSKY_EXP_UNROLL
+#define CSKY_EXP_UNROLL 1
+#endif
 template <int VARIANT, int SEG>
-__global__ __launch_bounds__(256, 7) void clouds_kernel(TexSet T, const FrameConsts* __restrict__ fcp, RenderGeom G, const uint32_t* __restrict__ order,
+__global__ __launch_bounds__(256, VARIANT == 3 ? CSKY_EXP_WAVES : 7) void clouds_kernel(TexSet T, const FrameConsts* __restrict__ fcp, RenderGeom G, const uint32_t* __restrict__ order,
                                                      uint2* __restrict__ out, unsigned long long* __restrict__ stats) {
     constexpr int BW = 32 / SEG;                               // workgroup footprint width in pixels
     const int tiles_x = (G.tile_w + BW - 1) / BW;
@@ -493,9 +626,10 @@ __global__ __launch_bounds__(256, 7) void clouds_kernel(TexSet T, const FrameCon
         static_assert(SEG == 1, "the lock-step reference variant marches whole rays");
         o = march(T, fc, ray);
     } else {
-        __shared__ float lds[4][Q_FLOATS];
+        __shared__ float lds[4][VARIANT == 3 ? CQ_FLOATS : Q_FLOATS];
         const int s0 = (fc.primary_steps * seg) / SEG, s1 = (fc.primary_steps * (seg + 1)) / SEG;
-        o = march_queue(T, fc, ray, &lds[wave][0], s0, s1);
+        if constexpr (VARIANT == 3) o = march_compact(T, fc, ray, &lds[wave][0], s0, s1);
+        else o = march_queue(T, fc, ray, &lds[wave][0], s0, s1);
         if constexpr (SEG > 1) {
             __shared__ float comb[4][5][64];
             comb[wave][0][lane] = o.r; comb[wave][1][lane] = o.g; comb[wave][2][lane] = o.b; comb[wave][3][lane] = o.t; comb[wave][4][lane] = o.a;
@@ -523,7 +657,7 @@ __global__ __launch_bounds__(256, 7) void clouds_kernel(TexSet T, const FrameCon
     }
 }
 
-static const char* const kVariantNames[] = {"lockstep", "queue", "queue-lds"};
+static const char* const kVariantNames[] = {"lockstep", "queue", "queue-lds", "compact"};
 int cloud_variant_count() { return (int)(sizeof(kVariantNames) / sizeof(kVariantNames[0])); }
 const char* cloud_variant_name(int v) { return (v >= 0 && v < cloud_variant_count()) ? kVariantNames[v] : nullptr; }
 
@@ -534,7 +668,10 @@ hipError_t launch_clouds(int variant, int seg, const TexSet& t, const FrameConst
     else if (variant == 1 && seg == 1) clouds_kernel<1, 1><<<grid, 256, 0, s>>>(t, d_fc, g, d_order, d_out, d_stats);
     else if (variant == 1 && seg == 2) clouds_kernel<1, 2><<<grid, 256, 0, s>>>(t, d_fc, g, d_order, d_out, d_stats);
     else if (variant == 1 && seg == 4) clouds_kernel<1, 4><<<grid, 256, 0, s>>>(t, d_fc, g, d_order, d_out, d_stats);
-    else if (variant == 1 && seg == 5) {                      // 5 = 4 interleaved segments, one tile per workgroup, 76 KB of LDS
+    else if (variant == 3 && seg == 1) clouds_kernel<3, 1><<<grid, 256, 0, s>>>(t, d_fc, g, d_order, d_out, d_stats);
+    else if (variant == 3 && seg == 2) clouds_kernel<3, 2><<<grid, 256, 0, s>>>(t, d_fc, g, d_order, d_out, d_stats);
+    else if (variant == 3 && seg == 4) clouds_kernel<3, 4><<<grid, 256, 0, s>>>(t, d_fc, g, d_order, d_out, d_stats);
+    else if ((variant == 1 || variant == 3) && seg == 5) {                      // 5 = 4 interleaved segments, one tile per workgroup, 76 KB of LDS
         // > 64 KB of dynamic LDS needs the opt-in attribute; it is per device, so set it on every launch (cheap, idempotent)
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&clouds_kernel_interleaved<0>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                            (int)(IL_BLOCK_FLOATS * sizeof(float)));

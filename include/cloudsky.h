@@ -151,7 +151,9 @@ int csky_composite_sky(csky_ctx* ctx, const csky_composite_params* p, const uint
 int csky_time_clouds(csky_ctx* ctx, const csky_cloud_params* p, int tile_w, const csky_bands* bands, int warmup,
                      int iters, float* mean_ms, csky_cloud_stats* stats);
 int csky_get_cloud_stats(csky_ctx* ctx, csky_cloud_stats* stats); /* tallies of the last stats-enabled launch */
-/* Kernel variant selector for A/B measurement (default = the fastest measured; csky_variant_name lists them).  Unknown ids -> CSKY_ERR_INVALID. */
+/* Kernel variant selector for A/B measurement (csky_variant_name lists them).  -1 = the default = the fastest measured
+ * (CSKY_DEFAULT_VARIANT, "compact").  Unknown ids -> CSKY_ERR_INVALID. */
+#define CSKY_DEFAULT_VARIANT 3
 int csky_set_variant(csky_ctx* ctx, int variant);
 /* Exact height-window reject (density() provably 0 above/below the cloud body for the bound weather map): on by default;
  * 0 disables it (A/B measurement, identical results). */

@@ -44,7 +44,7 @@ def test_sky_lut(gpu_ctx, o_skies):
         assert (gpu_ctx.read_sky_lut().view(np.uint16) == s.view(np.uint16)).all()
 
 
-@pytest.mark.parametrize("variant", [0, 1, 2])
+@pytest.mark.parametrize("variant", [0, 1, 2, 3])
 @pytest.mark.parametrize("sun_name", list(SUNS))
 def test_clouds_vs_oracle_default_config(gpu_ctx, oracle, otex, o_skies, sun_name, variant):
     sun = SUNS[sun_name]
@@ -62,7 +62,7 @@ def test_clouds_vs_oracle_default_config(gpu_ctx, oracle, otex, o_skies, sun_nam
     assert st["primary_samples"] == st_o["primary_samples"]
     f = img.astype(np.float32)
     assert (f[0] == 0).all() and (f[:, 0] == 0).all()
-    gpu_ctx.set_variant(1)
+    gpu_ctx.set_variant(-1)
 
 
 def test_variants_and_schedules_agree(gpu_ctx, oracle):
@@ -91,6 +91,16 @@ def test_variants_and_schedules_agree(gpu_ctx, oracle):
         img = gpu_ctx.render_clouds(p)
         ok, info = cloud_close(img, imgs[1][0], frac=0.9999, atol=5e-4, rtol=2e-3)
         assert ok and gpu_ctx.cloud_stats() == imgs[1][1], (sch, info)
+    # the "compact" variant (64 queued samples per flush, one light march per lane): same march, same counts, whole rays or segments
+    gpu_ctx.set_variant(3)
+    for seg in (1, 2, 4):
+        gpu_ctx.set_segments(seg)
+        for sch in (5, 2):
+            gpu_ctx.set_schedule(sch)
+            img = gpu_ctx.render_clouds(p)
+            ok, info = cloud_close(img, imgs[1][0], frac=0.9999, atol=5e-4, rtol=2e-3)
+            assert ok and gpu_ctx.cloud_stats() == imgs[1][1], (seg, sch, info)
+    gpu_ctx.set_segments(0)
     gpu_ctx.set_variant(1); gpu_ctx.set_schedule(-1)
     # ray segments (1, 2, 4 wavefronts per ray): identical sample positions and in-cloud counts, re-associated compositing
     for seg in (1, 2, 4, 5):
@@ -101,7 +111,7 @@ def test_variants_and_schedules_agree(gpu_ctx, oracle):
             ok, info = cloud_close(img, imgs[1][0], frac=0.9999, atol=5e-4, rtol=2e-3)
             assert ok, (seg, info)
             assert gpu_ctx.cloud_stats() == imgs[1][1], seg
-    gpu_ctx.set_segments(0); gpu_ctx.set_schedule(-1)
+    gpu_ctx.set_segments(0); gpu_ctx.set_schedule(-1); gpu_ctx.set_variant(-1)
 
 
 def test_clouds_vs_numpy_fixture(gpu_ctx, oracle):
@@ -126,9 +136,11 @@ def test_config_c2_512x256_64x4_zenith(gpu_ctx, oracle, otex, o_skies):
     gpu_ctx.set_march(128, 6)
 
 
+@pytest.mark.parametrize("variant", [1, 3])
 @pytest.mark.parametrize("seg", [2, 4, 5])
-def test_segments_vs_oracle_ragged(gpu_ctx, oracle, otex, o_skies, seg):
+def test_segments_vs_oracle_ragged(gpu_ctx, oracle, otex, o_skies, seg, variant):
     """Segmented march on a ragged tile (45 x 21, 64 and 100 primary steps: not divisible by the segment count)."""
+    gpu_ctx.set_variant(variant)
     gpu_ctx.set_segments(seg)
     gpu_ctx.render_sky_lut(norm((1, 1, 0)), 200, 100)
     for steps in (64, 100):
@@ -138,7 +150,7 @@ def test_segments_vs_oracle_ragged(gpu_ctx, oracle, otex, o_skies, seg):
         ref = oracle.clouds(otex, p, o_skies["deg45"], rect=(0, 0, 45, 21), primary_steps=steps)
         ok, info = cloud_close(img, ref)
         assert ok, (steps, info)
-    gpu_ctx.set_march(128, 6); gpu_ctx.set_segments(0)
+    gpu_ctx.set_march(128, 6); gpu_ctx.set_segments(0); gpu_ctx.set_variant(-1)
 
 
 def test_windy_offset_tile(gpu_ctx, oracle, otex):

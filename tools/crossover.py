@@ -12,8 +12,8 @@ ctx = gvcd_amd.Context(0)
 ctx.set_noise(*gvcd_amd.assets.load_default_noise())
 ctx.render_transmittance(256, 64)
 ctx.render_sky_lut(s, 200, 100, readback=False)
-ctx.set_variant(1)
-for nb in (128, 64, 32, 16, 8, 4):
+ctx.set_variant(int(sys.argv[1]) if len(sys.argv) > 1 else -1)
+for nb in (128, 64, 32, 16, 8, 4, 2, 1):
     bands = (8, 0, nb, H // 8 // nb)
     row = []
     for seg in (1, 2, 4, 5):
