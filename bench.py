@@ -234,6 +234,7 @@ def main():
             if ok < 0.9999:
                 raise SystemExit("bench.py: multi-rank frame differs from the single-rank frame")
         traffic = None
+        valu_insts = None
         pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")   # written from the committed rocprofv3 --pmc passes (tools/summarize_prof.py)
         traffic_note = "not collected in this run"
         if os.path.exists(pmc):
@@ -242,6 +243,7 @@ def main():
                 if j.get("workload") == args.config and world == 1:
                     traffic = j.get("hbm_bytes_per_launch")
                     traffic_note = j.get("note", "")
+                    valu_insts = j.get("valu_insts_per_launch")
             except Exception:
                 pass
         out = {
@@ -266,8 +268,12 @@ def main():
                          "algorithmic_bytes_incl_light_march": total_bytes,
                          "achieved_incl_light_march_GBps": total_bytes / (k_ms * 1e-3) / 1e9,
                          "incloud_fraction": f_incloud,
+                         # the unit that actually binds: VALU issue.  cycles each SIMD had per VALU instruction it issued (live kernel
+                         # time x 2.4 GHz x 1024 SIMDs / committed SQ_INSTS_VALU); the instruction kinds cost 2.5 - 4.4 cycles to issue
+                         "valu_issue": None if not valu_insts else {"insts_per_launch": valu_insts, "simd_cycles_per_inst": k_ms * 1e-3 * 2.4e9 * 1024 / valu_insts,
+                                                                    "issue_cost_range_cycles": [2.5, 4.4]},
                          "note": "algorithmic tap bytes (80 B/sample x 128 + 8 B/ray = 10 248 B/ray), not DRAM bytes: the "
-                                 "unique inputs (~27 MB) live in L2/Infinity Cache, so frac may exceed what HBM could deliver"},
+                                 "unique inputs (~82 MB of baked textures) live in L2/Infinity Cache, so frac may exceed what HBM could deliver"},
         }
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(large, small, weather, params, sun_n, W, H, primary, light)

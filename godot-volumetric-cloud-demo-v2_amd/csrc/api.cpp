@@ -42,6 +42,9 @@ struct csky_ctx {
     int segments = 0;                                 // ray segments per ray: 0 = auto, 1, 2, 4
     // workgroup schedule (physical workgroup -> slab), cached per render geometry
     uint32_t* d_order = nullptr; size_t order_cap = 0; int order_grid = 0;
+    // cost-feedback schedule (mode 7): per-workgroup costs of the last launch -> heaviest-first order of the next one
+    uint32_t* d_wg_cost = nullptr; uint32_t* d_lpt_order = nullptr; uint32_t* d_lpt_hist = nullptr; size_t lpt_cap = 0;
+    bool lpt_valid = false; long long lpt_key[11] = {-1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1};
     std::vector<uint32_t> h_order; long long order_key[11] = {-1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1};
     csky_cloud_stats last_stats = {0, 0, 0};
     char err[512] = {0};
@@ -204,23 +207,57 @@ int clouds_dev(csky_ctx* c, const csky_cloud_params* p, int tile_w, const csky_b
     }
     RenderGeom g; g.tile_w = tile_w; g.band_rows = b->band_rows; g.first_band = b->first_band; g.band_stride = b->band_stride; g.n_bands = b->n_bands;
     g.pitch_px = (uint32_t)(pitch_bytes / 8);
-    // ray segments: more, shorter wavefronts when the launch is too small to fill the chip with whole-ray wavefronts.
-    // Launch-size policy (measured, tools/crossover.py, "compact" variant, kernel ms at 256 / 1024 / 4096 / 8192 / 16384 / 32768
-    // tiles of 8x8 rays = 1/128 .. 1/1 of the headline frame):
-    //   whole rays, slab rows per XCD (seg 1, sched 5)      0.50  0.55  0.58  0.94  1.36  2.20   <- throughput: large launches
-    //   4 step-range segments, natural order (seg 4, 2)     0.22  0.28  0.50  0.81  1.48  2.81   <- one GPU's 1/8 .. 1/4 of a frame
-    //   4 interleaved segments, natural order (seg 5, 2)    0.16  0.30  0.80  1.52  2.96  5.77   <- latency: the reference's 96x96 tiles
+    // Launch-size policy: ray segments (more, shorter wavefronts) when the launch is too small to fill the chip with whole-ray
+    // wavefronts, and the cost-feedback order (mode 7) when it is only a few resident workgroups deep.  Measured with
+    // tools/crossover.py, "compact" variant, kernel ms at 256 / 1024 / 4096 / 8192 / 16384 / 32768 tiles of 8x8 rays
+    // (= 1/128 .. 1/1 of the headline frame; profiles/r01/launch_size_crossover_compact.txt):
+    //   whole rays, slab rows per XCD   (seg 1, sched 5)    0.50  0.56  0.58  0.94  1.39  2.15   <- full frames
+    //   whole rays, cost feedback       (seg 1, sched 7)    0.50  0.51  0.66  0.80  1.10  2.18   <- 1/2 frame (one of 2 GPUs)
+    //   2 step-range segments, feedback (seg 2, sched 7)    0.33  0.45  0.53  0.65  1.20  2.37   <- 1/4 frame
+    //   4 step-range segments, feedback (seg 4, sched 7)    0.22  0.30  0.42  0.75  1.43  2.81   <- 1/8 frame
+    //   4 step-range segments, natural  (seg 4, sched 2)    0.22  0.28  0.50  0.81  1.48  2.83
+    //   4 interleaved segments, natural (seg 5, sched 2)    0.16  0.30  0.80  1.52  2.95  5.75   <- latency: the reference's 96x96 tiles
     // A lone wavefront is bound by its chain of dependent gathers, so small launches want more, shorter wavefronts; large
-    // launches want the fewest instructions.  (The "queue" variant crosses over earlier: 6144 / 1536 wavefronts.)
+    // launches want the fewest instructions.  (The "queue" variant keeps its own, earlier crossovers: 6144 / 1536 wavefronts.)
     const long long waves = ((long long)(tile_w + 7) / 8) * (((long long)b->n_bands * b->band_rows + 7) / 8);
     const bool queued = c->variant == 1 || c->variant == 3;
-    const long long big = c->variant == 3 ? 12288 : 6144, small = c->variant == 3 ? 768 : 1536;
     int seg = queued ? c->segments : 1;
-    if (queued && seg == 0) seg = waves >= big ? 1 : (waves >= small ? 4 : 5);
+    int auto_mode;
+    if (c->variant == 3) {
+        if (queued && seg == 0) seg = waves >= 12288 ? 1 : (waves >= 6144 ? 2 : (waves >= 768 ? 4 : 5));
+        auto_mode = waves >= 24576 ? 5 : (waves >= 1536 ? 7 : 2);
+    } else {
+        if (queued && seg == 0) seg = waves >= 6144 ? 1 : (waves >= 1536 ? 4 : 5);
+        auto_mode = waves >= 6144 ? 5 : 2;
+    }
     if (c->variant == 2) seg = 16;
-    const int mode = c->sched_mode >= 0 ? c->sched_mode : (waves >= big ? 5 : 2);
-    if ((rc = build_schedule(c, cp, g, seg, mode, s))) return rc;
-    HIPCHK(c, launch_clouds(c->variant, seg, texset(c), c->d_fc, g, c->d_order, c->order_grid, d_out, d_stats, s));
+    const int mode = c->sched_mode >= 0 ? c->sched_mode : auto_mode;
+    const int static_mode = mode == 7 ? (waves >= 12288 ? 5 : 2) : mode;     // order of the first launch of a geometry under mode 7
+    const bool feedback = mode == 7 && queued && seg != 5;       // kernels that record per-workgroup costs
+    if ((rc = build_schedule(c, cp, g, seg, static_mode, s))) return rc;
+    if (!feedback) {
+        HIPCHK(c, launch_clouds(c->variant, seg, texset(c), c->d_fc, g, c->d_order, c->order_grid, d_out, d_stats, nullptr, s));
+        return CSKY_OK;
+    }
+    // mode 7: this launch runs in the order sorted from the previous launch's costs (same geometry), records its own costs and
+    // sorts them for the next one.  The first launch of a geometry uses a static order.
+    const int bw = 32 / seg, tiles_x = (g.tile_w + bw - 1) / bw, nblocks = tiles_x * ((g.n_bands * g.band_rows + 7) >> 3);
+    if (c->lpt_cap < (size_t)nblocks) {
+        HIPCHK(c, hipStreamSynchronize(s));
+        (void)hipFree(c->d_wg_cost); (void)hipFree(c->d_lpt_order); c->d_wg_cost = c->d_lpt_order = nullptr; c->lpt_cap = 0; c->lpt_valid = false;
+        HIPCHK(c, hipMalloc(reinterpret_cast<void**>(&c->d_wg_cost), (size_t)nblocks * sizeof(uint32_t)));
+        HIPCHK(c, hipMalloc(reinterpret_cast<void**>(&c->d_lpt_order), (size_t)nblocks * sizeof(uint32_t)));
+        if (!c->d_lpt_hist) HIPCHK(c, hipMalloc(reinterpret_cast<void**>(&c->d_lpt_hist), 1024 * sizeof(uint32_t)));
+        c->lpt_cap = (size_t)nblocks;
+    }
+    if (memcmp(c->lpt_key, c->order_key, sizeof c->lpt_key) != 0) { c->lpt_valid = false; memcpy(c->lpt_key, c->order_key, sizeof c->lpt_key); }
+    HIPCHK(c, hipMemsetAsync(c->d_wg_cost, 0, (size_t)nblocks * sizeof(uint32_t), s));
+    HIPCHK(c, launch_clouds(c->variant, seg, texset(c), c->d_fc, g, c->lpt_valid ? c->d_lpt_order : c->d_order, c->lpt_valid ? nblocks : c->order_grid,
+                            d_out, d_stats, c->d_wg_cost, s));
+    int shift = 0;
+    while ((((long long)256 * (c->primary_steps + 16)) >> shift) >= 1024) shift++;     // largest cost: 4 wavefronts x 64 rays x (steps + 16)
+    HIPCHK(c, launch_lpt_order(c->d_wg_cost, nblocks, shift, c->d_lpt_hist, c->d_lpt_order, s));
+    c->lpt_valid = true;
     return CSKY_OK;
 }
 
@@ -265,7 +302,7 @@ void csky_destroy(csky_ctx* c) {
     if (!c) return;
     (void)hipSetDevice(c->device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
-    void* ptrs[] = {c->d_shape, c->d_detail, c->d_weather, c->d_trans_h, c->d_trans_f, c->d_sky_h, c->d_sky_f, c->d_fc, c->d_stats, c->d_frame, c->d_order, c->d_detail_h};
+    void* ptrs[] = {c->d_shape, c->d_detail, c->d_weather, c->d_trans_h, c->d_trans_f, c->d_sky_h, c->d_sky_f, c->d_fc, c->d_stats, c->d_frame, c->d_order, c->d_detail_h, c->d_wg_cost, c->d_lpt_order, c->d_lpt_hist};
     for (void* p : ptrs) if (p) (void)hipFree(p);
     if (c->ev0) (void)hipEventDestroy(c->ev0);
     if (c->ev1) (void)hipEventDestroy(c->ev1);
@@ -338,7 +375,7 @@ int csky_set_variant(csky_ctx* c, int variant) {
 }
 int csky_set_schedule(csky_ctx* c, int mode) {
     if (!c) return fail(nullptr, CSKY_ERR_INVALID, "csky_set_schedule: ctx is NULL");
-    if (mode < -1 || mode > 6) return fail(c, CSKY_ERR_INVALID, "csky_set_schedule: mode must be 0 (azimuth wedges, horizon first), 1 (contiguous eighths), 2 (natural), 3 (wedges, zenith first) or 4 (wedges, alternating)");
+    if (mode < -1 || mode > 7) return fail(c, CSKY_ERR_INVALID, "csky_set_schedule: mode must be -1 (auto) or 0..7 (see cloudsky.h)");
     c->sched_mode = mode; return CSKY_OK;
 }
 int csky_set_segments(csky_ctx* c, int segments) {

@@ -173,6 +173,14 @@ CSKY_HD void frame_setup(const CloudParams& P, const float4* sky, int sky_w, int
 // =================================================================================================
 #pragma clang fp contract(fast)
 
+// host-only analysis hook (tools/stage_trace): how far a sample_density() call got before an exact reject stopped it
+#if defined(CSKY_TRACE_STAGES) && !defined(__HIP_DEVICE_COMPILE__)
+extern thread_local int csky_stage;
+#define CSKY_STAGE(s) (csky_stage = (s))
+#else
+#define CSKY_STAGE(s) ((void)0)
+#endif
+
 // a + f*d for an fp16 pair packed in one dword: lo = texel(x) = a, hi = texel(x+1) - texel(x) = d (the x-neighbour DIFFERENCE is
 // stored, not the neighbour: an integer in [-2040, 2040], exact in fp16).  On gfx950 this is ONE v_fma_mix_f32: the f16 -> f32
 // widening is free inside the FMA (4.4 cycles; byte texels needed cvt + cvt + sub + fma = 17, tools/ubench/valu_rates.hip), and
@@ -324,6 +332,7 @@ CSKY_HD float density(const TexSet& T, const FrameConsts& fc, float px, float py
     shape_coord(fc, px, py, pz, qx, qy, qz, sx, sy, sz);
     float nr, fbm;
     shape_tap(T, lod_shape, sx, sy, sz, nr, fbm);                           // :117-118
+    CSKY_STAGE(2);
     const float omf = 1.0f - fbm;
     float base = (nr + omf) * fast_rcp(1.0f + omf);                         // :122 remap(n.r, -(1-fbm), 1, 0, 1)
     // :124-125: remap(base*g, 1-wc, 1, 0, 1) * wc = (base*g - omw) / (1 - omw) * wc.  In fp32 1 - omw = 1 - (1 - wc) equals wc up to
@@ -332,6 +341,7 @@ CSKY_HD float density(const TexSet& T, const FrameConsts& fc, float px, float py
     if (!(base > 0.0f)) return 0.0f;                                        // exact reject (2)
     detail_coord(fc, qx, qy, qz, sx, sy, sz);                               // :128-129
     float hfbm = detail_tap(T, lod_detail, sx, sy, sz);                     // :132-133
+    CSKY_STAGE(3);
     const float k = sat(hf * 4.0f);
     hfbm = hfbm + k * (1.0f - 2.0f * hfbm);                                 // :134 mix(hfbm, 1-hfbm, k)
     const float hm = hfbm * 0.4f * hf;
@@ -346,10 +356,12 @@ CSKY_HD float density(const TexSet& T, const FrameConsts& fc, float px, float py
 // the weather tap and the gradient are skipped.  Samples above/below the cloud body cost ~20 VALU instead of ~100.
 CSKY_HD float sample_density(const TexSet& T, const FrameConsts& fc, float px, float py, float pz, float hf, float wx, float wy,
                              int lod_shape, int lod_detail) {
+    CSKY_STAGE(0);
     if (!(hf > fc.hf_lo && hf < fc.hf_hi)) return 0.0f;
     float wsx, wsy, wr, wb;
     weather_coord(px, pz, wx, wy, wsx, wsy);
     weather_tap(T.weather, wsx, wsy, wr, wb);
+    CSKY_STAGE(1);
     return density(T, fc, px, py, pz, hf, wr, wb, lod_shape, lod_detail);
 }
 

@@ -311,11 +311,7 @@ __device__ __forceinline__ MarchOut march_compact(const TexSet& T, const FrameCo
         if (lane < n) {
             const float ex = ev_px[lane], ey = ev_py[lane], ez = ev_pz[lane];
             float lx = ex, ly = ey, lz = ez, cd = 0.0f;
-#if CSKY_EXP_UNROLL
-#pragma unroll
-#else
-#pragma unroll 1
-#endif
+#pragma unroll 1                                                 // scalar j: one loop body (unrolling measured no faster, 6x the code)
             for (int j = 0; j < 6; j++) {                                                                      // :186 (light_steps <= 6)
                 if (j >= ls) break;
                 advance(lx, ly, lz, fc.linc[j][0], fc.linc[j][1], fc.linc[j][2]);                              // :187
@@ -508,7 +504,7 @@ __device__ __forceinline__ void march_interleaved(const TexSet& T, const FrameCo
 
 template <int DUMMY>
 __global__ __launch_bounds__(256) void clouds_kernel_interleaved(TexSet T, const FrameConsts* __restrict__ fcp, RenderGeom G, const uint32_t* __restrict__ order,
-                                                                 uint2* __restrict__ out, unsigned long long* __restrict__ stats) {
+                                                                 uint2* __restrict__ out, unsigned long long* __restrict__ stats, uint32_t* __restrict__ wg_cost) {
     extern __shared__ __attribute__((aligned(16))) float il_smem[];
     const int tiles_x = (G.tile_w + 7) >> 3;
     const int local_rows = G.n_bands * G.band_rows;
@@ -545,7 +541,7 @@ __global__ __launch_bounds__(256) void clouds_kernel_interleaved(TexSet T, const
 // alternative; the default keeps the detail volume oct-packed in L2 (one 16-byte gather per tap).
 template <int DUMMY>
 __global__ __launch_bounds__(1024) void clouds_kernel_lds(TexSet T, const FrameConsts* __restrict__ fcp, RenderGeom G, const uint32_t* __restrict__ order,
-                                                          uint2* __restrict__ out, unsigned long long* __restrict__ stats) {
+                                                          uint2* __restrict__ out, unsigned long long* __restrict__ stats, uint32_t* __restrict__ wg_cost) {
     extern __shared__ __attribute__((aligned(16))) float lds_all[];
     uint16_t* detail_s = reinterpret_cast<uint16_t*>(lds_all);
     constexpr int DETAIL_FLOATS = (DETAIL_CHAIN_TEXELS + 7) / 8 * 4;            // rounded up to 16 bytes
@@ -577,10 +573,13 @@ __global__ __launch_bounds__(1024) void clouds_kernel_lds(TexSet T, const FrameC
         const uint32_t lo = (uint32_t)f2h(o.r) | ((uint32_t)f2h(o.g) << 16), hi = (uint32_t)f2h(o.b) | ((uint32_t)f2h(o.a) << 16);
         out[(size_t)lr * G.pitch_px + gx] = make_uint2(lo, hi);
     }
-    if (stats) {
+    if (stats || wg_cost) {
         unsigned ic = o.incloud, ab = ray.above ? 1u : 0u;
         for (int off = 32; off > 0; off >>= 1) { ic += __shfl_down(ic, off); ab += __shfl_down(ab, off); }
-        if (lane == 0) { atomicAdd(&stats[0], (unsigned long long)ic); atomicAdd(&stats[1], (unsigned long long)ab); }
+        if (lane == 0) {
+            if (stats) { atomicAdd(&stats[0], (unsigned long long)ic); atomicAdd(&stats[1], (unsigned long long)ab); }
+            if (wg_cost) atomicAdd(&wg_cost[logical], ic + 16u * ab);   // cost model of the feedback schedule: light marches + live primary marches
+        }
     }
 }
 
@@ -594,15 +593,12 @@ __global__ __launch_bounds__(1024) void clouds_kernel_lds(TexSet T, const FrameC
 //              segments divide it by SEG.  Sample positions stay bit-identical; the compositing sums are re-associated.
 // Workgroup order: physical workgroup b runs on XCD b % 8 (observed, speed only); `order` (api.cpp::build_schedule)
 // maps b to a workgroup footprint.
-#ifndef CSKY_EXP_WAVES
-#define CSKY_EXP_WAVES 8   // waves/SIMD asked of the "compact" variant (62 VGPRs, 3.6 KB LDS per wavefront): 8 measured 1.5 % faster than 7
-#endif
-#ifndef CSKY_EXP_UNROLL
-#define CSKY_EXP_UNROLL 1
+#ifndef CSKY_COMPACT_WAVES
+#define CSKY_COMPACT_WAVES 8   // waves/SIMD asked of the "compact" variant (62 VGPRs, 3.6 KB LDS per wavefront): 8 measured 1.5 % faster than 7
 #endif
 template <int VARIANT, int SEG>
-__global__ __launch_bounds__(256, VARIANT == 3 ? CSKY_EXP_WAVES : 7) void clouds_kernel(TexSet T, const FrameConsts* __restrict__ fcp, RenderGeom G, const uint32_t* __restrict__ order,
-                                                     uint2* __restrict__ out, unsigned long long* __restrict__ stats) {
+__global__ __launch_bounds__(256, VARIANT == 3 ? CSKY_COMPACT_WAVES : 7) void clouds_kernel(TexSet T, const FrameConsts* __restrict__ fcp, RenderGeom G, const uint32_t* __restrict__ order,
+                                                     uint2* __restrict__ out, unsigned long long* __restrict__ stats, uint32_t* __restrict__ wg_cost) {
     constexpr int BW = 32 / SEG;                               // workgroup footprint width in pixels
     const int tiles_x = (G.tile_w + BW - 1) / BW;
     const int local_rows = G.n_bands * G.band_rows;
@@ -650,11 +646,59 @@ __global__ __launch_bounds__(256, VARIANT == 3 ? CSKY_EXP_WAVES : 7) void clouds
         const uint32_t lo = (uint32_t)f2h(o.r) | ((uint32_t)f2h(o.g) << 16), hi = (uint32_t)f2h(o.b) | ((uint32_t)f2h(o.a) << 16);
         out[(size_t)lr * G.pitch_px + gx] = make_uint2(lo, hi);  // imageStore, clouds.glsl:264
     }
-    if (stats) {
+    if (stats || wg_cost) {
         unsigned ic = o.incloud, ab = (ray.above && seg == 0) ? 1u : 0u;
         for (int off = 32; off > 0; off >>= 1) { ic += __shfl_down(ic, off); ab += __shfl_down(ab, off); }
-        if (lane == 0) { atomicAdd(&stats[0], (unsigned long long)ic); atomicAdd(&stats[1], (unsigned long long)ab); }
+        if (lane == 0) {
+            if (stats) { atomicAdd(&stats[0], (unsigned long long)ic); atomicAdd(&stats[1], (unsigned long long)ab); }
+            if (wg_cost) atomicAdd(&wg_cost[logical], ic + 16u * ab);   // cost model of the feedback schedule: light marches + live primary marches
+        }
     }
+}
+
+// ---- cost-feedback schedule (api.cpp, schedule mode 7) -----------------------------------------------------------------
+// Workgroups differ 10x in cost (in-cloud samples per tile) and a C3 frame is only ~4 waves of resident workgroups deep, so
+// the order they start in decides the tail.  Every launch records a cost per workgroup (wg_cost: in-cloud samples + live rays);
+// these three kernels turn it into the NEXT launch's order, heaviest first (longest-processing-time-first list scheduling;
+// consecutive blocks land on consecutive XCDs, so each XCD also receives a descending sequence).  Counting sort on 1024 cost
+// buckets; ties are placed in arrival order (the schedule may differ run to run, the frame cannot: every ray's arithmetic is
+// independent of where and when its workgroup runs, tests/test_gpu_parity.py::test_variants_and_schedules_agree).
+constexpr int LPT_BUCKETS = 1024;
+__device__ __forceinline__ int lpt_bucket(uint32_t cost, int shift) {
+    const uint32_t b = cost >> shift;
+    return LPT_BUCKETS - 1 - (int)(b > (uint32_t)(LPT_BUCKETS - 1) ? (uint32_t)(LPT_BUCKETS - 1) : b);   // bucket 0 = heaviest
+}
+__global__ __launch_bounds__(256) void lpt_hist_kernel(const uint32_t* __restrict__ cost, int n, int shift, uint32_t* __restrict__ hist) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i < n) atomicAdd(&hist[lpt_bucket(cost[i], shift)], 1u);
+}
+__global__ __launch_bounds__(LPT_BUCKETS) void lpt_scan_kernel(uint32_t* __restrict__ hist) {   // in place: counts -> exclusive offsets
+    __shared__ uint32_t sh[LPT_BUCKETS];
+    const int t = threadIdx.x;
+    const uint32_t own = hist[t];
+    sh[t] = own;
+    __syncthreads();
+    for (int off = 1; off < LPT_BUCKETS; off <<= 1) {
+        const uint32_t v = t >= off ? sh[t - off] : 0u;
+        __syncthreads();
+        sh[t] += v;
+        __syncthreads();
+    }
+    hist[t] = sh[t] - own;
+}
+__global__ __launch_bounds__(256) void lpt_scatter_kernel(const uint32_t* __restrict__ cost, int n, int shift, uint32_t* __restrict__ offsets,
+                                                          uint32_t* __restrict__ order) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i < n) order[atomicAdd(&offsets[lpt_bucket(cost[i], shift)], 1u)] = (uint32_t)i;
+}
+hipError_t launch_lpt_order(const uint32_t* d_cost, int n, int shift, uint32_t* d_hist, uint32_t* d_order, hipStream_t s) {
+    if (n <= 0) return hipSuccess;
+    hipError_t e = hipMemsetAsync(d_hist, 0, LPT_BUCKETS * sizeof(uint32_t), s);
+    if (e != hipSuccess) return e;
+    lpt_hist_kernel<<<(n + 255) / 256, 256, 0, s>>>(d_cost, n, shift, d_hist);
+    lpt_scan_kernel<<<1, LPT_BUCKETS, 0, s>>>(d_hist);
+    lpt_scatter_kernel<<<(n + 255) / 256, 256, 0, s>>>(d_cost, n, shift, d_hist, d_order);
+    return hipGetLastError();
 }
 
 static const char* const kVariantNames[] = {"lockstep", "queue", "queue-lds", "compact"};
@@ -662,27 +706,27 @@ int cloud_variant_count() { return (int)(sizeof(kVariantNames) / sizeof(kVariant
 const char* cloud_variant_name(int v) { return (v >= 0 && v < cloud_variant_count()) ? kVariantNames[v] : nullptr; }
 
 hipError_t launch_clouds(int variant, int seg, const TexSet& t, const FrameConsts* d_fc, const RenderGeom& g, const uint32_t* d_order, int grid,
-                         uint2* d_out, unsigned long long* d_stats, hipStream_t s) {
+                         uint2* d_out, unsigned long long* d_stats, uint32_t* d_wg_cost, hipStream_t s) {
     if (grid <= 0) return hipSuccess;
-    if (variant == 0 && seg == 1) clouds_kernel<0, 1><<<grid, 256, 0, s>>>(t, d_fc, g, d_order, d_out, d_stats);
-    else if (variant == 1 && seg == 1) clouds_kernel<1, 1><<<grid, 256, 0, s>>>(t, d_fc, g, d_order, d_out, d_stats);
-    else if (variant == 1 && seg == 2) clouds_kernel<1, 2><<<grid, 256, 0, s>>>(t, d_fc, g, d_order, d_out, d_stats);
-    else if (variant == 1 && seg == 4) clouds_kernel<1, 4><<<grid, 256, 0, s>>>(t, d_fc, g, d_order, d_out, d_stats);
-    else if (variant == 3 && seg == 1) clouds_kernel<3, 1><<<grid, 256, 0, s>>>(t, d_fc, g, d_order, d_out, d_stats);
-    else if (variant == 3 && seg == 2) clouds_kernel<3, 2><<<grid, 256, 0, s>>>(t, d_fc, g, d_order, d_out, d_stats);
-    else if (variant == 3 && seg == 4) clouds_kernel<3, 4><<<grid, 256, 0, s>>>(t, d_fc, g, d_order, d_out, d_stats);
+    if (variant == 0 && seg == 1) clouds_kernel<0, 1><<<grid, 256, 0, s>>>(t, d_fc, g, d_order, d_out, d_stats, d_wg_cost);
+    else if (variant == 1 && seg == 1) clouds_kernel<1, 1><<<grid, 256, 0, s>>>(t, d_fc, g, d_order, d_out, d_stats, d_wg_cost);
+    else if (variant == 1 && seg == 2) clouds_kernel<1, 2><<<grid, 256, 0, s>>>(t, d_fc, g, d_order, d_out, d_stats, d_wg_cost);
+    else if (variant == 1 && seg == 4) clouds_kernel<1, 4><<<grid, 256, 0, s>>>(t, d_fc, g, d_order, d_out, d_stats, d_wg_cost);
+    else if (variant == 3 && seg == 1) clouds_kernel<3, 1><<<grid, 256, 0, s>>>(t, d_fc, g, d_order, d_out, d_stats, d_wg_cost);
+    else if (variant == 3 && seg == 2) clouds_kernel<3, 2><<<grid, 256, 0, s>>>(t, d_fc, g, d_order, d_out, d_stats, d_wg_cost);
+    else if (variant == 3 && seg == 4) clouds_kernel<3, 4><<<grid, 256, 0, s>>>(t, d_fc, g, d_order, d_out, d_stats, d_wg_cost);
     else if ((variant == 1 || variant == 3) && seg == 5) {                      // 5 = 4 interleaved segments, one tile per workgroup, 76 KB of LDS
         // > 64 KB of dynamic LDS needs the opt-in attribute; it is per device, so set it on every launch (cheap, idempotent)
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&clouds_kernel_interleaved<0>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                            (int)(IL_BLOCK_FLOATS * sizeof(float)));
         if (e != hipSuccess) return e;
-        clouds_kernel_interleaved<0><<<grid, 256, IL_BLOCK_FLOATS * sizeof(float), s>>>(t, d_fc, g, d_order, d_out, d_stats);
+        clouds_kernel_interleaved<0><<<grid, 256, IL_BLOCK_FLOATS * sizeof(float), s>>>(t, d_fc, g, d_order, d_out, d_stats, d_wg_cost);
     }
     else if (variant == 2) {                                  // detail noise staged in LDS, 16 wavefronts per workgroup
         constexpr size_t bytes = ((DETAIL_CHAIN_TEXELS + 7) / 8 * 4 + 16 * Q_FLOATS) * sizeof(float);
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&clouds_kernel_lds<0>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
         if (e != hipSuccess) return e;
-        clouds_kernel_lds<0><<<grid, 1024, bytes, s>>>(t, d_fc, g, d_order, d_out, d_stats);
+        clouds_kernel_lds<0><<<grid, 1024, bytes, s>>>(t, d_fc, g, d_order, d_out, d_stats, d_wg_cost);
     }
     else return hipErrorInvalidValue;
     return hipGetLastError();

@@ -161,7 +161,9 @@ int csky_set_height_window(csky_ctx* ctx, int enabled);
 int csky_variant_count(void);
 /* Workgroup -> XCD schedule (tuning knob, results are identical): -1 = auto (default: 5 for large launches, 2 for small);
  * 5 = slab rows round-robin over the XCDs;
- * 1 = contiguous eighths; 2 = natural order; 0/3/4 = azimuth wedges; 6 = 5 with horizon rows first. */
+ * 1 = contiguous eighths; 2 = natural order; 0/3/4 = azimuth wedges; 6 = 5 with horizon rows first;
+ * 7 = cost feedback: every launch records a cost per workgroup (in-cloud samples) and the next launch of the same geometry
+ *     starts its workgroups heaviest first (the first launch runs as mode 5). */
 int csky_set_schedule(csky_ctx* ctx, int mode);
 /* Ray segments: the primary march of every ray is cut into `segments` pieces marched by different wavefronts of one
  * workgroup and composited front to back (T and L are associative).  0 = auto (whole rays for large launches, 4 step

@@ -73,7 +73,7 @@ def test_variants_and_schedules_agree(gpu_ctx, oracle):
     p = oracle.default_params(256, 128, (1, 1, 0))
     imgs = {}
     for v in (0, 1):
-        for sch in (0, 1, 2, 3, 4, 5, 6):
+        for sch in (0, 1, 2, 3, 4, 5, 6, 7, 7):                    # 7 twice: the second launch runs in the cost-sorted order
             gpu_ctx.set_variant(v); gpu_ctx.set_schedule(sch)
             img = gpu_ctx.render_clouds(p)
             st = gpu_ctx.cloud_stats()
@@ -95,7 +95,7 @@ def test_variants_and_schedules_agree(gpu_ctx, oracle):
     gpu_ctx.set_variant(3)
     for seg in (1, 2, 4):
         gpu_ctx.set_segments(seg)
-        for sch in (5, 2):
+        for sch in (5, 2, 7, 7):
             gpu_ctx.set_schedule(sch)
             img = gpu_ctx.render_clouds(p)
             ok, info = cloud_close(img, imgs[1][0], frac=0.9999, atol=5e-4, rtol=2e-3)

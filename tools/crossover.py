@@ -18,7 +18,7 @@ for nb in (128, 64, 32, 16, 8, 4, 2, 1):
     row = []
     for seg in (1, 2, 4, 5):
         ctx.set_segments(seg)
-        for sched in (2, 5):
+        for sched in (2, 5, 7):
             ctx.set_schedule(sched)
             ms, _ = ctx.time_clouds(p, W, bands, warmup=1, iters=6)
             row.append("g%d/s%d %.3f" % (seg, sched, ms))

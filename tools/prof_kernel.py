@@ -14,7 +14,7 @@ CONFIGS = {"C2": (512, 256, 64, 4, (0.0, 1.0, 0.0)), "C3": (2048, 1024, 128, 6, 
 ap = argparse.ArgumentParser()
 ap.add_argument("--config", default="C3")
 ap.add_argument("--frames", type=int, default=5)
-ap.add_argument("--variant", type=int, default=1)
+ap.add_argument("--variant", type=int, default=-1)
 ap.add_argument("--sched", type=int, default=-1)
 ap.add_argument("--early-out", type=float, default=0.0)
 ap.add_argument("--coverage", type=float, default=0.2)

@@ -12,7 +12,7 @@ ctx = gvcd_amd.Context(0)
 ctx.set_noise(*gvcd_amd.assets.load_default_noise())
 ctx.render_transmittance(256, 64)
 ctx.render_sky_lut(s, 200, 100, readback=False)
-ctx.set_variant(1)
+ctx.set_variant(-1)
 for seg in (1, 4, 5):
     ctx.set_segments(seg)
     out = []
