@@ -62,9 +62,16 @@ def cpu_baseline(large, small, weather, params, sun, W, H, primary, light, every
     _, st = O.clouds_bands(tex, params, sk, W, (8, 0, every, nb), primary, light, nthreads=cores)
     dt = time.perf_counter() - t0
     rays = nb * 8 * W
+    # SURVEY 8(d) also asks for the single-thread rate: a smaller sample (every 16th band, the first quarter of the columns)
+    nb1, w1 = max(1, (H // 8 + 15) // 16), max(8, W // 4)
+    t0 = time.perf_counter()
+    O.clouds_bands(tex, params, sk, w1, (8, 0, 16, nb1), primary, light, nthreads=1)
+    dt1 = time.perf_counter() - t0
     return {"value": rays / dt / 1e6, "unit": "Mrays/s", "cores": cores, "kind": "port",
             "sample": "every %dth 8-row band of the %dx%d frame (%d rays, %.2f s wall, %.0f core-seconds), oracle/cloudsky_oracle.c "
-                      "gcc -O2 fp32, OpenMP %d threads" % (every, W, H, rays, dt, dt * cores, cores)}
+                      "gcc -O2 fp32, OpenMP %d threads" % (every, W, H, rays, dt, dt * cores, cores),
+            "single_thread": {"value": nb1 * 8 * w1 / dt1 / 1e6, "unit": "Mrays/s", "cores": 1,
+                              "sample": "every 16th 8-row band, columns 0..%d (%d rays, %.2f s)" % (w1 - 1, nb1 * 8 * w1, dt1)}}
 
 
 def main():

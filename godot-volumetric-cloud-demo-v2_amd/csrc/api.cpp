@@ -247,11 +247,15 @@ int clouds_dev(csky_ctx* c, const csky_cloud_params* p, int tile_w, const csky_b
         (void)hipFree(c->d_wg_cost); (void)hipFree(c->d_lpt_order); c->d_wg_cost = c->d_lpt_order = nullptr; c->lpt_cap = 0; c->lpt_valid = false;
         HIPCHK(c, hipMalloc(reinterpret_cast<void**>(&c->d_wg_cost), (size_t)nblocks * sizeof(uint32_t)));
         HIPCHK(c, hipMalloc(reinterpret_cast<void**>(&c->d_lpt_order), (size_t)nblocks * sizeof(uint32_t)));
-        if (!c->d_lpt_hist) HIPCHK(c, hipMalloc(reinterpret_cast<void**>(&c->d_lpt_hist), 1024 * sizeof(uint32_t)));
+        if (!c->d_lpt_hist) {
+            HIPCHK(c, hipMalloc(reinterpret_cast<void**>(&c->d_lpt_hist), 2048 * sizeof(uint32_t)));
+            HIPCHK(c, hipMemsetAsync(c->d_lpt_hist, 0, 2048 * sizeof(uint32_t), s));
+        }
+        HIPCHK(c, hipMemsetAsync(c->d_wg_cost, 0, (size_t)nblocks * sizeof(uint32_t), s));    // the sort kernels leave both zeroed afterwards
+        HIPCHK(c, hipStreamSynchronize(s));                                                    // (re)allocation is rare; later calls may use another stream
         c->lpt_cap = (size_t)nblocks;
     }
     if (memcmp(c->lpt_key, c->order_key, sizeof c->lpt_key) != 0) { c->lpt_valid = false; memcpy(c->lpt_key, c->order_key, sizeof c->lpt_key); }
-    HIPCHK(c, hipMemsetAsync(c->d_wg_cost, 0, (size_t)nblocks * sizeof(uint32_t), s));
     HIPCHK(c, launch_clouds(c->variant, seg, texset(c), c->d_fc, g, c->lpt_valid ? c->d_lpt_order : c->d_order, c->lpt_valid ? nblocks : c->order_grid,
                             d_out, d_stats, c->d_wg_cost, s));
     int shift = 0;

@@ -21,8 +21,9 @@ hipError_t launch_frame_setup(const CloudParams& p, const float4* d_sky, int sw,
 // d_order[grid]: physical workgroup -> workgroup-footprint id (0xffffffff = idle), see api.cpp::build_schedule.
 hipError_t launch_clouds(int variant, int seg, const TexSet& t, const FrameConsts* d_fc, const RenderGeom& g, const uint32_t* d_order, int grid,
                          uint2* d_out, unsigned long long* d_stats, uint32_t* d_wg_cost, hipStream_t s);
-// next launch's workgroup order from this launch's per-workgroup costs, heaviest first (d_hist: 1024 words of scratch)
-hipError_t launch_lpt_order(const uint32_t* d_cost, int n, int shift, uint32_t* d_hist, uint32_t* d_order, hipStream_t s);
+// next launch's workgroup order from this launch's per-workgroup costs, heaviest first.  d_cost[n] and d_scratch[2048] must be zero
+// before their first use and are left zeroed (the cloud kernel accumulates the next costs into d_cost).
+hipError_t launch_lpt_order(uint32_t* d_cost, int n, int shift, uint32_t* d_scratch, uint32_t* d_order, hipStream_t s);
 
 // clouds.gdshader sky() on an equirectangular panorama (all pointers in `a` are device pointers)
 hipError_t launch_composite(const CompositeArgs& a, uint2* d_out, hipStream_t s);

@@ -672,10 +672,11 @@ __global__ __launch_bounds__(256) void lpt_hist_kernel(const uint32_t* __restric
     const int i = blockIdx.x * 256 + threadIdx.x;
     if (i < n) atomicAdd(&hist[lpt_bucket(cost[i], shift)], 1u);
 }
-__global__ __launch_bounds__(LPT_BUCKETS) void lpt_scan_kernel(uint32_t* __restrict__ hist) {   // in place: counts -> exclusive offsets
-    __shared__ uint32_t sh[LPT_BUCKETS];
+__global__ __launch_bounds__(LPT_BUCKETS) void lpt_scan_kernel(uint32_t* __restrict__ hist, uint32_t* __restrict__ offsets) {
+    __shared__ uint32_t sh[LPT_BUCKETS];                       // counts -> exclusive offsets; the histogram is left zeroed for the next launch
     const int t = threadIdx.x;
     const uint32_t own = hist[t];
+    hist[t] = 0u;
     sh[t] = own;
     __syncthreads();
     for (int off = 1; off < LPT_BUCKETS; off <<= 1) {
@@ -684,20 +685,22 @@ __global__ __launch_bounds__(LPT_BUCKETS) void lpt_scan_kernel(uint32_t* __restr
         sh[t] += v;
         __syncthreads();
     }
-    hist[t] = sh[t] - own;
+    offsets[t] = sh[t] - own;
 }
-__global__ __launch_bounds__(256) void lpt_scatter_kernel(const uint32_t* __restrict__ cost, int n, int shift, uint32_t* __restrict__ offsets,
+__global__ __launch_bounds__(256) void lpt_scatter_kernel(uint32_t* __restrict__ cost, int n, int shift, uint32_t* __restrict__ offsets,
                                                           uint32_t* __restrict__ order) {
     const int i = blockIdx.x * 256 + threadIdx.x;
-    if (i < n) order[atomicAdd(&offsets[lpt_bucket(cost[i], shift)], 1u)] = (uint32_t)i;
+    if (i < n) {
+        order[atomicAdd(&offsets[lpt_bucket(cost[i], shift)], 1u)] = (uint32_t)i;
+        cost[i] = 0u;                                          // the next launch accumulates into a clean array: no memset nodes per frame
+    }
 }
-hipError_t launch_lpt_order(const uint32_t* d_cost, int n, int shift, uint32_t* d_hist, uint32_t* d_order, hipStream_t s) {
+// d_cost[n] and d_scratch[2 * LPT_BUCKETS] must be zero before their first use (api.cpp clears them at allocation); both are left zeroed
+hipError_t launch_lpt_order(uint32_t* d_cost, int n, int shift, uint32_t* d_scratch, uint32_t* d_order, hipStream_t s) {
     if (n <= 0) return hipSuccess;
-    hipError_t e = hipMemsetAsync(d_hist, 0, LPT_BUCKETS * sizeof(uint32_t), s);
-    if (e != hipSuccess) return e;
-    lpt_hist_kernel<<<(n + 255) / 256, 256, 0, s>>>(d_cost, n, shift, d_hist);
-    lpt_scan_kernel<<<1, LPT_BUCKETS, 0, s>>>(d_hist);
-    lpt_scatter_kernel<<<(n + 255) / 256, 256, 0, s>>>(d_cost, n, shift, d_hist, d_order);
+    lpt_hist_kernel<<<(n + 255) / 256, 256, 0, s>>>(d_cost, n, shift, d_scratch);
+    lpt_scan_kernel<<<1, LPT_BUCKETS, 0, s>>>(d_scratch, d_scratch + LPT_BUCKETS);
+    lpt_scatter_kernel<<<(n + 255) / 256, 256, 0, s>>>(d_cost, n, shift, d_scratch + LPT_BUCKETS, d_order);
     return hipGetLastError();
 }
 
