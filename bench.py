@@ -46,13 +46,32 @@ def default_params(w, h, sun, coverage=0.2, density=0.05):
                      1.0, 0.0, 0.0, density, coverage, 0.0], np.float32), s
 
 
+def usable_cores():
+    """Host cores this process may actually use: the affinity mask capped by the cgroup CPU quota (the GPU box shows 256 logical
+    CPUs but a cpu.max of 16 CPUs; running 128 OpenMP threads there only adds scheduling overhead and misreports `cores`)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except (OSError, ValueError):
+        try:
+            q = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+            per = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if q > 0:
+                n = min(n, max(1, q // per))
+        except (OSError, ValueError):
+            pass
+    return n
+
+
 def cpu_baseline(large, small, weather, params, sun, W, H, primary, light, every=4):
     """Time the CPU oracle (kind "port": a scalar fp32 restatement of the GLSL, oracle/cloudsky_oracle.c) on a
     bounded sample of the SAME frame: every `every`-th 8-row band, all columns (evenly spread over elevation), on all
-    host cores via OpenMP over (row, 64-column chunk) items.  Reported baseline only, never the optimisation target."""
+    usable host cores (affinity capped by the cgroup CPU quota) via OpenMP over (row, 64-column chunk) items.  Reported baseline only, never the optimisation target."""
     from oracle import oracle as O
 
-    cores = O.max_threads()
+    cores = max(1, min(O.max_threads(), usable_cores()))
     tex = O.OracleTextures(large, small, weather)
     tr = O.transmittance_lut(256, 64)
     sk = O.sky_lut(sun, tr, 200, 100)
