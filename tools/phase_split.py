@@ -12,14 +12,14 @@ ctx = gvcd_amd.Context(0)
 ctx.set_noise(*gvcd_amd.assets.load_default_noise())
 ctx.render_transmittance(256, 64)
 ctx.render_sky_lut(s, 200, 100, readback=False)
-for v in (1, 0):
+for v in (3, 1, 0):
     ctx.set_variant(v)
     for ls in (0, 1, 2, 3, 4, 5, 6):
         ctx.set_march(128, ls)
         ms, st = ctx.time_clouds(p, W, (8, 0, 1, H // 8), warmup=2, iters=10)
         print("variant %d light_steps %d: %.3f ms" % (v, ls, ms), flush=True)
 cov = p.copy()
-ctx.set_variant(1); ctx.set_march(128, 6)
+ctx.set_variant(-1); ctx.set_march(128, 6)
 for c in (1e-6, 0.1, 0.2, 0.3, 0.5):
     cov[26] = c
     ms, st = ctx.time_clouds(cov, W, (8, 0, 1, H // 8), warmup=2, iters=10)
