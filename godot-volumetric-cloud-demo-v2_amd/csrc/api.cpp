@@ -51,6 +51,11 @@ struct csky_ctx {
 };
 
 namespace {
+#ifdef CSKY_TIMELINE
+constexpr size_t CSKY_STATS_WORDS = 2 + 4 * 4 * 70000;   // + {t0, t1, where, what} per wavefront of up to 70 000 workgroups (analysis build)
+#else
+constexpr size_t CSKY_STATS_WORDS = 2;
+#endif
 thread_local char g_err[512];
 
 int fail(csky_ctx* c, int code, const char* fmt, ...) {
@@ -297,7 +302,7 @@ int csky_create(csky_ctx** out, int device_id) {
     if ((e = hipEventCreate(&c->ev0)) != hipSuccess) return bail("hipEventCreate", e);
     if ((e = hipEventCreate(&c->ev1)) != hipSuccess) return bail("hipEventCreate", e);
     if ((e = hipMalloc(reinterpret_cast<void**>(&c->d_fc), sizeof(FrameConsts))) != hipSuccess) return bail("hipMalloc", e);
-    if ((e = hipMalloc(reinterpret_cast<void**>(&c->d_stats), 2 * sizeof(unsigned long long))) != hipSuccess) return bail("hipMalloc", e);
+    if ((e = hipMalloc(reinterpret_cast<void**>(&c->d_stats), CSKY_STATS_WORDS * sizeof(unsigned long long))) != hipSuccess) return bail("hipMalloc", e);
     *out = c;
     return CSKY_OK;
 }
@@ -499,6 +504,17 @@ int csky_time_clouds(csky_ctx* c, const csky_cloud_params* p, int tile_w, const 
     HIPCHK(c, hipMemcpy(st, c->d_stats, 16, hipMemcpyDeviceToHost));
     c->last_stats.rays = (uint64_t)tile_w * rows; c->last_stats.incloud_samples = st[0]; c->last_stats.primary_samples = st[1] * (uint64_t)c->primary_steps;
     if (stats) *stats = c->last_stats;
+#ifdef CSKY_TIMELINE
+    if (const char* path = getenv("CSKY_TIMELINE")) {        // analysis build: one more launch, per-wavefront timestamps -> file
+        HIPCHK(c, hipMemsetAsync(c->d_stats, 0, 16, c->stream));
+        if ((rc = clouds_dev(c, p, tile_w, bands, c->d_frame, pitch, c->stream, c->d_stats, false))) return rc;
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        const size_t n = std::min((size_t)c->order_grid, (size_t)70000) * 16;
+        std::vector<unsigned long long> h(n);
+        HIPCHK(c, hipMemcpy(h.data(), c->d_stats + 2, n * 8, hipMemcpyDeviceToHost));
+        if (FILE* f = fopen(path, "wb")) { fwrite(h.data(), 8, n, f); fclose(f); }
+    }
+#endif
     return CSKY_OK;
 }
 

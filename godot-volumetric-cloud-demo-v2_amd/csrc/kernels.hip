@@ -613,6 +613,9 @@ __global__ __launch_bounds__(256, VARIANT == 3 ? CSKY_COMPACT_WAVES : 7) void cl
     const int band = lr / G.band_rows, rib = lr - band * G.band_rows;
     const int gy = (G.first_band + band * G.band_stride) * G.band_rows + rib;
 
+#ifdef CSKY_TIMELINE
+    const unsigned long long tl0 = wall_clock64();             // analysis build only (make timeline, tools/timeline.py)
+#endif
     const FrameConsts& fc = *fcp;
     T.detail_lds = nullptr;                                    // compile-time constant here: the LDS tap path folds away
     Ray ray = ray_setup(fc, valid ? gx : 0, valid ? gy : 0);
@@ -646,6 +649,15 @@ __global__ __launch_bounds__(256, VARIANT == 3 ? CSKY_COMPACT_WAVES : 7) void cl
         const uint32_t lo = (uint32_t)f2h(o.r) | ((uint32_t)f2h(o.g) << 16), hi = (uint32_t)f2h(o.b) | ((uint32_t)f2h(o.a) << 16);
         out[(size_t)lr * G.pitch_px + gx] = make_uint2(lo, hi);  // imageStore, clouds.glsl:264
     }
+#ifdef CSKY_TIMELINE
+    if (stats && lane == 0) {                                  // per wavefront: start, end (100 MHz ticks), XCD | HW_ID, workgroup id | lane 0's samples
+        unsigned xcc, hwid;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid));
+        unsigned long long* tl = stats + 2 + 4 * ((size_t)blockIdx.x * 4 + wave);
+        tl[0] = tl0; tl[1] = wall_clock64(); tl[2] = ((unsigned long long)xcc << 32) | hwid; tl[3] = ((unsigned long long)logical << 32) | o.incloud;
+    }
+#endif
     if (stats || wg_cost) {
         unsigned ic = o.incloud, ab = (ray.above && seg == 0) ? 1u : 0u;
         for (int off = 32; off > 0; off >>= 1) { ic += __shfl_down(ic, off); ab += __shfl_down(ab, off); }

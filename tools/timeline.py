@@ -1,7 +1,9 @@
 #!/usr/bin/env python
-"""Occupancy over time of one cloud-kernel launch, from per-wavefront start/end timestamps (needs a library built with the
-timeline instrumentation of tools/README: CSKY_TIMELINE=<file> makes csky_time_clouds dump [t0, t1, xcc<<32|hw_id, logical<<32|events]
-per wavefront).  Prints the active-wavefront profile, per-XCD finish times and the tail share."""
+"""Occupancy over time of one cloud-kernel launch, from per-wavefront start/end timestamps.  Needs the analysis build:
+    make -C godot-volumetric-cloud-demo-v2_amd/csrc timeline
+    CSKY_LIBRARY=$PWD/godot-volumetric-cloud-demo-v2_amd/libcloudsky_timeline.so python tools/timeline.py [1/N of the frame] [schedule]
+(csky_time_clouds of that build dumps [t0, t1, xcc<<32|hw_id, workgroup<<32|samples] per wavefront to $CSKY_TIMELINE).
+Prints the active-wavefront profile, per-XCD finish times and how wavefront duration tracks in-cloud samples."""
 import os, sys
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
