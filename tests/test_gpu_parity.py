@@ -251,6 +251,16 @@ def test_error_behaviour(pkg, noise):
     with pytest.raises(pkg.CloudSkyError) as e:                      # clouds before noise (cloud_sky.gd:379 order)
         ctx.render_clouds(p)
     assert e.value.code == pkg._lib.ERR_STATE
+    with pytest.raises(pkg.CloudSkyError) as e:                      # no textures bound yet: nothing to report on
+        ctx.noise_inexact_coeffs()
+    assert e.value.code == pkg._lib.ERR_STATE
+    for bad in (-2, 8):
+        with pytest.raises(pkg.CloudSkyError) as e:
+            ctx.set_schedule(bad)
+        assert e.value.code == pkg._lib.ERR_INVALID
+    with pytest.raises(pkg.CloudSkyError):
+        ctx.set_segments(3)
+    ctx.set_variant(-1); ctx.set_schedule(-1); ctx.set_segments(0)  # the documented "default" selectors
     ctx.set_noise(*noise)
     with pytest.raises(pkg.CloudSkyError) as e:                      # clouds before any sky LUT
         ctx.render_clouds(p)
