@@ -122,8 +122,12 @@ int build_schedule(csky_ctx* c, const CloudParams& p, const RenderGeom& g, int s
     const int bw = seg == 5 ? 8 : (seg == 16 ? 128 : 32 / seg);   // seg 16 = the 16-wavefront "lds" variant: a 128 x 8 pixel strip           // workgroup footprint = bw x 8 pixels (seg 5 = 4 interleaved segments: one tile)
     const int tiles_x = (g.tile_w + bw - 1) / bw, local_rows = g.n_bands * g.band_rows, slabs = (local_rows + 7) >> 3;
     const int nblocks = tiles_x * slabs;
-    const long long key[11] = {g.tile_w, g.band_rows, g.first_band, g.band_stride, g.n_bands, (long long)p.texture_size[0], (long long)p.texture_size[1],
-                               (long long)p.update_position[0], (long long)p.update_position[1], mode, seg};
+    // modes 1, 2, 5 depend on the launch geometry only; the wedge modes and mode 6 also on where the tile sits in the texture (the
+    // reference's tile walk moves update_position every frame: the table must not be rebuilt for that)
+    const bool positional = !(mode == 1 || mode == 2 || mode == 5);
+    const long long key[11] = {g.tile_w, g.band_rows, g.first_band, g.band_stride, g.n_bands, positional ? (long long)p.texture_size[0] : 0,
+                               positional ? (long long)p.texture_size[1] : 0, positional ? (long long)p.update_position[0] : 0,
+                               positional ? (long long)p.update_position[1] : 0, mode, seg};
     if (c->d_order && memcmp(key, c->order_key, sizeof key) == 0) return CSKY_OK;
     std::vector<uint32_t>& ord = c->h_order;
     if (mode == 2) {
@@ -260,7 +264,10 @@ int clouds_dev(csky_ctx* c, const csky_cloud_params* p, int tile_w, const csky_b
         HIPCHK(c, hipStreamSynchronize(s));                                                    // (re)allocation is rare; later calls may use another stream
         c->lpt_cap = (size_t)nblocks;
     }
-    if (memcmp(c->lpt_key, c->order_key, sizeof c->lpt_key) != 0) { c->lpt_valid = false; memcpy(c->lpt_key, c->order_key, sizeof c->lpt_key); }
+    // the costs belong to one view of one tile: same launch geometry AND same place in the texture (a tile walk never reuses them)
+    const long long fkey[11] = {g.tile_w, g.band_rows, g.first_band, g.band_stride, g.n_bands, (long long)cp.texture_size[0], (long long)cp.texture_size[1],
+                                (long long)cp.update_position[0], (long long)cp.update_position[1], static_mode, seg};
+    if (memcmp(c->lpt_key, fkey, sizeof fkey) != 0) { c->lpt_valid = false; memcpy(c->lpt_key, fkey, sizeof fkey); }
     HIPCHK(c, launch_clouds(c->variant, seg, texset(c), c->d_fc, g, c->lpt_valid ? c->d_lpt_order : c->d_order, c->lpt_valid ? nblocks : c->order_grid,
                             d_out, d_stats, c->d_wg_cost, s));
     int shift = 0;
