@@ -300,6 +300,22 @@ def test_full_size_c3_properties(gpu_ctx, oracle, otex, o_skies):
         assert (np.abs(a - b) <= 2e-3 + 1e-2 * np.abs(b)).mean() >= 0.98, (tx, ty)
 
 
+def test_full_size_c5_subsamples_to_c3(gpu_ctx, oracle):
+    """BASELINE configs[4] frame size (4096x2048 @ 128x6).  uv = pos / texture_size (clouds.glsl:261), so pixel (2x, 2y) of the
+    4096x2048 frame is the SAME ray as pixel (x, y) of the 2048x1024 frame (2x/4096 == x/2048 exactly in fp32): every second
+    pixel of every second row must reproduce the C3 frame bit for bit, and the sample counters must scale accordingly."""
+    gpu_ctx.set_march(128, 6)
+    gpu_ctx.render_sky_lut(norm((1, 1, 0)), 200, 100)
+    c3 = gpu_ctx.render_clouds(oracle.default_params(2048, 1024, (1, 1, 0)))
+    c5 = gpu_ctx.render_clouds(oracle.default_params(4096, 2048, (1, 1, 0)))
+    st = gpu_ctx.cloud_stats()
+    assert c5.shape == (2048, 4096, 4)
+    assert (c5[::2, ::2].view(np.uint16) == c3.view(np.uint16)).all()
+    f = c5.astype(np.float32)
+    assert np.isfinite(f).all() and (f[0] == 0).all() and (f[:, 0] == 0).all() and f[..., 3].max() <= 1
+    assert st["rays"] == 4096 * 2048 and st["primary_samples"] == 4095 * 2047 * 128
+
+
 def test_cloud_sky_host_class_on_gpu(pkg, noise, oracle, otex, o_skies):
     """The GDScript mirror end to end on the device-buffer path (torch tensors, current stream)."""
     import torch
