@@ -227,6 +227,9 @@ def test_edge_cases(pkg, gpu_ctx, oracle, otex, o_skies):
     for cov in (0.0, 1e-6):
         img = gpu_ctx.render_clouds(oracle.default_params(64, 32, (0, 1, 0), coverage=cov)).astype(np.float32)
         assert (img == 0).all()
+    # density == 0: every step transmittance is exp(0) = 1, nothing is absorbed or scattered (clouds.glsl:178,207-210): exactly zero
+    pz = oracle.default_params(64, 32, (0, 1, 0)); pz[25] = 0.0
+    assert (gpu_ctx.render_clouds(pz).view(np.uint16) == 0).all() and gpu_ctx.cloud_stats()["incloud_samples"] > 0
     # sun below the horizon (cloud_sky.gd:72 default LIGHT_DIRECTION = (0,-1,0)): finite, matches the oracle
     gpu_ctx.render_sky_lut(norm((0, -1, 0)), 200, 100)
     p = oracle.default_params(64, 32, (0, -1, 0))
