@@ -159,16 +159,18 @@ int csky_set_variant(csky_ctx* ctx, int variant);
  * 0 disables it (A/B measurement, identical results). */
 int csky_set_height_window(csky_ctx* ctx, int enabled);
 int csky_variant_count(void);
-/* Workgroup -> XCD schedule (tuning knob, results are identical): -1 = auto (default: 5 for large launches, 2 for small);
+/* Workgroup -> XCD schedule (tuning knob, results are identical): -1 = auto (default: 5 for whole frames, 7 for a share of a
+ * frame such as one GPU's 1/2 .. 1/8, 2 for tile-sized launches);
  * 5 = slab rows round-robin over the XCDs;
  * 1 = contiguous eighths; 2 = natural order; 0/3/4 = azimuth wedges; 6 = 5 with horizon rows first;
  * 7 = cost feedback: every launch records a cost per workgroup (in-cloud samples) and the next launch of the same geometry
- *     starts its workgroups heaviest first (the first launch runs as mode 5). */
+ *     and view starts its workgroups heaviest first (the first launch runs in a static order).  Only the ORDER comes from the
+ *     previous launch; every sample is recomputed. */
 int csky_set_schedule(csky_ctx* ctx, int mode);
 /* Ray segments: the primary march of every ray is cut into `segments` pieces marched by different wavefronts of one
- * workgroup and composited front to back (T and L are associative).  0 = auto (whole rays for large launches, 4 step
- * ranges for one GPU's share of a split frame, 4 interleaved step sets for tile-sized launches such as the reference's
- * 96x96 temporal tiles), 1, 2, 4 (step ranges) or 5 (4 interleaved). */
+ * workgroup and composited front to back (T and L are associative).  0 = auto (whole rays for large launches, 2 or 4
+ * step ranges for one GPU's share of a split frame, 4 interleaved step sets for tile-sized launches such as the
+ * reference's 96x96 temporal tiles), 1, 2, 4 (step ranges) or 5 (4 interleaved). */
 int csky_set_segments(csky_ctx* ctx, int segments);
 const char* csky_variant_name(int variant);
 
