@@ -100,3 +100,28 @@ def gpu_ctx(pkg, noise):
     ctx.set_noise(*noise)
     yield ctx
     ctx.close()
+
+
+def fuzz_case(seed):
+    """A random but reproducible push-constant block + march lengths + tile (used by the CPU and GPU fuzz parity tests):
+    every field of clouds.glsl:18-40 that the shader reads is varied, incl. wind offsets, time, tile origin and ragged sizes."""
+    rng = np.random.default_rng(1000 + seed)
+    w, h = int(rng.integers(6, 20)) * 8, int(rng.integers(4, 12)) * 8
+    sun = np.array([rng.normal(), abs(rng.normal()) + 0.05 if seed % 4 else -0.3, rng.normal()])
+    sun = (sun / np.linalg.norm(sun)).astype(np.float32)
+    p = np.zeros(28, np.float32)
+    p[0:2] = (w, h)
+    tw, th = int(rng.integers(9, w - 4)), int(rng.integers(5, h - 2))                 # ragged tile inside the texture
+    p[2:4] = (int(rng.integers(0, w - tw)), int(rng.integers(0, h - th)))            # update_position
+    p[4:10] = rng.uniform(-5.0, 5.0, 6)                                              # cloud_pos, detailed_pos, weather_pos
+    p[12:16] = (*rng.uniform(0.0, 0.6, 3), 1.0)                                      # ground_color
+    p[16:19] = sun
+    p[19] = rng.uniform(0.2, 3.0)                                                    # LIGHT_ENERGY
+    p[20:23] = rng.uniform(0.3, 1.0, 3)                                              # LIGHT_COLOR
+    p[23] = rng.uniform(0.0, 100.0)                                                  # time
+    p[25] = rng.uniform(0.01, 0.2)                                                   # density
+    p[26] = rng.uniform(0.05, 0.6)                                                   # cloud_coverage
+    p[27] = rng.uniform(0.0, 10.0)                                                   # time_offset (unused by the shader)
+    primary = int(rng.choice([32, 64, 100, 128]))
+    light = int(rng.integers(0, 7))
+    return p, sun, (tw, th), primary, light

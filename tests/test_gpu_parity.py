@@ -414,3 +414,25 @@ def test_white_noise_textures(pkg, oracle, o_trans):
             assert got > 0 and abs(got - st["incloud_samples"]) <= 1e-3 * st["incloud_samples"] + 1, cov
     finally:
         ctx.close()
+
+
+def test_fuzz_parameters_vs_oracle(gpu_ctx, oracle, otex, o_trans):
+    """Random push-constant blocks (every field the shader reads, incl. wind offsets, time, light colour/energy, suns below the
+    horizon), march lengths 32..128 x 0..6 and ragged offset tiles: the HIP path vs the oracle on the same inputs."""
+    from conftest import fuzz_case
+    try:
+        for seed in range(12):
+            p, sun, (tw, th), primary, light = fuzz_case(seed)
+            gpu_ctx.set_march(primary, light)
+            gpu_ctx.render_sky_lut(sun, 200, 100)
+            sk = oracle.sky_lut(sun, o_trans)
+            d = ulp_diff(gpu_ctx.read_sky_lut(), sk)
+            assert d.max() <= 4 and (d <= 1).mean() >= 0.99, (seed, d.max())
+            ref, st = oracle.clouds(otex, p, sk, rect=(0, 0, tw, th), primary_steps=primary, light_steps=light, return_stats=True)
+            img = gpu_ctx.render_clouds(p, tw, th)
+            ok, info = cloud_close(img, ref)
+            assert ok, (seed, info)
+            got = int(gpu_ctx.cloud_stats()["incloud_samples"])
+            assert abs(got - st["incloud_samples"]) <= 1e-3 * st["incloud_samples"] + 2, (seed, got, st["incloud_samples"])
+    finally:
+        gpu_ctx.set_march(128, 6)

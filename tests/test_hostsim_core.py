@@ -147,3 +147,16 @@ def test_white_noise_textures(hostsim, pkg, oracle, o_trans):
         ok, info = cloud_close(img, ref, frac=0.9995, atol=1e-3, rtol=2e-3)
         assert ok, (cov, info)
         assert ic == st["incloud_samples"] and ic > 0, cov
+
+
+def test_fuzz_parameters_vs_oracle(hostsim, pkg, oracle, noise, otex, o_trans):
+    """Random push-constant blocks, march lengths and ragged offset tiles (conftest.fuzz_case) through the kernel cores."""
+    from conftest import fuzz_case
+    for seed in range(4):
+        p, sun, (tw, th), primary, light = fuzz_case(seed)
+        sk = oracle.sky_lut(sun, o_trans)
+        ref, st = oracle.clouds(otex, p, sk, rect=(0, 0, tw, th), primary_steps=primary, light_steps=light, return_stats=True)
+        rows = (th + 7) // 8
+        img, ic = hs_clouds(hostsim, pkg, noise, p, sk, tw, (8, 0, 1, rows), primary=primary, light=light)
+        ok, info = cloud_close(img[:th], ref, frac=0.9995, atol=1e-3, rtol=2e-3)
+        assert ok, (seed, info)
