@@ -31,8 +31,17 @@ struct csky_ctx {
     float win_cov = -1e30f, win_lo = -1.0f, win_hi = 2.0f; bool use_window = true;
     // LUTs: RGBA16F image + float4 copy of the rounded values
     uint16_t* d_trans_h = nullptr; float4* d_trans_f = nullptr; int tw = 0, th = 0; bool have_trans = false;
-    uint16_t* d_sky_h = nullptr; float4* d_sky_f = nullptr; int sw = 0, sh = 0; bool have_sky = false;
-    FrameConsts* d_fc = nullptr;
+    uint16_t* d_sky_h = nullptr; float4* d_sky_f = nullptr; int sw = 0, sh = 0; bool have_sky = false;   // = ring slot sky_cur
+    FrameConsts* d_fc = nullptr;                                                                          // = ring slot fc_cur
+    // Frame prologue pipeline.  The sky LUT and the frame set-up of frame k+1 are small dependent kernels; enqueued behind the
+    // cloud kernel of frame k they cost their run time plus two launch gaps per frame (6 % of one GPU's 1/8-frame share).  They
+    // run on the context's own prologue stream instead, into the other slot of a two-deep ring (the reference keeps three-deep
+    // texture rings for the same reason, sky_lut.gd:143-146), so they overlap the march of the previous frame; events order
+    // set-up -> clouds (ev_setup) and clouds -> the next writer of that slot (ev_clouds).  All sky-LUT readers run on `pro`.
+    hipStream_t pro = nullptr;
+    uint16_t* sky_h_ring[2] = {nullptr, nullptr}; float4* sky_f_ring[2] = {nullptr, nullptr}; int sky_cur = 0;
+    FrameConsts* fc_ring[2] = {nullptr, nullptr}; int fc_cur = 0;
+    hipEvent_t ev_setup[2] = {nullptr, nullptr}, ev_clouds[2] = {nullptr, nullptr}; bool clouds_pending[2] = {false, false};
     unsigned long long* d_stats = nullptr;
     uint2* d_frame = nullptr; size_t frame_px = 0;  // internal frame for the host-buffer form / timing
     int primary_steps = 128, light_steps = 6;        // clouds.glsl:228, :186
@@ -81,8 +90,12 @@ int ensure_trans(csky_ctx* c, int w, int h) {
 }
 int ensure_sky(csky_ctx* c, int w, int h) {
     if (c->d_sky_h && c->sw == w && c->sh == h) return CSKY_OK;
-    int rc; if ((rc = dev_alloc(c, &c->d_sky_h, (size_t)w * h * 4))) return rc;
-    if ((rc = dev_alloc(c, &c->d_sky_f, (size_t)w * h))) return rc;
+    if (c->pro) HIPCHK(c, hipStreamSynchronize(c->pro));     // a size change is rare: drain the prologue stream, rebuild both slots
+    for (int k = 0; k < 2; k++) {
+        int rc; if ((rc = dev_alloc(c, &c->sky_h_ring[k], (size_t)w * h * 4))) return rc;
+        if ((rc = dev_alloc(c, &c->sky_f_ring[k], (size_t)w * h))) return rc;
+    }
+    c->sky_cur = 0; c->d_sky_h = c->sky_h_ring[0]; c->d_sky_f = c->sky_f_ring[0];
     c->sw = w; c->sh = h; c->have_sky = false; return CSKY_OK;
 }
 int ensure_frame(csky_ctx* c, size_t px) {
@@ -212,7 +225,13 @@ int clouds_dev(csky_ctx* c, const csky_cloud_params* p, int tile_w, const csky_b
             c->win_cov = cp.cloud_coverage;
         }
         const float lo = c->use_window ? c->win_lo : -1.0f, hi = c->use_window ? c->win_hi : 2.0f;
-        HIPCHK(c, launch_frame_setup(cp, c->d_sky_f, c->sw, c->sh, c->primary_steps, c->light_steps, c->early_eps, lo, hi, c->d_fc, s));
+        // frame set-up on the prologue stream into the other constants slot (its last reader, the march two frames ago, must be done)
+        const int f = c->fc_cur ^ 1;
+        if (c->clouds_pending[f]) HIPCHK(c, hipStreamWaitEvent(c->pro, c->ev_clouds[f], 0));
+        HIPCHK(c, launch_frame_setup(cp, c->d_sky_f, c->sw, c->sh, c->primary_steps, c->light_steps, c->early_eps, lo, hi, c->fc_ring[f], c->pro));
+        HIPCHK(c, hipEventRecord(c->ev_setup[f], c->pro));
+        c->fc_cur = f; c->d_fc = c->fc_ring[f];
+        HIPCHK(c, hipStreamWaitEvent(s, c->ev_setup[f], 0));
     }
     RenderGeom g; g.tile_w = tile_w; g.band_rows = b->band_rows; g.first_band = b->first_band; g.band_stride = b->band_stride; g.n_bands = b->n_bands;
     g.pitch_px = (uint32_t)(pitch_bytes / 8);
@@ -246,6 +265,7 @@ int clouds_dev(csky_ctx* c, const csky_cloud_params* p, int tile_w, const csky_b
     if ((rc = build_schedule(c, cp, g, seg, static_mode, s))) return rc;
     if (!feedback) {
         HIPCHK(c, launch_clouds(c->variant, seg, texset(c), c->d_fc, g, c->d_order, c->order_grid, d_out, d_stats, nullptr, s));
+        HIPCHK(c, hipEventRecord(c->ev_clouds[c->fc_cur], s)); c->clouds_pending[c->fc_cur] = true;
         return CSKY_OK;
     }
     // mode 7: this launch runs in the order sorted from the previous launch's costs (same geometry), records its own costs and
@@ -274,6 +294,7 @@ int clouds_dev(csky_ctx* c, const csky_cloud_params* p, int tile_w, const csky_b
     while ((((long long)256 * (c->primary_steps + 16)) >> shift) >= 1024) shift++;     // largest cost: 4 wavefronts x 64 rays x (steps + 16)
     HIPCHK(c, launch_lpt_order(c->d_wg_cost, nblocks, shift, c->d_lpt_hist, c->d_lpt_order, s));
     c->lpt_valid = true;
+    HIPCHK(c, hipEventRecord(c->ev_clouds[c->fc_cur], s)); c->clouds_pending[c->fc_cur] = true;
     return CSKY_OK;
 }
 
@@ -308,7 +329,13 @@ int csky_create(csky_ctx** out, int device_id) {
     if ((e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking)) != hipSuccess) return bail("hipStreamCreate", e);
     if ((e = hipEventCreate(&c->ev0)) != hipSuccess) return bail("hipEventCreate", e);
     if ((e = hipEventCreate(&c->ev1)) != hipSuccess) return bail("hipEventCreate", e);
-    if ((e = hipMalloc(reinterpret_cast<void**>(&c->d_fc), sizeof(FrameConsts))) != hipSuccess) return bail("hipMalloc", e);
+    if ((e = hipStreamCreateWithFlags(&c->pro, hipStreamNonBlocking)) != hipSuccess) return bail("hipStreamCreate", e);
+    for (int k = 0; k < 2; k++) {
+        if ((e = hipEventCreateWithFlags(&c->ev_setup[k], hipEventDisableTiming)) != hipSuccess) return bail("hipEventCreate", e);
+        if ((e = hipEventCreateWithFlags(&c->ev_clouds[k], hipEventDisableTiming)) != hipSuccess) return bail("hipEventCreate", e);
+        if ((e = hipMalloc(reinterpret_cast<void**>(&c->fc_ring[k]), sizeof(FrameConsts))) != hipSuccess) return bail("hipMalloc", e);
+    }
+    c->d_fc = c->fc_ring[0];
     if ((e = hipMalloc(reinterpret_cast<void**>(&c->d_stats), CSKY_STATS_WORDS * sizeof(unsigned long long))) != hipSuccess) return bail("hipMalloc", e);
     *out = c;
     return CSKY_OK;
@@ -317,11 +344,13 @@ int csky_create(csky_ctx** out, int device_id) {
 void csky_destroy(csky_ctx* c) {
     if (!c) return;
     (void)hipSetDevice(c->device);
-    if (c->stream) (void)hipStreamSynchronize(c->stream);
-    void* ptrs[] = {c->d_shape, c->d_detail, c->d_weather, c->d_trans_h, c->d_trans_f, c->d_sky_h, c->d_sky_f, c->d_fc, c->d_stats, c->d_frame, c->d_order, c->d_detail_h, c->d_wg_cost, c->d_lpt_order, c->d_lpt_hist};
+    (void)hipDeviceSynchronize();                              // launches may sit on caller streams too
+    void* ptrs[] = {c->d_shape, c->d_detail, c->d_weather, c->d_trans_h, c->d_trans_f, c->sky_h_ring[0], c->sky_h_ring[1], c->sky_f_ring[0], c->sky_f_ring[1],
+                    c->fc_ring[0], c->fc_ring[1], c->d_stats, c->d_frame, c->d_order, c->d_detail_h, c->d_wg_cost, c->d_lpt_order, c->d_lpt_hist};
     for (void* p : ptrs) if (p) (void)hipFree(p);
-    if (c->ev0) (void)hipEventDestroy(c->ev0);
-    if (c->ev1) (void)hipEventDestroy(c->ev1);
+    hipEvent_t evs[] = {c->ev0, c->ev1, c->ev_setup[0], c->ev_setup[1], c->ev_clouds[0], c->ev_clouds[1]};
+    for (hipEvent_t ev : evs) if (ev) (void)hipEventDestroy(ev);
+    if (c->pro) (void)hipStreamDestroy(c->pro);
     if (c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
 }
@@ -409,6 +438,7 @@ const char* csky_variant_name(int v) { return cloud_variant_name(v); }
 int csky_sync(csky_ctx* c) {
     if (!c) return fail(nullptr, CSKY_ERR_INVALID, "csky_sync: ctx is NULL");
     int rc; if ((rc = bind(c))) return rc;
+    HIPCHK(c, hipStreamSynchronize(c->pro));
     HIPCHK(c, hipStreamSynchronize(c->stream));
     return CSKY_OK;
 }
@@ -419,6 +449,7 @@ int csky_render_transmittance(csky_ctx* c, const csky_transmittance_params* p, u
     const int w = (int)p->texture_size[0], h = (int)p->texture_size[1];
     if (w < 1 || h < 1 || w > 8192 || h > 8192) return fail(c, CSKY_ERR_INVALID, "csky_render_transmittance: texture_size out of range");
     int rc; if ((rc = bind(c))) return rc;
+    HIPCHK(c, hipStreamSynchronize(c->pro));                 // sky LUTs in flight read the old transmittance LUT
     if ((rc = render_trans_dev(c, w, h, c->stream))) return rc;
     if (out) HIPCHK(c, hipMemcpyAsync(out, c->d_trans_h, (size_t)w * h * 8, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
@@ -431,10 +462,12 @@ int csky_render_sky_lut_device(csky_ctx* c, const csky_sky_params* p, void* hip_
     const int w = (int)p->texture_size[0], h = (int)p->texture_size[1];
     if (w < 1 || h < 1 || w > 8192 || h > 8192) return fail(c, CSKY_ERR_INVALID, "csky_render_sky_lut: texture_size out of range");
     int rc; if ((rc = bind(c))) return rc;
-    hipStream_t s = hip_stream ? (hipStream_t)hip_stream : c->stream;
-    if (!c->have_trans && (rc = render_trans_dev(c, 256, 64, s))) return rc;   // transmittance_lut.gd:6 default size
+    (void)hip_stream;   // the LUT has no inputs of the caller's: it is rendered on the prologue stream and its consumers are ordered by events
+    if (!c->have_trans && (rc = render_trans_dev(c, 256, 64, c->pro))) return rc;   // transmittance_lut.gd:6 default size
     if ((rc = ensure_sky(c, w, h))) return rc;
-    HIPCHK(c, launch_sky_lut(w, h, p->sun_direction, c->d_trans_f, c->tw, c->th, c->d_sky_h, c->d_sky_f, s));
+    const int k = c->have_sky ? c->sky_cur ^ 1 : c->sky_cur;  // the other ring slot: frame set-ups still reading the current one are ahead on `pro`
+    HIPCHK(c, launch_sky_lut(w, h, p->sun_direction, c->d_trans_f, c->tw, c->th, c->sky_h_ring[k], c->sky_f_ring[k], c->pro));
+    c->sky_cur = k; c->d_sky_h = c->sky_h_ring[k]; c->d_sky_f = c->sky_f_ring[k];
     c->have_sky = true;
     return CSKY_OK;
 }
@@ -442,8 +475,8 @@ int csky_render_sky_lut_device(csky_ctx* c, const csky_sky_params* p, void* hip_
 int csky_render_sky_lut(csky_ctx* c, const csky_sky_params* p, uint16_t* out) {
     int rc = csky_render_sky_lut_device(c, p, nullptr);
     if (rc) return rc;
-    if (out) HIPCHK(c, hipMemcpyAsync(out, c->d_sky_h, (size_t)c->sw * c->sh * 8, hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(c, hipStreamSynchronize(c->stream));
+    if (out) HIPCHK(c, hipMemcpyAsync(out, c->d_sky_h, (size_t)c->sw * c->sh * 8, hipMemcpyDeviceToHost, c->pro));
+    HIPCHK(c, hipStreamSynchronize(c->pro));
     return CSKY_OK;
 }
 
@@ -477,7 +510,7 @@ int csky_read_transmittance(csky_ctx* c, uint16_t* out, int* w, int* h) {
     if (!c->have_trans) return fail(c, CSKY_ERR_STATE, "csky_read_transmittance: LUT not rendered yet");
     int rc; if ((rc = bind(c))) return rc;
     if (w) *w = c->tw; if (h) *h = c->th;
-    if (out) { HIPCHK(c, hipStreamSynchronize(c->stream)); HIPCHK(c, hipMemcpy(out, c->d_trans_h, (size_t)c->tw * c->th * 8, hipMemcpyDeviceToHost)); }
+    if (out) { HIPCHK(c, hipStreamSynchronize(c->pro)); HIPCHK(c, hipStreamSynchronize(c->stream)); HIPCHK(c, hipMemcpy(out, c->d_trans_h, (size_t)c->tw * c->th * 8, hipMemcpyDeviceToHost)); }
     return CSKY_OK;
 }
 int csky_read_sky_lut(csky_ctx* c, uint16_t* out, int* w, int* h) {
@@ -485,7 +518,7 @@ int csky_read_sky_lut(csky_ctx* c, uint16_t* out, int* w, int* h) {
     if (!c->have_sky) return fail(c, CSKY_ERR_STATE, "csky_read_sky_lut: LUT not rendered yet");
     int rc; if ((rc = bind(c))) return rc;
     if (w) *w = c->sw; if (h) *h = c->sh;
-    if (out) { HIPCHK(c, hipStreamSynchronize(c->stream)); HIPCHK(c, hipMemcpy(out, c->d_sky_h, (size_t)c->sw * c->sh * 8, hipMemcpyDeviceToHost)); }
+    if (out) { HIPCHK(c, hipStreamSynchronize(c->pro)); HIPCHK(c, hipMemcpy(out, c->d_sky_h, (size_t)c->sw * c->sh * 8, hipMemcpyDeviceToHost)); }
     return CSKY_OK;
 }
 
@@ -532,6 +565,7 @@ int csky_composite_sky(csky_ctx* c, const csky_composite_params* p, const uint16
     if (p->out_w < 1 || p->out_h < 1 || p->cloud_w < 1 || p->cloud_h < 1 || p->sky_w < 1 || p->sky_h < 1 || p->out_w > 16384 || p->out_h > 16384)
         return fail(c, CSKY_ERR_INVALID, "csky_composite_sky: bad image size");
     int rc; if ((rc = bind(c))) return rc;
+    HIPCHK(c, hipStreamSynchronize(c->pro));                                                // the transmittance LUT may have been rendered there
     if (!c->have_trans && (rc = render_trans_dev(c, 256, 64, c->stream))) return rc;       // source_transmittance, clouds_material.tres
     const size_t cb = (size_t)p->cloud_w * p->cloud_h * 8, sb = (size_t)p->sky_w * p->sky_h * 8, ob = (size_t)p->out_w * p->out_h * 8;
     uint8_t* d = nullptr;

@@ -117,11 +117,15 @@ int csky_render_clouds(csky_ctx* ctx, const csky_cloud_params* p, int tile_w, in
 /* ---- device-buffer forms (no host copy, asynchronous on `hip_stream`) -----------------------------
  * d_out is a DEVICE pointer the caller owns (e.g. a torch tensor's data_ptr); hip_stream is a
  * hipStream_t passed as void* (NULL = the context's own stream).  The LUT inputs of later calls are
- * always the context's internal copies, so the chain transmittance -> sky -> clouds needs no host hop. */
+ * always the context's internal copies, so the chain transmittance -> sky -> clouds needs no host hop.
+ * The sky LUT and the per-frame constants derived from it are rendered on an internal "prologue" stream into two-deep
+ * rings (like the reference's texture rings, sky_lut.gd:143-146): when frames are enqueued back to back, the prologue of
+ * frame k+1 overlaps the march of frame k.  The library orders prologue -> march -> reuse of a ring slot with events, so a
+ * caller only has to order its own reads of d_out behind `hip_stream`; csky_render_sky_lut_device ignores `hip_stream`. */
 int csky_render_sky_lut_device(csky_ctx* ctx, const csky_sky_params* p, void* hip_stream);
 int csky_render_clouds_device(csky_ctx* ctx, const csky_cloud_params* p, int tile_w, const csky_bands* bands,
                               void* d_out_rgba16f, size_t row_pitch_bytes, void* hip_stream);
-int csky_sync(csky_ctx* ctx); /* wait for the context's own stream */
+int csky_sync(csky_ctx* ctx); /* wait for the context's own streams (work on caller streams is the caller's to wait for) */
 
 /* Read back the context's internal LUT copies (tests, the compositor, Texture2DRD.texture_update). */
 int csky_read_transmittance(csky_ctx* ctx, uint16_t* out_rgba16f, int* w, int* h);
