@@ -12,6 +12,11 @@ N > 1: one process per GPU (torch.distributed, backend nccl = RCCL); the frame's
 the ranks with no collective during the march and ONE gather to rank 0 per frame ("scaling": "strong": the frame
 is fixed, each rank renders 1/N of it).
 
+N = 1: consecutive frames are independent, so by default two frames are in flight (alternating streams): the tail of frame
+k's launch overlaps the head of frame k+1's (`--frames-in-flight 1` = strictly one frame at a time; both are whole-job rates of
+the same K frames).  `roofline.kernel_ms` is the mean duration of the cloud-kernel launches OF THE TIMED REGION (HIP event pairs
+on each launch's stream, recorded inside libcloudsky), the quantity rocprofv3 --kernel-trace --stats reports for this command.
+
 Prints ONE JSON line on rank 0.
 """
 import argparse
@@ -21,6 +26,12 @@ import sys
 import time
 
 import numpy as np
+
+# Two frames in flight need their two streams on DIFFERENT hardware queues.  The HIP runtime multiplexes all streams of a process
+# onto GPU_MAX_HW_QUEUES (default 4) queues, in first-use order; with torch's default stream, the library's two internal streams
+# and the two frame streams, four are not enough to keep the frame streams apart (measured: no overlap at 4, overlap at 8).  Must
+# be set before the HIP runtime initialises, i.e. before torch / libcloudsky are imported.
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
@@ -103,7 +114,11 @@ def main():
     ap.add_argument("--early-out", type=float, default=0.0, help="wave early-out threshold on transmittance (0 = reference behaviour)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--also-early-out", action="store_true", help="add a secondary measurement with the wave early-out (eps = 1e-3) to the JSON line")
-    ap.add_argument("--kernel-iters", type=int, default=20)
+    ap.add_argument("--kernel-iters", type=int, default=1, help="solo (one launch in flight) cloud-kernel launches timed after the timed region")
+    ap.add_argument("--frames-in-flight", type=int, default=None,
+                    help="N = 1: consecutive frames alternate between this many streams (default 2: the tail of frame k overlaps the "
+                         "head of frame k+1; 1 = strictly one frame at a time).  N > 1 always marches one frame at a time per rank "
+                         "(its gather overlaps the next march instead)")
     args = ap.parse_args()
 
     import torch
@@ -151,14 +166,19 @@ def main():
         ctx.set_variant(args.variant)
     ctx.render_transmittance(256, 64)               # once at load, transmittance_lut.gd:15-18
 
-    stream = torch.cuda.current_stream().cuda_stream
+    # N = 1: frames are independent and a whole-frame launch ends in a tail of few, long wavefronts; with two frames in flight on two
+    # streams the next frame's workgroups fill that tail (the library keeps per-frame state in two-deep rings ordered by events).
+    # Measured: 2.19 -> 1.87 ms per frame.  One rank's share at N > 1 runs in cost-sorted order and has no such tail to fill.
+    fif = 1 if world > 1 else max(1, args.frames_in_flight if args.frames_in_flight is not None else 2)
+    streams = [torch.cuda.Stream(device=dev) for _ in range(fif)] if fif > 1 else [torch.cuda.current_stream()]
+    stream = streams[0].cuda_stream
     bands = tiling.bands_for_rank(H, rank, world)
     mb = tiling.max_bands(H, world)
     # N > 1: frames are independent, so the gather of frame k (RCCL, its own stream) overlaps the march of frame k+1:
     # two band buffers per rank, two gather targets on rank 0 (async_op gather; wait() only orders the compute stream behind
     # that one collective).  CSKY_BENCH_SYNC_GATHER=1 falls back to gather-then-render.
     overlap = world > 1 and os.environ.get("CSKY_BENCH_SYNC_GATHER") != "1"
-    nbuf = 2 if overlap else 1
+    nbuf = 2 if overlap else fif
     local = [torch.zeros((mb * tiling.BAND_ROWS, W, 4), dtype=torch.int16, device=dev) for _ in range(nbuf)]
     local_b = [t.view(torch.uint8) for t in local]   # collectives move raw bytes (RCCL has no int16 type)
     gdev = "cpu" if debug_one_gpu else dev
@@ -180,10 +200,11 @@ def main():
         counter[0] += 1
         bset = k % nbuf
         fp, fs = (params, sun_n) if sweep is None else sweep[k % len(sweep)]
-        ctx.render_sky_lut_device(fs, 200, 100, stream)                                        # sky_lut.gd:122-148
-        ctx.render_clouds_device(fp, W, bands, local[bset].data_ptr(), W * 8, stream)         # cloud_sky.gd:234-248
+        st_k = streams[k % fif].cuda_stream
+        ctx.render_sky_lut_device(fs, 200, 100, st_k)                                          # sky_lut.gd:122-148
+        ctx.render_clouds_device(fp, W, bands, local[bset].data_ptr(), W * 8, st_k)           # cloud_sky.gd:234-248
         if world == 1:
-            frame[0] = local[0]
+            frame[0] = local[bset]
             return
         src = local_b[bset].cpu() if debug_one_gpu else local_b[bset]
         pending[bset] = dist.gather(src, gather_list=parts[bset], dst=0, async_op=True)
@@ -205,6 +226,7 @@ def main():
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
+    ctx.set_kernel_timing(True)                      # HIP event pairs around every cloud-kernel launch of the timed region, on its stream
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
@@ -213,13 +235,20 @@ def main():
         dist.barrier()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
+    k_total, k_launches = ctx.kernel_ms()
+    ctx.set_kernel_timing(False)
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if debug_one_gpu else dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
-    # dominant kernel (clouds_kernel) alone: HIP events on the stream it is launched on, inside libcloudsky
-    k_ms, st = ctx.time_clouds(params, W, bands, warmup=2, iters=args.kernel_iters)
+    # dominant kernel (clouds_kernel): average launch duration over the timed region (event pairs on the launch's stream, inside
+    # libcloudsky).  With two frames in flight a launch shares the GPU with its neighbour, so it lasts ~2 frame times; the same
+    # kernel alone (one frame at a time) is timed afterwards over --kernel-iters launches, which also reads the sample counters.
+    k_ms = k_total / max(1, k_launches)
+    k_solo, st = ctx.time_clouds(params, W, bands, warmup=0, iters=max(1, args.kernel_iters))     # (also reads the sample counters)
+    if fif == 1:
+        k_solo = k_ms                                    # one frame at a time: the timed region already is the solo measurement
     rays_launch = bands[3] * bands[0] * W
     f_incloud = st["incloud_samples"] / max(1, st["primary_samples"])
     floor_bytes = rays_launch * (8 + BYTES_PER_SAMPLE * primary)                           # 10 248 B/ray at 128 steps
@@ -286,20 +315,28 @@ def main():
                                    % (args.config, W, H, primary, light, sun_n[0], sun_n[1], sun_n[2]),
                        "texture_size": [W, H], "primary_steps": primary, "light_steps": light, "early_out_eps": args.early_out, "with_early_out": early,
                        "variant": gvcd_amd.lib().csky_variant_name(args.variant if args.variant is not None else gvcd_amd._lib.DEFAULT_VARIANT).decode(),
-                       "parallelism": "bands%d%s" % (world, "+overlapped-gather" if overlap else ""), "alpha_mean": alpha_mean, "finite": finite},
+                       "parallelism": "bands%d%s" % (world, "+overlapped-gather" if overlap else ""), "frames_in_flight": fif,
+                       "alpha_mean": alpha_mean, "finite": finite},
             "roofline": {"bound": "hbm", "kernel": "clouds_kernel", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_note": traffic_note,
-                         "kernel_ms": k_ms, "rays_per_launch": rays_launch,
+                         "kernel_ms": k_ms, "kernel_launches_timed": k_launches, "frames_in_flight": fif,
+                         "kernel_ms_solo": k_solo, "frac_solo": floor_bytes / (k_solo * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                         "frac_per_frame_time": floor_bytes / (elapsed / args.steps) / 1e9 / HBM_PEAK_GBS if world == 1 else None,
+                         "rays_per_launch": rays_launch,
                          "algorithmic_bytes_per_launch": floor_bytes,
                          "algorithmic_bytes_incl_light_march": total_bytes,
                          "achieved_incl_light_march_GBps": total_bytes / (k_ms * 1e-3) / 1e9,
                          "incloud_fraction": f_incloud,
                          # the unit that actually binds: VALU issue.  cycles each SIMD had per VALU instruction it issued (live kernel
                          # time x 2.4 GHz x 1024 SIMDs / committed SQ_INSTS_VALU); the instruction kinds cost 2.5 - 4.4 cycles to issue
-                         "valu_issue": None if not valu_insts else {"insts_per_launch": valu_insts, "simd_cycles_per_inst": k_ms * 1e-3 * 2.4e9 * 1024 / valu_insts,
+                         "valu_issue": None if not valu_insts else {"insts_per_launch": valu_insts, "simd_cycles_per_inst": k_solo * 1e-3 * 2.4e9 * 1024 / valu_insts,
                                                                     "issue_cost_range_cycles": [2.5, 4.4]},
                          "note": "algorithmic tap bytes (80 B/sample x 128 + 8 B/ray = 10 248 B/ray), not DRAM bytes: the "
-                                 "unique inputs (~82 MB of baked textures) live in L2/Infinity Cache, so frac may exceed what HBM could deliver"},
+                                 "unique inputs (~82 MB of baked textures) live in L2/Infinity Cache, so frac may exceed what HBM could deliver.  "
+                                 "achieved/frac use kernel_ms = the mean launch duration over the timed region (what rocprofv3 reports for the "
+                                 "same command); with frames_in_flight = 2 each launch overlaps its neighbour and lasts about two frame "
+                                 "times, so frac_solo (the kernel with the GPU to itself) and frac_per_frame_time (bytes per launch / "
+                                 "ms_per_step) bracket it"},
         }
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(large, small, weather, params, sun_n, W, H, primary, light)

@@ -64,6 +64,8 @@ SYMBOLS = [
     ("csky_composite_sky", C.c_int, [C.c_void_p, C.POINTER(CompositeParams), C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     ("csky_time_clouds", C.c_int, [C.c_void_p, C.POINTER(CloudParams), C.c_int, C.POINTER(Bands), C.c_int, C.c_int, C.POINTER(C.c_float), C.POINTER(CloudStats)]),
     ("csky_get_cloud_stats", C.c_int, [C.c_void_p, C.POINTER(CloudStats)]),
+    ("csky_set_kernel_timing", C.c_int, [C.c_void_p, C.c_int]),
+    ("csky_get_kernel_ms", C.c_int, [C.c_void_p, C.POINTER(C.c_float), C.POINTER(C.c_int)]),
     ("csky_set_variant", C.c_int, [C.c_void_p, C.c_int]),
     ("csky_variant_count", C.c_int, []),
     ("csky_set_schedule", C.c_int, [C.c_void_p, C.c_int]),
@@ -260,6 +262,15 @@ class Context:
         st = CloudStats()
         self._chk(self._L.csky_time_clouds(self._h, C.byref(p), int(tile_w), C.byref(b), warmup, iters, C.byref(ms), C.byref(st)))
         return ms.value, dict(rays=st.rays, primary_samples=st.primary_samples, incloud_samples=st.incloud_samples)
+
+    def set_kernel_timing(self, enabled=True):
+        self._chk(self._L.csky_set_kernel_timing(self._h, int(bool(enabled))))
+
+    def kernel_ms(self):
+        """(sum of cloud-kernel durations in ms, launches) since the last call; waits for those launches."""
+        ms, n = C.c_float(), C.c_int()
+        self._chk(self._L.csky_get_kernel_ms(self._h, C.byref(ms), C.byref(n)))
+        return ms.value, n.value
 
     def cloud_stats(self):
         st = CloudStats()

@@ -53,8 +53,11 @@ struct csky_ctx {
     uint32_t* d_order = nullptr; size_t order_cap = 0; int order_grid = 0;
     // cost-feedback schedule (mode 7): per-workgroup costs of the last launch -> heaviest-first order of the next one
     uint32_t* d_wg_cost = nullptr; uint32_t* d_lpt_order = nullptr; uint32_t* d_lpt_hist = nullptr; size_t lpt_cap = 0;
-    bool lpt_valid = false; long long lpt_key[11] = {-1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1};
+    bool lpt_valid[2] = {false, false}; long long lpt_key[2][11] = {{-1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1}, {-1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1}};
     std::vector<uint32_t> h_order; long long order_key[11] = {-1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1};
+    // optional per-launch timing of the cloud kernel (csky_set_kernel_timing): HIP event pairs recorded around the launch on ITS stream
+    static constexpr int KT_PAIRS = 256;
+    bool kt_on = false; std::vector<hipEvent_t> kt_ev; int kt_count = 0;
     csky_cloud_stats last_stats = {0, 0, 0};
     char err[512] = {0};
 };
@@ -196,8 +199,9 @@ int build_schedule(csky_ctx* c, const CloudParams& p, const RenderGeom& g, int s
             }
         }
     }
+    HIPCHK(c, hipDeviceSynchronize());   // the table is rebuilt only when the geometry changes; frames on other streams may still read the old one
     if (c->order_cap < ord.size()) {
-        if (c->d_order) { HIPCHK(c, hipStreamSynchronize(s)); (void)hipFree(c->d_order); c->d_order = nullptr; }
+        if (c->d_order) { (void)hipFree(c->d_order); c->d_order = nullptr; }
         HIPCHK(c, hipMalloc(reinterpret_cast<void**>(&c->d_order), ord.size() * sizeof(uint32_t)));
         c->order_cap = ord.size();
     }
@@ -262,38 +266,49 @@ int clouds_dev(csky_ctx* c, const csky_cloud_params* p, int tile_w, const csky_b
     const int mode = c->sched_mode >= 0 ? c->sched_mode : auto_mode;
     const int static_mode = mode == 7 ? (waves >= 12288 ? 5 : 2) : mode;     // order of the first launch of a geometry under mode 7
     const bool feedback = mode == 7 && queued && seg != 5;       // kernels that record per-workgroup costs
+    hipEvent_t* kt = nullptr;                                    // timing pair of this launch (csky_set_kernel_timing)
+    if (c->kt_on) { kt = &c->kt_ev[(size_t)(c->kt_count % csky_ctx::KT_PAIRS) * 2]; c->kt_count++; }
     if ((rc = build_schedule(c, cp, g, seg, static_mode, s))) return rc;
     if (!feedback) {
+        if (kt) HIPCHK(c, hipEventRecord(kt[0], s));
         HIPCHK(c, launch_clouds(c->variant, seg, texset(c), c->d_fc, g, c->d_order, c->order_grid, d_out, d_stats, nullptr, s));
+        if (kt) HIPCHK(c, hipEventRecord(kt[1], s));
         HIPCHK(c, hipEventRecord(c->ev_clouds[c->fc_cur], s)); c->clouds_pending[c->fc_cur] = true;
         return CSKY_OK;
     }
-    // mode 7: this launch runs in the order sorted from the previous launch's costs (same geometry), records its own costs and
-    // sorts them for the next one.  The first launch of a geometry uses a static order.
+    // mode 7: this launch runs in the order sorted from the costs of the previous launch ON THE SAME RING SLOT (same geometry and
+    // view), records its own costs and sorts them for the next one.  The first launch of a geometry uses a static order.  Costs,
+    // order and sort scratch are per ring slot (= per frame parity, like the frame constants), so two frames in flight on two
+    // streams never share them; reuse of a slot is ordered by ev_clouds, recorded below after the sort.
     const int bw = 32 / seg, tiles_x = (g.tile_w + bw - 1) / bw, nblocks = tiles_x * ((g.n_bands * g.band_rows + 7) >> 3);
     if (c->lpt_cap < (size_t)nblocks) {
-        HIPCHK(c, hipStreamSynchronize(s));
-        (void)hipFree(c->d_wg_cost); (void)hipFree(c->d_lpt_order); c->d_wg_cost = c->d_lpt_order = nullptr; c->lpt_cap = 0; c->lpt_valid = false;
-        HIPCHK(c, hipMalloc(reinterpret_cast<void**>(&c->d_wg_cost), (size_t)nblocks * sizeof(uint32_t)));
-        HIPCHK(c, hipMalloc(reinterpret_cast<void**>(&c->d_lpt_order), (size_t)nblocks * sizeof(uint32_t)));
+        HIPCHK(c, hipDeviceSynchronize());                   // (re)allocation is rare; frames may be in flight on other streams
+        (void)hipFree(c->d_wg_cost); (void)hipFree(c->d_lpt_order); c->d_wg_cost = c->d_lpt_order = nullptr; c->lpt_cap = 0;
+        c->lpt_valid[0] = c->lpt_valid[1] = false;
+        HIPCHK(c, hipMalloc(reinterpret_cast<void**>(&c->d_wg_cost), 2 * (size_t)nblocks * sizeof(uint32_t)));
+        HIPCHK(c, hipMalloc(reinterpret_cast<void**>(&c->d_lpt_order), 2 * (size_t)nblocks * sizeof(uint32_t)));
         if (!c->d_lpt_hist) {
-            HIPCHK(c, hipMalloc(reinterpret_cast<void**>(&c->d_lpt_hist), 2048 * sizeof(uint32_t)));
-            HIPCHK(c, hipMemsetAsync(c->d_lpt_hist, 0, 2048 * sizeof(uint32_t), s));
+            HIPCHK(c, hipMalloc(reinterpret_cast<void**>(&c->d_lpt_hist), 2 * 2048 * sizeof(uint32_t)));
+            HIPCHK(c, hipMemset(c->d_lpt_hist, 0, 2 * 2048 * sizeof(uint32_t)));
         }
-        HIPCHK(c, hipMemsetAsync(c->d_wg_cost, 0, (size_t)nblocks * sizeof(uint32_t), s));    // the sort kernels leave both zeroed afterwards
-        HIPCHK(c, hipStreamSynchronize(s));                                                    // (re)allocation is rare; later calls may use another stream
+        HIPCHK(c, hipMemset(c->d_wg_cost, 0, 2 * (size_t)nblocks * sizeof(uint32_t)));       // the sort kernels leave both zeroed afterwards
         c->lpt_cap = (size_t)nblocks;
     }
+    const int slot = c->fc_cur;
+    uint32_t* const cost = c->d_wg_cost + (size_t)slot * c->lpt_cap;
+    uint32_t* const lorder = c->d_lpt_order + (size_t)slot * c->lpt_cap;
     // the costs belong to one view of one tile: same launch geometry AND same place in the texture (a tile walk never reuses them)
     const long long fkey[11] = {g.tile_w, g.band_rows, g.first_band, g.band_stride, g.n_bands, (long long)cp.texture_size[0], (long long)cp.texture_size[1],
                                 (long long)cp.update_position[0], (long long)cp.update_position[1], static_mode, seg};
-    if (memcmp(c->lpt_key, fkey, sizeof fkey) != 0) { c->lpt_valid = false; memcpy(c->lpt_key, fkey, sizeof fkey); }
-    HIPCHK(c, launch_clouds(c->variant, seg, texset(c), c->d_fc, g, c->lpt_valid ? c->d_lpt_order : c->d_order, c->lpt_valid ? nblocks : c->order_grid,
-                            d_out, d_stats, c->d_wg_cost, s));
+    if (memcmp(c->lpt_key[slot], fkey, sizeof fkey) != 0) { c->lpt_valid[slot] = false; memcpy(c->lpt_key[slot], fkey, sizeof fkey); }
+    if (kt) HIPCHK(c, hipEventRecord(kt[0], s));
+    HIPCHK(c, launch_clouds(c->variant, seg, texset(c), c->d_fc, g, c->lpt_valid[slot] ? lorder : c->d_order, c->lpt_valid[slot] ? nblocks : c->order_grid,
+                            d_out, d_stats, cost, s));
+    if (kt) HIPCHK(c, hipEventRecord(kt[1], s));
     int shift = 0;
     while ((((long long)256 * (c->primary_steps + 16)) >> shift) >= 1024) shift++;     // largest cost: 4 wavefronts x 64 rays x (steps + 16)
-    HIPCHK(c, launch_lpt_order(c->d_wg_cost, nblocks, shift, c->d_lpt_hist, c->d_lpt_order, s));
-    c->lpt_valid = true;
+    HIPCHK(c, launch_lpt_order(cost, nblocks, shift, c->d_lpt_hist + slot * 2048, lorder, s));
+    c->lpt_valid[slot] = true;
     HIPCHK(c, hipEventRecord(c->ev_clouds[c->fc_cur], s)); c->clouds_pending[c->fc_cur] = true;
     return CSKY_OK;
 }
@@ -350,6 +365,7 @@ void csky_destroy(csky_ctx* c) {
     for (void* p : ptrs) if (p) (void)hipFree(p);
     hipEvent_t evs[] = {c->ev0, c->ev1, c->ev_setup[0], c->ev_setup[1], c->ev_clouds[0], c->ev_clouds[1]};
     for (hipEvent_t ev : evs) if (ev) (void)hipEventDestroy(ev);
+    for (hipEvent_t ev : c->kt_ev) if (ev) (void)hipEventDestroy(ev);
     if (c->pro) (void)hipStreamDestroy(c->pro);
     if (c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
@@ -519,6 +535,32 @@ int csky_read_sky_lut(csky_ctx* c, uint16_t* out, int* w, int* h) {
     int rc; if ((rc = bind(c))) return rc;
     if (w) *w = c->sw; if (h) *h = c->sh;
     if (out) { HIPCHK(c, hipStreamSynchronize(c->pro)); HIPCHK(c, hipMemcpy(out, c->d_sky_h, (size_t)c->sw * c->sh * 8, hipMemcpyDeviceToHost)); }
+    return CSKY_OK;
+}
+
+int csky_set_kernel_timing(csky_ctx* c, int enabled) {
+    if (!c) return fail(nullptr, CSKY_ERR_INVALID, "csky_set_kernel_timing: ctx is NULL");
+    int rc; if ((rc = bind(c))) return rc;
+    if (enabled && c->kt_ev.empty()) {
+        c->kt_ev.assign((size_t)csky_ctx::KT_PAIRS * 2, nullptr);
+        for (hipEvent_t& ev : c->kt_ev) HIPCHK(c, hipEventCreate(&ev));
+    }
+    c->kt_on = enabled != 0; c->kt_count = 0;
+    return CSKY_OK;
+}
+
+int csky_get_kernel_ms(csky_ctx* c, float* total_ms, int* launches) {
+    if (!c || !total_ms || !launches) return fail(c, CSKY_ERR_INVALID, "csky_get_kernel_ms: NULL argument");
+    int rc; if ((rc = bind(c))) return rc;
+    const int n = c->kt_count < csky_ctx::KT_PAIRS ? c->kt_count : csky_ctx::KT_PAIRS;   // the pool keeps the last KT_PAIRS launches
+    float sum = 0.0f;
+    for (int i = 0; i < n; i++) {
+        HIPCHK(c, hipEventSynchronize(c->kt_ev[(size_t)i * 2 + 1]));
+        float ms = 0.0f;
+        HIPCHK(c, hipEventElapsedTime(&ms, c->kt_ev[(size_t)i * 2], c->kt_ev[(size_t)i * 2 + 1]));
+        sum += ms;
+    }
+    *total_ms = sum; *launches = n; c->kt_count = 0;
     return CSKY_OK;
 }
 

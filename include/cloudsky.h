@@ -155,6 +155,11 @@ int csky_composite_sky(csky_ctx* ctx, const csky_composite_params* p, const uint
 int csky_time_clouds(csky_ctx* ctx, const csky_cloud_params* p, int tile_w, const csky_bands* bands, int warmup,
                      int iters, float* mean_ms, csky_cloud_stats* stats);
 int csky_get_cloud_stats(csky_ctx* ctx, csky_cloud_stats* stats); /* tallies of the last stats-enabled launch */
+/* Per-launch timing of the cloud kernel inside the caller's own frame loop: while enabled, every csky_render_clouds* launch is
+ * bracketed by a pair of HIP events recorded on the stream the kernel is launched on.  csky_get_kernel_ms waits for the launches
+ * recorded since the last call (at most the last 256), returns the sum of their durations and their number, and resets. */
+int csky_set_kernel_timing(csky_ctx* ctx, int enabled);
+int csky_get_kernel_ms(csky_ctx* ctx, float* total_ms, int* launches);
 /* Kernel variant selector for A/B measurement (csky_variant_name lists them).  -1 = the default = the fastest measured
  * (CSKY_DEFAULT_VARIANT, "compact").  Unknown ids -> CSKY_ERR_INVALID. */
 #define CSKY_DEFAULT_VARIANT 3
