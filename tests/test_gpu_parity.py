@@ -436,3 +436,37 @@ def test_fuzz_parameters_vs_oracle(gpu_ctx, oracle, otex, o_trans):
             assert abs(got - st["incloud_samples"]) <= 1e-3 * st["incloud_samples"] + 2, (seed, got, st["incloud_samples"])
     finally:
         gpu_ctx.set_march(128, 6)
+
+
+def test_frames_in_flight_are_independent(pkg, gpu_ctx, oracle):
+    """Four frames with different suns enqueued back to back on two alternating streams (device form; the library keeps sky LUT,
+    frame constants and the feedback schedule in two-deep rings ordered by events) must each equal their strictly serial render,
+    bit for bit, on every repetition - for a share-sized launch (segments + cost-feedback order) and for a whole-frame launch."""
+    import torch
+    suns = [(1, 1, 0), (0, 1, 0), (-1, 0.3, 0.2), (0.2, 0.9, -0.4)]
+    gpu_ctx.set_march(64, 6)
+    try:
+        for (W, H) in ((512, 256), (1024, 512)):
+            bands = (8, 0, 1, H // 8)
+            refs = []
+            for sun in suns:
+                gpu_ctx.render_sky_lut(norm(sun), 200, 100)
+                refs.append(gpu_ctx.render_clouds(oracle.default_params(W, H, sun)).view(np.uint16).copy())
+            assert not (refs[0] == refs[1]).all()
+            streams = [torch.cuda.Stream() for _ in range(2)]
+            outs = [torch.zeros((H, W, 4), dtype=torch.int16, device="cuda") for _ in suns]
+            gpu_ctx.set_kernel_timing(True)
+            for rep in range(3):
+                for k, sun in enumerate(suns):
+                    st = streams[k % 2].cuda_stream
+                    gpu_ctx.render_sky_lut_device(norm(sun), 200, 100, st)
+                    gpu_ctx.render_clouds_device(oracle.default_params(W, H, sun), W, bands, outs[k].data_ptr(), W * 8, st)
+                torch.cuda.synchronize()
+                for k in range(len(suns)):
+                    assert (outs[k].cpu().numpy().view(np.uint16) == refs[k]).all(), (W, rep, k)
+            ms, n = gpu_ctx.kernel_ms()
+            assert n == 12 and 0.0 < ms < 1000.0
+            gpu_ctx.set_kernel_timing(False)
+    finally:
+        gpu_ctx.set_kernel_timing(False)
+        gpu_ctx.set_march(128, 6)
