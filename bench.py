@@ -12,10 +12,11 @@ N > 1: one process per GPU (torch.distributed, backend nccl = RCCL); the frame's
 the ranks with no collective during the march and ONE gather to rank 0 per frame ("scaling": "strong": the frame
 is fixed, each rank renders 1/N of it).
 
-N = 1: consecutive frames are independent, so by default two frames are in flight (alternating streams): the tail of frame
-k's launch overlaps the head of frame k+1's (`--frames-in-flight 1` = strictly one frame at a time; both are whole-job rates of
-the same K frames).  `roofline.kernel_ms` is the mean duration of the cloud-kernel launches OF THE TIMED REGION (HIP event pairs
-on each launch's stream, recorded inside libcloudsky), the quantity rocprofv3 --kernel-trace --stats reports for this command.
+Consecutive frames are independent, so by default every rank keeps two frames in flight (alternating streams): the tail of
+frame k's launch overlaps the head of frame k+1's and, at N > 1, frame k's gather (`--frames-in-flight 1` = strictly one frame
+at a time; both are whole-job rates of the same K frames).  `roofline.kernel_ms` is the mean duration of the cloud-kernel
+launches OF THE TIMED REGION (HIP event pairs on each launch's stream, recorded inside libcloudsky), the quantity rocprofv3
+--kernel-trace --stats reports for this command.
 
 Prints ONE JSON line on rank 0.
 """
@@ -116,9 +117,8 @@ def main():
     ap.add_argument("--also-early-out", action="store_true", help="add a secondary measurement with the wave early-out (eps = 1e-3) to the JSON line")
     ap.add_argument("--kernel-iters", type=int, default=1, help="solo (one launch in flight) cloud-kernel launches timed after the timed region")
     ap.add_argument("--frames-in-flight", type=int, default=None,
-                    help="N = 1: consecutive frames alternate between this many streams (default 2: the tail of frame k overlaps the "
-                         "head of frame k+1; 1 = strictly one frame at a time).  N > 1 always marches one frame at a time per rank "
-                         "(its gather overlaps the next march instead)")
+                    help="consecutive frames alternate between this many streams per rank (default 2: the tail of frame k overlaps the head "
+                         "of frame k+1 and, at N > 1, its gather; 1 = strictly one frame at a time)")
     args = ap.parse_args()
 
     import torch
@@ -166,19 +166,22 @@ def main():
         ctx.set_variant(args.variant)
     ctx.render_transmittance(256, 64)               # once at load, transmittance_lut.gd:15-18
 
-    # N = 1: frames are independent and a whole-frame launch ends in a tail of few, long wavefronts; with two frames in flight on two
-    # streams the next frame's workgroups fill that tail (the library keeps per-frame state in two-deep rings ordered by events).
-    # Measured: 2.19 -> 1.87 ms per frame.  One rank's share at N > 1 runs in cost-sorted order and has no such tail to fill.
-    fif = 1 if world > 1 else max(1, args.frames_in_flight if args.frames_in_flight is not None else 2)
+    # Frames are independent and a launch ends in a tail of few, long wavefronts; with two frames in flight on two streams the next
+    # frame's workgroups fill that tail (the library keeps per-frame state in two-deep rings ordered by events).  Measured on one
+    # GPU: whole frame 2.19 -> 1.90 ms; one rank's 1/2, 1/4, 1/8 share 1.09 -> 0.96, 0.67 -> 0.52, 0.43 -> 0.34 ms per frame
+    # (tools/share_matrix.py).  Buffer set b = frame parity: band buffer, stream, gather target.
+    fif = max(1, min(2, args.frames_in_flight if args.frames_in_flight is not None else 2))
+    if os.environ.get("CSKY_BENCH_SYNC_GATHER") == "1":
+        fif = 1                                      # debugging aid: gather-then-render, one frame at a time
+    ctx.set_frames_in_flight(fif)
     streams = [torch.cuda.Stream(device=dev) for _ in range(fif)] if fif > 1 else [torch.cuda.current_stream()]
     stream = streams[0].cuda_stream
     bands = tiling.bands_for_rank(H, rank, world)
     mb = tiling.max_bands(H, world)
-    # N > 1: frames are independent, so the gather of frame k (RCCL, its own stream) overlaps the march of frame k+1:
-    # two band buffers per rank, two gather targets on rank 0 (async_op gather; wait() only orders the compute stream behind
-    # that one collective).  CSKY_BENCH_SYNC_GATHER=1 falls back to gather-then-render.
-    overlap = world > 1 and os.environ.get("CSKY_BENCH_SYNC_GATHER") != "1"
-    nbuf = 2 if overlap else fif
+    # N > 1: the gather of frame k (RCCL, its own stream, ordered behind the stream of frame k at the call) overlaps the march of
+    # frame k+1 on the other stream; wait() orders frame k's stream behind its collective before that buffer set is reused.
+    overlap = world > 1 and fif > 1
+    nbuf = fif
     local = [torch.zeros((mb * tiling.BAND_ROWS, W, 4), dtype=torch.int16, device=dev) for _ in range(nbuf)]
     local_b = [t.view(torch.uint8) for t in local]   # collectives move raw bytes (RCCL has no int16 type)
     gdev = "cpu" if debug_one_gpu else dev
@@ -189,25 +192,27 @@ def main():
     counter = [0]
 
     def finish(o):
-        """Frame in buffer set o has been gathered: order the compute stream behind it and assemble the frame on rank 0."""
-        pending[o].wait()
-        pending[o] = None
-        if rank == 0:
-            frame[0] = tiling.interleave(gathered[o].to(dev) if debug_one_gpu else gathered[o], H, world)
+        """Frame in buffer set o has been gathered: order ITS stream behind the collective and assemble the frame on rank 0."""
+        with torch.cuda.stream(streams[o]):
+            pending[o].wait()
+            pending[o] = None
+            if rank == 0:
+                frame[0] = tiling.interleave(gathered[o].to(dev) if debug_one_gpu else gathered[o], H, world)
 
     def step():
         k = counter[0]
         counter[0] += 1
         bset = k % nbuf
         fp, fs = (params, sun_n) if sweep is None else sweep[k % len(sweep)]
-        st_k = streams[k % fif].cuda_stream
+        st_k = streams[bset].cuda_stream
         ctx.render_sky_lut_device(fs, 200, 100, st_k)                                          # sky_lut.gd:122-148
         ctx.render_clouds_device(fp, W, bands, local[bset].data_ptr(), W * 8, st_k)           # cloud_sky.gd:234-248
         if world == 1:
             frame[0] = local[bset]
             return
-        src = local_b[bset].cpu() if debug_one_gpu else local_b[bset]
-        pending[bset] = dist.gather(src, gather_list=parts[bset], dst=0, async_op=True)
+        with torch.cuda.stream(streams[bset]):       # the collective is ordered behind the CURRENT stream: make it this frame's
+            src = local_b[bset].cpu() if debug_one_gpu else local_b[bset]
+            pending[bset] = dist.gather(src, gather_list=parts[bset], dst=0, async_op=True)
         if overlap:
             o = 1 - bset
             if pending[o] is not None:

@@ -66,6 +66,7 @@ SYMBOLS = [
     ("csky_get_cloud_stats", C.c_int, [C.c_void_p, C.POINTER(CloudStats)]),
     ("csky_set_kernel_timing", C.c_int, [C.c_void_p, C.c_int]),
     ("csky_get_kernel_ms", C.c_int, [C.c_void_p, C.POINTER(C.c_float), C.POINTER(C.c_int)]),
+    ("csky_set_frames_in_flight", C.c_int, [C.c_void_p, C.c_int]),
     ("csky_set_variant", C.c_int, [C.c_void_p, C.c_int]),
     ("csky_variant_count", C.c_int, []),
     ("csky_set_schedule", C.c_int, [C.c_void_p, C.c_int]),
@@ -262,6 +263,9 @@ class Context:
         st = CloudStats()
         self._chk(self._L.csky_time_clouds(self._h, C.byref(p), int(tile_w), C.byref(b), warmup, iters, C.byref(ms), C.byref(st)))
         return ms.value, dict(rays=st.rays, primary_samples=st.primary_samples, incloud_samples=st.incloud_samples)
+
+    def set_frames_in_flight(self, frames):
+        self._chk(self._L.csky_set_frames_in_flight(self._h, int(frames)))
 
     def set_kernel_timing(self, enabled=True):
         self._chk(self._L.csky_set_kernel_timing(self._h, int(bool(enabled))))

@@ -49,6 +49,7 @@ struct csky_ctx {
     int variant = CSKY_DEFAULT_VARIANT;
     int sched_mode = -1;                              // -1 = auto (5 for large launches, 2 for small ones)
     int segments = 0;                                 // ray segments per ray: 0 = auto, 1, 2, 4
+    int frames_in_flight = 1;                         // policy hint (csky_set_frames_in_flight): the caller alternates two streams
     // workgroup schedule (physical workgroup -> slab), cached per render geometry
     uint32_t* d_order = nullptr; size_t order_cap = 0; int order_grid = 0;
     // cost-feedback schedule (mode 7): per-workgroup costs of the last launch -> heaviest-first order of the next one
@@ -255,7 +256,13 @@ int clouds_dev(csky_ctx* c, const csky_cloud_params* p, int tile_w, const csky_b
     const bool queued = c->variant == 1 || c->variant == 3;
     int seg = queued ? c->segments : 1;
     int auto_mode;
-    if (c->variant == 3) {
+    if (c->variant == 3 && c->frames_in_flight >= 2) {
+        // the caller keeps two frames in flight on two streams (csky_set_frames_in_flight): the next frame's workgroups fill this
+        // launch's tail, so fewer, longer wavefronts win (tools/share_matrix.py, ms per frame at 1/2, 1/4, 1/8, 1/16 of the frame):
+        //   seg 1: 0.96 (s5) 0.52 (s7) 0.42 0.35    seg 2: 1.18 0.61 0.34 (s7) 0.29    seg 4: 1.27 0.75 0.39 0.22 (s7)
+        if (queued && seg == 0) seg = waves >= 6144 ? 1 : (waves >= 3072 ? 2 : (waves >= 768 ? 4 : 5));
+        auto_mode = waves >= 12288 ? 5 : (waves >= 768 ? 7 : 2);
+    } else if (c->variant == 3) {
         if (queued && seg == 0) seg = waves >= 12288 ? 1 : (waves >= 6144 ? 2 : (waves >= 768 ? 4 : 5));
         auto_mode = waves >= 24576 ? 5 : (waves >= 1536 ? 7 : 2);
     } else {
@@ -438,6 +445,11 @@ int csky_set_schedule(csky_ctx* c, int mode) {
     if (!c) return fail(nullptr, CSKY_ERR_INVALID, "csky_set_schedule: ctx is NULL");
     if (mode < -1 || mode > 7) return fail(c, CSKY_ERR_INVALID, "csky_set_schedule: mode must be -1 (auto) or 0..7 (see cloudsky.h)");
     c->sched_mode = mode; return CSKY_OK;
+}
+int csky_set_frames_in_flight(csky_ctx* c, int frames) {
+    if (!c) return fail(nullptr, CSKY_ERR_INVALID, "csky_set_frames_in_flight: ctx is NULL");
+    if (frames < 1 || frames > 2) return fail(c, CSKY_ERR_INVALID, "csky_set_frames_in_flight: 1 or 2 (the rings are two deep)");
+    c->frames_in_flight = frames; return CSKY_OK;
 }
 int csky_set_segments(csky_ctx* c, int segments) {
     if (!c) return fail(nullptr, CSKY_ERR_INVALID, "csky_set_segments: ctx is NULL");

@@ -181,6 +181,10 @@ int csky_set_schedule(csky_ctx* ctx, int mode);
  * step ranges for one GPU's share of a split frame, 4 interleaved step sets for tile-sized launches such as the
  * reference's 96x96 temporal tiles), 1, 2, 4 (step ranges) or 5 (4 interleaved). */
 int csky_set_segments(csky_ctx* ctx, int segments);
+/* Policy hint for the automatic segment / schedule choice: 2 = the caller keeps two frames in flight by alternating two streams
+ * between consecutive csky_render_*_device calls (always safe: per-frame state lives in two-deep rings ordered by events); the
+ * next frame then fills the tail of this one and fewer, longer wavefronts are the better choice for partial frames.  Default 1. */
+int csky_set_frames_in_flight(csky_ctx* ctx, int frames);
 const char* csky_variant_name(int variant);
 
 /* ---- asset layer (host only; usable without a GPU) ------------------------------------------------

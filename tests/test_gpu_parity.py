@@ -446,7 +446,8 @@ def test_frames_in_flight_are_independent(pkg, gpu_ctx, oracle):
     suns = [(1, 1, 0), (0, 1, 0), (-1, 0.3, 0.2), (0.2, 0.9, -0.4)]
     gpu_ctx.set_march(64, 6)
     try:
-        for (W, H) in ((512, 256), (1024, 512)):
+        for (W, H), hint in (((512, 256), 1), ((1024, 512), 1), ((512, 256), 2), ((1024, 512), 2)):
+            gpu_ctx.set_frames_in_flight(hint)                 # launch-policy hint (segments / schedule); the serial reference uses the same
             bands = (8, 0, 1, H // 8)
             refs = []
             for sun in suns:
@@ -463,10 +464,11 @@ def test_frames_in_flight_are_independent(pkg, gpu_ctx, oracle):
                     gpu_ctx.render_clouds_device(oracle.default_params(W, H, sun), W, bands, outs[k].data_ptr(), W * 8, st)
                 torch.cuda.synchronize()
                 for k in range(len(suns)):
-                    assert (outs[k].cpu().numpy().view(np.uint16) == refs[k]).all(), (W, rep, k)
+                    assert (outs[k].cpu().numpy().view(np.uint16) == refs[k]).all(), (W, hint, rep, k)
             ms, n = gpu_ctx.kernel_ms()
             assert n == 12 and 0.0 < ms < 1000.0
             gpu_ctx.set_kernel_timing(False)
     finally:
         gpu_ctx.set_kernel_timing(False)
+        gpu_ctx.set_frames_in_flight(1)
         gpu_ctx.set_march(128, 6)

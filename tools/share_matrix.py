@@ -1,0 +1,37 @@
+#!/usr/bin/env python
+"""One rank's share of the frame (1/4, 1/8): ms per frame for ray segments x schedule x frames in flight."""
+import os, sys, time
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+import numpy as np
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import torch
+import gvcd_amd
+W, H = 2048, 1024
+s = (np.array([1.0, 1.0, 0.0]) / np.sqrt(2)).astype(np.float32)
+p = np.array([W, H, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0.270588, 0.188235, 0.027451, 1.0, s[0], s[1], s[2], 1.0, 1.0, 1.0, 1.0, 0.0, 0.0, 0.05, 0.2, 0.0], np.float32)
+ctx = gvcd_amd.Context(0)
+ctx.set_noise(*gvcd_amd.assets.load_default_noise())
+ctx.render_transmittance(256, 64)
+pool = [torch.cuda.Stream() for _ in range(3)]
+for share in [int(a) for a in sys.argv[1:]] or (2, 4, 8):
+    bands = (8, 0, share, H // 8 // share)
+    outs = [torch.zeros((bands[3] * 8, W, 4), dtype=torch.int16, device="cuda") for _ in range(3)]
+    for seg in (1, 2, 4, 5):
+        row = []
+        for sched in (5, 7):
+            for ns in (1, 2, 3):
+                ctx.set_segments(seg); ctx.set_schedule(sched)
+                def step(k):
+                    i = k % ns
+                    ctx.render_sky_lut_device(s, 200, 100, pool[i].cuda_stream)
+                    ctx.render_clouds_device(p, W, bands, outs[i].data_ptr(), W * 8, pool[i].cuda_stream)
+                for k in range(9):
+                    step(k)
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                for k in range(60):
+                    step(k)
+                torch.cuda.synchronize()
+                row.append("s%d/x%d %.3f" % (sched, ns, (time.perf_counter() - t0) / 60 * 1e3))
+        print("1/%d frame, seg %d: %s" % (share, seg, "  ".join(row)), flush=True)
