@@ -403,7 +403,7 @@ int csky_set_noise(csky_ctx* c, const uint8_t* large_rgba8, const uint8_t* small
     }
     for (int l = 0; l < SHAPE_LEVELS; l++) if (c->shape_off[l] != shape_level_offset(l)) return fail(c, CSKY_ERR_INVALID, "internal: shape mip offset mismatch");
     for (int l = 0; l < DETAIL_LEVELS; l++) if (c->detail_off[l] != detail_level_offset(l)) return fail(c, CSKY_ERR_INVALID, "internal: detail mip offset mismatch");
-    HIPCHK(c, hipStreamSynchronize(c->stream));
+    HIPCHK(c, hipDeviceSynchronize());                        // frames reading the old textures may be in flight on caller streams
     if ((rc = dev_alloc(c, &c->d_shape, shape.size()))) return rc;
     if ((rc = dev_alloc(c, &c->d_detail, detail.size()))) return rc;
     if ((rc = dev_alloc(c, &c->d_weather, weather.size()))) return rc;
