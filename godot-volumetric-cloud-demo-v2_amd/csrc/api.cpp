@@ -233,7 +233,9 @@ int clouds_dev(csky_ctx* c, const csky_cloud_params* p, int tile_w, const csky_b
         // frame set-up on the prologue stream into the other constants slot (its last reader, the march two frames ago, must be done)
         const int f = c->fc_cur ^ 1;
         if (c->clouds_pending[f]) HIPCHK(c, hipStreamWaitEvent(c->pro, c->ev_clouds[f], 0));
-        HIPCHK(c, launch_frame_setup(cp, c->d_sky_f, c->sw, c->sh, c->primary_steps, c->light_steps, c->early_eps, lo, hi, c->fc_ring[f], c->pro));
+        // cloud-type range of the weather map (texel values 0..255): all >= 128 or all <= 127 fixes the branch of the height gradient
+        const int ctm = !c->use_window ? 0 : (c->w_rmin * 255.0 >= 127.5 ? 1 : (c->w_rmax * 255.0 <= 127.5 ? 2 : 0));
+        HIPCHK(c, launch_frame_setup(cp, c->d_sky_f, c->sw, c->sh, c->primary_steps, c->light_steps, c->early_eps, lo, hi, ctm, c->fc_ring[f], c->pro));
         HIPCHK(c, hipEventRecord(c->ev_setup[f], c->pro));
         c->fc_cur = f; c->d_fc = c->fc_ring[f];
         HIPCHK(c, hipStreamWaitEvent(s, c->ev_setup[f], 0));

@@ -166,6 +166,7 @@ CSKY_HD void frame_setup(const CloudParams& P, const float4* sky, int sky_w, int
     fc.primary_steps = primary_steps; fc.light_steps = light_steps; fc.steps_f = (float)primary_steps;
     fc.early_eps = early_eps;
     fc.hf_lo = hf_lo; fc.hf_hi = hf_hi;
+    fc.ct_mode = 0;                   // set by the caller that knows the weather map's range (api.cpp; kernels.hip frame_setup_kernel)
 }
 
 // =================================================================================================
@@ -304,14 +305,23 @@ CSKY_HD float smoothstep_fast(float e0, float e1, float x) {
 // clouds.glsl:82-95.  mixGradients() is piecewise linear in the cloud type ct: below 0.5 only stratus (1-2ct) and
 // stratocumulus (2ct) are non-zero, above 0.5 only stratocumulus (2-2ct) and cumulus (2ct-1), so each of the four
 // gradient corners is A + ct*B with (A,B) picked by the branch (8 selects + 4 FMA instead of 3 weights x 4 x 2 FMA).
-CSKY_HD float density_height_gradient(float hf, float ct) {
-    const bool hi = ct >= 0.5f;
+CSKY_HD float density_height_gradient(const FrameConsts& fc, float hf, float ct) {
     const float c = ct;                                       // ct is a filtered UNORM8 texel: always in [0,1]
     // ct < 0.5 : STRATUS + ct*2*(STRATOCUMULUS - STRATUS)   ; ct >= 0.5 : (2*STRATOCUMULUS - CUMULUS) + ct*2*(CUMULUS - STRATOCUMULUS)
-    const float gx = (hi ? 0.03f : 0.02f) + c * (hi ? -0.02f : 0.0f);
-    const float gy = (hi ? 0.3375f : 0.05f) + c * (hi ? -0.275f : 0.3f);
-    const float gz = (hi ? 0.18f : 0.09f) + c * (hi ? 0.6f : 0.78f);
-    const float gw = (hi ? 0.25f : 0.11f) + c * (hi ? 0.75f : 1.03f);
+    float gx, gy, gz, gw;
+    if (fc.ct_mode == 1) {
+        // every texel of the bound weather map is >= 128/255, and bilinear filtering stays inside the texel range: the branch of
+        // the piecewise form is known for the whole frame (a scalar test) and its 8 selects + compare disappear.  Same arithmetic.
+        gx = 0.03f + c * -0.02f; gy = 0.3375f + c * -0.275f; gz = 0.18f + c * 0.6f; gw = 0.25f + c * 0.75f;
+    } else if (fc.ct_mode == 2) {
+        gx = 0.02f + c * 0.0f; gy = 0.05f + c * 0.3f; gz = 0.09f + c * 0.78f; gw = 0.11f + c * 1.03f;
+    } else {
+        const bool hi = ct >= 0.5f;
+        gx = (hi ? 0.03f : 0.02f) + c * (hi ? -0.02f : 0.0f);
+        gy = (hi ? 0.3375f : 0.05f) + c * (hi ? -0.275f : 0.3f);
+        gz = (hi ? 0.18f : 0.09f) + c * (hi ? 0.6f : 0.78f);
+        gw = (hi ? 0.25f : 0.11f) + c * (hi ? 0.75f : 1.03f);
+    }
     return smoothstep_fast(gx, gy, hf) - smoothstep_fast(gz, gw, hf);
 }
 
@@ -325,7 +335,7 @@ CSKY_HD float density_height_gradient(float hf, float ct) {
 CSKY_HD float density(const TexSet& T, const FrameConsts& fc, float px, float py, float pz, float hf, float wr, float wb,
                       int lod_shape, int lod_detail) {
     const float wc = fc.coverage * wb;                                       // :123
-    const float g = density_height_gradient(hf, wr);                        // :121
+    const float g = density_height_gradient(fc, hf, wr);                    // :121
     const float omw = 1.0f - wc;
     if (!(g > omw)) return 0.0f;                                             // exact reject (1)
     float qx, qy, qz, sx, sy, sz;

@@ -85,6 +85,7 @@ struct FrameConsts {
     float steps_f;
     float early_eps;                  // wave early-out threshold on T (0 = off; not in the reference)
     float hf_lo, hf_hi;               // height-fraction window outside which density() is provably 0 (bake.h height_window)
+    int ct_mode;                      // cloud-type range of the bound weather map: 1 = every texel >= 0.5, 2 = every texel < 0.5, 0 = mixed (density_height_gradient)
 };
 
 // Which rows a launch renders (cloudsky.h csky_bands) + output addressing.

@@ -14,7 +14,7 @@ hipError_t launch_sky_lut(int w, int h, const float sun[3], const float4* d_tran
                           float4* d_float, hipStream_t s);
 // per-frame constants of clouds.glsl:143-170 (one wave)
 hipError_t launch_frame_setup(const CloudParams& p, const float4* d_sky, int sw, int sh, int primary_steps, int light_steps,
-                              float early_eps, float hf_lo, float hf_hi, FrameConsts* d_fc, hipStream_t s);
+                              float early_eps, float hf_lo, float hf_hi, int ct_mode, FrameConsts* d_fc, hipStream_t s);
 // clouds.glsl main() over the rows described by `g`.  d_stats (may be null): [0] += in-cloud samples,
 // [1] += rays above the horizon.
 // seg = ray segments per ray (1, 2 or 4; variant 1 only): a workgroup covers 4/seg tiles of 8x8 pixels.

@@ -102,16 +102,17 @@ hipError_t launch_composite(const CompositeArgs& a, uint2* d_out, hipStream_t s)
 
 // ------------------------------------------------------------------------------------------------ clouds
 __global__ __launch_bounds__(64) void frame_setup_kernel(CloudParams p, const float4* __restrict__ sky, int sw, int sh, int primary_steps,
-                                                         int light_steps, float early_eps, float hf_lo, float hf_hi, FrameConsts* __restrict__ out) {
+                                                         int light_steps, float early_eps, float hf_lo, float hf_hi, int ct_mode, FrameConsts* __restrict__ out) {
     if (threadIdx.x == 0 && blockIdx.x == 0) {
         FrameConsts fc;
         frame_setup(p, sky, sw, sh, primary_steps, light_steps, early_eps, hf_lo, hf_hi, fc);
+        fc.ct_mode = ct_mode;
         *out = fc;
     }
 }
 hipError_t launch_frame_setup(const CloudParams& p, const float4* d_sky, int sw, int sh, int primary_steps, int light_steps, float early_eps,
-                              float hf_lo, float hf_hi, FrameConsts* d_fc, hipStream_t s) {
-    frame_setup_kernel<<<1, 64, 0, s>>>(p, d_sky, sw, sh, primary_steps, light_steps, early_eps, hf_lo, hf_hi, d_fc);
+                              float hf_lo, float hf_hi, int ct_mode, FrameConsts* d_fc, hipStream_t s) {
+    frame_setup_kernel<<<1, 64, 0, s>>>(p, d_sky, sw, sh, primary_steps, light_steps, early_eps, hf_lo, hf_hi, ct_mode, d_fc);
     return hipGetLastError();
 }
 

@@ -75,6 +75,11 @@ void hostsim_clouds(const uint8_t* large_chain, const uint8_t* small_chain, cons
     }
     if (window_out) { window_out[0] = hlo; window_out[1] = hhi; }
     frame_setup(P, sky.data(), sw, sh, primary_steps, light_steps, early_eps, hlo, hhi, fc);
+    if (use_window) {                                        // like api.cpp: the exact specialisations are switched together
+        int rmin = 255, rmax = 0;
+        for (size_t i = 0; i < (size_t)WEATHER_N * WEATHER_N; i++) { const int r = weather_rgb8[3 * i]; rmin = r < rmin ? r : rmin; rmax = r > rmax ? r : rmax; }
+        fc.ct_mode = rmin >= 128 ? 1 : (rmax <= 127 ? 2 : 0);
+    }
     uint64_t ic = 0;
     const int rows = n_bands * band_rows;
     for (int lr = 0; lr < rows; lr++) {

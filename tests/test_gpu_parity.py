@@ -472,3 +472,30 @@ def test_frames_in_flight_are_independent(pkg, gpu_ctx, oracle):
         gpu_ctx.set_kernel_timing(False)
         gpu_ctx.set_frames_in_flight(1)
         gpu_ctx.set_march(128, 6)
+
+
+def test_stratus_only_weather_map(pkg, noise, oracle, o_trans):
+    """Cloud-type channel below 0.5 everywhere: the 'all low' frame-wide specialisation of the height gradient (ct_mode 2) vs the
+    oracle, and bit-identical to the general form (csky_set_height_window(0) switches the exact specialisations off)."""
+    large, small, weather = noise
+    w2 = weather.copy(); w2[..., 0] = w2[..., 0] // 2
+    otex = oracle.OracleTextures(large, small, w2)
+    sun = norm((1, 1, 0))
+    sk = oracle.sky_lut(sun, o_trans)
+    ctx = pkg.Context(0)
+    try:
+        ctx.set_noise(large, small, w2)
+        ctx.render_transmittance(256, 64)
+        ctx.render_sky_lut(sun, 200, 100)
+        for cov in (0.3, 0.6):
+            p = oracle.default_params(128, 64, (1, 1, 0), coverage=cov)
+            ref, st = oracle.clouds(otex, p, sk, return_stats=True)
+            img = ctx.render_clouds(p)
+            ok, info = cloud_close(img, ref)
+            assert ok, (cov, info)
+            assert st["incloud_samples"] > 0 and int(ctx.cloud_stats()["incloud_samples"]) == st["incloud_samples"], cov
+            ctx.set_height_window(0)
+            assert (ctx.render_clouds(p).view(np.uint16) == img.view(np.uint16)).all(), cov
+            ctx.set_height_window(1)
+    finally:
+        ctx.close()

@@ -160,3 +160,21 @@ def test_fuzz_parameters_vs_oracle(hostsim, pkg, oracle, noise, otex, o_trans):
         img, ic = hs_clouds(hostsim, pkg, noise, p, sk, tw, (8, 0, 1, rows), primary=primary, light=light)
         ok, info = cloud_close(img[:th], ref, frac=0.9995, atol=1e-3, rtol=2e-3)
         assert ok, (seed, info)
+
+
+def test_stratus_only_weather_map(hostsim, pkg, oracle, noise, o_skies):
+    """A weather map whose cloud-type channel stays below 0.5 everywhere (stratus .. stratocumulus): the height gradient takes its
+    'all low' frame-wide specialisation (FrameConsts.ct_mode == 2); the shipped map exercises 'all high', white noise the mixed path."""
+    large, small, weather = noise
+    w2 = weather.copy(); w2[..., 0] = w2[..., 0] // 2
+    assert w2[..., 0].max() <= 127
+    otex = oracle.OracleTextures(large, small, w2)
+    for cov in (0.3, 0.6):
+        p = oracle.default_params(64, 32, SUNS["deg45"], coverage=cov)
+        ref, st = oracle.clouds(otex, p, o_skies["deg45"], return_stats=True)
+        for window in (True, False):                               # False: general (select) form, no height window
+            img, ic = hs_clouds(hostsim, pkg, (large, small, w2), p, o_skies["deg45"], 64, (8, 0, 1, 4), window=window)
+            ok, info = cloud_close(img, ref, frac=0.9995, atol=1e-3, rtol=2e-3)
+            assert ok, (cov, window, info)
+            assert ic == st["incloud_samples"], (cov, window)
+        assert st["incloud_samples"] > 0, cov
