@@ -257,6 +257,14 @@ constexpr int CQ_CAP = 128;                                  // a flush is taken
 constexpr int CQ_STEPS = 66;                                 // steps-with-events between flushes: <= 1 carried + 64 (>= 1 event each)
 constexpr int CQ_FLOATS = 5 * CQ_CAP + 64 + 3 * CQ_STEPS;    // pos(3) t hf | cd | per-step mask lo/hi + base = 3.6 KB per wavefront
 
+#ifndef CSKY_EAGER_LIGHT
+#define CSKY_EAGER_LIGHT 1
+#endif
+#if CSKY_EAGER_LIGHT
+#define CSKY_LIGHT_SAMPLE sample_density_eager
+#else
+#define CSKY_LIGHT_SAMPLE sample_density
+#endif
 __device__ __forceinline__ MarchOut march_compact(const TexSet& T, const FrameConsts& fc, Ray ray, float* __restrict__ q, int step_begin, int step_end) {
     float* __restrict__ ev_px = q;
     float* __restrict__ ev_py = q + CQ_CAP;
@@ -317,13 +325,13 @@ __device__ __forceinline__ MarchOut march_compact(const TexSet& T, const FrameCo
                 if (j >= ls) break;
                 advance(lx, ly, lz, fc.linc[j][0], fc.linc[j][1], fc.linc[j][2]);                              // :187
                 const float lhf = height_fraction(length3_exact(lx, ly, lz));                                  // :188
-                cd += sample_density(T, fc, lx, ly, lz, lhf, fc.wpos_x, fc.wpos_y, j > 2 ? j - 2 : 0, j);      // :189-191
+                cd += CSKY_LIGHT_SAMPLE(T, fc, lx, ly, lz, lhf, fc.wpos_x, fc.wpos_y, j > 2 ? j - 2 : 0, j);   // :189-191
             }
             {   // distant sample, :195-199
                 lx = ex; ly = ey; lz = ez;
                 advance(lx, ly, lz, fc.ldist[0], fc.ldist[1], fc.ldist[2]);
                 const float lhf = height_fraction(length3_exact(lx, ly, lz));
-                const float ld = sample_density(T, fc, lx, ly, lz, lhf, 0.0f, 0.0f, 3, 5);                     // :197 has no weather_pos
+                const float ld = CSKY_LIGHT_SAMPLE(T, fc, lx, ly, lz, lhf, 0.0f, 0.0f, 3, 5);                  // :197 has no weather_pos
                 cd += fast_pow(ld, (1.0f - lhf) * 0.8f + 0.5f);                                                // :198 (second pow)
             }
             ev_cd[lane] = cd;
@@ -595,7 +603,8 @@ __global__ __launch_bounds__(1024) void clouds_kernel_lds(TexSet T, const FrameC
 // Workgroup order: physical workgroup b runs on XCD b % 8 (observed, speed only); `order` (api.cpp::build_schedule)
 // maps b to a workgroup footprint.
 #ifndef CSKY_COMPACT_WAVES
-#define CSKY_COMPACT_WAVES 8   // waves/SIMD asked of the "compact" variant (62 VGPRs, 3.6 KB LDS per wavefront): 8 measured 1.5 % faster than 7
+#define CSKY_COMPACT_WAVES 7   // waves/SIMD asked of the "compact" variant.  With the eager light-march fetches (three gathers of a sample in flight
+                               // together) 7 waves x 72 VGPRs beat 8 waves x 64 VGPRs + spills: whole frame 1.83 -> 1.80 ms, 1/4 frame 0.49 -> 0.48
 #endif
 template <int VARIANT, int SEG>
 __global__ __launch_bounds__(256, VARIANT == 3 ? CSKY_COMPACT_WAVES : 7) void clouds_kernel(TexSet T, const FrameConsts* __restrict__ fcp, RenderGeom G, const uint32_t* __restrict__ order,

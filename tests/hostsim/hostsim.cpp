@@ -96,6 +96,30 @@ void hostsim_clouds(const uint8_t* large_chain, const uint8_t* small_chain, cons
     if (incloud) *incloud = ic;
 }
 
+// sample_density() vs sample_density_eager() (all fetches of a sample issued up front) on n sample points of the default frame set-up:
+// out[2*i] = lazy, out[2*i+1] = eager.  pos = 3 floats per point, lods = {shape, detail} per point.
+void hostsim_density_forms(const uint8_t* large_chain, const uint8_t* small_chain, const uint8_t* weather_rgb8, const float params[28],
+                           const uint16_t* sky_h, int sw, int sh, int n, const float* pos, const int* lods, float* out) {
+    std::vector<uint8_t> lc(large_chain, large_chain + csky_mip_offset(SHAPE_N, SHAPE_LEVELS, 4));
+    std::vector<uint8_t> sc(small_chain, small_chain + csky_mip_offset(DETAIL_N, DETAIL_LEVELS, 3));
+    std::vector<ShapeTexel> shape; std::vector<uint4> detail, weather;
+    uint32_t so[SHAPE_LEVELS], dof[DETAIL_LEVELS];
+    bake_shape(lc, shape, so); bake_detail(sc, detail, dof); bake_weather(weather_rgb8, weather);
+    std::vector<float4> sky = widen(sky_h, sw, sh);
+    TexSet T; T.shape = shape.data(); T.detail = detail.data(); T.weather = weather.data(); T.sky = sky.data(); T.sky_w = sw; T.sky_h = sh;
+    T.detail_h = nullptr; T.detail_lds = nullptr;
+    { const uint8_t* t5 = sc.data() + csky_mip_offset(DETAIL_N, 5, 3); T.detail_lod5 = (float)(5 * t5[0] + 2 * t5[1] + t5[2]) * (1.0f / (8.0f * 255.0f)); }
+    CloudParams P; memcpy(&P, params, sizeof P);
+    FrameConsts fc;
+    frame_setup(P, sky.data(), sw, sh, 128, 6, 0.0f, -1.0f, 2.0f, fc);
+    for (int i = 0; i < n; i++) {
+        const float x = pos[3 * i], y = pos[3 * i + 1], z = pos[3 * i + 2];
+        const float hf = height_fraction(length3_exact(x, y, z));
+        out[2 * i] = sample_density(T, fc, x, y, z, hf, fc.wpos_x, fc.wpos_y, lods[2 * i], lods[2 * i + 1]);
+        out[2 * i + 1] = sample_density_eager(T, fc, x, y, z, hf, fc.wpos_x, fc.wpos_y, lods[2 * i], lods[2 * i + 1]);
+    }
+}
+
 void hostsim_composite(int out_w, int out_h, const uint16_t* cf, const uint16_t* ct, int cw, int ch, const uint16_t* sf, const uint16_t* st, int sw, int sh,
                        const uint16_t* trans_h, int tw, int th, float blend, float sun_disk_scale, const float sun[3], uint16_t* out_h_) {
     std::vector<float4> tf = widen(trans_h, tw, th);

@@ -178,3 +178,24 @@ def test_stratus_only_weather_map(hostsim, pkg, oracle, noise, o_skies):
             assert ok, (cov, window, info)
             assert ic == st["incloud_samples"], (cov, window)
         assert st["incloud_samples"] > 0, cov
+
+
+def test_eager_fetch_density_is_the_same_function(hostsim, pkg, oracle, noise, o_skies):
+    """The light march evaluates density through sample_density_eager() (all three gathers of a sample issued before any of the
+    arithmetic).  On the host both forms must return bit-identical values for random points of the cloud shell at every LOD pair."""
+    rng = np.random.default_rng(21)
+    large, small, weather = noise
+    lc, sc = pkg.assets.build_mips(large, 8), pkg.assets.build_mips(small, 6)
+    n = 20000
+    d = rng.normal(size=(n, 3)); d[:, 1] = np.abs(d[:, 1]) + 0.05; d /= np.linalg.norm(d, axis=1, keepdims=True)
+    r = rng.uniform(6001400.0, 6004100.0, n)                                   # a little beyond both shells
+    pos = (d * r[:, None]).astype(np.float32)
+    j = rng.integers(0, 7, n)
+    lods = np.stack([np.where(j == 6, 3, np.maximum(j - 2, 0)), np.where(j == 6, 5, j)], 1).astype(np.int32)   # the march's LOD pairs
+    out = np.zeros(2 * n, np.float32)
+    p = np.ascontiguousarray(oracle.default_params(64, 32, SUNS["deg45"], coverage=0.6), np.float32)
+    sk = np.ascontiguousarray(o_skies["deg45"]).view(np.uint16)
+    hostsim.hostsim_density_forms(P(lc), P(sc), P(weather), P(p), P(sk), sk.shape[1], sk.shape[0], n, P(pos), P(lods), P(out))
+    lazy, eager = out[0::2], out[1::2]
+    assert (lazy.view(np.uint32) == eager.view(np.uint32)).all()
+    assert (lazy > 0).mean() > 0.02 and (lazy == 0).mean() > 0.05            # both outcomes are exercised
