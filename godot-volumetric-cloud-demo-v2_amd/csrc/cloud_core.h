@@ -381,6 +381,9 @@ CSKY_HD float sample_density(const TexSet& T, const FrameConsts& fc, float px, f
 // 8 -> 5 waves/SIMD costs 25 %).  Same arithmetic, same exact rejects (a rejected sample discards what it fetched).  Used for
 // the light march, where 94 % of the samples need all three taps anyway (tools/stage_trace); the primary march keeps the lazy form.
 #if CSKY_SHAPE_POLY == 3
+// EAGER_DETAIL = false fetches the weather and shape cells together and the detail cell only after reject (2): the form for the
+// primary march, where 77 % of the samples inside the height window reach the shape tap but only 31 % the detail tap.
+template <bool EAGER_DETAIL = true>
 CSKY_HD float sample_density_eager(const TexSet& T, const FrameConsts& fc, float px, float py, float pz, float hf, float wx, float wy,
                                    int lod_shape, int lod_detail) {
     if (!(hf > fc.hf_lo && hf < fc.hf_hi)) return 0.0f;
@@ -404,7 +407,7 @@ CSKY_HD float sample_density_eager(const TexSet& T, const FrameConsts& fc, float
     detail_coord(fc, qx, qy, qz, dsx, dsy, dsz);
     uint4 dq = uint4{0u, 0u, 0u, 0u};
     float dax = 0.0f, day = 0.0f, daz = 0.0f;
-    if (lod_detail != 5) {                                    // wave-uniform; LOD 5 is one texel (detail_tap)
+    if (EAGER_DETAIL && lod_detail != 5) {                    // wave-uniform; LOD 5 is one texel (detail_tap)
         const int dn = DETAIL_N >> lod_detail, dm = dn - 1;
         const float dfn = (float)dn;
         int dix, diy, diz;
@@ -426,8 +429,13 @@ CSKY_HD float sample_density_eager(const TexSet& T, const FrameConsts& fc, float
     float base = (nr + omf) * fast_rcp(1.0f + omf);                         // :122
     base = base * g - omw;                                                   // :124-125 (see density())
     if (!(base > 0.0f)) return 0.0f;                                        // exact reject (2)
-    float hfbm = lod_detail == 5 ? T.detail_lod5
-                                 : fmaf(daz, fmaf(day, lerp_h(dq.w, dax), lerp_h(dq.z, dax)), fmaf(day, lerp_h(dq.y, dax), lerp_h(dq.x, dax))) * (1.0f / (8.0f * 255.0f));
+    float hfbm;
+    if (EAGER_DETAIL) {
+        hfbm = lod_detail == 5 ? T.detail_lod5
+                               : fmaf(daz, fmaf(day, lerp_h(dq.w, dax), lerp_h(dq.z, dax)), fmaf(day, lerp_h(dq.y, dax), lerp_h(dq.x, dax))) * (1.0f / (8.0f * 255.0f));
+    } else {
+        hfbm = detail_tap(T, lod_detail, dsx, dsy, dsz);                    // :132-133, fetched now
+    }
     const float k = sat(hf * 4.0f);
     hfbm = hfbm + k * (1.0f - 2.0f * hfbm);                                 // :134
     const float hm = hfbm * 0.4f * hf;
@@ -435,6 +443,7 @@ CSKY_HD float sample_density_eager(const TexSet& T, const FrameConsts& fc, float
     return fast_pow(sat(base), (1.0f - hf) * 0.8f + 0.5f);                  // :136
 }
 #else
+template <bool EAGER_DETAIL = true>
 CSKY_HD float sample_density_eager(const TexSet& T, const FrameConsts& fc, float px, float py, float pz, float hf, float wx, float wy,
                                    int lod_shape, int lod_detail) {
     return sample_density(T, fc, px, py, pz, hf, wx, wy, lod_shape, lod_detail);

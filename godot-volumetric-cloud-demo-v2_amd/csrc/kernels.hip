@@ -261,9 +261,20 @@ constexpr int CQ_FLOATS = 5 * CQ_CAP + 64 + 3 * CQ_STEPS;    // pos(3) t hf | cd
 #define CSKY_EAGER_LIGHT 1
 #endif
 #if CSKY_EAGER_LIGHT
-#define CSKY_LIGHT_SAMPLE sample_density_eager
+#define CSKY_LIGHT_SAMPLE sample_density_eager<true>
 #else
 #define CSKY_LIGHT_SAMPLE sample_density
+#endif
+#ifndef CSKY_EAGER_PRIMARY
+#define CSKY_EAGER_PRIMARY 0   // eager fetches in the PRIMARY march measured slower (1: weather + shape together +1 %, 2: all three +4.5 %): only
+                               // 56 % / 22 % of its samples need the shape / detail cell, the extra gathers cost more than the latency they hide
+#endif
+#if CSKY_EAGER_PRIMARY == 1
+#define CSKY_PRIMARY_SAMPLE sample_density_eager<false>
+#elif CSKY_EAGER_PRIMARY == 2
+#define CSKY_PRIMARY_SAMPLE sample_density_eager<true>
+#else
+#define CSKY_PRIMARY_SAMPLE sample_density
 #endif
 __device__ __forceinline__ MarchOut march_compact(const TexSet& T, const FrameConsts& fc, Ray ray, float* __restrict__ q, int step_begin, int step_end) {
     float* __restrict__ ev_px = q;
@@ -298,7 +309,7 @@ __device__ __forceinline__ MarchOut march_compact(const TexSet& T, const FrameCo
             if (live) {
                 advance(px, py, pz, ray.sx, ray.sy, ray.sz);                                                   // :173
                 hf = height_fraction(length3_exact(px, py, pz));                                               // :175
-                t = sample_density(T, fc, px, py, pz, hf, fc.wpos_x, fc.wpos_y, 0, 0);                         // :174, :177
+                t = CSKY_PRIMARY_SAMPLE(T, fc, px, py, pz, hf, fc.wpos_x, fc.wpos_y, 0, 0);                    // :174, :177
             }
             const bool have = t > 0.0f;                                                                        // :184
             const unsigned long long m = __ballot(have);

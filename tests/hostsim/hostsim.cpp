@@ -116,7 +116,8 @@ void hostsim_density_forms(const uint8_t* large_chain, const uint8_t* small_chai
         const float x = pos[3 * i], y = pos[3 * i + 1], z = pos[3 * i + 2];
         const float hf = height_fraction(length3_exact(x, y, z));
         out[2 * i] = sample_density(T, fc, x, y, z, hf, fc.wpos_x, fc.wpos_y, lods[2 * i], lods[2 * i + 1]);
-        out[2 * i + 1] = sample_density_eager(T, fc, x, y, z, hf, fc.wpos_x, fc.wpos_y, lods[2 * i], lods[2 * i + 1]);
+        out[2 * i + 1] = (i & 1) ? sample_density_eager<true>(T, fc, x, y, z, hf, fc.wpos_x, fc.wpos_y, lods[2 * i], lods[2 * i + 1])
+                                 : sample_density_eager<false>(T, fc, x, y, z, hf, fc.wpos_x, fc.wpos_y, lods[2 * i], lods[2 * i + 1]);
     }
 }
 
