@@ -223,13 +223,20 @@ CSKY_HD void split_coord(float u, int& i, float& f) {
 }
 
 // REPEAT + LINEAR bilinear tap of the quad-packed weather map (clouds.glsl:174).  Returns r (cloud type), b (coverage).
-CSKY_HD void weather_tap(const uint4* __restrict__ w, float sx, float sy, float& wr, float& wb) {
-    int ix, iy; float ax, ay;
+CSKY_HD void weather_fetch(const uint4* __restrict__ w, float sx, float sy, uint4& q, float& ax, float& ay) {
+    int ix, iy;
     split_coord(sx * 512.0f - 0.5f, ix, ax); split_coord(sy * 512.0f - 0.5f, iy, ay);
     const int x0 = ix & 511, y0 = iy & 511;
-    const uint4 q = *reinterpret_cast<const uint4*>(reinterpret_cast<const char*>(w) + ((((uint32_t)y0 << 9) | (uint32_t)x0) << 4));
+    q = *reinterpret_cast<const uint4*>(reinterpret_cast<const char*>(w) + ((((uint32_t)y0 << 9) | (uint32_t)x0) << 4));
+}
+CSKY_HD void weather_filter(const uint4& q, float ax, float ay, float& wr, float& wb) {
     wr = fmaf(ay, lerp_h(q.y, ax), lerp_h(q.x, ax)) * (1.0f / 255.0f);      // polynomial cell: (c0 + c1 fx) + fy (c2 + c3 fx)
     wb = fmaf(ay, lerp_h(q.w, ax), lerp_h(q.z, ax)) * (1.0f / 255.0f);
+}
+CSKY_HD void weather_tap(const uint4* __restrict__ w, float sx, float sy, float& wr, float& wb) {
+    uint4 q; float ax, ay;
+    weather_fetch(w, sx, sy, q, ax, ay);
+    weather_filter(q, ax, ay, wr, wb);
 }
 
 // texel offset of mip level l inside the packed chains: sum_{i<l} (N>>i)^3 = (N^3*8 - (N>>l)^3*8) / 7, computed
