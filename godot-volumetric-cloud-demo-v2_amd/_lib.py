@@ -58,6 +58,7 @@ SYMBOLS = [
     ("csky_render_clouds", C.c_int, [C.c_void_p, C.POINTER(CloudParams), C.c_int, C.c_int, C.c_void_p, C.c_size_t]),
     ("csky_render_sky_lut_device", C.c_int, [C.c_void_p, C.POINTER(SkyParams), C.c_void_p]),
     ("csky_render_clouds_device", C.c_int, [C.c_void_p, C.POINTER(CloudParams), C.c_int, C.POINTER(Bands), C.c_void_p, C.c_size_t, C.c_void_p]),
+    ("csky_copy_sky_lut_device", C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
     ("csky_sync", C.c_int, [C.c_void_p]),
     ("csky_read_transmittance", C.c_int, [C.c_void_p, C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     ("csky_read_sky_lut", C.c_int, [C.c_void_p, C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
@@ -73,6 +74,17 @@ SYMBOLS = [
     ("csky_set_height_window", C.c_int, [C.c_void_p, C.c_int]),
     ("csky_set_segments", C.c_int, [C.c_void_p, C.c_int]),
     ("csky_variant_name", C.c_char_p, [C.c_int]),
+    ("csky_multi_create", C.c_int, [C.POINTER(C.c_void_p), C.POINTER(C.c_int), C.c_int]),
+    ("csky_multi_destroy", None, [C.c_void_p]),
+    ("csky_multi_device_count", C.c_int, [C.c_void_p]),
+    ("csky_multi_ctx", C.c_void_p, [C.c_void_p, C.c_int]),
+    ("csky_multi_last_error", C.c_char_p, [C.c_void_p]),
+    ("csky_multi_set_noise", C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    ("csky_multi_set_march", C.c_int, [C.c_void_p, C.c_int, C.c_int]),
+    ("csky_multi_render_sky_lut", C.c_int, [C.c_void_p, C.POINTER(SkyParams)]),
+    ("csky_multi_render_clouds_device", C.c_int, [C.c_void_p, C.POINTER(CloudParams), C.c_int, C.c_int, C.c_void_p, C.c_size_t, C.c_void_p]),
+    ("csky_multi_render_clouds", C.c_int, [C.c_void_p, C.POINTER(CloudParams), C.c_int, C.c_int, C.c_void_p, C.c_size_t]),
+    ("csky_multi_sync", C.c_int, [C.c_void_p]),
     ("csky_load_bmp_rgb8", C.c_int, [C.c_char_p, C.POINTER(C.c_int), C.POINTER(C.c_int), C.c_void_p, C.c_size_t]),
     ("csky_load_tga_rgba8", C.c_int, [C.c_char_p, C.POINTER(C.c_int), C.POINTER(C.c_int), C.c_void_p, C.c_size_t]),
     ("csky_strip_to_volume", C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
@@ -85,6 +97,7 @@ SYMBOLS = [
 
 
 DEFAULT_VARIANT = 3   # include/cloudsky.h CSKY_DEFAULT_VARIANT ("compact"); set_variant(-1) selects it
+ABI_VERSION = 2       # include/cloudsky.h CSKY_ABI_VERSION
 
 
 def library_path():
@@ -132,8 +145,13 @@ def cloud_params(values):
 class Context:
     """One csky_ctx = one GPU.  Thin, explicit wrapper; raises CloudSkyError on any non-zero return."""
 
-    def __init__(self, device_id=0):
+    def __init__(self, device_id=0, _borrowed=None):
         self._L = lib()
+        self._owned = _borrowed is None
+        if _borrowed is not None:                 # a context owned by a MultiContext (csky_multi_ctx): never destroyed from here
+            self._h = C.c_void_p(_borrowed)
+            self.device_id = int(device_id)
+            return
         h = C.c_void_p()
         rc = self._L.csky_create(C.byref(h), int(device_id))
         if rc != OK:
@@ -147,7 +165,8 @@ class Context:
 
     def close(self):
         if getattr(self, "_h", None):
-            self._L.csky_destroy(self._h)
+            if self._owned:
+                self._L.csky_destroy(self._h)
             self._h = None
 
     __del__ = close
@@ -160,6 +179,10 @@ class Context:
         if a.size != 128 ** 3 * 4 or b.size != 32 ** 3 * 3 or c.size != 512 * 512 * 3:
             raise ValueError("set_noise: expected 128^3 RGBA8, 32^3 RGB8, 512^2 RGB8")
         self._chk(self._L.csky_set_noise(self._h, _ptr(a), _ptr(b), _ptr(c)))
+        n = self.noise_inexact_coeffs()
+        if n:   # never silent.  The taps stay within the parity tolerance (test_white_noise_textures) but are no longer exact
+            import warnings
+            warnings.warn((self._L.csky_last_error(self._h) or b"").decode() or "csky_set_noise: %d inexact fp16 coefficients" % n, RuntimeWarning)
 
     def noise_inexact_coeffs(self):
         """Finite-difference coefficients of the bound textures that fp16 could not hold exactly (0 for natural noise)."""
@@ -222,6 +245,10 @@ class Context:
         self._chk(self._L.csky_render_clouds_device(self._h, C.byref(p), int(tile_w), C.byref(b), C.c_void_p(int(d_out)), int(pitch_bytes),
                                                     C.c_void_p(stream or 0)))
 
+    def copy_sky_lut_device(self, d_out, stream=None):
+        """Async device copy of the sky LUT rendered last (w*h*8 bytes of RGBA16F) into a caller-owned device buffer."""
+        self._chk(self._L.csky_copy_sky_lut_device(self._h, C.c_void_p(int(d_out)), C.c_void_p(stream or 0)))
+
     def sync(self):
         self._chk(self._L.csky_sync(self._h))
 
@@ -280,3 +307,70 @@ class Context:
         st = CloudStats()
         self._chk(self._L.csky_get_cloud_stats(self._h, C.byref(st)))
         return dict(rays=st.rays, primary_samples=st.primary_samples, incloud_samples=st.incloud_samples)
+
+
+class MultiContext:
+    """csky_multi: the GPUs of one node behind one handle, one host thread (include/cloudsky.h).  Device i of n renders the
+    8-row bands i, i+n, ... and stores them straight into the frame on the first device (xGMI peer access)."""
+
+    def __init__(self, device_ids):
+        self._L = lib()
+        ids = (C.c_int * len(device_ids))(*[int(d) for d in device_ids])
+        h = C.c_void_p()
+        rc = self._L.csky_multi_create(C.byref(h), ids, len(device_ids))
+        if rc != OK:
+            raise CloudSkyError(rc, (self._L.csky_multi_last_error(None) or b"").decode())
+        self._h = h
+        self.device_ids = [int(d) for d in device_ids]
+
+    def _chk(self, rc):
+        if rc != OK:
+            raise CloudSkyError(rc, (self._L.csky_multi_last_error(self._h) or b"").decode())
+
+    def __len__(self):
+        return self._L.csky_multi_device_count(self._h)
+
+    def ctx(self, i):
+        """The per-device context (borrowed: per-context settings such as set_variant / set_schedule go through it)."""
+        p = self._L.csky_multi_ctx(self._h, int(i))
+        if not p:
+            raise IndexError(i)
+        return Context(self.device_ids[i], _borrowed=p)
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._L.csky_multi_destroy(self._h)
+            self._h = None
+
+    __del__ = close
+
+    def set_noise(self, large_rgba8, small_rgb8, weather_rgb8):
+        a, b, c = (np.ascontiguousarray(x, np.uint8) for x in (large_rgba8, small_rgb8, weather_rgb8))
+        if a.size != 128 ** 3 * 4 or b.size != 32 ** 3 * 3 or c.size != 512 * 512 * 3:
+            raise ValueError("set_noise: expected 128^3 RGBA8, 32^3 RGB8, 512^2 RGB8")
+        self._chk(self._L.csky_multi_set_noise(self._h, _ptr(a), _ptr(b), _ptr(c)))
+
+    def set_march(self, primary_steps=128, light_steps=6):
+        self._chk(self._L.csky_multi_set_march(self._h, primary_steps, light_steps))
+
+    def render_sky_lut(self, sun_dir, w=200, h=100):
+        p = SkyParams()
+        p.f[0], p.f[1] = float(w), float(h)
+        p.f[4], p.f[5], p.f[6] = [float(x) for x in sun_dir]
+        self._chk(self._L.csky_multi_render_sky_lut(self._h, C.byref(p)))
+
+    def render_clouds(self, params, tile_w=None, tile_h=None):
+        p = cloud_params(params)
+        w = int(p.f[0]) if tile_w is None else int(tile_w)
+        h = int(p.f[1]) if tile_h is None else int(tile_h)
+        out = np.zeros((h, w, 4), np.uint16)
+        self._chk(self._L.csky_multi_render_clouds(self._h, C.byref(p), w, h, _ptr(out), w * 8))
+        return out.view(np.float16)
+
+    def render_clouds_device(self, params, tile_w, tile_h, d_out, pitch_bytes, stream=None):
+        p = cloud_params(params)
+        self._chk(self._L.csky_multi_render_clouds_device(self._h, C.byref(p), int(tile_w), int(tile_h), C.c_void_p(int(d_out)), int(pitch_bytes),
+                                                          C.c_void_p(stream or 0)))
+
+    def sync(self):
+        self._chk(self._L.csky_multi_sync(self._h))

@@ -96,14 +96,18 @@ class CloudSky:
         self.blend_amount = 0.0
         self.can_run = False
         self.needs_full_sky_init = True
-        self.clock = clock if clock is not None else (lambda: _time.monotonic())
+        if clock is None:           # Time.get_ticks_msec() counts from engine start (cloud_sky.gd:176): seconds since construction, so the
+            t0 = _time.monotonic()  # first delta is ~0 like the reference's and wind offsets stay in fp32's accurate range
+            clock = lambda: _time.monotonic() - t0  # noqa: E731
+        self.clock = clock
         self.device_buffers = bool(device_buffers)
         self.rank, self.world_size, self.dist = int(rank), int(world_size), dist
         self.last_frame = None
+        self._side_stream = None
         # render-thread side (cloud_sky.gd:218-232): the C-ABI context owns every device resource
         self.ctx = ctx if ctx is not None else Context(device_id)
         self.transmittance_tex = TransmittanceLut(self.ctx)                    # cloud_sky.gd:92
-        self.sky_lut = SkyLut(self.ctx, self.transmittance_tex)                # cloud_sky.gd:91
+        self.sky_lut = SkyLut(self.ctx, self.transmittance_tex, device_buffers=self.device_buffers)   # cloud_sky.gd:91
         large, small, weather = noise if noise is not None else _assets.load_default_noise()
         self.ctx.set_noise(large, small, weather)                              # _create_noise_uniform_set, :298-341
         self.update_performance()
@@ -208,7 +212,9 @@ class CloudSky:
         fd._detailed_pos = fd._detailed_pos + delta * wdn
         fd._cloud_pos = fd._cloud_pos + delta * wdn * fd.wind_speed
         fd._weather_pos = fd._weather_pos + delta2 * wdn * fd.wind_speed
-        self.sky_lut.update_lut(fd.LIGHT_DIRECTION, self._stream())
+        stream, done = self._march_stream()
+        self.sky_lut.update_lut(fd.LIGHT_DIRECTION, stream)
+        done()
 
     def cleanup(self):  # cloud_sky.gd:197-212
         self.can_run = False
@@ -227,18 +233,27 @@ class CloudSky:
         def host(t):
             return t.cpu().numpy() if hasattr(t, "cpu") else t
         bf, bt = host(self.textures[self.texture_to_blend_from]), host(self.textures[self.texture_to_blend_to])
-        sky = self.sky_lut.image
-        back = self.sky_lut.back_texture
-        sf = back[0] if back[0] is not None else sky          # sky_blend_from/to_texture (cloud_sky.gd:147-148)
-        st = back[1] if back[1] is not None else sky
+        sf, st = (host(t) for t in self.sky_lut.back_texture)   # sky_blend_from/to_texture = the two OLDER ring copies (cloud_sky.gd:147-148)
         return self.ctx.composite_sky(bf, bt, sf, st, self.frame_data.LIGHT_DIRECTION, self.blend_amount, self.sun_disk_scale, out_w, out_h)
 
     # ---- render thread ------------------------------------------------------------------------------------
-    def _stream(self):
+    def _march_stream(self):
+        """(hip stream handle, done()) for one batch of library calls in device-buffer mode.  The work is enqueued on torch's CURRENT
+        stream so that torch work before it (tensor creation / fills) and after it (copies, .cpu(), collectives) is ordered around it
+        without a device-wide synchronise.  torch's default stream is the HIP null stream, whose handle is 0 = "use the context's own
+        non-blocking stream" to the library, which the null stream does NOT order against: in that case the batch runs
+        on a private side stream that waits for the default stream first, and done() makes the default stream wait for it."""
         if not self.device_buffers:
-            return None
+            return None, (lambda: None)
         import torch
-        return torch.cuda.current_stream().cuda_stream
+        cur = torch.cuda.current_stream()
+        if cur.cuda_stream != 0:
+            return cur.cuda_stream, (lambda: None)
+        if self._side_stream is None:
+            self._side_stream = torch.cuda.Stream(device=torch.device("cuda", self.ctx.device_id))
+        side = self._side_stream
+        side.wait_stream(cur)
+        return side.cuda_stream, (lambda: cur.wait_stream(side))
 
     def _fill_push_constant(self):  # cloud_sky.gd:251-289, same order incl. padding
         fd = self.frame_data
@@ -281,18 +296,21 @@ class CloudSky:
             self.last_frame = tex
             return tex
         import torch
-        stream = self._stream()
         if self._frames_to_update == 1:
             # full hemisphere per call, sharded over the ranks of one node
             def render_bands(bands, out):
+                stream, done = self._march_stream()                             # after `out` was created / cleared on torch's stream
                 self.ctx.render_clouds_device(pc, W, bands, out.data_ptr(), W * 8, stream)
+                done()                                                          # the gather / interleave that follow run on torch's stream
             frame = _tiling.render_sharded(render_bands, H, W, self.rank, self.world_size, self.dist, tex.device)
             if frame is not None:
                 self.textures[p_texture_to_update] = frame.view(torch.float16)
                 self.last_frame = self.textures[p_texture_to_update]
             return self.last_frame if self.rank == 0 else None
         region = torch.empty((rh, rw, 4), dtype=torch.float16, device=tex.device)
+        stream, done = self._march_stream()
         self.ctx.render_clouds_device(pc, rw, (rh, 0, 1, 1), region.data_ptr(), rw * 8, stream)
+        done()
         tex[y0:y0 + rh, x0:x0 + rw] = region
         self.last_frame = tex
         return tex

@@ -5,6 +5,7 @@
 #include <hip/hip_runtime_api.h>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <new>
 #include <algorithm>
@@ -22,7 +23,7 @@ static_assert(sizeof(csky_cloud_params) == sizeof(CloudParams), "ABI struct mism
 struct csky_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
-    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr, ev_copy = nullptr;
     // noise set (cloud_sky.gd:298-341)
     ShapeTexel* d_shape = nullptr; unsigned long long inexact_coeffs = 0; uint4* d_detail = nullptr; uint4* d_weather = nullptr; uint16_t* d_detail_h = nullptr; bool have_noise = false;
     uint32_t shape_off[SHAPE_LEVELS] = {}, detail_off[DETAIL_LEVELS] = {};
@@ -50,15 +51,18 @@ struct csky_ctx {
     int sched_mode = -1;                              // -1 = auto (5 for large launches, 2 for small ones)
     int segments = 0;                                 // ray segments per ray: 0 = auto, 1, 2, 4
     int frames_in_flight = 1;                         // policy hint (csky_set_frames_in_flight): the caller alternates two streams
-    // workgroup schedule (physical workgroup -> slab), cached per render geometry
-    uint32_t* d_order = nullptr; size_t order_cap = 0; int order_grid = 0;
+    // static workgroup order (physical workgroup -> slab), written on the device, one table per ring slot (= frame parity, so two
+    // frames in flight with different geometries never share one), cached per launch geometry
+    uint32_t* d_order_ring[2] = {nullptr, nullptr}; size_t order_cap[2] = {0, 0}; int order_grid_ring[2] = {0, 0};
+    long long order_key_ring[2][6] = {{-1, -1, -1, -1, -1, -1}, {-1, -1, -1, -1, -1, -1}};
+    float tail_beta = 0.65f;                          // deadline schedule (mode 8): how far forward the heaviest workgroup is pulled
+    float tail_f4 = 0.10f, tail_f2 = 0.10f;           // mixed-segment launch (mode 9): share of the order's end run as 4- / 2-segment workgroups
     // cost-feedback schedule (mode 7): per-workgroup costs of the last launch -> heaviest-first order of the next one
     uint32_t* d_wg_cost = nullptr; uint32_t* d_lpt_order = nullptr; uint32_t* d_lpt_hist = nullptr; size_t lpt_cap = 0;
     bool lpt_valid[2] = {false, false}; long long lpt_key[2][11] = {{-1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1}, {-1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1}};
-    std::vector<uint32_t> h_order; long long order_key[11] = {-1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1};
     // optional per-launch timing of the cloud kernel (csky_set_kernel_timing): HIP event pairs recorded around the launch on ITS stream
-    static constexpr int KT_PAIRS = 256;
-    bool kt_on = false; std::vector<hipEvent_t> kt_ev; int kt_count = 0;
+    bool kt_on = false; std::vector<hipEvent_t> kt_ev; int kt_count = 0;   // the event pool grows on demand (clouds_dev)
+    uint8_t* d_composite = nullptr; size_t composite_cap = 0;              // grow-only scratch of csky_composite_sky
     csky_cloud_stats last_stats = {0, 0, 0};
     char err[512] = {0};
 };
@@ -126,96 +130,37 @@ int check_bands(csky_ctx* c, const csky_bands* b, int tile_w) {
     return CSKY_OK;
 }
 
-// Workgroup schedule.  A slab = one 32 x 8 pixel workgroup footprint (4 wavefront tiles); physical workgroup b runs on
-// XCD b % 8 (observed placement, used for speed only).  Modes (measured on the headline frame, queue kernel):
-//   5 (default) slab ROWS dealt round-robin to the XCDs, each XCD walks its rows left to right: every XCD sees the same
-//               mix of elevations (balanced) and concurrently running workgroups are neighbours (shared L1/L2 lines)  3.93 ms
-//   1 contiguous eighths of the frame per XCD (unbalanced: the zenith eighths finish early)                        4.80 ms
-//   2 natural order                                                                                                  4.92 ms
-//   0/3/4 45-degree azimuth wedges per XCD ordered by elevation (horizon first / zenith first / alternating): balanced
-//               but consecutive workgroups are not neighbours                                                   5.3-5.8 ms
-//   6 = 5 with the rows farthest from the zenith row first                                                          4.77 ms
-int build_schedule(csky_ctx* c, const CloudParams& p, const RenderGeom& g, int seg, int mode, hipStream_t s) {
-    const int bw = seg == 5 ? 8 : (seg == 16 ? 128 : 32 / seg);   // seg 16 = the 16-wavefront "lds" variant: a 128 x 8 pixel strip           // workgroup footprint = bw x 8 pixels (seg 5 = 4 interleaved segments: one tile)
-    const int tiles_x = (g.tile_w + bw - 1) / bw, local_rows = g.n_bands * g.band_rows, slabs = (local_rows + 7) >> 3;
+// Static workgroup order for ring slot `slot` (kernels.hip::static_order_kernel; modes 1, 2, 5).  Measured on the headline frame
+// (queue kernel, round 1): 5 (slab rows round-robin over the XCDs) 3.93 ms, 1 (contiguous eighths) 4.80 ms, 2 (natural) 4.92 ms;
+// azimuth-wedge and horizon-first orders (5.3-5.8 / 4.77 ms) were dropped in round 2.  The table depends on the launch geometry
+// only (not on update_position: the reference's tile walk re-uses it) and is written by a kernel on the launch's stream.
+int ensure_order(csky_ctx* c, int slot, int mode, int tile_w, int tiles_x, int slabs, int t2, int t4, hipStream_t s) {
     const int nblocks = tiles_x * slabs;
-    // modes 1, 2, 5 depend on the launch geometry only; the wedge modes and mode 6 also on where the tile sits in the texture (the
-    // reference's tile walk moves update_position every frame: the table must not be rebuilt for that)
-    const bool positional = !(mode == 1 || mode == 2 || mode == 5);
-    const long long key[11] = {g.tile_w, g.band_rows, g.first_band, g.band_stride, g.n_bands, positional ? (long long)p.texture_size[0] : 0,
-                               positional ? (long long)p.texture_size[1] : 0, positional ? (long long)p.update_position[0] : 0,
-                               positional ? (long long)p.update_position[1] : 0, mode, seg};
-    if (c->d_order && memcmp(key, c->order_key, sizeof key) == 0) return CSKY_OK;
-    std::vector<uint32_t>& ord = c->h_order;
-    if (mode == 2) {
-        ord.resize(nblocks);
-        for (int i = 0; i < nblocks; i++) ord[i] = (uint32_t)i;
-    } else if (mode == 1) {
-        const int per = (nblocks + 7) >> 3;
-        ord.assign((size_t)per * 8, 0xffffffffu);
-        for (int b = 0; b < per * 8; b++) { const int l = (b & 7) * per + (b >> 3); if (l < nblocks) ord[b] = (uint32_t)l; }
-    } else if (mode == 5 || mode == 6) {
-        // slab rows dealt round-robin to the XCDs (every XCD sees the same mix of elevations); each XCD walks its rows
-        // left to right, so concurrently running workgroups are neighbours.  mode 6 additionally starts with the rows
-        // farthest from the zenith row (longest marches first).
-        std::vector<int> rows(slabs);
-        for (int i = 0; i < slabs; i++) rows[i] = i;
-        if (mode == 6) {
-            auto elev = [&](int slab) {
-                const int lr = slab * 8 + 4, band = lr / g.band_rows, rib = lr - band * g.band_rows;
-                const float gy = (float)((g.first_band + band * g.band_stride) * g.band_rows + rib) + p.update_position[1];
-                return std::fabs(gy / p.texture_size[1] - 0.5f);
-            };
-            std::stable_sort(rows.begin(), rows.end(), [&](int a, int b) { return elev(a) > elev(b); });
-        }
-        const int rows_per = (slabs + 7) >> 3;
-        ord.assign((size_t)rows_per * tiles_x * 8, 0xffffffffu);
-        for (int i = 0; i < slabs; i++) {
-            const int x = i & 7, k = i >> 3;
-            for (int bx = 0; bx < tiles_x; bx++) ord[((size_t)k * tiles_x + bx) * 8 + x] = (uint32_t)(rows[i] * tiles_x + bx);
-        }
-    } else {
-        std::vector<std::pair<float, uint32_t>> wedge[8];
-        for (int slab = 0; slab < slabs; slab++) for (int bx = 0; bx < tiles_x; bx++) {
-            const int lr = slab * 8 + 4, band = lr / g.band_rows, rib = lr - band * g.band_rows;
-            const float gy = (float)((g.first_band + band * g.band_stride) * g.band_rows + rib) + p.update_position[1];
-            const float gx = (float)(bx * bw + bw / 2) + p.update_position[0];
-            const float u = gx / p.texture_size[0], v = gy / p.texture_size[1];
-            const float nx = u - v, ny = (u + v) - 1.0f, nz = 1.0f - std::fabs(nx) - std::fabs(ny);
-            int w = (int)std::floor((std::atan2(ny, nx) + 3.14159265f) * (4.0f / 3.14159265f));
-            w = w < 0 ? 0 : (w > 7 ? 7 : w);
-            wedge[w].push_back({nz, (uint32_t)(slab * tiles_x + bx)});
-        }
-        size_t longest = 0;
-        for (auto& w : wedge) { std::stable_sort(w.begin(), w.end(), [](const std::pair<float, uint32_t>& a, const std::pair<float, uint32_t>& b) { return a.first < b.first; }); longest = std::max(longest, w.size()); }
-        ord.assign(longest * 8, 0xffffffffu);
-        for (int x = 0; x < 8; x++) {
-            std::vector<std::pair<float, uint32_t>>& w = wedge[x];
-            const size_t n = w.size();
-            for (size_t i = 0; i < n; i++) {
-                size_t src = i;                                            // mode 0: horizon first
-                if (mode == 3) src = n - 1 - i;                   // mode 3: zenith first
-                if (mode == 4) src = (i & 1) ? n - 1 - i / 2 : i / 2;   // mode 4: alternate horizon / zenith
-                ord[i * 8 + x] = w[src].second;
-            }
-        }
+    int grid;
+    if (mode == 2) grid = nblocks;
+    else if (mode == 1) grid = ((nblocks + 7) >> 3) * 8;
+    else if (mode == 9) grid = mixed_order_grid(tiles_x, slabs, t2, t4);     // tiles_x = 32-pixel slabs per row here
+    else grid = ((slabs + 7) >> 3) * tiles_x * 8;
+    const long long key[6] = {tile_w, tiles_x, slabs, mode, t2, t4};
+    if (c->d_order_ring[slot] && memcmp(key, c->order_key_ring[slot], sizeof key) == 0) return CSKY_OK;
+    if (c->order_cap[slot] < (size_t)grid) {
+        HIPCHK(c, hipDeviceSynchronize());                   // growing the table is rare; an older launch may still read the old one
+        if (c->d_order_ring[slot]) { (void)hipFree(c->d_order_ring[slot]); c->d_order_ring[slot] = nullptr; c->order_cap[slot] = 0; }
+        HIPCHK(c, hipMalloc(reinterpret_cast<void**>(&c->d_order_ring[slot]), (size_t)grid * sizeof(uint32_t)));
+        c->order_cap[slot] = (size_t)grid;
     }
-    HIPCHK(c, hipDeviceSynchronize());   // the table is rebuilt only when the geometry changes; frames on other streams may still read the old one
-    if (c->order_cap < ord.size()) {
-        if (c->d_order) { (void)hipFree(c->d_order); c->d_order = nullptr; }
-        HIPCHK(c, hipMalloc(reinterpret_cast<void**>(&c->d_order), ord.size() * sizeof(uint32_t)));
-        c->order_cap = ord.size();
-    }
-    HIPCHK(c, hipMemcpyAsync(c->d_order, ord.data(), ord.size() * sizeof(uint32_t), hipMemcpyHostToDevice, s));
-    HIPCHK(c, hipStreamSynchronize(s));   // h_order is pageable; the table is rebuilt only when the geometry changes
-    c->order_grid = (int)ord.size();
-    memcpy(c->order_key, key, sizeof key);
+    // the last reader of this slot's table is the march of two frames ago; the caller has already ordered `s` behind it (ev_clouds -> pro ->
+    // ev_setup -> s), exactly like the frame constants of the slot
+    if (mode == 9) HIPCHK(c, launch_mixed_order(tile_w, slabs, t2, t4, c->d_order_ring[slot], s));
+    else HIPCHK(c, launch_static_order(mode, tiles_x, slabs, grid, c->d_order_ring[slot], s));
+    c->order_grid_ring[slot] = grid;
+    memcpy(c->order_key_ring[slot], key, sizeof key);
     return CSKY_OK;
 }
 
 // frame_setup + clouds on stream s into d_out (compact rows).  stats: optional device counters.
 int clouds_dev(csky_ctx* c, const csky_cloud_params* p, int tile_w, const csky_bands* b, uint2* d_out, size_t pitch_bytes, hipStream_t s,
-               unsigned long long* d_stats, bool setup) {
+               unsigned long long* d_stats, bool setup, bool out_full = false) {
     if (!p) return fail(c, CSKY_ERR_INVALID, "render_clouds: params is NULL");
     if (!c->have_noise) return fail(c, CSKY_ERR_STATE, "render_clouds: csky_set_noise has not been called");
     if (!c->have_sky) return fail(c, CSKY_ERR_STATE, "render_clouds: no sky LUT yet (call csky_render_sky_lut first; cloud_sky.gd:187,242)");
@@ -241,7 +186,7 @@ int clouds_dev(csky_ctx* c, const csky_cloud_params* p, int tile_w, const csky_b
         HIPCHK(c, hipStreamWaitEvent(s, c->ev_setup[f], 0));
     }
     RenderGeom g; g.tile_w = tile_w; g.band_rows = b->band_rows; g.first_band = b->first_band; g.band_stride = b->band_stride; g.n_bands = b->n_bands;
-    g.pitch_px = (uint32_t)(pitch_bytes / 8);
+    g.pitch_px = (uint32_t)(pitch_bytes / 8); g.out_full = out_full ? 1 : 0;
     // Launch-size policy: ray segments (more, shorter wavefronts) when the launch is too small to fill the chip with whole-ray
     // wavefronts, and the cost-feedback order (mode 7) when it is only a few resident workgroups deep.  Measured with
     // tools/crossover.py, "compact" variant, kernel ms at 256 / 1024 / 4096 / 8192 / 16384 / 32768 tiles of 8x8 rays
@@ -272,51 +217,81 @@ int clouds_dev(csky_ctx* c, const csky_cloud_params* p, int tile_w, const csky_b
         auto_mode = waves >= 6144 ? 5 : 2;
     }
     if (c->variant == 2) seg = 16;
-    const int mode = c->sched_mode >= 0 ? c->sched_mode : auto_mode;
-    const int static_mode = mode == 7 ? (waves >= 12288 ? 5 : 2) : mode;     // order of the first launch of a geometry under mode 7
-    const bool feedback = mode == 7 && queued && seg != 5;       // kernels that record per-workgroup costs
+    int mode = c->sched_mode >= 0 ? c->sched_mode : auto_mode;
+    const int bw = seg == 5 ? 8 : (seg == 16 ? 128 : 32 / seg);   // workgroup footprint = bw x 8 pixels (seg 5: one tile; seg 16: the 16-wavefront "lds" strip)
+    const int tiles_x = (g.tile_w + bw - 1) / bw, slabs = (g.n_bands * g.band_rows + 7) >> 3, nblocks = tiles_x * slabs;
+    if (mode == 9 && !(c->variant == 3 && seg == 1)) mode = 5;   // the mixed-segment kernel is the "compact" march on whole-ray footprints
+    bool feedback = (mode == 7 || mode == 8) && queued && seg != 5;       // kernels that record per-workgroup costs
+    if (mode == 8 && (!feedback || ((slabs + 7) >> 3) * tiles_x * 8 > deadline_order_max_grid())) { mode = 5; feedback = false; }
+    if (mode == 7 && !feedback) mode = waves >= 12288 ? 5 : 2;
+    const int static_mode = mode == 8 ? 5 : (mode == 7 ? (waves >= 12288 ? 5 : 2) : mode);   // order of the first launch of a geometry under feedback
+    const int slot = c->fc_cur;
     hipEvent_t* kt = nullptr;                                    // timing pair of this launch (csky_set_kernel_timing)
-    if (c->kt_on) { kt = &c->kt_ev[(size_t)(c->kt_count % csky_ctx::KT_PAIRS) * 2]; c->kt_count++; }
-    if ((rc = build_schedule(c, cp, g, seg, static_mode, s))) return rc;
-    if (!feedback) {
+    if (c->kt_on) {
+        if ((size_t)c->kt_count * 2 + 2 > c->kt_ev.size()) {    // the pool grows on demand: no launch is ever dropped from the sum
+            const size_t old_n = c->kt_ev.size();
+            c->kt_ev.resize(old_n ? old_n * 2 : 512, nullptr);
+            for (size_t i = old_n; i < c->kt_ev.size(); i++) HIPCHK(c, hipEventCreate(&c->kt_ev[i]));
+        }
+        kt = &c->kt_ev[(size_t)c->kt_count * 2]; c->kt_count++;
+    }
+    if (mode == 9) {
+        // the order's last stretch as 4-, the stretch before it as 2-segment workgroups (kernels.hip::clouds_kernel_mixed)
+        const int n = ((slabs + 7) >> 3) * tiles_x;                       // slab positions per XCD
+        const int t4 = (int)(c->tail_f4 * (float)n + 0.5f), t2 = std::min(n - t4, (int)(c->tail_f2 * (float)n + 0.5f));
+        if ((rc = ensure_order(c, slot, 9, g.tile_w, tiles_x, slabs, t2, t4, s))) return rc;
         if (kt) HIPCHK(c, hipEventRecord(kt[0], s));
-        HIPCHK(c, launch_clouds(c->variant, seg, texset(c), c->d_fc, g, c->d_order, c->order_grid, d_out, d_stats, nullptr, s));
+        HIPCHK(c, launch_clouds_mixed(texset(c), c->d_fc, g, c->d_order_ring[slot], c->order_grid_ring[slot], d_out, d_stats, s));
         if (kt) HIPCHK(c, hipEventRecord(kt[1], s));
         HIPCHK(c, hipEventRecord(c->ev_clouds[c->fc_cur], s)); c->clouds_pending[c->fc_cur] = true;
         return CSKY_OK;
     }
-    // mode 7: this launch runs in the order sorted from the costs of the previous launch ON THE SAME RING SLOT (same geometry and
-    // view), records its own costs and sorts them for the next one.  The first launch of a geometry uses a static order.  Costs,
+    if ((rc = ensure_order(c, slot, static_mode, g.tile_w, tiles_x, slabs, 0, 0, s))) return rc;
+    uint32_t* const d_static = c->d_order_ring[slot];
+    const int static_grid = c->order_grid_ring[slot];
+    if (!feedback) {
+        if (kt) HIPCHK(c, hipEventRecord(kt[0], s));
+        HIPCHK(c, launch_clouds(c->variant, seg, texset(c), c->d_fc, g, d_static, static_grid, d_out, d_stats, nullptr, s));
+        if (kt) HIPCHK(c, hipEventRecord(kt[1], s));
+        HIPCHK(c, hipEventRecord(c->ev_clouds[c->fc_cur], s)); c->clouds_pending[c->fc_cur] = true;
+        return CSKY_OK;
+    }
+    // modes 7 / 8: this launch runs in the order derived from the costs of the previous launch ON THE SAME RING SLOT (same geometry and
+    // view), records its own costs and derives the next order from them.  The first launch of a geometry uses the static order.  Costs,
     // order and sort scratch are per ring slot (= per frame parity, like the frame constants), so two frames in flight on two
     // streams never share them; reuse of a slot is ordered by ev_clouds, recorded below after the sort.
-    const int bw = 32 / seg, tiles_x = (g.tile_w + bw - 1) / bw, nblocks = tiles_x * ((g.n_bands * g.band_rows + 7) >> 3);
-    if (c->lpt_cap < (size_t)nblocks) {
+    const size_t need = (size_t)(static_grid > nblocks ? static_grid : nblocks);
+    if (c->lpt_cap < need) {
         HIPCHK(c, hipDeviceSynchronize());                   // (re)allocation is rare; frames may be in flight on other streams
         (void)hipFree(c->d_wg_cost); (void)hipFree(c->d_lpt_order); c->d_wg_cost = c->d_lpt_order = nullptr; c->lpt_cap = 0;
         c->lpt_valid[0] = c->lpt_valid[1] = false;
-        HIPCHK(c, hipMalloc(reinterpret_cast<void**>(&c->d_wg_cost), 2 * (size_t)nblocks * sizeof(uint32_t)));
-        HIPCHK(c, hipMalloc(reinterpret_cast<void**>(&c->d_lpt_order), 2 * (size_t)nblocks * sizeof(uint32_t)));
+        HIPCHK(c, hipMalloc(reinterpret_cast<void**>(&c->d_wg_cost), 2 * need * sizeof(uint32_t)));
+        HIPCHK(c, hipMalloc(reinterpret_cast<void**>(&c->d_lpt_order), 2 * need * sizeof(uint32_t)));
         if (!c->d_lpt_hist) {
             HIPCHK(c, hipMalloc(reinterpret_cast<void**>(&c->d_lpt_hist), 2 * 2048 * sizeof(uint32_t)));
             HIPCHK(c, hipMemset(c->d_lpt_hist, 0, 2 * 2048 * sizeof(uint32_t)));
         }
-        HIPCHK(c, hipMemset(c->d_wg_cost, 0, 2 * (size_t)nblocks * sizeof(uint32_t)));       // the sort kernels leave both zeroed afterwards
-        c->lpt_cap = (size_t)nblocks;
+        HIPCHK(c, hipMemset(c->d_wg_cost, 0, 2 * need * sizeof(uint32_t)));       // the sort kernels leave both zeroed afterwards
+        c->lpt_cap = need;
     }
-    const int slot = c->fc_cur;
     uint32_t* const cost = c->d_wg_cost + (size_t)slot * c->lpt_cap;
     uint32_t* const lorder = c->d_lpt_order + (size_t)slot * c->lpt_cap;
     // the costs belong to one view of one tile: same launch geometry AND same place in the texture (a tile walk never reuses them)
     const long long fkey[11] = {g.tile_w, g.band_rows, g.first_band, g.band_stride, g.n_bands, (long long)cp.texture_size[0], (long long)cp.texture_size[1],
-                                (long long)cp.update_position[0], (long long)cp.update_position[1], static_mode, seg};
+                                (long long)cp.update_position[0], (long long)cp.update_position[1], mode * 16 + static_mode, seg};
     if (memcmp(c->lpt_key[slot], fkey, sizeof fkey) != 0) { c->lpt_valid[slot] = false; memcpy(c->lpt_key[slot], fkey, sizeof fkey); }
+    const int fb_grid = mode == 8 ? static_grid : nblocks;       // the deadline order keeps the static order's idle padding
     if (kt) HIPCHK(c, hipEventRecord(kt[0], s));
-    HIPCHK(c, launch_clouds(c->variant, seg, texset(c), c->d_fc, g, c->lpt_valid[slot] ? lorder : c->d_order, c->lpt_valid[slot] ? nblocks : c->order_grid,
+    HIPCHK(c, launch_clouds(c->variant, seg, texset(c), c->d_fc, g, c->lpt_valid[slot] ? lorder : d_static, c->lpt_valid[slot] ? fb_grid : static_grid,
                             d_out, d_stats, cost, s));
     if (kt) HIPCHK(c, hipEventRecord(kt[1], s));
-    int shift = 0;
-    while ((((long long)256 * (c->primary_steps + 16)) >> shift) >= 1024) shift++;     // largest cost: 4 wavefronts x 64 rays x (steps + 16)
-    HIPCHK(c, launch_lpt_order(cost, nblocks, shift, c->d_lpt_hist + slot * 2048, lorder, s));
+    if (mode == 8) {
+        HIPCHK(c, launch_deadline_order(d_static, static_grid, cost, c->tail_beta, lorder, s));
+    } else {
+        int shift = 0;
+        while ((((long long)256 * (c->primary_steps + 16)) >> shift) >= 1024) shift++;     // largest cost: 4 wavefronts x 64 rays x (steps + 16)
+        HIPCHK(c, launch_lpt_order(cost, nblocks, shift, c->d_lpt_hist + slot * 2048, lorder, s));
+    }
     c->lpt_valid[slot] = true;
     HIPCHK(c, hipEventRecord(c->ev_clouds[c->fc_cur], s)); c->clouds_pending[c->fc_cur] = true;
     return CSKY_OK;
@@ -353,6 +328,7 @@ int csky_create(csky_ctx** out, int device_id) {
     if ((e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking)) != hipSuccess) return bail("hipStreamCreate", e);
     if ((e = hipEventCreate(&c->ev0)) != hipSuccess) return bail("hipEventCreate", e);
     if ((e = hipEventCreate(&c->ev1)) != hipSuccess) return bail("hipEventCreate", e);
+    if ((e = hipEventCreateWithFlags(&c->ev_copy, hipEventDisableTiming)) != hipSuccess) return bail("hipEventCreate", e);
     if ((e = hipStreamCreateWithFlags(&c->pro, hipStreamNonBlocking)) != hipSuccess) return bail("hipStreamCreate", e);
     for (int k = 0; k < 2; k++) {
         if ((e = hipEventCreateWithFlags(&c->ev_setup[k], hipEventDisableTiming)) != hipSuccess) return bail("hipEventCreate", e);
@@ -360,6 +336,9 @@ int csky_create(csky_ctx** out, int device_id) {
         if ((e = hipMalloc(reinterpret_cast<void**>(&c->fc_ring[k]), sizeof(FrameConsts))) != hipSuccess) return bail("hipMalloc", e);
     }
     c->d_fc = c->fc_ring[0];
+    if (const char* t4 = getenv("CSKY_TAIL_SEG4")) { const float v = (float)atof(t4); if (v >= 0.0f && v <= 1.0f) c->tail_f4 = v; }        // tuning experiments only
+    if (const char* t2 = getenv("CSKY_TAIL_SEG2")) { const float v = (float)atof(t2); if (v >= 0.0f && v <= 1.0f) c->tail_f2 = v; }
+    if (const char* tb = getenv("CSKY_TAIL_BETA")) { const float v = (float)atof(tb); if (v >= 0.0f && v <= 1.0f) c->tail_beta = v; }   // tuning experiments only
     if ((e = hipMalloc(reinterpret_cast<void**>(&c->d_stats), CSKY_STATS_WORDS * sizeof(unsigned long long))) != hipSuccess) return bail("hipMalloc", e);
     *out = c;
     return CSKY_OK;
@@ -370,9 +349,9 @@ void csky_destroy(csky_ctx* c) {
     (void)hipSetDevice(c->device);
     (void)hipDeviceSynchronize();                              // launches may sit on caller streams too
     void* ptrs[] = {c->d_shape, c->d_detail, c->d_weather, c->d_trans_h, c->d_trans_f, c->sky_h_ring[0], c->sky_h_ring[1], c->sky_f_ring[0], c->sky_f_ring[1],
-                    c->fc_ring[0], c->fc_ring[1], c->d_stats, c->d_frame, c->d_order, c->d_detail_h, c->d_wg_cost, c->d_lpt_order, c->d_lpt_hist};
+                    c->fc_ring[0], c->fc_ring[1], c->d_stats, c->d_frame, c->d_order_ring[0], c->d_order_ring[1], c->d_composite, c->d_detail_h, c->d_wg_cost, c->d_lpt_order, c->d_lpt_hist};
     for (void* p : ptrs) if (p) (void)hipFree(p);
-    hipEvent_t evs[] = {c->ev0, c->ev1, c->ev_setup[0], c->ev_setup[1], c->ev_clouds[0], c->ev_clouds[1]};
+    hipEvent_t evs[] = {c->ev0, c->ev1, c->ev_copy, c->ev_setup[0], c->ev_setup[1], c->ev_clouds[0], c->ev_clouds[1]};
     for (hipEvent_t ev : evs) if (ev) (void)hipEventDestroy(ev);
     for (hipEvent_t ev : c->kt_ev) if (ev) (void)hipEventDestroy(ev);
     if (c->pro) (void)hipStreamDestroy(c->pro);
@@ -415,6 +394,10 @@ int csky_set_noise(csky_ctx* c, const uint8_t* large_rgba8, const uint8_t* small
     HIPCHK(c, hipMemcpy(c->d_detail, detail.data(), detail.size() * sizeof(uint4), hipMemcpyHostToDevice));
     HIPCHK(c, hipMemcpy(c->d_weather, weather.data(), weather.size() * sizeof(uint4), hipMemcpyHostToDevice));
     c->have_noise = true;
+    c->err[0] = 0;
+    if (c->inexact_coeffs)     // still CSKY_OK (the taps stay within the parity tolerance), but never silent: cloudsky.h csky_noise_inexact_coeffs
+        snprintf(c->err, sizeof c->err, "csky_set_noise: warning: %llu finite-difference coefficients of these textures are not exact in fp16 "
+                 "(|coefficient| > 2048); taps through them carry a relative 2^-11 error", c->inexact_coeffs);
     return CSKY_OK;
 }
 
@@ -445,7 +428,8 @@ int csky_set_variant(csky_ctx* c, int variant) {
 }
 int csky_set_schedule(csky_ctx* c, int mode) {
     if (!c) return fail(nullptr, CSKY_ERR_INVALID, "csky_set_schedule: ctx is NULL");
-    if (mode < -1 || mode > 7) return fail(c, CSKY_ERR_INVALID, "csky_set_schedule: mode must be -1 (auto) or 0..7 (see cloudsky.h)");
+    if (!(mode == -1 || mode == 1 || mode == 2 || mode == 5 || mode == 7 || mode == 8 || mode == 9))
+        return fail(c, CSKY_ERR_INVALID, "csky_set_schedule: mode must be -1 (auto), 1, 2, 5, 7, 8 or 9 (see cloudsky.h)");
     c->sched_mode = mode; return CSKY_OK;
 }
 int csky_set_frames_in_flight(csky_ctx* c, int frames) {
@@ -555,10 +539,6 @@ int csky_read_sky_lut(csky_ctx* c, uint16_t* out, int* w, int* h) {
 int csky_set_kernel_timing(csky_ctx* c, int enabled) {
     if (!c) return fail(nullptr, CSKY_ERR_INVALID, "csky_set_kernel_timing: ctx is NULL");
     int rc; if ((rc = bind(c))) return rc;
-    if (enabled && c->kt_ev.empty()) {
-        c->kt_ev.assign((size_t)csky_ctx::KT_PAIRS * 2, nullptr);
-        for (hipEvent_t& ev : c->kt_ev) HIPCHK(c, hipEventCreate(&ev));
-    }
     c->kt_on = enabled != 0; c->kt_count = 0;
     return CSKY_OK;
 }
@@ -566,7 +546,7 @@ int csky_set_kernel_timing(csky_ctx* c, int enabled) {
 int csky_get_kernel_ms(csky_ctx* c, float* total_ms, int* launches) {
     if (!c || !total_ms || !launches) return fail(c, CSKY_ERR_INVALID, "csky_get_kernel_ms: NULL argument");
     int rc; if ((rc = bind(c))) return rc;
-    const int n = c->kt_count < csky_ctx::KT_PAIRS ? c->kt_count : csky_ctx::KT_PAIRS;   // the pool keeps the last KT_PAIRS launches
+    const int n = c->kt_count;                                 // every launch since the last call (the pool grows on demand)
     float sum = 0.0f;
     for (int i = 0; i < n; i++) {
         HIPCHK(c, hipEventSynchronize(c->kt_ev[(size_t)i * 2 + 1]));
@@ -605,7 +585,7 @@ int csky_time_clouds(csky_ctx* c, const csky_cloud_params* p, int tile_w, const 
         HIPCHK(c, hipMemsetAsync(c->d_stats, 0, 16, c->stream));
         if ((rc = clouds_dev(c, p, tile_w, bands, c->d_frame, pitch, c->stream, c->d_stats, false))) return rc;
         HIPCHK(c, hipStreamSynchronize(c->stream));
-        const size_t n = std::min((size_t)c->order_grid, (size_t)70000) * 16;
+        const size_t n = std::min((size_t)c->order_grid_ring[c->fc_cur], (size_t)70000) * 16;
         std::vector<unsigned long long> h(n);
         HIPCHK(c, hipMemcpy(h.data(), c->d_stats + 2, n * 8, hipMemcpyDeviceToHost));
         if (FILE* f = fopen(path, "wb")) { fwrite(h.data(), 8, n, f); fclose(f); }
@@ -624,8 +604,13 @@ int csky_composite_sky(csky_ctx* c, const csky_composite_params* p, const uint16
     HIPCHK(c, hipStreamSynchronize(c->pro));                                                // the transmittance LUT may have been rendered there
     if (!c->have_trans && (rc = render_trans_dev(c, 256, 64, c->stream))) return rc;       // source_transmittance, clouds_material.tres
     const size_t cb = (size_t)p->cloud_w * p->cloud_h * 8, sb = (size_t)p->sky_w * p->sky_h * 8, ob = (size_t)p->out_w * p->out_h * 8;
-    uint8_t* d = nullptr;
-    HIPCHK(c, hipMalloc(reinterpret_cast<void**>(&d), 2 * cb + 2 * sb + ob));
+    const size_t need = 2 * cb + 2 * sb + ob;
+    if (c->composite_cap < need) {                            // grow-only scratch: no allocation per call once the sizes have been seen
+        if (c->d_composite) { (void)hipFree(c->d_composite); c->d_composite = nullptr; c->composite_cap = 0; }
+        HIPCHK(c, hipMalloc(reinterpret_cast<void**>(&c->d_composite), need));
+        c->composite_cap = need;
+    }
+    uint8_t* d = c->d_composite;
     hipError_t e = hipSuccess;
     auto up = [&](size_t off, const void* src, size_t n) { if (e == hipSuccess) e = hipMemcpyAsync(d + off, src, n, hipMemcpyHostToDevice, c->stream); };
     up(0, cloud_from, cb); up(cb, cloud_to, cb); up(2 * cb, sky_from, sb); up(2 * cb + sb, sky_to, sb);
@@ -639,7 +624,6 @@ int csky_composite_sky(csky_ctx* c, const csky_composite_params* p, const uint16
     if (e == hipSuccess) e = launch_composite(a, reinterpret_cast<uint2*>(d + 2 * cb + 2 * sb), c->stream);
     if (e == hipSuccess) e = hipMemcpyAsync(out, d + 2 * cb + 2 * sb, ob, hipMemcpyDeviceToHost, c->stream);
     if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
-    (void)hipFree(d);
     if (e != hipSuccess) return fail(c, CSKY_ERR_HIP, "csky_composite_sky: %s", hipGetErrorString(e));
     return CSKY_OK;
 }
@@ -662,6 +646,168 @@ int csky_generate_shape_noise_device(csky_ctx* c, uint32_t seed, int n, uint8_t*
 int csky_get_cloud_stats(csky_ctx* c, csky_cloud_stats* stats) {
     if (!c || !stats) return fail(c, CSKY_ERR_INVALID, "csky_get_cloud_stats: NULL argument");
     *stats = c->last_stats; return CSKY_OK;
+}
+
+
+int csky_copy_sky_lut_device(csky_ctx* c, void* d_out, void* hip_stream) {
+    if (!c) return fail(nullptr, CSKY_ERR_INVALID, "csky_copy_sky_lut_device: ctx is NULL");
+    if (!d_out) return fail(c, CSKY_ERR_INVALID, "csky_copy_sky_lut_device: d_out is NULL");
+    if (!c->have_sky) return fail(c, CSKY_ERR_STATE, "csky_copy_sky_lut_device: LUT not rendered yet");
+    int rc; if ((rc = bind(c))) return rc;
+    hipStream_t s = hip_stream ? (hipStream_t)hip_stream : c->stream;
+    // the copy runs on the prologue stream right behind the LUT's render (a later render goes to the other ring slot and, like every
+    // writer of a slot, is queued behind this reader on the same stream); the caller's stream then waits for it
+    HIPCHK(c, hipMemcpyAsync(d_out, c->d_sky_h, (size_t)c->sw * c->sh * 8, hipMemcpyDeviceToDevice, c->pro));
+    HIPCHK(c, hipEventRecord(c->ev_copy, c->pro));
+    HIPCHK(c, hipStreamWaitEvent(s, c->ev_copy, 0));
+    return CSKY_OK;
+}
+
+// ---- multi-GPU: n contexts, one frame on the first device written by peer stores (cloudsky.h) ----------------------------
+struct csky_multi {
+    std::vector<csky_ctx*> ctx;
+    std::vector<hipEvent_t> ev_done;      // one per device: its march of the current frame has finished
+    hipEvent_t ev_begin = nullptr;        // on the first device: the consumer stream's position when the frame was requested
+    uint2* d_frame = nullptr; size_t frame_px = 0;   // host-buffer form: internal frame on the first device
+    char err[512] = {0};
+};
+namespace {
+int mfail(csky_multi* m, int code, const char* fmt, ...) {
+    char* dst = m ? m->err : g_err;
+    va_list ap; va_start(ap, fmt); vsnprintf(dst, 512, fmt, ap); va_end(ap);
+    return code;
+}
+int mpass(csky_multi* m, int i, int rc) {      // propagate a per-device error text
+    if (rc) snprintf(m->err, sizeof m->err, "device %d (index %d): %s", m->ctx[i]->device, i, m->ctx[i]->err);
+    return rc;
+}
+}  // namespace
+
+int csky_multi_create(csky_multi** out, const int* device_ids, int n) {
+    if (!out) return mfail(nullptr, CSKY_ERR_INVALID, "csky_multi_create: out is NULL");
+    *out = nullptr;
+    if (!device_ids || n < 1 || n > 64) return mfail(nullptr, CSKY_ERR_INVALID, "csky_multi_create: need 1..64 device ids");
+    csky_multi* m = new (std::nothrow) csky_multi();
+    if (!m) return mfail(nullptr, CSKY_ERR_INVALID, "csky_multi_create: out of host memory");
+    for (int i = 0; i < n; i++) {
+        csky_ctx* c = nullptr;
+        const int rc = csky_create(&c, device_ids[i]);
+        if (rc) { csky_multi_destroy(m); return rc; }           // g_err already holds csky_create's text
+        m->ctx.push_back(c);
+    }
+    auto bail = [&](int code, const char* what, hipError_t e) { mfail(nullptr, code, "csky_multi_create: %s: %s", what, hipGetErrorString(e)); csky_multi_destroy(m); return code; };
+    const int d0 = device_ids[0];
+    hipError_t e;
+    for (int i = 0; i < n; i++) {
+        const int di = device_ids[i];
+        if ((e = hipSetDevice(di)) != hipSuccess) return bail(CSKY_ERR_HIP, "hipSetDevice", e);
+        hipEvent_t ev = nullptr;
+        if ((e = hipEventCreateWithFlags(&ev, hipEventDisableTiming)) != hipSuccess) return bail(CSKY_ERR_HIP, "hipEventCreate", e);
+        m->ev_done.push_back(ev);
+        if (di != d0) {                                          // the march on device di stores into the frame on d0: xGMI peer access
+            int can = 0;
+            if ((e = hipDeviceCanAccessPeer(&can, di, d0)) != hipSuccess) return bail(CSKY_ERR_HIP, "hipDeviceCanAccessPeer", e);
+            if (!can) { mfail(nullptr, CSKY_ERR_NO_DEVICE, "csky_multi_create: device %d cannot access device %d (peer access is required)", di, d0); csky_multi_destroy(m); return CSKY_ERR_NO_DEVICE; }
+            e = hipDeviceEnablePeerAccess(d0, 0);
+            if (e != hipSuccess && e != hipErrorPeerAccessAlreadyEnabled) return bail(CSKY_ERR_HIP, "hipDeviceEnablePeerAccess", e);
+            (void)hipGetLastError();
+        }
+    }
+    if ((e = hipSetDevice(d0)) != hipSuccess) return bail(CSKY_ERR_HIP, "hipSetDevice", e);
+    if ((e = hipEventCreateWithFlags(&m->ev_begin, hipEventDisableTiming)) != hipSuccess) return bail(CSKY_ERR_HIP, "hipEventCreate", e);
+    *out = m;
+    return CSKY_OK;
+}
+
+void csky_multi_destroy(csky_multi* m) {
+    if (!m) return;
+    for (size_t i = 0; i < m->ctx.size(); i++) {
+        (void)hipSetDevice(m->ctx[i]->device);
+        (void)hipDeviceSynchronize();
+        if (i < m->ev_done.size() && m->ev_done[i]) (void)hipEventDestroy(m->ev_done[i]);
+    }
+    if (!m->ctx.empty()) {
+        (void)hipSetDevice(m->ctx[0]->device);
+        if (m->ev_begin) (void)hipEventDestroy(m->ev_begin);
+        if (m->d_frame) (void)hipFree(m->d_frame);
+    }
+    for (csky_ctx* c : m->ctx) csky_destroy(c);
+    delete m;
+}
+
+int csky_multi_device_count(const csky_multi* m) { return m ? (int)m->ctx.size() : 0; }
+csky_ctx* csky_multi_ctx(csky_multi* m, int i) { return (m && i >= 0 && i < (int)m->ctx.size()) ? m->ctx[i] : nullptr; }
+const char* csky_multi_last_error(const csky_multi* m) { return m ? m->err : g_err; }
+
+int csky_multi_set_noise(csky_multi* m, const uint8_t* large, const uint8_t* small, const uint8_t* weather) {
+    if (!m) return mfail(nullptr, CSKY_ERR_INVALID, "csky_multi_set_noise: handle is NULL");
+    for (size_t i = 0; i < m->ctx.size(); i++) { const int rc = csky_set_noise(m->ctx[i], large, small, weather); if (rc) return mpass(m, (int)i, rc); }
+    return CSKY_OK;
+}
+int csky_multi_set_march(csky_multi* m, int primary_steps, int light_steps) {
+    if (!m) return mfail(nullptr, CSKY_ERR_INVALID, "csky_multi_set_march: handle is NULL");
+    for (size_t i = 0; i < m->ctx.size(); i++) { const int rc = csky_set_march(m->ctx[i], primary_steps, light_steps); if (rc) return mpass(m, (int)i, rc); }
+    return CSKY_OK;
+}
+int csky_multi_render_sky_lut(csky_multi* m, const csky_sky_params* p) {
+    if (!m) return mfail(nullptr, CSKY_ERR_INVALID, "csky_multi_render_sky_lut: handle is NULL");
+    for (size_t i = 0; i < m->ctx.size(); i++) { const int rc = csky_render_sky_lut_device(m->ctx[i], p, nullptr); if (rc) return mpass(m, (int)i, rc); }
+    return CSKY_OK;
+}
+
+int csky_multi_render_clouds_device(csky_multi* m, const csky_cloud_params* p, int tile_w, int tile_h, void* d_out, size_t pitch, void* hip_stream) {
+    if (!m) return mfail(nullptr, CSKY_ERR_INVALID, "csky_multi_render_clouds_device: handle is NULL");
+    if (!d_out || !p) return mfail(m, CSKY_ERR_INVALID, "csky_multi_render_clouds_device: NULL argument");
+    if (tile_w < 1 || tile_h < 8 || (tile_h & 7)) return mfail(m, CSKY_ERR_INVALID, "csky_multi_render_clouds_device: tile_h must be a positive multiple of 8 (bands are 8 rows)");
+    const int n = (int)m->ctx.size(), total = tile_h / 8;
+    csky_ctx* c0 = m->ctx[0];
+    int rc; if ((rc = bind(c0))) return mpass(m, 0, rc);
+    hipStream_t consumer = hip_stream ? (hipStream_t)hip_stream : c0->stream;
+    // no device may store into the frame before the consumer's earlier work on it (reads of the previous frame) is done
+    if (hipEventRecord(m->ev_begin, consumer) != hipSuccess) return mfail(m, CSKY_ERR_HIP, "csky_multi_render_clouds_device: hipEventRecord failed");
+    for (int i = 0; i < n; i++) {
+        csky_ctx* c = m->ctx[i];
+        if ((rc = bind(c))) return mpass(m, i, rc);
+        const int nb = i < total ? (total - i + n - 1) / n : 0;
+        if (nb == 0) continue;
+        hipStream_t s = (i == 0) ? consumer : c->stream;
+        if (i != 0 && hipStreamWaitEvent(s, m->ev_begin, 0) != hipSuccess) return mfail(m, CSKY_ERR_HIP, "csky_multi_render_clouds_device: hipStreamWaitEvent failed");
+        const csky_bands b = {8, i, n, nb};
+        if ((rc = clouds_dev(c, p, tile_w, &b, (uint2*)d_out, pitch, s, nullptr, true, /*out_full=*/true))) return mpass(m, i, rc);
+        if (i != 0 && hipEventRecord(m->ev_done[i], s) != hipSuccess) return mfail(m, CSKY_ERR_HIP, "csky_multi_render_clouds_device: hipEventRecord failed");
+    }
+    if ((rc = bind(c0))) return mpass(m, 0, rc);
+    for (int i = 1; i < n; i++) {
+        if (i >= total) continue;
+        if (hipStreamWaitEvent(consumer, m->ev_done[i], 0) != hipSuccess) return mfail(m, CSKY_ERR_HIP, "csky_multi_render_clouds_device: hipStreamWaitEvent failed");
+    }
+    return CSKY_OK;
+}
+
+int csky_multi_render_clouds(csky_multi* m, const csky_cloud_params* p, int tile_w, int tile_h, uint16_t* out, size_t pitch) {
+    if (!m) return mfail(nullptr, CSKY_ERR_INVALID, "csky_multi_render_clouds: handle is NULL");
+    if (tile_w < 1 || tile_h < 1) return mfail(m, CSKY_ERR_INVALID, "csky_multi_render_clouds: empty tile");
+    if (out && pitch < (size_t)tile_w * 8) return mfail(m, CSKY_ERR_INVALID, "csky_multi_render_clouds: row_pitch_bytes < tile_w*8");
+    csky_ctx* c0 = m->ctx[0];
+    int rc; if ((rc = bind(c0))) return mpass(m, 0, rc);
+    const size_t px = (size_t)tile_w * tile_h;
+    if (m->frame_px < px) {
+        if (m->d_frame) { (void)hipFree(m->d_frame); m->d_frame = nullptr; m->frame_px = 0; }
+        if (hipMalloc(reinterpret_cast<void**>(&m->d_frame), px * 8) != hipSuccess) return mfail(m, CSKY_ERR_HIP, "csky_multi_render_clouds: hipMalloc failed");
+        m->frame_px = px;
+    }
+    if ((rc = csky_multi_render_clouds_device(m, p, tile_w, tile_h, m->d_frame, (size_t)tile_w * 8, nullptr))) return rc;
+    if ((rc = bind(c0))) return mpass(m, 0, rc);
+    if (out && hipMemcpy2DAsync(out, pitch, m->d_frame, (size_t)tile_w * 8, (size_t)tile_w * 8, tile_h, hipMemcpyDeviceToHost, c0->stream) != hipSuccess)
+        return mfail(m, CSKY_ERR_HIP, "csky_multi_render_clouds: copy to host failed");
+    if (hipStreamSynchronize(c0->stream) != hipSuccess) return mfail(m, CSKY_ERR_HIP, "csky_multi_render_clouds: hipStreamSynchronize failed");
+    return CSKY_OK;
+}
+
+int csky_multi_sync(csky_multi* m) {
+    if (!m) return mfail(nullptr, CSKY_ERR_INVALID, "csky_multi_sync: handle is NULL");
+    for (size_t i = 0; i < m->ctx.size(); i++) { const int rc = csky_sync(m->ctx[i]); if (rc) return mpass(m, (int)i, rc); }
+    return CSKY_OK;
 }
 
 }  // extern "C"

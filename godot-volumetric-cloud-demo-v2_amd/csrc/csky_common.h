@@ -93,6 +93,8 @@ struct RenderGeom {
     int tile_w;        // pixels per row rendered (gl_GlobalInvocationID.x range)
     int band_rows, first_band, band_stride, n_bands;
     uint32_t pitch_px; // output row pitch in pixels (8 bytes each)
+    int out_full;      // 0: compact output (row = band-local row); 1: row = the pixel row inside the tile (multi-GPU: every device stores
+                       // its bands at their place in ONE frame, csky_multi_render_clouds_device)
 };
 
 struct CloudParams {  // == csky_cloud_params (clouds.glsl:18-40)

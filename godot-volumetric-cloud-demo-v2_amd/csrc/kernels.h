@@ -25,6 +25,19 @@ hipError_t launch_clouds(int variant, int seg, const TexSet& t, const FrameConst
 // before their first use and are left zeroed (the cloud kernel accumulates the next costs into d_cost).
 hipError_t launch_lpt_order(uint32_t* d_cost, int n, int shift, uint32_t* d_scratch, uint32_t* d_order, hipStream_t s);
 
+// static workgroup orders 1, 2, 5 written on the device (kernels.hip); grid = padded number of physical workgroups
+hipError_t launch_static_order(int mode, int tiles_x, int slabs, int grid, uint32_t* d_order, hipStream_t s);
+// deadline order (mode 8) of the next launch from this launch's costs and the static order; d_cost is left zeroed.  grid % 8 == 0
+hipError_t launch_deadline_order(const uint32_t* d_static, int grid, uint32_t* d_cost, float beta, uint32_t* d_order, hipStream_t s);
+int deadline_order_max_grid();
+
+// mixed-segment launch (schedule mode 9): mode-5 order whose last t4 (then t2) slab positions per XCD are expanded into 4- (2-)segment
+// workgroups; order entries carry the segment count (kernels.hip::mixed_order_kernel), "compact" march only
+int mixed_order_grid(int tiles32_x, int slabs, int t2, int t4);
+hipError_t launch_mixed_order(int tile_w, int slabs, int t2, int t4, uint32_t* d_order, hipStream_t s);
+hipError_t launch_clouds_mixed(const TexSet& t, const FrameConsts* d_fc, const RenderGeom& g, const uint32_t* d_order, int grid, uint2* d_out,
+                               unsigned long long* d_stats, hipStream_t s);
+
 // clouds.gdshader sky() on an equirectangular panorama (all pointers in `a` are device pointers)
 hipError_t launch_composite(const CompositeArgs& a, uint2* d_out, hipStream_t s);
 

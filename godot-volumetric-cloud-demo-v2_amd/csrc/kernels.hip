@@ -545,7 +545,7 @@ __global__ __launch_bounds__(256) void clouds_kernel_interleaved(TexSet T, const
     march_interleaved(T, fc, ray, il_smem, wave, lane, r, g, b, a, ic);
     if (valid && wave == 0) {
         const uint32_t lo = (uint32_t)f2h(r) | ((uint32_t)f2h(g) << 16), hi = (uint32_t)f2h(b) | ((uint32_t)f2h(a) << 16);
-        out[(size_t)lr * G.pitch_px + gx] = make_uint2(lo, hi);
+        out[(size_t)(G.out_full ? gy : lr) * G.pitch_px + gx] = make_uint2(lo, hi);
     }
     if (stats) {
         unsigned ab = (ray.above && wave == 0) ? 1u : 0u;
@@ -591,7 +591,7 @@ __global__ __launch_bounds__(1024) void clouds_kernel_lds(TexSet T, const FrameC
     const MarchOut o = march_queue(Tl, fc, ray, queues + wave * Q_FLOATS, 0, fc.primary_steps);
     if (valid) {
         const uint32_t lo = (uint32_t)f2h(o.r) | ((uint32_t)f2h(o.g) << 16), hi = (uint32_t)f2h(o.b) | ((uint32_t)f2h(o.a) << 16);
-        out[(size_t)lr * G.pitch_px + gx] = make_uint2(lo, hi);
+        out[(size_t)(G.out_full ? gy : lr) * G.pitch_px + gx] = make_uint2(lo, hi);
     }
     if (stats || wg_cost) {
         unsigned ic = o.incloud, ab = ray.above ? 1u : 0u;
@@ -668,7 +668,7 @@ __global__ __launch_bounds__(256, VARIANT == 3 ? CSKY_COMPACT_WAVES : 7) void cl
     }
     if (valid && seg == 0) {
         const uint32_t lo = (uint32_t)f2h(o.r) | ((uint32_t)f2h(o.g) << 16), hi = (uint32_t)f2h(o.b) | ((uint32_t)f2h(o.a) << 16);
-        out[(size_t)lr * G.pitch_px + gx] = make_uint2(lo, hi);  // imageStore, clouds.glsl:264
+        out[(size_t)(G.out_full ? gy : lr) * G.pitch_px + gx] = make_uint2(lo, hi);  // imageStore, clouds.glsl:264
     }
 #ifdef CSKY_TIMELINE
     if (stats && lane == 0) {                                  // per wavefront: start, end (100 MHz ticks), XCD | HW_ID, workgroup id | lane 0's samples
@@ -687,6 +687,100 @@ __global__ __launch_bounds__(256, VARIANT == 3 ? CSKY_COMPACT_WAVES : 7) void cl
             if (wg_cost) atomicAdd(&wg_cost[logical], ic + 16u * ab);   // cost model of the feedback schedule: light marches + live primary marches
         }
     }
+}
+
+// ---- mixed-segment launch (api.cpp, schedule mode 9): whole rays first, ray segments for the workgroups that start last ----------
+// A whole-frame launch is ~4 resident workgroup sets deep.  Once the last workgroup has been dispatched nothing refills the slots
+// that free up, and the launch drains for as long as the workgroups that started LAST take: 0.5 ms of a 2.1 ms span with the chip
+// 3/4 empty on average (profiles/r02/timeline_s5_s8.txt).  Reordering does not help: whatever starts last still takes a wavefront's
+// whole march (heaviest-first and the deadline order of mode 8 measured no gain), and a second launch cannot start before the first
+// has drained.  So the LAST workgroups of the order are made short instead: in one launch, the order's final stretch is expanded into
+// 2- and then 4-segment workgroups (the ray-segment machinery of clouds_kernel<3, 2|4>: a tile's rays are cut into step ranges marched
+// by the wavefronts of one workgroup and combined front to back through LDS), so the drain lasts a quarter of a march.  The segment
+// count is carried per workgroup in the order entry (bits 31:30 = log2 segments, bits 29:0 = index of the workgroup's first 8x8
+// tile): a workgroup-uniform value, every branch on it is scalar.  Static: nothing comes from a previous frame.
+__device__ __forceinline__ uint32_t mixed_entry(int code, uint32_t fine) { return ((uint32_t)code << 30) | fine; }
+__global__ __launch_bounds__(256) void mixed_order_kernel(int tiles8_x, int tiles32_x, int slabs, int t2, int t4, int grid, uint32_t* __restrict__ out) {
+    // one thread per SOURCE position (XCD x, position j of its mode-5 sequence of n = rows_per * tiles32_x slabs)
+    const int rows_per = (slabs + 7) >> 3, n = rows_per * tiles32_x;
+    const int src = blockIdx.x * 256 + threadIdx.x;
+    if (src >= n * 8) return;
+    const int x = src & 7, j = src >> 3;
+    const int k = j / tiles32_x, bx = j - k * tiles32_x, i = 8 * k + x;                 // slab row i, slab column bx (as static mode 5)
+    const bool live = i < slabs;
+    const uint32_t fine = (uint32_t)(i * tiles8_x + bx * 4);
+    const int n1 = n - t2 - t4;
+    if (j < n1) { out[8 * j + x] = live ? mixed_entry(0, fine) : 0xffffffffu; return; }
+    if (j < n1 + t2) {
+        const int q = n1 + 2 * (j - n1);
+        for (int h = 0; h < 2; h++) out[8 * (q + h) + x] = (live && bx * 4 + 2 * h < tiles8_x) ? mixed_entry(1, fine + 2 * h) : 0xffffffffu;
+        return;
+    }
+    const int q = n1 + 2 * t2 + 4 * (j - n1 - t2);
+    for (int h = 0; h < 4; h++) out[8 * (q + h) + x] = (live && bx * 4 + h < tiles8_x) ? mixed_entry(2, fine + h) : 0xffffffffu;
+}
+// returns the grid (number of physical workgroups) through *grid_out; d_order must hold 8 * (n + t2 + 3 t4) entries
+int mixed_order_grid(int tiles32_x, int slabs, int t2, int t4) { const int n = ((slabs + 7) >> 3) * tiles32_x; return 8 * (n + t2 + 3 * t4); }
+hipError_t launch_mixed_order(int tile_w, int slabs, int t2, int t4, uint32_t* d_order, hipStream_t s) {
+    const int tiles8_x = (tile_w + 7) >> 3, tiles32_x = (tile_w + 31) >> 5;
+    const int n = ((slabs + 7) >> 3) * tiles32_x, grid = mixed_order_grid(tiles32_x, slabs, t2, t4);
+    if (n <= 0) return hipSuccess;
+    mixed_order_kernel<<<(n * 8 + 255) / 256, 256, 0, s>>>(tiles8_x, tiles32_x, slabs, t2, t4, grid, d_order);
+    return hipGetLastError();
+}
+
+__global__ __launch_bounds__(256, CSKY_COMPACT_WAVES) void clouds_kernel_mixed(TexSet T, const FrameConsts* __restrict__ fcp, RenderGeom G, const uint32_t* __restrict__ order,
+                                                                               uint2* __restrict__ out, unsigned long long* __restrict__ stats) {
+    const uint32_t e = order[blockIdx.x];
+    if (e == 0xffffffffu) return;                              // workgroup-uniform
+    const int code = (int)(e >> 30), SEG = 1 << code;          // 1, 2 or 4 segments per ray (scalar)
+    const int fine = (int)(e & 0x3fffffffu);
+    const int tiles8_x = (G.tile_w + 7) >> 3;
+    const int local_rows = G.n_bands * G.band_rows;
+    const int slab = fine / tiles8_x, tx8 = fine - slab * tiles8_x;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int tile = wave >> code, seg = wave & (SEG - 1);
+    const int gx = (tx8 + tile) * 8 + (lane & 7);
+    const int lr = slab * 8 + (lane >> 3);
+    const bool valid = gx < G.tile_w && lr < local_rows;
+    const int band = lr / G.band_rows, rib = lr - band * G.band_rows;
+    const int gy = (G.first_band + band * G.band_stride) * G.band_rows + rib;
+    const FrameConsts& fc = *fcp;
+    T.detail_lds = nullptr;
+    Ray ray = ray_setup(fc, valid ? gx : 0, valid ? gy : 0);
+    if (!valid) ray.above = false;
+    __shared__ float lds[4][CQ_FLOATS];
+    __shared__ float comb[4][5][64];
+    const int s0 = (fc.primary_steps * seg) >> code, s1 = (fc.primary_steps * (seg + 1)) >> code;
+    MarchOut o = march_compact(T, fc, ray, &lds[wave][0], s0, s1);
+    if (SEG > 1) {                                             // scalar branch: front-to-back combine of the ray's segments (as clouds_kernel<3, SEG>)
+        comb[wave][0][lane] = o.r; comb[wave][1][lane] = o.g; comb[wave][2][lane] = o.b; comb[wave][3][lane] = o.t; comb[wave][4][lane] = o.a;
+        __syncthreads();
+        if (seg == 0) {
+            float Tr = o.t, na = 1.0f - o.a;
+            for (int q = 1; q < SEG; q++) {
+                const int w = tile * SEG + q;
+                o.r += Tr * comb[w][0][lane]; o.g += Tr * comb[w][1][lane]; o.b += Tr * comb[w][2][lane];
+                Tr *= comb[w][3][lane]; na *= 1.0f - comb[w][4][lane];
+            }
+            o.a = sat(1.0f - na); o.t = Tr;
+        }
+    }
+    if (valid && seg == 0) {
+        const uint32_t lo = (uint32_t)f2h(o.r) | ((uint32_t)f2h(o.g) << 16), hi = (uint32_t)f2h(o.b) | ((uint32_t)f2h(o.a) << 16);
+        out[(size_t)(G.out_full ? gy : lr) * G.pitch_px + gx] = make_uint2(lo, hi);  // imageStore, clouds.glsl:264
+    }
+    if (stats) {
+        unsigned ic = o.incloud, ab = (ray.above && seg == 0) ? 1u : 0u;
+        for (int off = 32; off > 0; off >>= 1) { ic += __shfl_down(ic, off); ab += __shfl_down(ab, off); }
+        if (lane == 0) { atomicAdd(&stats[0], (unsigned long long)ic); atomicAdd(&stats[1], (unsigned long long)ab); }
+    }
+}
+hipError_t launch_clouds_mixed(const TexSet& t, const FrameConsts* d_fc, const RenderGeom& g, const uint32_t* d_order, int grid, uint2* d_out,
+                               unsigned long long* d_stats, hipStream_t s) {
+    if (grid <= 0) return hipSuccess;
+    clouds_kernel_mixed<<<grid, 256, 0, s>>>(t, d_fc, g, d_order, d_out, d_stats);
+    return hipGetLastError();
 }
 
 // ---- cost-feedback schedule (api.cpp, schedule mode 7) -----------------------------------------------------------------
@@ -736,6 +830,89 @@ hipError_t launch_lpt_order(uint32_t* d_cost, int n, int shift, uint32_t* d_scra
     lpt_scatter_kernel<<<(n + 255) / 256, 256, 0, s>>>(d_cost, n, shift, d_scratch + LPT_BUCKETS, d_order);
     return hipGetLastError();
 }
+
+// ---- static workgroup orders, generated on the device (api.cpp::ensure_order) -------------------------------------------
+// Physical workgroup b runs on XCD b % 8 (observed placement, used for speed only).  A "slab" is one 32 x 8 pixel workgroup
+// footprint (bw x 8 for segmented launches); `grid` entries, 0xffffffff = idle padding.
+//   mode 2: natural order
+//   mode 1: contiguous eighths of the launch per XCD
+//   mode 5: slab ROWS dealt round-robin to the XCDs, every XCD walks its rows left to right: all XCDs see the same mix of
+//           elevations and concurrently running workgroups are neighbours (shared cache lines)
+// Written by a kernel on the launch's own stream: no host table, no pageable copy, no device-wide synchronisation when the
+// geometry changes (a 64-tile walk re-uses the table anyway: these orders depend on the launch geometry only).
+__global__ __launch_bounds__(256) void static_order_kernel(int mode, int tiles_x, int slabs, int grid, uint32_t* __restrict__ out) {
+    const int b = blockIdx.x * 256 + threadIdx.x;
+    if (b >= grid) return;
+    const int nblocks = tiles_x * slabs;
+    uint32_t l = 0xffffffffu;
+    if (mode == 2) { if (b < nblocks) l = (uint32_t)b; }
+    else if (mode == 1) { const int per = (nblocks + 7) >> 3, v = (b & 7) * per + (b >> 3); if ((b >> 3) < per && v < nblocks) l = (uint32_t)v; }
+    else { const int x = b & 7, j = b >> 3, k = j / tiles_x, bx = j - k * tiles_x, i = 8 * k + x; if (i < slabs) l = (uint32_t)(i * tiles_x + bx); }
+    out[b] = l;
+}
+hipError_t launch_static_order(int mode, int tiles_x, int slabs, int grid, uint32_t* d_order, hipStream_t s) {
+    if (grid <= 0) return hipSuccess;
+    static_order_kernel<<<(grid + 255) / 256, 256, 0, s>>>(mode, tiles_x, slabs, grid, d_order);
+    return hipGetLastError();
+}
+
+// ---- deadline schedule (api.cpp, schedule mode 8) ----------------------------------------------------------------------
+// A whole-frame launch is ~4 resident workgroup sets deep and ends in a tail of few, long wavefronts: a workgroup that
+// marches through a lot of cloud lasts 3x the mean, and when one of those STARTS late the launch waits for it with most of
+// the chip idle (profiles/r01/occupancy_timeline.txt: 75 % time-integral of occupancy).  Sorting everything heaviest-first
+// (mode 7) removes the tail but makes the heavy workgroups run together and breaks up neighbours (+13 % wave duration).
+// Here the static order is kept and only the workgroups that would finish too late are moved forward, just far enough:
+// with the per-workgroup costs c of the PREVIOUS launch of the same view (as mode 7: only the ORDER comes from the previous
+// frame, every sample is recomputed, frames are bit-identical under every order), position j of an XCD's sequence of n gets
+//     key = min(j, n * (1 - beta * max(0, c - mean) / max))                   ("latest start" of a workgroup of cost c)
+// and the sequence is re-ranked by (key, j): a stable merge in which on-time workgroups keep their order and neighbours.
+// One 1024-thread workgroup per XCD sequence; rank by counting (n <= 8192 per XCD: n^2 / 1024 compares per thread from LDS).
+constexpr int DL_MAX_N = 8192;
+__global__ __launch_bounds__(1024) void deadline_order_kernel(const uint32_t* __restrict__ S, int n, uint32_t* __restrict__ cost, float beta,
+                                                              uint32_t* __restrict__ out) {
+    extern __shared__ uint32_t dl_comp[];                       // [n] composite sort keys (key << 14 | j), then reduction scratch behind them
+    __shared__ float red_sum[16], red_max[16];
+    const int x = blockIdx.x, t = threadIdx.x;
+    float lsum = 0.0f, lmax = 0.0f; int lcnt = 0;
+    for (int j = t; j < n; j += 1024) {
+        const uint32_t l = S[8 * j + x];
+        if (l != 0xffffffffu) { const float c = (float)cost[l]; lsum += c; lmax = fmaxf(lmax, c); lcnt++; }
+    }
+    float lc = (float)lcnt;
+    for (int off = 32; off > 0; off >>= 1) { lsum += __shfl_down(lsum, off); lc += __shfl_down(lc, off); lmax = fmaxf(lmax, __shfl_down(lmax, off)); }
+    __shared__ float red_cnt[16];
+    if ((t & 63) == 0) { red_sum[t >> 6] = lsum; red_cnt[t >> 6] = lc; red_max[t >> 6] = lmax; }
+    __syncthreads();
+    float sum = 0.0f, cnt = 0.0f, mx = 0.0f;
+    for (int w = 0; w < 16; w++) { sum += red_sum[w]; cnt += red_cnt[w]; mx = fmaxf(mx, red_max[w]); }
+    const float mean = cnt > 0.0f ? sum / cnt : 0.0f, inv = mx > 0.0f ? 1.0f / mx : 0.0f;
+    for (int j = t; j < n; j += 1024) {
+        const uint32_t l = S[8 * j + x];
+        uint32_t key = (uint32_t)n;                             // idle padding goes last
+        if (l != 0xffffffffu) {
+            const float c = (float)cost[l];
+            const float latest = (float)n * (1.0f - beta * fmaxf(0.0f, c - mean) * inv);
+            const int lk = (int)fmaxf(0.0f, latest);
+            key = (uint32_t)(lk < j ? lk : j);
+            cost[l] = 0u;                                        // the next launch accumulates into a clean array (own entries only)
+        }
+        dl_comp[j] = (key << 14) | (uint32_t)j;
+    }
+    __syncthreads();
+    for (int j = t; j < n; j += 1024) {
+        const uint32_t mine = dl_comp[j];
+        int rank = 0;
+        for (int k = 0; k < n; k++) rank += dl_comp[k] < mine ? 1 : 0;
+        out[8 * rank + x] = S[8 * j + x];
+    }
+}
+hipError_t launch_deadline_order(const uint32_t* d_static, int grid, uint32_t* d_cost, float beta, uint32_t* d_order, hipStream_t s) {
+    const int n = grid / 8;
+    if (n <= 0 || (grid & 7) || n > DL_MAX_N) return hipErrorInvalidValue;
+    deadline_order_kernel<<<8, 1024, (size_t)n * sizeof(uint32_t), s>>>(d_static, n, d_cost, beta, d_order);
+    return hipGetLastError();
+}
+int deadline_order_max_grid() { return DL_MAX_N * 8; }
 
 static const char* const kVariantNames[] = {"lockstep", "queue", "queue-lds", "compact"};
 int cloud_variant_count() { return (int)(sizeof(kVariantNames) / sizeof(kVariantNames[0])); }

@@ -1,7 +1,7 @@
 // lut_core.h -- per-texel bodies of the two atmosphere LUT kernels (transmittance-lut.glsl, sky-lut.glsl),
 // one texel per lane.  Host+device so tests/hostsim can run them on a CPU; the product only instantiates
 // them in lut_kernels.hip.  These kernels are tiny (16 384 and 20 000 lanes), so everything is compiled with
-// FP contraction off and the accurate OCML exp/log/pow/sin/cos: parity (<= 1 fp16 ulp) matters, speed does not.
+// FP contraction off and correctly rounded exp/log/pow/sin/cos (below): parity (<= 1 fp16 ulp) matters, speed does not.
 // Citations: T: = cloud_sky/transmittance-lut.glsl, S: = cloud_sky/sky-lut.glsl.  Units: km.
 #pragma once
 #include "csky_common.h"
@@ -23,7 +23,24 @@ CSKY_HD F4 operator-(F4 a, F4 b) { return f4(a.x - b.x, a.y - b.y, a.z - b.z, a.
 CSKY_HD F4 operator*(F4 a, F4 b) { return f4(a.x * b.x, a.y * b.y, a.z * b.z, a.w * b.w); }
 CSKY_HD F4 operator/(F4 a, F4 b) { return f4(a.x / b.x, a.y / b.y, a.z / b.z, a.w / b.w); }
 CSKY_HD F4 operator*(F4 a, float s) { return f4(a.x * s, a.y * s, a.z * s, a.w * s); }
-CSKY_HD F4 exp4(F4 a) { return f4(expf(a.x), expf(a.y), expf(a.z), expf(a.w)); }
+// Transcendentals of the LUT kernels.  The oracle's glibc expf/logf/powf/sinf/cosf are correctly rounded in all but ~1e-5 of the
+// cases; OCML's float versions are 1-ulp functions, and the Hillaire integration S - S*exp(-dt*ext) (S:270) cancels and amplifies
+// that ulp to 3-4 fp16 ulp of the sky LUT.  On the device they are therefore evaluated in double and rounded once (correctly
+// rounded except ~1e-8 of the cases): these kernels are 16 384 + 20 000 x 30 lanes, the fp64 rate is irrelevant (25 us).
+#if defined(__HIP_DEVICE_COMPILE__)
+CSKY_HD float exp_cr(float x) { return (float)exp((double)x); }
+CSKY_HD float log_cr(float x) { return (float)log((double)x); }
+CSKY_HD float pow_cr(float x, float y) { return (float)pow((double)x, (double)y); }
+CSKY_HD float sin_cr(float x) { return (float)sin((double)x); }
+CSKY_HD float cos_cr(float x) { return (float)cos((double)x); }
+#else
+CSKY_HD float exp_cr(float x) { return expf(x); }
+CSKY_HD float log_cr(float x) { return logf(x); }
+CSKY_HD float pow_cr(float x, float y) { return powf(x, y); }
+CSKY_HD float sin_cr(float x) { return sinf(x); }
+CSKY_HD float cos_cr(float x) { return cosf(x); }
+#endif
+CSKY_HD F4 exp4(F4 a) { return f4(exp_cr(a.x), exp_cr(a.y), exp_cr(a.z), exp_cr(a.w)); }
 
 // T:89-98 / S:100-109
 CSKY_HD float ray_sphere_intersection(float ox, float oy, float oz, float dx, float dy, float dz, float radius) {
@@ -40,15 +57,15 @@ struct Coeffs { F4 aerosol_scattering, molecular_scattering, extinction; };
 // T:104-145 / S:132-135,170-202
 CSKY_HD Coeffs atmosphere_collision_coefficients(float h) {
     h = fmaxf(h, 0.0f);
-    const float aerosol_density = 1.3681e20f * (expf(-h / 0.73f) + (float)(2e6 / 1.3681e20));
+    const float aerosol_density = 1.3681e20f * (exp_cr(-h / 0.73f) + (float)(2e6 / 1.3681e20));
     const F4 aa = f4(2.8722e-24f, 4.6168e-24f, 7.9706e-24f, 1.3578e-23f) * aerosol_density;
     const F4 as = f4(1.5908e-22f, 1.7711e-22f, 2.0942e-22f, 2.4033e-22f) * aerosol_density;
     const float h2 = h + 1e-4f;
-    const float t = logf(h2) - 3.22261f;
-    const float ozone_density = 3.78547397e20f * (1.0f / h2) * expf(-t * t * 5.55555555f);
+    const float t = log_cr(h2) - 3.22261f;
+    const float ozone_density = 3.78547397e20f * (1.0f / h2) * exp_cr(-t * t * 5.55555555f);
     const F4 ma = f4((float)(3.472e-21 * 1e-4 * 350.0), (float)(3.914e-21 * 1e-4 * 350.0), (float)(1.349e-21 * 1e-4 * 350.0),
                      (float)(11.03e-23 * 1e-4 * 350.0)) * ozone_density;
-    const F4 ms = f4(6.605e-3f, 1.067e-2f, 1.842e-2f, 3.156e-2f) * expf(-0.07771971f * powf(h, 1.16364243f));
+    const F4 ms = f4(6.605e-3f, 1.067e-2f, 1.842e-2f, 3.156e-2f) * exp_cr(-0.07771971f * pow_cr(h, 1.16364243f));
     Coeffs c; c.aerosol_scattering = as; c.molecular_scattering = ms; c.extinction = aa + as + ma + ms;
     return c;
 }
@@ -99,7 +116,7 @@ CSKY_HD SkyRay sky_ray(int px, int py, float w, float h, const float sun[3]) {
     const float azimuth = (float)(2.0 * LUT_PI) * uvx;                                // S:286
     const float l = uvy * 2.0f - 1.0f;                                                // S:290
     const float elev = l * l * signf(l) * (float)LUT_PI * 0.5f;                       // S:291
-    r.rdx = cosf(elev) * cosf(azimuth); r.rdy = cosf(elev) * sinf(azimuth); r.rdz = sinf(elev);   // S:293-295
+    r.rdx = cos_cr(elev) * cos_cr(azimuth); r.rdy = cos_cr(elev) * sin_cr(azimuth); r.rdz = sin_cr(elev);   // S:293-295
     r.oz = 6371.5f;                                                                   // S:61-62
     const float atmos_dist = ray_sphere_intersection(0, 0, r.oz, r.rdx, r.rdy, r.rdz, ATMOSPHERE_RADIUS);
     const float ground_dist = ray_sphere_intersection(0, 0, r.oz, r.rdx, r.rdy, r.rdz, EARTH_RADIUS);
@@ -131,7 +148,7 @@ CSKY_HD SkyStep sky_step(const SkyRay& r, int i, const float4* trans, int tw, in
     const F4 T_g2s = transmittance_from_lut(trans, tw, th, 1.0f, 0.0f) / transmittance_from_lut(trans, tw, th, 1.0f, nalt);
     const float ks = (float)(0.25 * (1.0 / LUT_PI)) * omega * (float)(0.3 / LUT_PI);
     const F4 L_ground = f4(ks, ks, ks, ks) * T_to_ground * T_g2s * sct;
-    const float fm = 1.0f / (1.0f + 5.0f * expf(-17.92f * sct));
+    const float fm = 1.0f / (1.0f + 5.0f * exp_cr(-17.92f * sct));
     const F4 L_ms = f4((float)(0.02 * 0.217), (float)(0.02 * 0.347), (float)(0.02 * 0.594), (float)(0.02 * 1.0)) * fm;
     const F4 ms = L_ms + L_ground;
     const F4 irr = f4(1.679f, 1.828f, 1.986f, 1.307f);                               // S:67

@@ -3,12 +3,14 @@ import numpy as np
 
 
 class SkyLut:
-    """sky_lut.gd:1-148.  Renders the 200x100 sky-view LUT for a sun direction; keeps the reference's
-    three-copy ring (`texture_rd[3]`, `current_texture`, `back_texture[2]`, :16-18,143-146) so the compositor
-    can cross-fade between the last two copies.  The clouds kernel always binds the copy rendered LAST
-    (cloud_sky.gd:242), which is the library context's internal LUT."""
+    """sky_lut.gd:1-148.  Renders the 200x100 sky-view LUT for a sun direction and keeps the reference's three-copy ring
+    (`texture_rd[3]`, `current_texture`, `back_texture[2]`, :16-18,143-146): every render fills ring slot `current_texture` and
+    advances it, so `back_texture` = the two OLDER copies, which clouds.gdshader cross-fades as sky_blend_from/to
+    (cloud_sky.gd:147-148).  The clouds kernel always binds the copy rendered LAST (cloud_sky.gd:242), which is the library
+    context's internal LUT.  Ring copies are numpy float16 arrays (host form) or torch float16 CUDA tensors filled by an
+    asynchronous device copy (`device_buffers=True`: no host hop, no synchronisation in the frame loop)."""
 
-    def __init__(self, ctx, transmittance, texture_size=(200, 100), keep_host_copies=False):
+    def __init__(self, ctx, transmittance, texture_size=(200, 100), device_buffers=False):
         self.ctx = ctx
         self.transmittance_tex = transmittance          # sky_lut.gd:22
         self.texture_size = tuple(int(v) for v in texture_size)   # sky_lut.gd:4
@@ -17,8 +19,8 @@ class SkyLut:
         self.initialized = transmittance is not None
         self.needs_full_update = True
         self.current_texture = 0
-        self.keep_host_copies = keep_host_copies
-        self.texture = [None, None, None]               # host copies of texture_rd[0..2] (optional)
+        self.device_buffers = bool(device_buffers)
+        self.texture = [None, None, None]               # texture_rd[0..2]
         self.renders = 0
 
     def request_update(self):  # sky_lut.gd:39-40
@@ -41,17 +43,22 @@ class SkyLut:
 
     def render_lut(self, stream=None):  # sky_lut.gd:122-148 (dispatch 25 x 13 groups)
         w, h = self.texture_size
-        if self.keep_host_copies:
-            self.texture[self.current_texture] = self.ctx.render_sky_lut(self.light_direction, w, h)
-        else:
+        c = self.current_texture
+        if self.device_buffers:
+            import torch
             self.ctx.render_sky_lut_device(self.light_direction, w, h, stream)
+            if self.texture[c] is None:
+                self.texture[c] = torch.empty((h, w, 4), dtype=torch.float16, device=torch.device("cuda", self.ctx.device_id))
+            self.ctx.copy_sky_lut_device(self.texture[c].data_ptr(), stream)
+        else:
+            self.texture[c] = self.ctx.render_sky_lut(self.light_direction, w, h)
         self.renders += 1
-        self.current_texture = (self.current_texture + 1) % 3
+        self.current_texture = (c + 1) % 3
         self.needs_update = False
 
     @property
     def image(self):
-        """The LUT rendered last, float16 [h, w, 4]."""
+        """The LUT rendered last, float16 [h, w, 4] (host copy)."""
         return self.ctx.read_sky_lut()
 
     @property

@@ -30,7 +30,7 @@ extern "C" {
 #define CSKY_ERR_IO (-4)         /* asset file problem                                       */
 #define CSKY_ERR_STATE (-5)      /* e.g. clouds requested before noise / LUTs exist          */
 
-#define CSKY_ABI_VERSION 1
+#define CSKY_ABI_VERSION 2
 
 typedef struct csky_ctx csky_ctx; /* opaque: owns every device allocation, the HIP stream and events */
 
@@ -90,7 +90,9 @@ const char* csky_last_error(const csky_ctx* ctx); /* ctx may be NULL: last creat
 int csky_set_noise(csky_ctx* ctx, const uint8_t* large_rgba8, const uint8_t* small_rgb8, const uint8_t* weather_rgb8);
 /* The device layouts store finite differences of neighbouring texels as fp16 (exact for integers up to 2048).  Returns how
  * many coefficients of the textures bound by the last csky_set_noise did NOT fit exactly (0 for natural noise; only
- * adversarial checkerboards of extreme values exceed the range and then carry a relative 2^-11 error on that term). */
+ * adversarial checkerboards of extreme values exceed the range and then carry a relative 2^-11 error on that term).
+ * csky_set_noise still returns CSKY_OK in that case but leaves a warning text in csky_last_error(ctx); callers that need the
+ * exact-parity guarantee must check this count (the Python binding warns, bench.py and smoke() assert it is 0). */
 int csky_noise_inexact_coeffs(csky_ctx* ctx, uint64_t* count);
 /* clouds.glsl:228 (128 primary steps) and clouds.glsl:186 (6 light steps) are literals in the reference;
  * this generalises them (BASELINE config 2 is 64 x 4).  light_steps in [0,6], primary_steps in [1,1024]. */
@@ -116,13 +118,21 @@ int csky_render_clouds(csky_ctx* ctx, const csky_cloud_params* p, int tile_w, in
 
 /* ---- device-buffer forms (no host copy, asynchronous on `hip_stream`) -----------------------------
  * d_out is a DEVICE pointer the caller owns (e.g. a torch tensor's data_ptr); hip_stream is a
- * hipStream_t passed as void* (NULL = the context's own stream).  The LUT inputs of later calls are
+ * hipStream_t passed as void*.  NULL = the context's own stream, which is created NON-BLOCKING: work on it is NOT ordered
+ * against the HIP null stream (and a null-stream handle cannot be told apart from NULL).  A caller whose own work runs on the
+ * null stream (torch's default stream) must therefore pass a real stream and order it with events on both sides, e.g.
+ * side.wait_stream(default) / default.wait_stream(side): the Python host class does exactly that (cloud_sky.py::_march_stream).
+ * The LUT inputs of later calls are
  * always the context's internal copies, so the chain transmittance -> sky -> clouds needs no host hop.
  * The sky LUT and the per-frame constants derived from it are rendered on an internal "prologue" stream into two-deep
  * rings (like the reference's texture rings, sky_lut.gd:143-146): when frames are enqueued back to back, the prologue of
  * frame k+1 overlaps the march of frame k.  The library orders prologue -> march -> reuse of a ring slot with events, so a
  * caller only has to order its own reads of d_out behind `hip_stream`; csky_render_sky_lut_device ignores `hip_stream`. */
 int csky_render_sky_lut_device(csky_ctx* ctx, const csky_sky_params* p, void* hip_stream);
+/* Copy the sky LUT rendered last (RGBA16F, w*h*8 bytes) into a caller-owned DEVICE buffer, asynchronously; the copy is ordered
+ * behind the LUT's render and `hip_stream` is made to wait for it.  What sky_lut.gd:143-146 does by rotating texture_rd[3]: a host
+ * that wants the reference's three-deep ring of LUT copies (for clouds.gdshader's sky_blend_from/to) keeps them with this. */
+int csky_copy_sky_lut_device(csky_ctx* ctx, void* d_out_rgba16f, void* hip_stream);
 int csky_render_clouds_device(csky_ctx* ctx, const csky_cloud_params* p, int tile_w, const csky_bands* bands,
                               void* d_out_rgba16f, size_t row_pitch_bytes, void* hip_stream);
 int csky_sync(csky_ctx* ctx); /* wait for the context's own streams (work on caller streams is the caller's to wait for) */
@@ -157,7 +167,8 @@ int csky_time_clouds(csky_ctx* ctx, const csky_cloud_params* p, int tile_w, cons
 int csky_get_cloud_stats(csky_ctx* ctx, csky_cloud_stats* stats); /* tallies of the last stats-enabled launch */
 /* Per-launch timing of the cloud kernel inside the caller's own frame loop: while enabled, every csky_render_clouds* launch is
  * bracketed by a pair of HIP events recorded on the stream the kernel is launched on.  csky_get_kernel_ms waits for the launches
- * recorded since the last call (at most the last 256), returns the sum of their durations and their number, and resets. */
+ * recorded since the last call (all of them: the event pool grows on demand), returns the sum of their durations and their
+ * number, and resets. */
 int csky_set_kernel_timing(csky_ctx* ctx, int enabled);
 int csky_get_kernel_ms(csky_ctx* ctx, float* total_ms, int* launches);
 /* Kernel variant selector for A/B measurement (csky_variant_name lists them).  -1 = the default = the fastest measured
@@ -168,13 +179,14 @@ int csky_set_variant(csky_ctx* ctx, int variant);
  * 0 disables it (A/B measurement, identical results). */
 int csky_set_height_window(csky_ctx* ctx, int enabled);
 int csky_variant_count(void);
-/* Workgroup -> XCD schedule (tuning knob, results are identical): -1 = auto (default: 5 for whole frames, 7 for a share of a
- * frame such as one GPU's 1/2 .. 1/8, 2 for tile-sized launches);
- * 5 = slab rows round-robin over the XCDs;
- * 1 = contiguous eighths; 2 = natural order; 0/3/4 = azimuth wedges; 6 = 5 with horizon rows first;
+/* Workgroup -> XCD schedule (tuning knob, results are identical): -1 = auto (see api.cpp::clouds_dev for the launch-size policy);
+ * 5 = slab rows round-robin over the XCDs; 1 = contiguous eighths; 2 = natural order (all three written on the device);
  * 7 = cost feedback: every launch records a cost per workgroup (in-cloud samples) and the next launch of the same geometry
- *     and view starts its workgroups heaviest first (the first launch runs in a static order).  Only the ORDER comes from the
- *     previous launch; every sample is recomputed. */
+ *     and view starts its workgroups heaviest first (the first launch runs in a static order);
+ * 8 = deadline feedback: order 5, except that workgroups whose previous-launch cost says they would finish after everybody
+ *     else are moved forward just far enough (kernels.hip::deadline_order_kernel): removes the launch tail of a lone frame
+ *     without breaking up neighbours.  Under 7 and 8 only the ORDER comes from the previous launch; every sample is recomputed.
+ * (0, 3, 4, 6 were azimuth-wedge / horizon-first orders of round 1, measured slower and removed.) */
 int csky_set_schedule(csky_ctx* ctx, int mode);
 /* Ray segments: the primary march of every ray is cut into `segments` pieces marched by different wavefronts of one
  * workgroup and composited front to back (T and L are associative).  0 = auto (whole rays for large launches, 2 or 4
@@ -186,6 +198,33 @@ int csky_set_segments(csky_ctx* ctx, int segments);
  * next frame then fills the tail of this one and fewer, longer wavefronts are the better choice for partial frames.  Default 1. */
 int csky_set_frames_in_flight(csky_ctx* ctx, int frames);
 const char* csky_variant_name(int variant);
+
+/* ---- multi-GPU: the devices of one node behind one handle ------------------------------
+ * One host thread drives n devices.  Rays are independent and the reference already renders disjoint tiles addressed by
+ * update_position with frozen parameters (cloud_sky.gd:54-55,142,156-161): device i of n renders the 8-row bands i, i+n, ...
+ * (interleaved for balance) with the same push-constant block, inputs replicated, and its wavefronts store their pixels
+ * STRAIGHT into the frame on the first device through xGMI peer access (64 contiguous bytes per tile row): there is no staging
+ * buffer, no gather step and no host hop.  Every device renders its own copy of the two LUTs (36 K texels: cheaper than a
+ * broadcast).  Events order the consumer stream on the first device behind all marches.  A device id may appear more than once
+ * (two contexts sharing one GPU): meaningless for speed, it lets a single-GPU box exercise the n > 1 path.
+ * csky_multi_ctx(m, i) gives the per-device context for the per-context settings (csky_set_march, csky_set_variant, ...);
+ * csky_multi_set_* apply one setting to all of them. */
+typedef struct csky_multi csky_multi;
+int csky_multi_create(csky_multi** out, const int* device_ids, int n_devices);
+void csky_multi_destroy(csky_multi* m);
+int csky_multi_device_count(const csky_multi* m);
+csky_ctx* csky_multi_ctx(csky_multi* m, int i);
+const char* csky_multi_last_error(const csky_multi* m);
+int csky_multi_set_noise(csky_multi* m, const uint8_t* large_rgba8, const uint8_t* small_rgb8, const uint8_t* weather_rgb8);
+int csky_multi_set_march(csky_multi* m, int primary_steps, int light_steps);
+int csky_multi_render_sky_lut(csky_multi* m, const csky_sky_params* p);
+/* Whole tile [0,tile_w) x [0,tile_h) into d_out on the FIRST device (row pitch in bytes), asynchronously: `hip_stream` (a stream of
+ * the first device; NULL = that context's own stream) is ordered behind every device's march.  tile_h must be a multiple of 8. */
+int csky_multi_render_clouds_device(csky_multi* m, const csky_cloud_params* p, int tile_w, int tile_h, void* d_out_rgba16f,
+                                    size_t row_pitch_bytes, void* hip_stream);
+/* Host-buffer form: renders as above into an internal frame on the first device, copies it out, blocks. */
+int csky_multi_render_clouds(csky_multi* m, const csky_cloud_params* p, int tile_w, int tile_h, uint16_t* out_rgba16f, size_t row_pitch_bytes);
+int csky_multi_sync(csky_multi* m);
 
 /* ---- asset layer (host only; usable without a GPU) ------------------------------------------------
  * What the reference gets from Godot's importers (weather.bmp.import, worlnoise.bmp.import,

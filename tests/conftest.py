@@ -8,6 +8,8 @@ import pytest
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
+if os.path.dirname(os.path.abspath(__file__)) not in sys.path:
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 
 GOLDEN = os.path.join(ROOT, "tests", "golden")
 SUNS = {"zenith": (0.0, 1.0, 0.0), "deg45": (1.0, 1.0, 0.0), "demo": (-0.998773, 0.0495291, 2.69869e-07)}
@@ -80,8 +82,9 @@ def ulp_diff(a, b):
 
 
 def cloud_close(test, ref, frac=0.999, atol=2e-3, rtol=1e-2):
-    """The stated cloud tolerance: per channel |d| <= 2e-3 + 1e-2*|ref| on >= 99.9 % of values, all
-    finite, and PSNR >= 50 dB on RGB."""
+    """The LOOSE cloud tolerance of SURVEY §8c (per channel |d| <= 2e-3 + 1e-2*|ref| on >= 99.9 % of values, all finite, PSNR >= 50 dB
+    on RGB).  Round 2 keeps it only for adversarial inputs (white noise, kernel-variant cross-checks); everything rendered from the
+    shipped assets goes through `cloud_tight` below."""
     a, b = np.asarray(test, np.float32), np.asarray(ref, np.float32)
     assert np.isfinite(a).all()
     err = np.abs(a - b)
@@ -89,7 +92,29 @@ def cloud_close(test, ref, frac=0.999, atol=2e-3, rtol=1e-2):
     mse = float(((a[..., :3] - b[..., :3]) ** 2).mean())
     peak = max(float(b[..., :3].max()), 1e-6)
     psnr = 10 * np.log10(peak * peak / max(mse, 1e-20))
+    _log_parity("loose", test, ref)
     return ok >= frac and psnr >= 50.0, dict(ok=float(ok), psnr=float(psnr), max_err=float(err.max()))
+
+
+def _log_parity(kind, test, ref):
+    """CSKY_PARITY_LOG=<file>: append the ulp statistics of every cloud comparison (how the gates were calibrated)."""
+    path = os.environ.get("CSKY_PARITY_LOG")
+    if path:
+        import json
+        from parity_metrics import cloud_ulp_stats
+        s = cloud_ulp_stats(test, ref)
+        s["gate"] = kind
+        s["test"] = os.environ.get("PYTEST_CURRENT_TEST", "")
+        with open(path, "a") as f:
+            f.write(json.dumps(s) + "\n")
+
+
+def cloud_tight(test, ref, **kw):
+    """The round-2 gate (thresholds and their calibration: tests/parity_metrics.py): >= 99.99 % of pixels with every
+    channel within 2 fp16 ulp-equivalents of the oracle, >= 99.9 % of values within 1, max |d| <= 2e-3, PSNR >= 70 dB."""
+    from parity_metrics import cloud_tight as _tight
+    _log_parity("tight", test, ref)
+    return _tight(test, ref, **kw)
 
 
 @pytest.fixture(scope="session")

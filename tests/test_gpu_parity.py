@@ -1,13 +1,15 @@
 """-m gpu: the HIP path through the C ABI (libcloudsky.so) vs the CPU oracle on the same seeded inputs, vs the
 committed numpy fixtures, and -- at BASELINE's full sizes -- through size-independent properties.
-Tolerances (stated): transmittance LUT <= 2 fp16 ulp; sky LUT <= 4 fp16 ulp with >= 99 % of texels within 1 ulp; clouds per channel |d| <= 2e-3 + 1e-2*|ref| on >= 99.9 % of
-values, PSNR >= 50 dB on RGB, in-cloud sample counts within 0.1 %."""
+Tolerances (stated; round 2, tightened to what the kernels achieve): transmittance and sky LUT <= 1 fp16 ulp (measured 0 and 1: the
+LUT kernels use correctly rounded transcendentals); clouds from the shipped assets: `cloud_tight` = >= 99.99 % of values within 2 fp16
+ulp-equivalents of the oracle, max |d| <= 2e-3, PSNR >= 70 dB (full C2/C3 frames: tests/test_gpu_round2.py); the loose SURVEY bound
+(`cloud_close`: |d| <= 2e-3 + 1e-2*|ref| on >= 99.9 %) survives only for adversarial white-noise inputs and kernel-variant cross-checks."""
 import os
 
 import numpy as np
 import pytest
 
-from conftest import GOLDEN, SUNS, cloud_close, norm, ulp_diff
+from conftest import GOLDEN, SUNS, cloud_close, cloud_tight, norm, ulp_diff
 
 pytestmark = pytest.mark.gpu
 
@@ -21,7 +23,7 @@ def test_native_library_is_what_runs(pkg, gpu_ctx):
 def test_transmittance_lut(gpu_ctx, o_trans):
     t = gpu_ctx.render_transmittance(256, 64)
     d = ulp_diff(t, o_trans)
-    assert d.max() <= 2, d.max()
+    assert d.max() <= 1 and (d > 0).mean() < 1e-3, (d.max(), (d > 0).mean())   # measured: bit-identical (correctly rounded transcendentals, lut_core.h)
     g = np.load(os.path.join(GOLDEN, "transmittance_lut_np.npz"))["lut"].view(np.float16)
     assert ulp_diff(t, g).max() <= 2
     assert (gpu_ctx.read_transmittance().view(np.uint16) == t.view(np.uint16)).all()
@@ -29,7 +31,7 @@ def test_transmittance_lut(gpu_ctx, o_trans):
 
 def test_transmittance_other_size(gpu_ctx, oracle):
     t = gpu_ctx.render_transmittance(64, 16)
-    assert ulp_diff(t, oracle.transmittance_lut(64, 16)).max() <= 2
+    assert ulp_diff(t, oracle.transmittance_lut(64, 16)).max() <= 1
     gpu_ctx.render_transmittance(256, 64)
 
 
@@ -39,7 +41,7 @@ def test_sky_lut(gpu_ctx, o_skies):
     for k, sun in SUNS.items():
         s = gpu_ctx.render_sky_lut(norm(sun), 200, 100)
         d = ulp_diff(s, o_skies[k])
-        assert d.max() <= 4 and (d <= 1).mean() >= 0.99 and (d > 0).mean() < 0.05, (k, d.max(), (d > 0).mean())
+        assert d.max() <= 1 and (d > 0).mean() < 0.02, (k, d.max(), (d > 0).mean())
         assert ulp_diff(s, g[k].view(np.float16)).max() <= 5    # the numpy fixture is itself +-1 ulp from the oracle
         assert (gpu_ctx.read_sky_lut().view(np.uint16) == s.view(np.uint16)).all()
 
@@ -56,7 +58,7 @@ def test_clouds_vs_oracle_default_config(gpu_ctx, oracle, otex, o_skies, sun_nam
     img = gpu_ctx.render_clouds(p)
     st = gpu_ctx.cloud_stats()
     ref, st_o = oracle.clouds(otex, p, o_skies[sun_name], nthreads=oracle.max_threads(), return_stats=True)
-    ok, info = cloud_close(img, ref)
+    ok, info = cloud_tight(img, ref)
     assert ok, info
     assert abs(int(st["incloud_samples"]) - st_o["incloud_samples"]) <= 1e-3 * st_o["incloud_samples"]
     assert st["primary_samples"] == st_o["primary_samples"]
@@ -73,7 +75,7 @@ def test_variants_and_schedules_agree(gpu_ctx, oracle):
     p = oracle.default_params(256, 128, (1, 1, 0))
     imgs = {}
     for v in (0, 1):
-        for sch in (0, 1, 2, 3, 4, 5, 6, 7, 7):                    # 7 twice: the second launch runs in the cost-sorted order
+        for sch in (1, 2, 5, 7, 7, 8, 8):                          # 7 / 8 twice: the second launch runs in the feedback order
             gpu_ctx.set_variant(v); gpu_ctx.set_schedule(sch)
             img = gpu_ctx.render_clouds(p)
             st = gpu_ctx.cloud_stats()
@@ -95,7 +97,7 @@ def test_variants_and_schedules_agree(gpu_ctx, oracle):
     gpu_ctx.set_variant(3)
     for seg in (1, 2, 4):
         gpu_ctx.set_segments(seg)
-        for sch in (5, 2, 7, 7):
+        for sch in (5, 2, 7, 7, 8, 8, 9):                       # 9: mixed-segment launch (whole rays, then 2- and 4-segment workgroups)
             gpu_ctx.set_schedule(sch)
             img = gpu_ctx.render_clouds(p)
             ok, info = cloud_close(img, imgs[1][0], frac=0.9999, atol=5e-4, rtol=2e-3)
@@ -120,7 +122,7 @@ def test_clouds_vs_numpy_fixture(gpu_ctx, oracle):
     for k, sun in SUNS.items():
         gpu_ctx.render_sky_lut(norm(sun), 200, 100)
         img = gpu_ctx.render_clouds(oracle.default_params(64, 32, sun))
-        ok, info = cloud_close(img, g[k].view(np.float16))
+        ok, info = cloud_tight(img, g[k].view(np.float16))
         assert ok, (k, info)
 
 
@@ -131,7 +133,7 @@ def test_config_c2_512x256_64x4_zenith(gpu_ctx, oracle, otex, o_skies):
     p = oracle.default_params(512, 256, (0, 1, 0))
     img = gpu_ctx.render_clouds(p)
     ref = oracle.clouds(otex, p, o_skies["zenith"], primary_steps=64, light_steps=4, nthreads=oracle.max_threads())
-    ok, info = cloud_close(img, ref)
+    ok, info = cloud_tight(img, ref)
     assert ok, info
     gpu_ctx.set_march(128, 6)
 
@@ -148,7 +150,7 @@ def test_segments_vs_oracle_ragged(gpu_ctx, oracle, otex, o_skies, seg, variant)
         p = oracle.default_params(90, 42, (1, 1, 0))
         img = gpu_ctx.render_clouds(p, 45, 21)
         ref = oracle.clouds(otex, p, o_skies["deg45"], rect=(0, 0, 45, 21), primary_steps=steps)
-        ok, info = cloud_close(img, ref)
+        ok, info = cloud_tight(img, ref)
         assert ok, (steps, info)
     gpu_ctx.set_march(128, 6); gpu_ctx.set_segments(0); gpu_ctx.set_variant(-1)
 
@@ -163,14 +165,14 @@ def test_windy_offset_tile(gpu_ctx, oracle, otex):
     d = ulp_diff(gpu_ctx.read_sky_lut(), sk_o)
     # LUT tolerance vs the C oracle: the Hillaire integration (sky-lut.glsl:270) computes S - S*exp(-dt*ext), which
     # cancels when dt*ext is small and amplifies the 1-ulp fp32 difference between OCML and glibc exp/pow
-    assert d.max() <= 4 and (d <= 1).mean() >= 0.99, (d.max(), (d <= 1).mean())
+    assert d.max() <= 1, (d.max(), (d <= 1).mean())
     assert ulp_diff(gpu_ctx.read_sky_lut(), g["windy_sky"].view(np.float16)).max() <= 5   # numpy fixture is itself +-1 from the oracle
     img = gpu_ctx.render_clouds(pw, 45, 21)                         # ragged: 45 x 21
     ref = oracle.clouds(otex, pw, g["windy_sky"].view(np.float16), rect=(0, 0, 45, 21), primary_steps=64, light_steps=4)
-    ok, info = cloud_close(img, ref)
+    ok, info = cloud_tight(img, ref)
     assert ok, info
     fix = g["windy"].view(np.float16)                                # numpy fixture: rect (8,4,48,24) of the same tile space
-    ok, info = cloud_close(img[4:21, 8:45], fix[:17, :37])
+    ok, info = cloud_tight(img[4:21, 8:45], fix[:17, :37])
     assert ok, info
     gpu_ctx.set_march(128, 6)
 
@@ -234,7 +236,7 @@ def test_edge_cases(pkg, gpu_ctx, oracle, otex, o_skies):
     gpu_ctx.render_sky_lut(norm((0, -1, 0)), 200, 100)
     p = oracle.default_params(64, 32, (0, -1, 0))
     sk = oracle.sky_lut(norm((0, -1, 0)), oracle.transmittance_lut())
-    ok, info = cloud_close(gpu_ctx.render_clouds(p), oracle.clouds(otex, p, sk))
+    ok, info = cloud_tight(gpu_ctx.render_clouds(p), oracle.clouds(otex, p, sk))
     assert ok, info
     # 1 x 1 tile, 8 x 8 texture
     tiny = gpu_ctx.render_clouds(oracle.default_params(8, 8, (0, 1, 0)), 1, 1)
@@ -243,7 +245,7 @@ def test_edge_cases(pkg, gpu_ctx, oracle, otex, o_skies):
     gpu_ctx.set_march(1024, 6)
     gpu_ctx.render_sky_lut(norm((0, 1, 0)), 200, 100)
     p = oracle.default_params(16, 8, (0, 1, 0))
-    ok, info = cloud_close(gpu_ctx.render_clouds(p), oracle.clouds(otex, p, o_skies["zenith"], primary_steps=1024))
+    ok, info = cloud_tight(gpu_ctx.render_clouds(p), oracle.clouds(otex, p, o_skies["zenith"], primary_steps=1024))
     assert ok, info
     gpu_ctx.set_march(128, 6)
 
@@ -257,7 +259,7 @@ def test_error_behaviour(pkg, noise):
     with pytest.raises(pkg.CloudSkyError) as e:                      # no textures bound yet: nothing to report on
         ctx.noise_inexact_coeffs()
     assert e.value.code == pkg._lib.ERR_STATE
-    for bad in (-2, 8):
+    for bad in (-2, 0, 3, 4, 6, 10):                               # 0/3/4/6: round-1 wedge orders, removed
         with pytest.raises(pkg.CloudSkyError) as e:
             ctx.set_schedule(bad)
         assert e.value.code == pkg._lib.ERR_INVALID
@@ -280,7 +282,7 @@ def test_error_behaviour(pkg, noise):
 
 
 def test_full_size_c3_properties(gpu_ctx, oracle, otex, o_skies):
-    """BASELINE configs[2] (2048x1024 @ 128x6): size-independent properties + oracle parity on sampled 8x8 tiles."""
+    """BASELINE configs[2] (2048x1024 @ 128x6): size-independent properties (full-frame oracle parity: test_gpu_round2.py)."""
     gpu_ctx.set_march(128, 6)
     gpu_ctx.render_sky_lut(norm((1, 1, 0)), 200, 100)
     W, H = 2048, 1024
@@ -295,12 +297,7 @@ def test_full_size_c3_properties(gpu_ctx, oracle, otex, o_skies):
     assert st["rays"] == W * H and st["primary_samples"] == (W - 1) * (H - 1) * 128
     assert 0.3 < f[..., 3].mean() < 0.7
     assert (gpu_ctx.render_clouds(p).view(np.uint16) == img.view(np.uint16)).all()   # idempotent / deterministic
-    rng = np.random.default_rng(5)
-    for _ in range(24):                                                        # oracle parity on random 8x8 tiles
-        tx, ty = int(rng.integers(0, W // 8)) * 8, int(rng.integers(0, H // 8)) * 8
-        ref = oracle.clouds(otex, p, o_skies["deg45"], rect=(tx, ty, 8, 8))
-        a, b = f[ty:ty + 8, tx:tx + 8], ref.astype(np.float32)
-        assert (np.abs(a - b) <= 2e-3 + 1e-2 * np.abs(b)).mean() >= 0.98, (tx, ty)
+    # oracle parity of this frame: the WHOLE frame at the tightened gate, tests/test_gpu_round2.py::test_full_frame_c3_vs_oracle_tight
 
 
 def test_full_size_c5_subsamples_to_c3(gpu_ctx, oracle):
@@ -327,7 +324,7 @@ def test_cloud_sky_host_class_on_gpu(pkg, noise, oracle, otex, o_skies):
     tex = sky.update_sky()
     torch.cuda.synchronize()
     ref = oracle.clouds(otex, oracle.default_params(128, 64, (1, 1, 0)), o_skies["deg45"])
-    ok, info = cloud_close(tex.cpu().numpy(), ref)
+    ok, info = cloud_tight(tex.cpu().numpy(), ref)
     assert ok, info
     sky.close()
 
@@ -362,9 +359,9 @@ def test_sun_sweep_time_of_day(gpu_ctx, oracle, otex, o_trans):
         sk = gpu_ctx.render_sky_lut(sun, 200, 100)
         sk_o = oracle.sky_lut(sun, o_trans)
         d = ulp_diff(sk, sk_o)
-        assert d.max() <= 4 and (d <= 1).mean() >= 0.99, (th, d.max())
+        assert d.max() <= 1, (th, d.max())
         p = oracle.default_params(128, 64, sun)
-        ok, info = cloud_close(gpu_ctx.render_clouds(p), oracle.clouds(otex, p, sk_o))
+        ok, info = cloud_tight(gpu_ctx.render_clouds(p), oracle.clouds(otex, p, sk_o))
         assert ok, (th, info)
 
 
@@ -373,7 +370,7 @@ def test_texture_size_limits(gpu_ctx, oracle, otex, o_skies):
     gpu_ctx.set_march(128, 6)
     gpu_ctx.render_sky_lut(norm((1, 1, 0)), 200, 100)
     p = oracle.default_params(32, 32, (1, 1, 0))
-    ok, info = cloud_close(gpu_ctx.render_clouds(p), oracle.clouds(otex, p, o_skies["deg45"]))
+    ok, info = cloud_tight(gpu_ctx.render_clouds(p), oracle.clouds(otex, p, o_skies["deg45"]))
     assert ok, info
     W = H = 8192
     p = oracle.default_params(W, H, (1, 1, 0))
@@ -381,7 +378,7 @@ def test_texture_size_limits(gpu_ctx, oracle, otex, o_skies):
     assert np.isfinite(band).all() and (band[0] == 0).all() and (band[:, 0] == 0).all() and band[..., 3].max() <= 1
     q = p.copy(); q[2:4] = (4096 - 32, 4096 - 32)                      # a 64x64 tile around the zenith pixel
     tile = gpu_ctx.render_clouds(q, 64, 64)
-    ok, info = cloud_close(tile, oracle.clouds(otex, q, o_skies["deg45"], rect=(0, 0, 64, 64)))
+    ok, info = cloud_tight(tile, oracle.clouds(otex, q, o_skies["deg45"], rect=(0, 0, 64, 64)))
     assert ok, info
 
 
@@ -427,10 +424,10 @@ def test_fuzz_parameters_vs_oracle(gpu_ctx, oracle, otex, o_trans):
             gpu_ctx.render_sky_lut(sun, 200, 100)
             sk = oracle.sky_lut(sun, o_trans)
             d = ulp_diff(gpu_ctx.read_sky_lut(), sk)
-            assert d.max() <= 4 and (d <= 1).mean() >= 0.99, (seed, d.max())
+            assert d.max() <= 1, (seed, d.max())
             ref, st = oracle.clouds(otex, p, sk, rect=(0, 0, tw, th), primary_steps=primary, light_steps=light, return_stats=True)
             img = gpu_ctx.render_clouds(p, tw, th)
-            ok, info = cloud_close(img, ref)
+            ok, info = cloud_tight(img, ref)
             assert ok, (seed, info)
             got = int(gpu_ctx.cloud_stats()["incloud_samples"])
             assert abs(got - st["incloud_samples"]) <= 1e-3 * st["incloud_samples"] + 2, (seed, got, st["incloud_samples"])
@@ -491,7 +488,7 @@ def test_stratus_only_weather_map(pkg, noise, oracle, o_trans):
             p = oracle.default_params(128, 64, (1, 1, 0), coverage=cov)
             ref, st = oracle.clouds(otex, p, sk, return_stats=True)
             img = ctx.render_clouds(p)
-            ok, info = cloud_close(img, ref)
+            ok, info = cloud_tight(img, ref)
             assert ok, (cov, info)
             assert st["incloud_samples"] > 0 and int(ctx.cloud_stats()["incloud_samples"]) == st["incloud_samples"], cov
             ctx.set_height_window(0)

@@ -1,0 +1,60 @@
+#!/usr/bin/env python
+"""Full-frame parity statistics, HIP (C ABI) vs the CPU oracle, at BASELINE's C2 and C3 sizes: the numbers the tightened
+gates of tests/test_gpu_parity.py are written against (GPU box; the oracle renders on all granted host cores)."""
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+import gvcd_amd  # noqa: E402
+from oracle import oracle as O  # noqa: E402
+from parity_metrics import cloud_ulp_stats  # noqa: E402
+from bench import usable_cores  # noqa: E402
+
+CASES = [("C2 512x256 64x4 zenith", 512, 256, 64, 4, (0.0, 1.0, 0.0)),
+         ("C3 2048x1024 128x6 sun45", 2048, 1024, 128, 6, (1.0, 1.0, 0.0)),
+         ("C3 2048x1024 128x6 demo-scene sun", 2048, 1024, 128, 6, (-0.998773, 0.0495291, 2.69869e-07)),
+         ("C3 2048x1024 128x6 zenith", 2048, 1024, 128, 6, (0.0, 1.0, 0.0))]
+
+
+def main():
+    large, small, weather = gvcd_amd.assets.load_default_noise()
+    ctx = gvcd_amd.Context(0)
+    ctx.set_noise(large, small, weather)
+    ctx.render_transmittance(256, 64)
+    tex = O.OracleTextures(large, small, weather)
+    tr = O.transmittance_lut(256, 64)
+    cores = max(1, min(O.max_threads(), usable_cores()))
+    out = []
+    for name, W, H, prim, light, sun in CASES:
+        s = np.asarray(sun, np.float64)
+        s = (s / np.linalg.norm(s)).astype(np.float32)
+        ctx.set_march(prim, light)
+        ctx.render_sky_lut(s, 200, 100)
+        p = O.default_params(W, H, sun)
+        img = ctx.render_clouds(p)
+        st = ctx.cloud_stats()
+        t0 = time.perf_counter()
+        ref, st_o = O.clouds(tex, p, O.sky_lut(s, tr, 200, 100), primary_steps=prim, light_steps=light, nthreads=cores, return_stats=True)
+        dt = time.perf_counter() - t0
+        d = cloud_ulp_stats(img, ref)
+        d.update(case=name, oracle_s=dt, cores=cores, incloud_gpu=int(st["incloud_samples"]), incloud_oracle=int(st_o["incloud_samples"]),
+                 primary_gpu=int(st["primary_samples"]), primary_oracle=int(st_o["primary_samples"]))
+        # where the values beyond 2 ulp sit: per-channel counts and the largest few
+        a, b = img.astype(np.float64), ref.astype(np.float64)
+        err = np.abs(a - b)
+        idx = np.argsort(err.reshape(-1))[-5:][::-1]
+        d["worst"] = [dict(y=int(i // (W * 4)), x=int((i // 4) % W), c=int(i % 4), test=float(a.reshape(-1)[i]), ref=float(b.reshape(-1)[i])) for i in idx]
+        out.append(d)
+        print(json.dumps(d), flush=True)
+    ctx.close()
+
+
+if __name__ == "__main__":
+    main()
