@@ -1,0 +1,349 @@
+/*
+ * cloudsky_gdextension.c -- the thin GDExtension shim over libcloudsky's C ABI (include/cloudsky.h).
+ *
+ * It registers ONE class, `CloudSkyHIP` (extends RefCounted), whose methods are the dispatch sites of the reference's
+ * GDScript drivers, so that cloud_sky.gd / sky_lut.gd / transmittance_lut.gd keep their resources, textures and
+ * materials and only swap the RenderingDevice dispatch for a call + `rd.texture_update()` (INTEGRATION.md shows the
+ * GDScript diff; the textures are created with TEXTURE_USAGE_CAN_UPDATE_BIT already: cloud_sky.gd:376, sky_lut.gd:91,
+ * transmittance_lut.gd:44):
+ *
+ *   create(device_id: int) -> int                                   cloud_sky.gd:355-408 `_initialize_compute_code`
+ *   set_noise(large, small, weather: PackedByteArray) -> int        cloud_sky.gd:298-341 `_create_noise_uniform_set`
+ *   set_march(primary_steps, light_steps: int) -> int               clouds.glsl:228 / :186 (literals in the reference)
+ *   render_transmittance(pc: PackedFloat32Array) -> PackedByteArray transmittance_lut.gd:66-77   (pc = its 4-float push constant)
+ *   render_sky_lut(pc: PackedFloat32Array) -> PackedByteArray       sky_lut.gd:122-148           (pc = its 8-float push constant)
+ *   render_clouds(pc: PackedFloat32Array, tile_w, tile_h: int) -> PackedByteArray
+ *                                                                   cloud_sky.gd:234-248         (pc = `_fill_push_constant()`, 28 floats)
+ *   get_status() -> int                                             0 or the CSKY_ERR_* code of the last call
+ *   get_last_error() -> String
+ *
+ * The render methods return the image as tightly packed RGBA16F bytes (what texture_update takes); on error they
+ * return an empty array and get_status() / get_last_error() say why.  Nothing here computes anything: every method is
+ * argument marshalling around one csky_* call.
+ *
+ * Build: gdext/Makefile.  Against a real engine define CSKY_HAVE_GODOT_HEADERS and put Godot's own
+ * gdextension_interface.h on the include path; in this repository it is compiled against gdextension_min.h and run
+ * against tests/gdext_mock_host.c (Godot is on neither box).
+ */
+#ifdef CSKY_HAVE_GODOT_HEADERS
+#include <gdextension_interface.h>
+#else
+#include "gdextension_min.h"
+#endif
+#include <string.h>
+#include "../include/cloudsky.h"
+
+/* builtin-method lookup (PackedByteArray.size / .resize) and default constructor: declared here because the minimal
+ * header keeps to plain typedefs */
+typedef void (*csky_builtin_method)(GDExtensionTypePtr p_base, const GDExtensionConstTypePtr *p_args, GDExtensionTypePtr r_return, int p_argument_count);
+typedef csky_builtin_method (*csky_get_builtin_method)(GDExtensionVariantType p_type, GDExtensionConstStringNamePtr p_method, GDExtensionInt p_hash);
+typedef void (*csky_ptr_constructor)(GDExtensionTypePtr p_base, const GDExtensionConstTypePtr *p_args);
+typedef csky_ptr_constructor (*csky_get_ptr_constructor)(GDExtensionVariantType p_type, int32_t p_constructor);
+
+/* method hashes from Godot 4.2's extension_api.json (builtin_classes / PackedByteArray, PackedFloat32Array) */
+#define CSKY_HASH_PACKED_SIZE 3173160232LL
+#define CSKY_HASH_PACKED_RESIZE 848867239LL
+
+#define CSKY_OPAQUE 16 /* sizeof(PackedByteArray) == sizeof(PackedFloat32Array) == 16 on 64-bit builds */
+typedef struct { uint8_t opaque[CSKY_OPAQUE]; } csky_packed;
+typedef struct { uint8_t opaque[8]; } csky_name;   /* StringName */
+typedef struct { uint8_t opaque[8]; } csky_string; /* String */
+typedef struct { uint8_t opaque[24]; } csky_variant;
+
+static struct {
+    GDExtensionClassLibraryPtr library;
+    GDExtensionInterfaceMemAlloc mem_alloc;
+    GDExtensionInterfaceMemFree mem_free;
+    GDExtensionInterfaceStringNameNewWithLatin1Chars string_name_new;
+    GDExtensionInterfaceStringNewWithUtf8Chars string_new;
+    GDExtensionInterfacePackedByteArrayOperatorIndex pba_index;
+    GDExtensionInterfacePackedByteArrayOperatorIndexConst pba_index_const;
+    GDExtensionInterfacePackedFloat32ArrayOperatorIndexConst pfa_index_const;
+    GDExtensionInterfaceClassdbConstructObject construct_object;
+    GDExtensionInterfaceObjectSetInstance object_set_instance;
+    GDExtensionInterfaceClassdbRegisterExtensionClass2 register_class;
+    GDExtensionInterfaceClassdbRegisterExtensionClassMethod register_method;
+    GDExtensionInterfaceClassdbUnregisterExtensionClass unregister_class;
+    GDExtensionInterfaceGetVariantToTypeConstructor to_type;
+    GDExtensionInterfaceGetVariantFromTypeConstructor from_type;
+    GDExtensionInterfaceVariantGetPtrDestructor get_destructor;
+    csky_ptr_constructor pba_default_ctor;
+    csky_builtin_method pba_size, pba_resize, pfa_size;
+    GDExtensionPtrDestructor pba_destroy, pfa_destroy;
+    csky_name class_name, parent_name;
+} G;
+
+typedef struct {
+    csky_ctx *ctx;
+    int status;
+    char err[512];
+} CloudSkyHIP;
+
+/* ---- small helpers ---------------------------------------------------------------------------------------------------- */
+static GDExtensionInt packed_size(csky_builtin_method size_fn, GDExtensionConstTypePtr arr) {
+    GDExtensionInt n = 0;
+    size_fn((GDExtensionTypePtr)arr, NULL, &n, 0);
+    return n;
+}
+/* r_out = PackedByteArray(); r_out.resize(bytes); returns its writable data pointer (NULL if bytes == 0) */
+static uint8_t *packed_byte_array_new(csky_packed *r_out, GDExtensionInt bytes) {
+    GDExtensionInt arg = bytes, ret = 0;
+    GDExtensionConstTypePtr args[1];
+    G.pba_default_ctor(r_out, NULL);
+    if (bytes <= 0) return NULL;
+    args[0] = &arg;
+    G.pba_resize(r_out, args, &ret, 1);
+    return G.pba_index(r_out, 0);
+}
+static int fail(CloudSkyHIP *self, int code, const char *text) {
+    self->status = code;
+    strncpy(self->err, text ? text : "", sizeof self->err - 1);
+    self->err[sizeof self->err - 1] = 0;
+    return code;
+}
+static int pass(CloudSkyHIP *self, int rc) { /* record the library's own error text */
+    if (rc != CSKY_OK) return fail(self, rc, csky_last_error(self->ctx));
+    self->status = CSKY_OK; self->err[0] = 0;
+    return rc;
+}
+static const float *float_args(CloudSkyHIP *self, GDExtensionConstTypePtr arr, GDExtensionInt want, const char *what) {
+    if (packed_size(G.pfa_size, arr) != want) { fail(self, CSKY_ERR_INVALID, what); return NULL; }
+    return G.pfa_index_const(arr, 0);
+}
+
+/* ---- the methods (ptrcall form: p_args[i] points to the native value) --------------------------------------------------- */
+static void m_create(void *ud, GDExtensionClassInstancePtr inst, const GDExtensionConstTypePtr *a, GDExtensionTypePtr r) {
+    CloudSkyHIP *self = (CloudSkyHIP *)inst; (void)ud;
+    int rc;
+    if (self->ctx) { csky_destroy(self->ctx); self->ctx = NULL; }
+    rc = csky_create(&self->ctx, (int)*(const GDExtensionInt *)a[0]);
+    if (rc != CSKY_OK) fail(self, rc, csky_last_error(NULL)); else pass(self, rc);
+    *(GDExtensionInt *)r = rc;
+}
+static void m_set_noise(void *ud, GDExtensionClassInstancePtr inst, const GDExtensionConstTypePtr *a, GDExtensionTypePtr r) {
+    CloudSkyHIP *self = (CloudSkyHIP *)inst; (void)ud;
+    int rc;
+    if (!self->ctx) rc = fail(self, CSKY_ERR_STATE, "CloudSkyHIP: create() has not been called");
+    else if (packed_size(G.pba_size, a[0]) != 128 * 128 * 128 * 4 || packed_size(G.pba_size, a[1]) != 32 * 32 * 32 * 3 || packed_size(G.pba_size, a[2]) != 512 * 512 * 3)
+        rc = fail(self, CSKY_ERR_INVALID, "set_noise: expected 128^3 RGBA8, 32^3 RGB8 and 512^2 RGB8 byte arrays (level 0 only)");
+    else rc = pass(self, csky_set_noise(self->ctx, G.pba_index_const(a[0], 0), G.pba_index_const(a[1], 0), G.pba_index_const(a[2], 0)));
+    *(GDExtensionInt *)r = rc;
+}
+static void m_set_march(void *ud, GDExtensionClassInstancePtr inst, const GDExtensionConstTypePtr *a, GDExtensionTypePtr r) {
+    CloudSkyHIP *self = (CloudSkyHIP *)inst; (void)ud;
+    *(GDExtensionInt *)r = self->ctx ? pass(self, csky_set_march(self->ctx, (int)*(const GDExtensionInt *)a[0], (int)*(const GDExtensionInt *)a[1]))
+                                     : fail(self, CSKY_ERR_STATE, "CloudSkyHIP: create() has not been called");
+}
+static void m_render_transmittance(void *ud, GDExtensionClassInstancePtr inst, const GDExtensionConstTypePtr *a, GDExtensionTypePtr r) {
+    CloudSkyHIP *self = (CloudSkyHIP *)inst; (void)ud;
+    csky_transmittance_params p;
+    const float *pc;
+    uint8_t *dst;
+    if (!self->ctx) { fail(self, CSKY_ERR_STATE, "CloudSkyHIP: create() has not been called"); packed_byte_array_new((csky_packed *)r, 0); return; }
+    pc = float_args(self, a[0], 4, "render_transmittance: push constant must be 4 floats (transmittance-lut.glsl:12-15)");
+    if (!pc) { packed_byte_array_new((csky_packed *)r, 0); return; }
+    memcpy(&p, pc, sizeof p);
+    dst = packed_byte_array_new((csky_packed *)r, (GDExtensionInt)p.texture_size[0] * (GDExtensionInt)p.texture_size[1] * 8);
+    if (pass(self, csky_render_transmittance(self->ctx, &p, (uint16_t *)dst)) != CSKY_OK) { G.pba_destroy(r); packed_byte_array_new((csky_packed *)r, 0); }
+}
+static void m_render_sky_lut(void *ud, GDExtensionClassInstancePtr inst, const GDExtensionConstTypePtr *a, GDExtensionTypePtr r) {
+    CloudSkyHIP *self = (CloudSkyHIP *)inst; (void)ud;
+    csky_sky_params p;
+    const float *pc;
+    uint8_t *dst;
+    if (!self->ctx) { fail(self, CSKY_ERR_STATE, "CloudSkyHIP: create() has not been called"); packed_byte_array_new((csky_packed *)r, 0); return; }
+    pc = float_args(self, a[0], 8, "render_sky_lut: push constant must be 8 floats (sky-lut.glsl:12-18)");
+    if (!pc) { packed_byte_array_new((csky_packed *)r, 0); return; }
+    memcpy(&p, pc, sizeof p);
+    dst = packed_byte_array_new((csky_packed *)r, (GDExtensionInt)p.texture_size[0] * (GDExtensionInt)p.texture_size[1] * 8);
+    if (pass(self, csky_render_sky_lut(self->ctx, &p, (uint16_t *)dst)) != CSKY_OK) { G.pba_destroy(r); packed_byte_array_new((csky_packed *)r, 0); }
+}
+static void m_render_clouds(void *ud, GDExtensionClassInstancePtr inst, const GDExtensionConstTypePtr *a, GDExtensionTypePtr r) {
+    CloudSkyHIP *self = (CloudSkyHIP *)inst; (void)ud;
+    csky_cloud_params p;
+    const float *pc;
+    const GDExtensionInt w = *(const GDExtensionInt *)a[1], h = *(const GDExtensionInt *)a[2];
+    uint8_t *dst;
+    if (!self->ctx) { fail(self, CSKY_ERR_STATE, "CloudSkyHIP: create() has not been called"); packed_byte_array_new((csky_packed *)r, 0); return; }
+    pc = float_args(self, a[0], 28, "render_clouds: push constant must be the 28 floats of _fill_push_constant() (clouds.glsl:18-40)");
+    if (!pc || w < 1 || h < 1 || w > 16384 || h > 16384) {
+        if (pc) fail(self, CSKY_ERR_INVALID, "render_clouds: tile size out of range");
+        packed_byte_array_new((csky_packed *)r, 0);
+        return;
+    }
+    memcpy(&p, pc, sizeof p);
+    dst = packed_byte_array_new((csky_packed *)r, w * h * 8);
+    if (pass(self, csky_render_clouds(self->ctx, &p, (int)w, (int)h, (uint16_t *)dst, (size_t)w * 8)) != CSKY_OK) { G.pba_destroy(r); packed_byte_array_new((csky_packed *)r, 0); }
+}
+static void m_get_status(void *ud, GDExtensionClassInstancePtr inst, const GDExtensionConstTypePtr *a, GDExtensionTypePtr r) {
+    (void)ud; (void)a;
+    *(GDExtensionInt *)r = ((CloudSkyHIP *)inst)->status;
+}
+static void m_get_last_error(void *ud, GDExtensionClassInstancePtr inst, const GDExtensionConstTypePtr *a, GDExtensionTypePtr r) {
+    (void)ud; (void)a;
+    G.string_new(r, ((CloudSkyHIP *)inst)->err);
+}
+
+/* ---- method table + the generic Variant-call trampoline ----------------------------------------------------------------- */
+typedef struct {
+    const char *name;
+    GDExtensionClassMethodPtrCall ptrcall;
+    int argc;
+    GDExtensionVariantType ret;
+    GDExtensionVariantType args[3];
+    const char *arg_names[3];
+} csky_method;
+
+static const csky_method METHODS[] = {
+    {"create", m_create, 1, GDEXTENSION_VARIANT_TYPE_INT, {GDEXTENSION_VARIANT_TYPE_INT}, {"device_id"}},
+    {"set_noise", m_set_noise, 3, GDEXTENSION_VARIANT_TYPE_INT,
+     {GDEXTENSION_VARIANT_TYPE_PACKED_BYTE_ARRAY, GDEXTENSION_VARIANT_TYPE_PACKED_BYTE_ARRAY, GDEXTENSION_VARIANT_TYPE_PACKED_BYTE_ARRAY}, {"large_rgba8", "small_rgb8", "weather_rgb8"}},
+    {"set_march", m_set_march, 2, GDEXTENSION_VARIANT_TYPE_INT, {GDEXTENSION_VARIANT_TYPE_INT, GDEXTENSION_VARIANT_TYPE_INT}, {"primary_steps", "light_steps"}},
+    {"render_transmittance", m_render_transmittance, 1, GDEXTENSION_VARIANT_TYPE_PACKED_BYTE_ARRAY, {GDEXTENSION_VARIANT_TYPE_PACKED_FLOAT32_ARRAY}, {"push_constant"}},
+    {"render_sky_lut", m_render_sky_lut, 1, GDEXTENSION_VARIANT_TYPE_PACKED_BYTE_ARRAY, {GDEXTENSION_VARIANT_TYPE_PACKED_FLOAT32_ARRAY}, {"push_constant"}},
+    {"render_clouds", m_render_clouds, 3, GDEXTENSION_VARIANT_TYPE_PACKED_BYTE_ARRAY,
+     {GDEXTENSION_VARIANT_TYPE_PACKED_FLOAT32_ARRAY, GDEXTENSION_VARIANT_TYPE_INT, GDEXTENSION_VARIANT_TYPE_INT}, {"push_constant", "tile_w", "tile_h"}},
+    {"get_status", m_get_status, 0, GDEXTENSION_VARIANT_TYPE_INT, {GDEXTENSION_VARIANT_TYPE_NIL}, {0}},
+    {"get_last_error", m_get_last_error, 0, GDEXTENSION_VARIANT_TYPE_STRING, {GDEXTENSION_VARIANT_TYPE_NIL}, {0}},
+};
+#define N_METHODS ((int)(sizeof METHODS / sizeof METHODS[0]))
+
+/* Variant call: unpack every argument to its native type, run the ptrcall body, pack the result (what godot-cpp's generated
+ * bindings do).  method_userdata = the table entry. */
+static void call_trampoline(void *method_userdata, GDExtensionClassInstancePtr inst, const GDExtensionConstVariantPtr *p_args, GDExtensionInt argc,
+                            GDExtensionVariantPtr r_return, GDExtensionCallError *r_error) {
+    const csky_method *m = (const csky_method *)method_userdata;
+    csky_packed native[3];                       /* large enough for every argument type used (int64 or a 16-byte packed array) */
+    GDExtensionConstTypePtr argp[3];
+    csky_packed ret;                             /* int64, String (8 bytes) or PackedByteArray (16 bytes) */
+    int i;
+    if (argc != m->argc) {
+        r_error->error = argc < m->argc ? GDEXTENSION_CALL_ERROR_TOO_FEW_ARGUMENTS : GDEXTENSION_CALL_ERROR_TOO_MANY_ARGUMENTS;
+        r_error->argument = m->argc; r_error->expected = m->argc;
+        return;
+    }
+    for (i = 0; i < m->argc; i++) {
+        memset(&native[i], 0, sizeof native[i]);
+        G.to_type(m->args[i])(&native[i], (GDExtensionVariantPtr)p_args[i]);
+        argp[i] = &native[i];
+    }
+    memset(&ret, 0, sizeof ret);
+    m->ptrcall(NULL, inst, argp, &ret);
+    G.from_type(m->ret)(r_return, &ret);
+    for (i = 0; i < m->argc; i++) {
+        if (m->args[i] == GDEXTENSION_VARIANT_TYPE_PACKED_BYTE_ARRAY) G.pba_destroy(&native[i]);
+        else if (m->args[i] == GDEXTENSION_VARIANT_TYPE_PACKED_FLOAT32_ARRAY) G.pfa_destroy(&native[i]);
+    }
+    if (m->ret == GDEXTENSION_VARIANT_TYPE_PACKED_BYTE_ARRAY) G.pba_destroy(&ret);
+    else if (m->ret == GDEXTENSION_VARIANT_TYPE_STRING) { GDExtensionPtrDestructor d = G.get_destructor(GDEXTENSION_VARIANT_TYPE_STRING); if (d) d(&ret); }
+    r_error->error = GDEXTENSION_CALL_OK;
+}
+
+/* ---- class plumbing ---------------------------------------------------------------------------------------------------- */
+static GDExtensionObjectPtr create_instance(void *class_userdata) {
+    GDExtensionObjectPtr obj = G.construct_object(&G.parent_name);
+    CloudSkyHIP *self = (CloudSkyHIP *)G.mem_alloc(sizeof(CloudSkyHIP));
+    (void)class_userdata;
+    memset(self, 0, sizeof *self);
+    G.object_set_instance(obj, &G.class_name, self);
+    return obj;
+}
+static void free_instance(void *class_userdata, GDExtensionClassInstancePtr inst) {   /* cloud_sky.gd:193-212 cleanup / NOTIFICATION_PREDELETE */
+    CloudSkyHIP *self = (CloudSkyHIP *)inst;
+    (void)class_userdata;
+    if (!self) return;
+    if (self->ctx) csky_destroy(self->ctx);
+    G.mem_free(self);
+}
+
+static void initialize_level(void *userdata, GDExtensionInitializationLevel level) {
+    GDExtensionClassCreationInfo2 ci;
+    int i, k;
+    (void)userdata;
+    if (level != GDEXTENSION_INITIALIZATION_SCENE) return;
+    G.string_name_new(&G.class_name, "CloudSkyHIP", 1);
+    G.string_name_new(&G.parent_name, "RefCounted", 1);
+    memset(&ci, 0, sizeof ci);
+    ci.is_exposed = 1;
+    ci.create_instance_func = create_instance;
+    ci.free_instance_func = free_instance;
+    G.register_class(G.library, &G.class_name, &G.parent_name, &ci);
+    for (i = 0; i < N_METHODS; i++) {
+        const csky_method *m = &METHODS[i];
+        csky_name mname, anames[3], empty;
+        GDExtensionPropertyInfo ret_info, arg_info[3];
+        GDExtensionClassMethodArgumentMetadata meta[3] = {GDEXTENSION_METHOD_ARGUMENT_METADATA_NONE, GDEXTENSION_METHOD_ARGUMENT_METADATA_NONE, GDEXTENSION_METHOD_ARGUMENT_METADATA_NONE};
+        GDExtensionClassMethodInfo mi;
+        csky_string no_hint;
+        G.string_name_new(&mname, m->name, 1);
+        G.string_name_new(&empty, "", 1);
+        G.string_new(&no_hint, "");
+        memset(&ret_info, 0, sizeof ret_info);
+        ret_info.type = m->ret; ret_info.name = &empty; ret_info.class_name = &empty; ret_info.hint_string = &no_hint; ret_info.usage = 6; /* PROPERTY_USAGE_DEFAULT */
+        for (k = 0; k < m->argc; k++) {
+            G.string_name_new(&anames[k], m->arg_names[k], 1);
+            memset(&arg_info[k], 0, sizeof arg_info[k]);
+            arg_info[k].type = m->args[k]; arg_info[k].name = &anames[k]; arg_info[k].class_name = &empty; arg_info[k].hint_string = &no_hint; arg_info[k].usage = 6;
+        }
+        memset(&mi, 0, sizeof mi);
+        mi.name = &mname;
+        mi.method_userdata = (void *)m;
+        mi.call_func = call_trampoline;
+        mi.ptrcall_func = m->ptrcall;
+        mi.method_flags = GDEXTENSION_METHOD_FLAGS_DEFAULT;
+        mi.has_return_value = 1;
+        mi.return_value_info = &ret_info;
+        mi.argument_count = (uint32_t)m->argc;
+        mi.arguments_info = arg_info;
+        mi.arguments_metadata = meta;
+        G.register_method(G.library, &G.class_name, &mi);
+    }
+}
+static void deinitialize_level(void *userdata, GDExtensionInitializationLevel level) {
+    (void)userdata;
+    if (level == GDEXTENSION_INITIALIZATION_SCENE && G.unregister_class) G.unregister_class(G.library, &G.class_name);
+}
+
+#define LOAD(field, type, name) do { G.field = (type)get_proc(name); if (!G.field) return 0; } while (0)
+
+/* entry_symbol of gdext/cloudsky.gdextension */
+GDExtensionBool csky_gdextension_init(GDExtensionInterfaceGetProcAddress get_proc, GDExtensionClassLibraryPtr library, GDExtensionInitialization *r_init) {
+    csky_get_builtin_method get_builtin;
+    csky_get_ptr_constructor get_ctor;
+    csky_name n_size, n_resize;
+    if (!get_proc || !r_init) return 0;
+    memset(&G, 0, sizeof G);
+    G.library = library;
+    LOAD(mem_alloc, GDExtensionInterfaceMemAlloc, "mem_alloc");
+    LOAD(mem_free, GDExtensionInterfaceMemFree, "mem_free");
+    LOAD(string_name_new, GDExtensionInterfaceStringNameNewWithLatin1Chars, "string_name_new_with_latin1_chars");
+    LOAD(string_new, GDExtensionInterfaceStringNewWithUtf8Chars, "string_new_with_utf8_chars");
+    LOAD(pba_index, GDExtensionInterfacePackedByteArrayOperatorIndex, "packed_byte_array_operator_index");
+    LOAD(pba_index_const, GDExtensionInterfacePackedByteArrayOperatorIndexConst, "packed_byte_array_operator_index_const");
+    LOAD(pfa_index_const, GDExtensionInterfacePackedFloat32ArrayOperatorIndexConst, "packed_float32_array_operator_index_const");
+    LOAD(construct_object, GDExtensionInterfaceClassdbConstructObject, "classdb_construct_object");
+    LOAD(object_set_instance, GDExtensionInterfaceObjectSetInstance, "object_set_instance");
+    LOAD(register_class, GDExtensionInterfaceClassdbRegisterExtensionClass2, "classdb_register_extension_class2");
+    LOAD(register_method, GDExtensionInterfaceClassdbRegisterExtensionClassMethod, "classdb_register_extension_class_method");
+    LOAD(unregister_class, GDExtensionInterfaceClassdbUnregisterExtensionClass, "classdb_unregister_extension_class");
+    LOAD(to_type, GDExtensionInterfaceGetVariantToTypeConstructor, "get_variant_to_type_constructor");
+    LOAD(from_type, GDExtensionInterfaceGetVariantFromTypeConstructor, "get_variant_from_type_constructor");
+    LOAD(get_destructor, GDExtensionInterfaceVariantGetPtrDestructor, "variant_get_ptr_destructor");
+    get_builtin = (csky_get_builtin_method)get_proc("variant_get_ptr_builtin_method");
+    get_ctor = (csky_get_ptr_constructor)get_proc("variant_get_ptr_constructor");
+    if (!get_builtin || !get_ctor) return 0;
+    G.string_name_new(&n_size, "size", 1);
+    G.string_name_new(&n_resize, "resize", 1);
+    G.pba_size = get_builtin(GDEXTENSION_VARIANT_TYPE_PACKED_BYTE_ARRAY, &n_size, CSKY_HASH_PACKED_SIZE);
+    G.pfa_size = get_builtin(GDEXTENSION_VARIANT_TYPE_PACKED_FLOAT32_ARRAY, &n_size, CSKY_HASH_PACKED_SIZE);
+    G.pba_resize = get_builtin(GDEXTENSION_VARIANT_TYPE_PACKED_BYTE_ARRAY, &n_resize, CSKY_HASH_PACKED_RESIZE);
+    G.pba_default_ctor = get_ctor(GDEXTENSION_VARIANT_TYPE_PACKED_BYTE_ARRAY, 0);
+    G.pba_destroy = G.get_destructor(GDEXTENSION_VARIANT_TYPE_PACKED_BYTE_ARRAY);
+    G.pfa_destroy = G.get_destructor(GDEXTENSION_VARIANT_TYPE_PACKED_FLOAT32_ARRAY);
+    if (!G.pba_size || !G.pfa_size || !G.pba_resize || !G.pba_default_ctor || !G.pba_destroy || !G.pfa_destroy) return 0;
+    r_init->minimum_initialization_level = GDEXTENSION_INITIALIZATION_SCENE;
+    r_init->userdata = NULL;
+    r_init->initialize = initialize_level;
+    r_init->deinitialize = deinitialize_level;
+    return 1;
+}

@@ -90,6 +90,10 @@ SYMBOLS = [
     ("csky_strip_to_volume", C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
     ("csky_generate_shape_noise", C.c_int, [C.c_uint32, C.c_int, C.c_void_p]),
     ("csky_generate_shape_noise_device", C.c_int, [C.c_void_p, C.c_uint32, C.c_int, C.c_void_p]),
+    ("csky_generate_detail_noise", C.c_int, [C.c_uint32, C.c_int, C.c_void_p]),
+    ("csky_generate_detail_noise_device", C.c_int, [C.c_void_p, C.c_uint32, C.c_int, C.c_void_p]),
+    ("csky_build_mips_device", C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int]),
+    ("csky_read_baked_texture", C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_size_t, C.POINTER(C.c_size_t)]),
     ("csky_mip_offset", C.c_size_t, [C.c_int, C.c_int, C.c_int]),
     ("csky_build_mips", C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int]),
     ("csky_assets_last_error", C.c_char_p, []),
@@ -281,6 +285,29 @@ class Context:
         vol = np.zeros((n, n, n, 4), np.uint8)
         self._chk(self._L.csky_generate_shape_noise_device(self._h, seed, n, _ptr(vol)))
         return vol
+
+    def generate_detail_noise(self, seed=1, n=32):
+        """GPU bake of a generated detail volume: uint8 [n, n, n, 3], byte-identical to assets.generate_detail_noise."""
+        vol = np.zeros((n, n, n, 3), np.uint8)
+        self._chk(self._L.csky_generate_detail_noise_device(self._h, seed, n, _ptr(vol)))
+        return vol
+
+    def build_mips(self, level0, levels):
+        """2x2x2 box mip chain on the GPU (flat uint8, level 0 first): byte-identical to assets.build_mips."""
+        level0 = np.ascontiguousarray(level0, np.uint8)
+        n, ch = level0.shape[0], level0.shape[3]
+        buf = np.zeros(self._L.csky_mip_offset(n, levels, ch), np.uint8)
+        buf[: level0.size] = level0.reshape(-1)
+        self._chk(self._L.csky_build_mips_device(self._h, _ptr(buf), n, ch, levels))
+        return buf
+
+    def read_baked_texture(self, which):
+        """Test hook: the device layouts / mip chains csky_set_noise built, as raw bytes (0 shape, 1 detail, 2 weather, 3 / 4 8-bit chains)."""
+        n = C.c_size_t()
+        self._chk(self._L.csky_read_baked_texture(self._h, int(which), None, 0, C.byref(n)))
+        out = np.zeros(n.value, np.uint8)
+        self._chk(self._L.csky_read_baked_texture(self._h, int(which), _ptr(out), out.nbytes, C.byref(n)))
+        return out
 
     # ---- measurement
     def time_clouds(self, params, tile_w, bands, warmup=2, iters=10):

@@ -62,6 +62,13 @@ def generate_shape_noise(seed=SHAPE_SEED, n=128):
     return vol
 
 
+def generate_detail_noise(seed=1, n=32):
+    """A generated detail volume in the role of worlnoise.bmp: [z,y,x,3] uint8 (three inverted-Worley fBm channels)."""
+    vol = np.zeros((n, n, n, 3), np.uint8)
+    _chk(_lib.lib().csky_generate_detail_noise(seed, n, vol.ctypes.data_as(C.c_void_p)))
+    return vol
+
+
 def build_mips(level0, levels):
     level0 = np.ascontiguousarray(level0, np.uint8)
     n, ch = level0.shape[0], level0.shape[3]

@@ -14,6 +14,7 @@
 #include "../../include/cloudsky.h"
 #include "kernels.h"
 #include "bake.h"
+#include "bake_core.h"
 #include "cloud_core.h"
 
 using namespace csky;
@@ -25,6 +26,7 @@ struct csky_ctx {
     hipStream_t stream = nullptr;
     hipEvent_t ev0 = nullptr, ev1 = nullptr, ev_copy = nullptr;
     // noise set (cloud_sky.gd:298-341)
+    uint8_t* d_raw_large = nullptr; uint8_t* d_raw_small = nullptr; uint8_t* d_raw_weather = nullptr; uint8_t* d_bake_meta = nullptr;   // 8-bit mip chains (inputs of the device bake)
     ShapeTexel* d_shape = nullptr; unsigned long long inexact_coeffs = 0; uint4* d_detail = nullptr; uint4* d_weather = nullptr; uint16_t* d_detail_h = nullptr; bool have_noise = false;
     uint32_t shape_off[SHAPE_LEVELS] = {}, detail_off[DETAIL_LEVELS] = {};
     float detail_lod5 = 0.0f;
@@ -54,9 +56,7 @@ struct csky_ctx {
     // static workgroup order (physical workgroup -> slab), written on the device, one table per ring slot (= frame parity, so two
     // frames in flight with different geometries never share one), cached per launch geometry
     uint32_t* d_order_ring[2] = {nullptr, nullptr}; size_t order_cap[2] = {0, 0}; int order_grid_ring[2] = {0, 0};
-    long long order_key_ring[2][6] = {{-1, -1, -1, -1, -1, -1}, {-1, -1, -1, -1, -1, -1}};
-    float tail_beta = 0.65f;                          // deadline schedule (mode 8): how far forward the heaviest workgroup is pulled
-    float tail_f4 = 0.10f, tail_f2 = 0.10f;           // mixed-segment launch (mode 9): share of the order's end run as 4- / 2-segment workgroups
+    long long order_key_ring[2][4] = {{-1, -1, -1, -1}, {-1, -1, -1, -1}};
     // cost-feedback schedule (mode 7): per-workgroup costs of the last launch -> heaviest-first order of the next one
     uint32_t* d_wg_cost = nullptr; uint32_t* d_lpt_order = nullptr; uint32_t* d_lpt_hist = nullptr; size_t lpt_cap = 0;
     bool lpt_valid[2] = {false, false}; long long lpt_key[2][11] = {{-1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1}, {-1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1}};
@@ -134,14 +134,13 @@ int check_bands(csky_ctx* c, const csky_bands* b, int tile_w) {
 // (queue kernel, round 1): 5 (slab rows round-robin over the XCDs) 3.93 ms, 1 (contiguous eighths) 4.80 ms, 2 (natural) 4.92 ms;
 // azimuth-wedge and horizon-first orders (5.3-5.8 / 4.77 ms) were dropped in round 2.  The table depends on the launch geometry
 // only (not on update_position: the reference's tile walk re-uses it) and is written by a kernel on the launch's stream.
-int ensure_order(csky_ctx* c, int slot, int mode, int tile_w, int tiles_x, int slabs, int t2, int t4, hipStream_t s) {
+int ensure_order(csky_ctx* c, int slot, int mode, int tile_w, int tiles_x, int slabs, hipStream_t s) {
     const int nblocks = tiles_x * slabs;
     int grid;
     if (mode == 2) grid = nblocks;
     else if (mode == 1) grid = ((nblocks + 7) >> 3) * 8;
-    else if (mode == 9) grid = mixed_order_grid(tiles_x, slabs, t2, t4);     // tiles_x = 32-pixel slabs per row here
     else grid = ((slabs + 7) >> 3) * tiles_x * 8;
-    const long long key[6] = {tile_w, tiles_x, slabs, mode, t2, t4};
+    const long long key[4] = {tile_w, slabs, mode, grid};
     if (c->d_order_ring[slot] && memcmp(key, c->order_key_ring[slot], sizeof key) == 0) return CSKY_OK;
     if (c->order_cap[slot] < (size_t)grid) {
         HIPCHK(c, hipDeviceSynchronize());                   // growing the table is rare; an older launch may still read the old one
@@ -151,8 +150,7 @@ int ensure_order(csky_ctx* c, int slot, int mode, int tile_w, int tiles_x, int s
     }
     // the last reader of this slot's table is the march of two frames ago; the caller has already ordered `s` behind it (ev_clouds -> pro ->
     // ev_setup -> s), exactly like the frame constants of the slot
-    if (mode == 9) HIPCHK(c, launch_mixed_order(tile_w, slabs, t2, t4, c->d_order_ring[slot], s));
-    else HIPCHK(c, launch_static_order(mode, tiles_x, slabs, grid, c->d_order_ring[slot], s));
+    HIPCHK(c, launch_static_order(mode, tiles_x, slabs, grid, c->d_order_ring[slot], s));
     c->order_grid_ring[slot] = grid;
     memcpy(c->order_key_ring[slot], key, sizeof key);
     return CSKY_OK;
@@ -220,11 +218,9 @@ int clouds_dev(csky_ctx* c, const csky_cloud_params* p, int tile_w, const csky_b
     int mode = c->sched_mode >= 0 ? c->sched_mode : auto_mode;
     const int bw = seg == 5 ? 8 : (seg == 16 ? 128 : 32 / seg);   // workgroup footprint = bw x 8 pixels (seg 5: one tile; seg 16: the 16-wavefront "lds" strip)
     const int tiles_x = (g.tile_w + bw - 1) / bw, slabs = (g.n_bands * g.band_rows + 7) >> 3, nblocks = tiles_x * slabs;
-    if (mode == 9 && !(c->variant == 3 && seg == 1)) mode = 5;   // the mixed-segment kernel is the "compact" march on whole-ray footprints
-    bool feedback = (mode == 7 || mode == 8) && queued && seg != 5;       // kernels that record per-workgroup costs
-    if (mode == 8 && (!feedback || ((slabs + 7) >> 3) * tiles_x * 8 > deadline_order_max_grid())) { mode = 5; feedback = false; }
+    bool feedback = mode == 7 && queued && seg != 5;             // kernels that record per-workgroup costs
     if (mode == 7 && !feedback) mode = waves >= 12288 ? 5 : 2;
-    const int static_mode = mode == 8 ? 5 : (mode == 7 ? (waves >= 12288 ? 5 : 2) : mode);   // order of the first launch of a geometry under feedback
+    const int static_mode = mode == 7 ? (waves >= 12288 ? 5 : 2) : mode;   // order of the first launch of a geometry under feedback
     const int slot = c->fc_cur;
     hipEvent_t* kt = nullptr;                                    // timing pair of this launch (csky_set_kernel_timing)
     if (c->kt_on) {
@@ -235,18 +231,7 @@ int clouds_dev(csky_ctx* c, const csky_cloud_params* p, int tile_w, const csky_b
         }
         kt = &c->kt_ev[(size_t)c->kt_count * 2]; c->kt_count++;
     }
-    if (mode == 9) {
-        // the order's last stretch as 4-, the stretch before it as 2-segment workgroups (kernels.hip::clouds_kernel_mixed)
-        const int n = ((slabs + 7) >> 3) * tiles_x;                       // slab positions per XCD
-        const int t4 = (int)(c->tail_f4 * (float)n + 0.5f), t2 = std::min(n - t4, (int)(c->tail_f2 * (float)n + 0.5f));
-        if ((rc = ensure_order(c, slot, 9, g.tile_w, tiles_x, slabs, t2, t4, s))) return rc;
-        if (kt) HIPCHK(c, hipEventRecord(kt[0], s));
-        HIPCHK(c, launch_clouds_mixed(texset(c), c->d_fc, g, c->d_order_ring[slot], c->order_grid_ring[slot], d_out, d_stats, s));
-        if (kt) HIPCHK(c, hipEventRecord(kt[1], s));
-        HIPCHK(c, hipEventRecord(c->ev_clouds[c->fc_cur], s)); c->clouds_pending[c->fc_cur] = true;
-        return CSKY_OK;
-    }
-    if ((rc = ensure_order(c, slot, static_mode, g.tile_w, tiles_x, slabs, 0, 0, s))) return rc;
+    if ((rc = ensure_order(c, slot, static_mode, g.tile_w, tiles_x, slabs, s))) return rc;
     uint32_t* const d_static = c->d_order_ring[slot];
     const int static_grid = c->order_grid_ring[slot];
     if (!feedback) {
@@ -256,7 +241,7 @@ int clouds_dev(csky_ctx* c, const csky_cloud_params* p, int tile_w, const csky_b
         HIPCHK(c, hipEventRecord(c->ev_clouds[c->fc_cur], s)); c->clouds_pending[c->fc_cur] = true;
         return CSKY_OK;
     }
-    // modes 7 / 8: this launch runs in the order derived from the costs of the previous launch ON THE SAME RING SLOT (same geometry and
+    // mode 7: this launch runs in the order derived from the costs of the previous launch ON THE SAME RING SLOT (same geometry and
     // view), records its own costs and derives the next order from them.  The first launch of a geometry uses the static order.  Costs,
     // order and sort scratch are per ring slot (= per frame parity, like the frame constants), so two frames in flight on two
     // streams never share them; reuse of a slot is ordered by ev_clouds, recorded below after the sort.
@@ -280,18 +265,14 @@ int clouds_dev(csky_ctx* c, const csky_cloud_params* p, int tile_w, const csky_b
     const long long fkey[11] = {g.tile_w, g.band_rows, g.first_band, g.band_stride, g.n_bands, (long long)cp.texture_size[0], (long long)cp.texture_size[1],
                                 (long long)cp.update_position[0], (long long)cp.update_position[1], mode * 16 + static_mode, seg};
     if (memcmp(c->lpt_key[slot], fkey, sizeof fkey) != 0) { c->lpt_valid[slot] = false; memcpy(c->lpt_key[slot], fkey, sizeof fkey); }
-    const int fb_grid = mode == 8 ? static_grid : nblocks;       // the deadline order keeps the static order's idle padding
+    const uint32_t* const use_order = c->lpt_valid[slot] ? lorder : d_static;
+    const int use_grid = c->lpt_valid[slot] ? nblocks : static_grid;
     if (kt) HIPCHK(c, hipEventRecord(kt[0], s));
-    HIPCHK(c, launch_clouds(c->variant, seg, texset(c), c->d_fc, g, c->lpt_valid[slot] ? lorder : d_static, c->lpt_valid[slot] ? fb_grid : static_grid,
-                            d_out, d_stats, cost, s));
+    HIPCHK(c, launch_clouds(c->variant, seg, texset(c), c->d_fc, g, use_order, use_grid, d_out, d_stats, cost, s));
     if (kt) HIPCHK(c, hipEventRecord(kt[1], s));
-    if (mode == 8) {
-        HIPCHK(c, launch_deadline_order(d_static, static_grid, cost, c->tail_beta, lorder, s));
-    } else {
-        int shift = 0;
-        while ((((long long)256 * (c->primary_steps + 16)) >> shift) >= 1024) shift++;     // largest cost: 4 wavefronts x 64 rays x (steps + 16)
-        HIPCHK(c, launch_lpt_order(cost, nblocks, shift, c->d_lpt_hist + slot * 2048, lorder, s));
-    }
+    int shift = 0;
+    while ((((long long)256 * (c->primary_steps + 16)) >> shift) >= 1024) shift++;     // largest cost: 4 wavefronts x 64 rays x (steps + 16)
+    HIPCHK(c, launch_lpt_order(cost, nblocks, shift, c->d_lpt_hist + slot * 2048, lorder, s));
     c->lpt_valid[slot] = true;
     HIPCHK(c, hipEventRecord(c->ev_clouds[c->fc_cur], s)); c->clouds_pending[c->fc_cur] = true;
     return CSKY_OK;
@@ -336,9 +317,6 @@ int csky_create(csky_ctx** out, int device_id) {
         if ((e = hipMalloc(reinterpret_cast<void**>(&c->fc_ring[k]), sizeof(FrameConsts))) != hipSuccess) return bail("hipMalloc", e);
     }
     c->d_fc = c->fc_ring[0];
-    if (const char* t4 = getenv("CSKY_TAIL_SEG4")) { const float v = (float)atof(t4); if (v >= 0.0f && v <= 1.0f) c->tail_f4 = v; }        // tuning experiments only
-    if (const char* t2 = getenv("CSKY_TAIL_SEG2")) { const float v = (float)atof(t2); if (v >= 0.0f && v <= 1.0f) c->tail_f2 = v; }
-    if (const char* tb = getenv("CSKY_TAIL_BETA")) { const float v = (float)atof(tb); if (v >= 0.0f && v <= 1.0f) c->tail_beta = v; }   // tuning experiments only
     if ((e = hipMalloc(reinterpret_cast<void**>(&c->d_stats), CSKY_STATS_WORDS * sizeof(unsigned long long))) != hipSuccess) return bail("hipMalloc", e);
     *out = c;
     return CSKY_OK;
@@ -349,7 +327,7 @@ void csky_destroy(csky_ctx* c) {
     (void)hipSetDevice(c->device);
     (void)hipDeviceSynchronize();                              // launches may sit on caller streams too
     void* ptrs[] = {c->d_shape, c->d_detail, c->d_weather, c->d_trans_h, c->d_trans_f, c->sky_h_ring[0], c->sky_h_ring[1], c->sky_f_ring[0], c->sky_f_ring[1],
-                    c->fc_ring[0], c->fc_ring[1], c->d_stats, c->d_frame, c->d_order_ring[0], c->d_order_ring[1], c->d_composite, c->d_detail_h, c->d_wg_cost, c->d_lpt_order, c->d_lpt_hist};
+                    c->fc_ring[0], c->fc_ring[1], c->d_stats, c->d_frame, c->d_order_ring[0], c->d_order_ring[1], c->d_composite, c->d_raw_large, c->d_raw_small, c->d_raw_weather, c->d_bake_meta, c->d_detail_h, c->d_wg_cost, c->d_lpt_order, c->d_lpt_hist};
     for (void* p : ptrs) if (p) (void)hipFree(p);
     hipEvent_t evs[] = {c->ev0, c->ev1, c->ev_copy, c->ev_setup[0], c->ev_setup[1], c->ev_clouds[0], c->ev_clouds[1]};
     for (hipEvent_t ev : evs) if (ev) (void)hipEventDestroy(ev);
@@ -363,41 +341,100 @@ int csky_set_noise(csky_ctx* c, const uint8_t* large_rgba8, const uint8_t* small
     if (!c) return fail(nullptr, CSKY_ERR_INVALID, "csky_set_noise: ctx is NULL");
     if (!large_rgba8 || !small_rgb8 || !weather_rgb8) return fail(c, CSKY_ERR_INVALID, "csky_set_noise: NULL texture pointer");
     int rc; if ((rc = bind(c))) return rc;
-    std::vector<uint8_t> lc(csky_mip_offset(SHAPE_N, SHAPE_LEVELS, 4)), sc(csky_mip_offset(DETAIL_N, DETAIL_LEVELS, 3));
-    memcpy(lc.data(), large_rgba8, (size_t)SHAPE_N * SHAPE_N * SHAPE_N * 4);
-    memcpy(sc.data(), small_rgb8, (size_t)DETAIL_N * DETAIL_N * DETAIL_N * 3);
-    csky_build_mips(lc.data(), SHAPE_N, 4, SHAPE_LEVELS);      // mipmaps/generate=true, perlworlnoise.tga.import:24
-    csky_build_mips(sc.data(), DETAIL_N, 3, DETAIL_LEVELS);    // worlnoise.bmp.import:24
-    std::vector<ShapeTexel> shape; std::vector<uint4> detail, weather;
-    c->inexact_coeffs = 0;
-    bake_shape(lc, shape, c->shape_off, &c->inexact_coeffs);
-    bake_detail(sc, detail, c->detail_off, &c->inexact_coeffs);
-    bake_weather(weather_rgb8, weather, &c->inexact_coeffs);
-    std::vector<uint16_t> detail_h;
-    bake_detail_unpacked(sc, detail_h);
-    if (detail_h.size() != (size_t)DETAIL_CHAIN_TEXELS) return fail(c, CSKY_ERR_INVALID, "internal: detail chain size");
-    { const uint8_t* t5 = sc.data() + csky_mip_offset(DETAIL_N, 5, 3); c->detail_lod5 = (float)(5 * t5[0] + 2 * t5[1] + t5[2]) * (1.0f / (8.0f * 255.0f)); }
-    {   // channel ranges of the weather map for the height-window reject
-        int rmin = 255, rmax = 0, bmax = 0;
-        for (size_t i = 0; i < (size_t)WEATHER_N * WEATHER_N; i++) { const int r = weather_rgb8[3 * i], b = weather_rgb8[3 * i + 2]; rmin = r < rmin ? r : rmin; rmax = r > rmax ? r : rmax; bmax = b > bmax ? b : bmax; }
-        c->w_rmin = rmin / 255.0; c->w_rmax = rmax / 255.0; c->w_bmax = bmax / 255.0; c->win_cov = -1e30f;
-    }
+    // The level-0 textures go to the device as they are (9.2 MB); mip chains (mipmaps/generate=true, perlworlnoise.tga.import:24,
+    // worlnoise.bmp.import:24) and the device layouts are built there (kernels.hip::launch_mip_chain / launch_bake).
+    const size_t large_l0 = (size_t)SHAPE_N * SHAPE_N * SHAPE_N * 4, small_l0 = (size_t)DETAIL_N * DETAIL_N * DETAIL_N * 3, weather_b = (size_t)WEATHER_N * WEATHER_N * 3;
+    const size_t large_chain = chain_offset(SHAPE_N, SHAPE_LEVELS, 4), small_chain = chain_offset(DETAIL_N, DETAIL_LEVELS, 3);
+    size_t shape_total = 0, detail_total = 0;
+    for (int l = 0; l < SHAPE_LEVELS; l++) { c->shape_off[l] = (uint32_t)shape_total; const size_t n = SHAPE_N >> l; shape_total += n * n * n; }
+    for (int l = 0; l < DETAIL_LEVELS; l++) { c->detail_off[l] = (uint32_t)detail_total; const size_t n = DETAIL_N >> l; detail_total += n * n * n; }
     for (int l = 0; l < SHAPE_LEVELS; l++) if (c->shape_off[l] != shape_level_offset(l)) return fail(c, CSKY_ERR_INVALID, "internal: shape mip offset mismatch");
     for (int l = 0; l < DETAIL_LEVELS; l++) if (c->detail_off[l] != detail_level_offset(l)) return fail(c, CSKY_ERR_INVALID, "internal: detail mip offset mismatch");
+    if (detail_total != (size_t)DETAIL_CHAIN_TEXELS) return fail(c, CSKY_ERR_INVALID, "internal: detail chain size");
     HIPCHK(c, hipDeviceSynchronize());                        // frames reading the old textures may be in flight on caller streams
-    if ((rc = dev_alloc(c, &c->d_shape, shape.size()))) return rc;
-    if ((rc = dev_alloc(c, &c->d_detail, detail.size()))) return rc;
-    if ((rc = dev_alloc(c, &c->d_weather, weather.size()))) return rc;
-    if ((rc = dev_alloc(c, &c->d_detail_h, detail_h.size() + 8))) return rc;
-    HIPCHK(c, hipMemcpy(c->d_detail_h, detail_h.data(), detail_h.size() * sizeof(uint16_t), hipMemcpyHostToDevice));
-    HIPCHK(c, hipMemcpy(c->d_shape, shape.data(), shape.size() * sizeof(ShapeTexel), hipMemcpyHostToDevice));
-    HIPCHK(c, hipMemcpy(c->d_detail, detail.data(), detail.size() * sizeof(uint4), hipMemcpyHostToDevice));
-    HIPCHK(c, hipMemcpy(c->d_weather, weather.data(), weather.size() * sizeof(uint4), hipMemcpyHostToDevice));
+    if ((rc = dev_alloc(c, &c->d_raw_large, large_chain))) return rc;
+    if ((rc = dev_alloc(c, &c->d_raw_small, small_chain))) return rc;
+    if ((rc = dev_alloc(c, &c->d_raw_weather, weather_b))) return rc;
+    if ((rc = dev_alloc(c, &c->d_shape, shape_total))) return rc;
+    if ((rc = dev_alloc(c, &c->d_detail, detail_total))) return rc;
+    if ((rc = dev_alloc(c, &c->d_weather, (size_t)WEATHER_N * WEATHER_N))) return rc;
+    if ((rc = dev_alloc(c, &c->d_detail_h, detail_total + 8))) return rc;
+    if (!c->d_bake_meta) HIPCHK(c, hipMalloc(reinterpret_cast<void**>(&c->d_bake_meta), 32));
+    struct { unsigned long long inexact; int range[3]; int pad; } meta = {0ull, {255, 0, 0}, 0};
+    hipStream_t s = c->stream;
+    HIPCHK(c, hipMemcpyAsync(c->d_bake_meta, &meta, sizeof meta, hipMemcpyHostToDevice, s));
+    HIPCHK(c, hipMemcpyAsync(c->d_raw_large, large_rgba8, large_l0, hipMemcpyHostToDevice, s));
+    HIPCHK(c, hipMemcpyAsync(c->d_raw_small, small_rgb8, small_l0, hipMemcpyHostToDevice, s));
+    HIPCHK(c, hipMemcpyAsync(c->d_raw_weather, weather_rgb8, weather_b, hipMemcpyHostToDevice, s));
+    HIPCHK(c, launch_mip_chain(c->d_raw_large, SHAPE_N, 4, SHAPE_LEVELS, s));
+    HIPCHK(c, launch_mip_chain(c->d_raw_small, DETAIL_N, 3, DETAIL_LEVELS, s));
+    HIPCHK(c, launch_bake(c->d_raw_large, c->d_raw_small, c->d_raw_weather, c->d_shape, c->d_detail, c->d_detail_h, c->d_weather,
+                          reinterpret_cast<unsigned long long*>(c->d_bake_meta), reinterpret_cast<int*>(c->d_bake_meta + 8), s));
+    uint8_t t5[3] = {0, 0, 0};                                // detail LOD 5 is one texel: every tap at that level returns it (cloud_core.h::detail_tap)
+    HIPCHK(c, hipMemcpyAsync(&meta, c->d_bake_meta, sizeof meta, hipMemcpyDeviceToHost, s));
+    HIPCHK(c, hipMemcpyAsync(t5, c->d_raw_small + chain_offset(DETAIL_N, 5, 3), 3, hipMemcpyDeviceToHost, s));
+    HIPCHK(c, hipStreamSynchronize(s));
+    c->inexact_coeffs = meta.inexact;
+    c->detail_lod5 = (float)(5 * t5[0] + 2 * t5[1] + t5[2]) * (1.0f / (8.0f * 255.0f));
+    c->w_rmin = meta.range[0] / 255.0; c->w_rmax = meta.range[1] / 255.0; c->w_bmax = meta.range[2] / 255.0; c->win_cov = -1e30f;   // channel ranges for the height-window reject
     c->have_noise = true;
     c->err[0] = 0;
     if (c->inexact_coeffs)     // still CSKY_OK (the taps stay within the parity tolerance), but never silent: cloudsky.h csky_noise_inexact_coeffs
         snprintf(c->err, sizeof c->err, "csky_set_noise: warning: %llu finite-difference coefficients of these textures are not exact in fp16 "
                  "(|coefficient| > 2048); taps through them carry a relative 2^-11 error", c->inexact_coeffs);
+    return CSKY_OK;
+}
+
+int csky_read_baked_texture(csky_ctx* c, int which, void* out, size_t capacity, size_t* bytes) {
+    if (!c || !bytes) return fail(c, CSKY_ERR_INVALID, "csky_read_baked_texture: NULL argument");
+    if (!c->have_noise) return fail(c, CSKY_ERR_STATE, "csky_read_baked_texture: csky_set_noise has not been called");
+    int rc; if ((rc = bind(c))) return rc;
+    size_t shape_total = 0;
+    for (int l = 0; l < SHAPE_LEVELS; l++) { const size_t n = SHAPE_N >> l; shape_total += n * n * n; }
+    const void* src = nullptr; size_t n = 0;
+    switch (which) {
+        case 0: src = c->d_shape; n = shape_total * sizeof(ShapeTexel); break;
+        case 1: src = c->d_detail; n = (size_t)DETAIL_CHAIN_TEXELS * sizeof(uint4); break;
+        case 2: src = c->d_weather; n = (size_t)WEATHER_N * WEATHER_N * sizeof(uint4); break;
+        case 3: src = c->d_raw_large; n = chain_offset(SHAPE_N, SHAPE_LEVELS, 4); break;
+        case 4: src = c->d_raw_small; n = chain_offset(DETAIL_N, DETAIL_LEVELS, 3); break;
+        default: return fail(c, CSKY_ERR_INVALID, "csky_read_baked_texture: which must be 0..4");
+    }
+    *bytes = n;
+    if (!out) return CSKY_OK;
+    if (capacity < n) return fail(c, CSKY_ERR_INVALID, "csky_read_baked_texture: buffer too small (%zu < %zu)", capacity, n);
+    HIPCHK(c, hipMemcpy(out, src, n, hipMemcpyDeviceToHost));
+    return CSKY_OK;
+}
+
+int csky_build_mips_device(csky_ctx* c, uint8_t* vol, int n, int ch, int levels) {
+    if (!c) return fail(nullptr, CSKY_ERR_INVALID, "csky_build_mips_device: ctx is NULL");
+    if (!vol || n < 1 || n > 1024 || (n & (n - 1)) || ch < 1 || ch > 4 || levels < 1 || (n >> (levels - 1)) < 1) return fail(c, CSKY_ERR_INVALID, "csky_build_mips_device: bad arguments");
+    int rc; if ((rc = bind(c))) return rc;
+    const size_t total = chain_offset(n, levels, ch), l0 = (size_t)n * n * n * ch;
+    uint8_t* d = nullptr;
+    HIPCHK(c, hipMalloc(reinterpret_cast<void**>(&d), total));
+    hipError_t e = hipMemcpyAsync(d, vol, l0, hipMemcpyHostToDevice, c->stream);
+    if (e == hipSuccess) e = launch_mip_chain(d, n, ch, levels, c->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(vol + l0, d + l0, total - l0, hipMemcpyDeviceToHost, c->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+    (void)hipFree(d);
+    if (e != hipSuccess) return fail(c, CSKY_ERR_HIP, "csky_build_mips_device: %s", hipGetErrorString(e));
+    return CSKY_OK;
+}
+
+int csky_generate_detail_noise_device(csky_ctx* c, uint32_t seed, int n, uint8_t* out_rgb8) {
+    if (!c) return fail(nullptr, CSKY_ERR_INVALID, "csky_generate_detail_noise_device: ctx is NULL");
+    if (!out_rgb8 || n < 8 || n > 256 || (n & (n - 1))) return fail(c, CSKY_ERR_INVALID, "csky_generate_detail_noise_device: n must be a power of two in [8, 256]");
+    int rc; if ((rc = bind(c))) return rc;
+    const size_t bytes = (size_t)n * n * n * 3;
+    uint8_t* d = nullptr;
+    HIPCHK(c, hipMalloc(reinterpret_cast<void**>(&d), bytes));
+    hipError_t e = launch_detail_noise(seed, n, d, c->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(out_rgb8, d, bytes, hipMemcpyDeviceToHost, c->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+    (void)hipFree(d);
+    if (e != hipSuccess) return fail(c, CSKY_ERR_HIP, "csky_generate_detail_noise_device: %s", hipGetErrorString(e));
     return CSKY_OK;
 }
 
@@ -428,8 +465,8 @@ int csky_set_variant(csky_ctx* c, int variant) {
 }
 int csky_set_schedule(csky_ctx* c, int mode) {
     if (!c) return fail(nullptr, CSKY_ERR_INVALID, "csky_set_schedule: ctx is NULL");
-    if (!(mode == -1 || mode == 1 || mode == 2 || mode == 5 || mode == 7 || mode == 8 || mode == 9))
-        return fail(c, CSKY_ERR_INVALID, "csky_set_schedule: mode must be -1 (auto), 1, 2, 5, 7, 8 or 9 (see cloudsky.h)");
+    if (!(mode == -1 || mode == 1 || mode == 2 || mode == 5 || mode == 7))
+        return fail(c, CSKY_ERR_INVALID, "csky_set_schedule: mode must be -1 (auto), 1, 2, 5 or 7 (see cloudsky.h)");
     c->sched_mode = mode; return CSKY_OK;
 }
 int csky_set_frames_in_flight(csky_ctx* c, int frames) {

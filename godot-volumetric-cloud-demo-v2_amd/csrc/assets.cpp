@@ -48,6 +48,12 @@ int csky_generate_shape_noise(uint32_t seed, int n, uint8_t* out_rgba8) {
     return CSKY_OK;
 }
 
+int csky_generate_detail_noise(uint32_t seed, int n, uint8_t* out_rgb8) {
+    if (!out_rgb8 || n < 8 || (n & (n - 1))) { snprintf(g_asset_err, sizeof g_asset_err, "generate_detail_noise: n must be a power of two >= 8"); return CSKY_ERR_INVALID; }
+    for (int z = 0; z < n; z++) for (int y = 0; y < n; y++) for (int x = 0; x < n; x++) csky::detail_voxel(seed, n, x, y, z, out_rgb8 + ((((size_t)z * n + y) * n + x) * 3));
+    return CSKY_OK;
+}
+
 size_t csky_mip_offset(int n, int level, int ch) {
     size_t off = 0;
     for (int l = 0; l < level; l++) { size_t m = (size_t)(n >> l); off += m * m * m * (size_t)ch; }

@@ -27,22 +27,20 @@ hipError_t launch_lpt_order(uint32_t* d_cost, int n, int shift, uint32_t* d_scra
 
 // static workgroup orders 1, 2, 5 written on the device (kernels.hip); grid = padded number of physical workgroups
 hipError_t launch_static_order(int mode, int tiles_x, int slabs, int grid, uint32_t* d_order, hipStream_t s);
-// deadline order (mode 8) of the next launch from this launch's costs and the static order; d_cost is left zeroed.  grid % 8 == 0
-hipError_t launch_deadline_order(const uint32_t* d_static, int grid, uint32_t* d_cost, float beta, uint32_t* d_order, hipStream_t s);
-int deadline_order_max_grid();
-
-// mixed-segment launch (schedule mode 9): mode-5 order whose last t4 (then t2) slab positions per XCD are expanded into 4- (2-)segment
-// workgroups; order entries carry the segment count (kernels.hip::mixed_order_kernel), "compact" march only
-int mixed_order_grid(int tiles32_x, int slabs, int t2, int t4);
-hipError_t launch_mixed_order(int tile_w, int slabs, int t2, int t4, uint32_t* d_order, hipStream_t s);
-hipError_t launch_clouds_mixed(const TexSet& t, const FrameConsts* d_fc, const RenderGeom& g, const uint32_t* d_order, int grid, uint2* d_out,
-                               unsigned long long* d_stats, hipStream_t s);
-
 // clouds.gdshader sky() on an equirectangular panorama (all pointers in `a` are device pointers)
 hipError_t launch_composite(const CompositeArgs& a, uint2* d_out, hipStream_t s);
 
 // stand-in shape noise bake: n^3 RGBA8 voxels (little-endian u32 = r | g<<8 | b<<16 | a<<24)
 hipError_t launch_shape_noise(uint32_t seed, int n, uint32_t* d_out, hipStream_t s);
+
+// generated 32^3 RGB detail volume (noise_core.h::detail_voxel), 3 bytes per voxel
+hipError_t launch_detail_noise(uint32_t seed, int n, uint8_t* d_out, hipStream_t s);
+// 2x2x2 box mips of a device chain whose level 0 is filled (level l at chain_offset(n, l, ch))
+hipError_t launch_mip_chain(uint8_t* d_chain, int n, int ch, int levels, hipStream_t s);
+// the three device texture layouts from the 8-bit chains; *d_inexact += coefficients not exact in fp16; d_range = {min R, max R, max B} of the
+// weather map (initialise to {255, 0, 0})
+hipError_t launch_bake(const uint8_t* d_large_chain, const uint8_t* d_small_chain, const uint8_t* d_weather, ShapeTexel* d_shape, uint4* d_detail, uint16_t* d_detail_h,
+                       uint4* d_weather_out, unsigned long long* d_inexact, int* d_range, hipStream_t s);
 
 int cloud_variant_count();
 const char* cloud_variant_name(int v);

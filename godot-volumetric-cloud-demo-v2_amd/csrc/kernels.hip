@@ -1,7 +1,7 @@
 // kernels.hip -- gfx950 (CDNA4, wave64) kernels of libcloudsky.
 //
-//   transmittance_kernel : transmittance-lut.glsl, one texel per lane                 (16 384 lanes, once)
-//   sky_lut_kernel       : sky-lut.glsl, one texel per lane                           (20 000 lanes, per sun change)
+//   transmittance_kernel : transmittance-lut.glsl, one texel per wavefront, 40 steps on 40 lanes   (16 384 wavefronts, once)
+//   sky_lut_kernel       : sky-lut.glsl, one texel per half wavefront, 30 steps on 30 lanes       (20 000 texels, per sun change)
 //   frame_setup_kernel   : the ray-invariant prologue of clouds.glsl march()          (1 lane, per frame)
 //   clouds_kernel        : clouds.glsl main(): one ray per lane, one 8x8-pixel tile per wavefront
 //
@@ -12,18 +12,36 @@
 #include "lut_core.h"
 #include "composite_core.h"
 #include "noise_core.h"
+#include "bake_core.h"
 
 namespace csky {
 
 // ------------------------------------------------------------------------------------------------ LUTs
-__global__ __launch_bounds__(64) void transmittance_kernel(int w, int h, uint16_t* __restrict__ out_h, float4* __restrict__ out_f) {
-    const int px = blockIdx.x * 8 + (threadIdx.x & 7), py = blockIdx.y * 8 + (threadIdx.x >> 3);  // 8x8 groups, T:5
-    if (px >= w || py >= h) return;  // (T:159 tests `>`; the extra row/column would be an out-of-image store)
-    const F4 t = transmittance_texel(px, py, (float)w, (float)h);
-    const uint16_t hx = f2h(t.x), hy = f2h(t.y), hz = f2h(t.z), hw = f2h(t.w);
-    const size_t i = (size_t)py * w + px;
-    reinterpret_cast<uint2*>(out_h)[i] = make_uint2((uint32_t)hx | ((uint32_t)hy << 16), (uint32_t)hz | ((uint32_t)hw << 16));
-    out_f[i] = make_float4(h2f(hx), h2f(hy), h2f(hz), h2f(hw));
+// transmittance-lut.glsl: one texel per wavefront: lanes 0..39 evaluate the 40 optical-depth steps in parallel (each ~150 VALU with five
+// correctly rounded transcendentals, independent of the others), park extinction * dt in LDS, then lane 0 replays the sum in the reference's
+// order (T:186-192; bit-identical to the one-lane-per-texel form, 40x shorter critical path).  Round 1 had the GLSL's own dispatch shape here
+// (8x8 groups, one texel per lane, a 40-step serial loop: 2 048 one-wave groups on 6 % of the chip).
+__global__ __launch_bounds__(256) void transmittance_kernel(int w, int h, uint16_t* __restrict__ out_h, float4* __restrict__ out_f) {
+    __shared__ float terms[4][TRANSMITTANCE_STEPS][4];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int texel = blockIdx.x * 4 + wave;
+    const bool live = texel < w * h;                              // (T:159 tests `>`; the extra row/column would be an out-of-image store)
+    const int px = live ? texel % w : 0, py = live ? texel / w : 0;
+    const TransRay r = transmittance_ray(px, py, (float)w, (float)h);
+    if (lane < TRANSMITTANCE_STEPS) {
+        const F4 e = transmittance_step(r, lane);
+        float* d = terms[wave][lane];
+        d[0] = e.x; d[1] = e.y; d[2] = e.z; d[3] = e.w;
+    }
+    __syncthreads();
+    if (lane == 0 && live) {
+        F4 result = f4(0, 0, 0, 0);
+        for (int i = 0; i < TRANSMITTANCE_STEPS; ++i) { const float* d = terms[wave][i]; result = result + f4(d[0], d[1], d[2], d[3]); }
+        const F4 t = transmittance_finish(result);
+        const uint16_t hx = f2h(t.x), hy = f2h(t.y), hz = f2h(t.z), hw = f2h(t.w);
+        reinterpret_cast<uint2*>(out_h)[texel] = make_uint2((uint32_t)hx | ((uint32_t)hy << 16), (uint32_t)hz | ((uint32_t)hw << 16));
+        out_f[texel] = make_float4(h2f(hx), h2f(hy), h2f(hz), h2f(hw));
+    }
 }
 
 struct Sun3 { float v[3]; };
@@ -61,7 +79,7 @@ __global__ __launch_bounds__(256) void sky_lut_kernel(int w, int h, Sun3 sun, co
 }
 
 hipError_t launch_transmittance(int w, int h, uint16_t* d_half, float4* d_float, hipStream_t s) {
-    transmittance_kernel<<<dim3((w + 7) / 8, (h + 7) / 8), 64, 0, s>>>(w, h, d_half, d_float);
+    transmittance_kernel<<<(w * h + 3) / 4, 256, 0, s>>>(w, h, d_half, d_float);
     return hipGetLastError();
 }
 hipError_t launch_sky_lut(int w, int h, const float sun[3], const float4* d_trans, int tw, int th, uint16_t* d_half, float4* d_float,
@@ -84,6 +102,90 @@ __global__ __launch_bounds__(256) void shape_noise_kernel(uint32_t seed, int n, 
 hipError_t launch_shape_noise(uint32_t seed, int n, uint32_t* d_out, hipStream_t s) {
     const size_t total = (size_t)n * n * n;
     shape_noise_kernel<<<(unsigned)((total + 255) / 256), 256, 0, s>>>(seed, n, d_out);
+    return hipGetLastError();
+}
+
+// the 32^3 RGB detail volume (noise_core.h::detail_voxel), one voxel per lane, 3 bytes each
+__global__ __launch_bounds__(256) void detail_noise_kernel(uint32_t seed, int n, uint8_t* __restrict__ out) {
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= (size_t)n * n * n) return;
+    const int x = (int)(i % n), y = (int)((i / n) % n), z = (int)(i / ((size_t)n * n));
+    uint8_t o[3];
+    detail_voxel(seed, n, x, y, z, o);
+    out[3 * i] = o[0]; out[3 * i + 1] = o[1]; out[3 * i + 2] = o[2];
+}
+hipError_t launch_detail_noise(uint32_t seed, int n, uint8_t* d_out, hipStream_t s) {
+    const size_t total = (size_t)n * n * n;
+    detail_noise_kernel<<<(unsigned)((total + 255) / 256), 256, 0, s>>>(seed, n, d_out);
+    return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------------ mip chains + texture bake on the device
+// csky_set_noise uploads the three 8-bit level-0 textures (9.2 MB) and does everything else here: 2x2x2 box mips (Godot's
+// mipmaps/generate=true), then one lane per texel of each device layout (bake_core.h: the same per-texel code as the host bake of
+// tests/hostsim, byte-identical).  Replaces ~1.5 s of host loops + 78 MB of pageable uploads per csky_set_noise by < 1 ms of kernels.
+__global__ __launch_bounds__(256) void mip_level_kernel(const uint8_t* __restrict__ src, uint8_t* __restrict__ dst, int nd, int ch) {
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x, total = (size_t)nd * nd * nd * ch;
+    if (i >= total) return;
+    const int c = (int)(i % ch); const size_t t = i / ch;
+    const int x = (int)(t % nd), y = (int)((t / nd) % nd), z = (int)(t / ((size_t)nd * nd));
+    dst[i] = mip_texel(src, nd * 2, ch, x, y, z, c);
+}
+hipError_t launch_mip_chain(uint8_t* d_chain, int n, int ch, int levels, hipStream_t s) {
+    for (int l = 1; l < levels; l++) {
+        const int nd = n >> l;
+        const size_t total = (size_t)nd * nd * nd * ch;
+        mip_level_kernel<<<(unsigned)((total + 255) / 256), 256, 0, s>>>(d_chain + chain_offset(n, l - 1, ch), d_chain + chain_offset(n, l, ch), nd, ch);
+    }
+    return hipGetLastError();
+}
+__device__ __forceinline__ void bake_tally(unsigned bad, unsigned long long* __restrict__ inexact) {
+    for (int off = 32; off > 0; off >>= 1) bad += __shfl_down(bad, off);
+    if ((threadIdx.x & 63) == 0 && bad) atomicAdd(inexact, (unsigned long long)bad);
+}
+template <int N, int LEVELS> __device__ __forceinline__ bool level_of(size_t i, int& l, int& n, size_t& local) {
+    size_t base = 0;
+    for (l = 0; l < LEVELS; l++) { n = N >> l; const size_t cnt = (size_t)n * n * n; if (i < base + cnt) { local = i - base; return true; } base += cnt; }
+    return false;
+}
+__global__ __launch_bounds__(256) void bake_shape_kernel(const uint8_t* __restrict__ chain, ShapeTexel* __restrict__ out, unsigned long long* __restrict__ inexact) {
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    int l, n; size_t local; unsigned bad = 0;
+    if (level_of<SHAPE_N, SHAPE_LEVELS>(i, l, n, local))
+        out[i] = bake_shape_texel(chain + chain_offset(SHAPE_N, l, 4), n, (int)(local % n), (int)((local / n) % n), (int)(local / ((size_t)n * n)), bad);
+    bake_tally(bad, inexact);
+}
+__global__ __launch_bounds__(256) void bake_detail_kernel(const uint8_t* __restrict__ chain, uint4* __restrict__ out, uint16_t* __restrict__ out_h, unsigned long long* __restrict__ inexact) {
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    int l, n; size_t local; unsigned bad = 0;
+    if (level_of<DETAIL_N, DETAIL_LEVELS>(i, l, n, local)) {
+        const uint8_t* src = chain + chain_offset(DETAIL_N, l, 3);
+        const int x = (int)(local % n), y = (int)((local / n) % n), z = (int)(local / ((size_t)n * n));
+        out[i] = bake_detail_texel(src, n, x, y, z, bad);
+        out_h[i] = f2h((float)detail_numerator(src, n, x, y, z));                 // unpacked fp16 chain: source of the "lds" variant's LDS copy
+    }
+    bake_tally(bad, inexact);
+}
+// also the channel ranges of the map (exact height-window reject, bake.h::height_window): range[0] = min R, [1] = max R, [2] = max B
+__global__ __launch_bounds__(256) void bake_weather_kernel(const uint8_t* __restrict__ rgb, uint4* __restrict__ out, unsigned long long* __restrict__ inexact, int* __restrict__ range) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    unsigned bad = 0;
+    if (i < WEATHER_N * WEATHER_N) {
+        out[i] = bake_weather_texel(rgb, i % WEATHER_N, i / WEATHER_N, bad);
+        int r = rgb[3 * i], b = rgb[3 * i + 2], rmin = r, rmax = r, bmax = b;
+        for (int off = 32; off > 0; off >>= 1) { rmin = min(rmin, __shfl_down(rmin, off)); rmax = max(rmax, __shfl_down(rmax, off)); bmax = max(bmax, __shfl_down(bmax, off)); }
+        if ((threadIdx.x & 63) == 0) { atomicMin(&range[0], rmin); atomicMax(&range[1], rmax); atomicMax(&range[2], bmax); }
+    }
+    bake_tally(bad, inexact);
+}
+hipError_t launch_bake(const uint8_t* d_large_chain, const uint8_t* d_small_chain, const uint8_t* d_weather, ShapeTexel* d_shape, uint4* d_detail, uint16_t* d_detail_h,
+                       uint4* d_weather_out, unsigned long long* d_inexact, int* d_range, hipStream_t s) {
+    size_t shape_total = 0, detail_total = 0;
+    for (int l = 0; l < SHAPE_LEVELS; l++) { const size_t n = SHAPE_N >> l; shape_total += n * n * n; }
+    for (int l = 0; l < DETAIL_LEVELS; l++) { const size_t n = DETAIL_N >> l; detail_total += n * n * n; }
+    bake_shape_kernel<<<(unsigned)((shape_total + 255) / 256), 256, 0, s>>>(d_large_chain, d_shape, d_inexact);
+    bake_detail_kernel<<<(unsigned)((detail_total + 255) / 256), 256, 0, s>>>(d_small_chain, d_detail, d_detail_h, d_inexact);
+    bake_weather_kernel<<<(WEATHER_N * WEATHER_N + 255) / 256, 256, 0, s>>>(d_weather, d_weather_out, d_inexact, d_range);
     return hipGetLastError();
 }
 
@@ -689,99 +791,14 @@ __global__ __launch_bounds__(256, VARIANT == 3 ? CSKY_COMPACT_WAVES : 7) void cl
     }
 }
 
-// ---- mixed-segment launch (api.cpp, schedule mode 9): whole rays first, ray segments for the workgroups that start last ----------
-// A whole-frame launch is ~4 resident workgroup sets deep.  Once the last workgroup has been dispatched nothing refills the slots
-// that free up, and the launch drains for as long as the workgroups that started LAST take: 0.5 ms of a 2.1 ms span with the chip
-// 3/4 empty on average (profiles/r02/timeline_s5_s8.txt).  Reordering does not help: whatever starts last still takes a wavefront's
-// whole march (heaviest-first and the deadline order of mode 8 measured no gain), and a second launch cannot start before the first
-// has drained.  So the LAST workgroups of the order are made short instead: in one launch, the order's final stretch is expanded into
-// 2- and then 4-segment workgroups (the ray-segment machinery of clouds_kernel<3, 2|4>: a tile's rays are cut into step ranges marched
-// by the wavefronts of one workgroup and combined front to back through LDS), so the drain lasts a quarter of a march.  The segment
-// count is carried per workgroup in the order entry (bits 31:30 = log2 segments, bits 29:0 = index of the workgroup's first 8x8
-// tile): a workgroup-uniform value, every branch on it is scalar.  Static: nothing comes from a previous frame.
-__device__ __forceinline__ uint32_t mixed_entry(int code, uint32_t fine) { return ((uint32_t)code << 30) | fine; }
-__global__ __launch_bounds__(256) void mixed_order_kernel(int tiles8_x, int tiles32_x, int slabs, int t2, int t4, int grid, uint32_t* __restrict__ out) {
-    // one thread per SOURCE position (XCD x, position j of its mode-5 sequence of n = rows_per * tiles32_x slabs)
-    const int rows_per = (slabs + 7) >> 3, n = rows_per * tiles32_x;
-    const int src = blockIdx.x * 256 + threadIdx.x;
-    if (src >= n * 8) return;
-    const int x = src & 7, j = src >> 3;
-    const int k = j / tiles32_x, bx = j - k * tiles32_x, i = 8 * k + x;                 // slab row i, slab column bx (as static mode 5)
-    const bool live = i < slabs;
-    const uint32_t fine = (uint32_t)(i * tiles8_x + bx * 4);
-    const int n1 = n - t2 - t4;
-    if (j < n1) { out[8 * j + x] = live ? mixed_entry(0, fine) : 0xffffffffu; return; }
-    if (j < n1 + t2) {
-        const int q = n1 + 2 * (j - n1);
-        for (int h = 0; h < 2; h++) out[8 * (q + h) + x] = (live && bx * 4 + 2 * h < tiles8_x) ? mixed_entry(1, fine + 2 * h) : 0xffffffffu;
-        return;
-    }
-    const int q = n1 + 2 * t2 + 4 * (j - n1 - t2);
-    for (int h = 0; h < 4; h++) out[8 * (q + h) + x] = (live && bx * 4 + h < tiles8_x) ? mixed_entry(2, fine + h) : 0xffffffffu;
-}
-// returns the grid (number of physical workgroups) through *grid_out; d_order must hold 8 * (n + t2 + 3 t4) entries
-int mixed_order_grid(int tiles32_x, int slabs, int t2, int t4) { const int n = ((slabs + 7) >> 3) * tiles32_x; return 8 * (n + t2 + 3 * t4); }
-hipError_t launch_mixed_order(int tile_w, int slabs, int t2, int t4, uint32_t* d_order, hipStream_t s) {
-    const int tiles8_x = (tile_w + 7) >> 3, tiles32_x = (tile_w + 31) >> 5;
-    const int n = ((slabs + 7) >> 3) * tiles32_x, grid = mixed_order_grid(tiles32_x, slabs, t2, t4);
-    if (n <= 0) return hipSuccess;
-    mixed_order_kernel<<<(n * 8 + 255) / 256, 256, 0, s>>>(tiles8_x, tiles32_x, slabs, t2, t4, grid, d_order);
-    return hipGetLastError();
-}
-
-__global__ __launch_bounds__(256, CSKY_COMPACT_WAVES) void clouds_kernel_mixed(TexSet T, const FrameConsts* __restrict__ fcp, RenderGeom G, const uint32_t* __restrict__ order,
-                                                                               uint2* __restrict__ out, unsigned long long* __restrict__ stats) {
-    const uint32_t e = order[blockIdx.x];
-    if (e == 0xffffffffu) return;                              // workgroup-uniform
-    const int code = (int)(e >> 30), SEG = 1 << code;          // 1, 2 or 4 segments per ray (scalar)
-    const int fine = (int)(e & 0x3fffffffu);
-    const int tiles8_x = (G.tile_w + 7) >> 3;
-    const int local_rows = G.n_bands * G.band_rows;
-    const int slab = fine / tiles8_x, tx8 = fine - slab * tiles8_x;
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const int tile = wave >> code, seg = wave & (SEG - 1);
-    const int gx = (tx8 + tile) * 8 + (lane & 7);
-    const int lr = slab * 8 + (lane >> 3);
-    const bool valid = gx < G.tile_w && lr < local_rows;
-    const int band = lr / G.band_rows, rib = lr - band * G.band_rows;
-    const int gy = (G.first_band + band * G.band_stride) * G.band_rows + rib;
-    const FrameConsts& fc = *fcp;
-    T.detail_lds = nullptr;
-    Ray ray = ray_setup(fc, valid ? gx : 0, valid ? gy : 0);
-    if (!valid) ray.above = false;
-    __shared__ float lds[4][CQ_FLOATS];
-    __shared__ float comb[4][5][64];
-    const int s0 = (fc.primary_steps * seg) >> code, s1 = (fc.primary_steps * (seg + 1)) >> code;
-    MarchOut o = march_compact(T, fc, ray, &lds[wave][0], s0, s1);
-    if (SEG > 1) {                                             // scalar branch: front-to-back combine of the ray's segments (as clouds_kernel<3, SEG>)
-        comb[wave][0][lane] = o.r; comb[wave][1][lane] = o.g; comb[wave][2][lane] = o.b; comb[wave][3][lane] = o.t; comb[wave][4][lane] = o.a;
-        __syncthreads();
-        if (seg == 0) {
-            float Tr = o.t, na = 1.0f - o.a;
-            for (int q = 1; q < SEG; q++) {
-                const int w = tile * SEG + q;
-                o.r += Tr * comb[w][0][lane]; o.g += Tr * comb[w][1][lane]; o.b += Tr * comb[w][2][lane];
-                Tr *= comb[w][3][lane]; na *= 1.0f - comb[w][4][lane];
-            }
-            o.a = sat(1.0f - na); o.t = Tr;
-        }
-    }
-    if (valid && seg == 0) {
-        const uint32_t lo = (uint32_t)f2h(o.r) | ((uint32_t)f2h(o.g) << 16), hi = (uint32_t)f2h(o.b) | ((uint32_t)f2h(o.a) << 16);
-        out[(size_t)(G.out_full ? gy : lr) * G.pitch_px + gx] = make_uint2(lo, hi);  // imageStore, clouds.glsl:264
-    }
-    if (stats) {
-        unsigned ic = o.incloud, ab = (ray.above && seg == 0) ? 1u : 0u;
-        for (int off = 32; off > 0; off >>= 1) { ic += __shfl_down(ic, off); ab += __shfl_down(ab, off); }
-        if (lane == 0) { atomicAdd(&stats[0], (unsigned long long)ic); atomicAdd(&stats[1], (unsigned long long)ab); }
-    }
-}
-hipError_t launch_clouds_mixed(const TexSet& t, const FrameConsts* d_fc, const RenderGeom& g, const uint32_t* d_order, int grid, uint2* d_out,
-                               unsigned long long* d_stats, hipStream_t s) {
-    if (grid <= 0) return hipSuccess;
-    clouds_kernel_mixed<<<grid, 256, 0, s>>>(t, d_fc, g, d_order, d_out, d_stats);
-    return hipGetLastError();
-}
+// ---- launch-tail / share experiments of round 2 (measured, removed; evidence under profiles/r02/) -----------------------------
+// A whole-frame launch drains for the last ~27 % of its span with the chip 3/4 empty (time-integral of occupancy 72-76 %).  Three
+// ways of filling that tail were built and measured on MI355X, none made the frame faster, and the code was removed again:
+//   * deadline order: static order, previous-frame costs pull late heavy workgroups forward             2.10 vs 2.07 ms (timeline_static_vs_deadline_order.txt)
+//   * mixed-segment launch: the order's last 10-25 % as 2-/4-segment workgroups in the SAME launch: occupancy integral 72 -> 85-87 %,
+//     frame 2.06-2.28 vs 2.09 ms: segments add 17 % wave-time and the launch is VALU/L1-throughput bound     (timeline_static_vs_mixed_segment_tail.txt)
+//   * adaptive segments per workgroup from previous-frame costs, for one GPU's 1/4..1/16 share             0.446 vs 0.434 ms at 1/8 (share_matrix_adaptive_segments.txt)
+// What does fill the tail is the NEXT frame's workgroups (two frames in flight, api.cpp): 2.12 -> 1.80 ms per frame.
 
 // ---- cost-feedback schedule (api.cpp, schedule mode 7) -----------------------------------------------------------------
 // Workgroups differ 10x in cost (in-cloud samples per tile) and a C3 frame is only ~4 waves of resident workgroups deep, so
@@ -855,64 +872,6 @@ hipError_t launch_static_order(int mode, int tiles_x, int slabs, int grid, uint3
     static_order_kernel<<<(grid + 255) / 256, 256, 0, s>>>(mode, tiles_x, slabs, grid, d_order);
     return hipGetLastError();
 }
-
-// ---- deadline schedule (api.cpp, schedule mode 8) ----------------------------------------------------------------------
-// A whole-frame launch is ~4 resident workgroup sets deep and ends in a tail of few, long wavefronts: a workgroup that
-// marches through a lot of cloud lasts 3x the mean, and when one of those STARTS late the launch waits for it with most of
-// the chip idle (profiles/r01/occupancy_timeline.txt: 75 % time-integral of occupancy).  Sorting everything heaviest-first
-// (mode 7) removes the tail but makes the heavy workgroups run together and breaks up neighbours (+13 % wave duration).
-// Here the static order is kept and only the workgroups that would finish too late are moved forward, just far enough:
-// with the per-workgroup costs c of the PREVIOUS launch of the same view (as mode 7: only the ORDER comes from the previous
-// frame, every sample is recomputed, frames are bit-identical under every order), position j of an XCD's sequence of n gets
-//     key = min(j, n * (1 - beta * max(0, c - mean) / max))                   ("latest start" of a workgroup of cost c)
-// and the sequence is re-ranked by (key, j): a stable merge in which on-time workgroups keep their order and neighbours.
-// One 1024-thread workgroup per XCD sequence; rank by counting (n <= 8192 per XCD: n^2 / 1024 compares per thread from LDS).
-constexpr int DL_MAX_N = 8192;
-__global__ __launch_bounds__(1024) void deadline_order_kernel(const uint32_t* __restrict__ S, int n, uint32_t* __restrict__ cost, float beta,
-                                                              uint32_t* __restrict__ out) {
-    extern __shared__ uint32_t dl_comp[];                       // [n] composite sort keys (key << 14 | j), then reduction scratch behind them
-    __shared__ float red_sum[16], red_max[16];
-    const int x = blockIdx.x, t = threadIdx.x;
-    float lsum = 0.0f, lmax = 0.0f; int lcnt = 0;
-    for (int j = t; j < n; j += 1024) {
-        const uint32_t l = S[8 * j + x];
-        if (l != 0xffffffffu) { const float c = (float)cost[l]; lsum += c; lmax = fmaxf(lmax, c); lcnt++; }
-    }
-    float lc = (float)lcnt;
-    for (int off = 32; off > 0; off >>= 1) { lsum += __shfl_down(lsum, off); lc += __shfl_down(lc, off); lmax = fmaxf(lmax, __shfl_down(lmax, off)); }
-    __shared__ float red_cnt[16];
-    if ((t & 63) == 0) { red_sum[t >> 6] = lsum; red_cnt[t >> 6] = lc; red_max[t >> 6] = lmax; }
-    __syncthreads();
-    float sum = 0.0f, cnt = 0.0f, mx = 0.0f;
-    for (int w = 0; w < 16; w++) { sum += red_sum[w]; cnt += red_cnt[w]; mx = fmaxf(mx, red_max[w]); }
-    const float mean = cnt > 0.0f ? sum / cnt : 0.0f, inv = mx > 0.0f ? 1.0f / mx : 0.0f;
-    for (int j = t; j < n; j += 1024) {
-        const uint32_t l = S[8 * j + x];
-        uint32_t key = (uint32_t)n;                             // idle padding goes last
-        if (l != 0xffffffffu) {
-            const float c = (float)cost[l];
-            const float latest = (float)n * (1.0f - beta * fmaxf(0.0f, c - mean) * inv);
-            const int lk = (int)fmaxf(0.0f, latest);
-            key = (uint32_t)(lk < j ? lk : j);
-            cost[l] = 0u;                                        // the next launch accumulates into a clean array (own entries only)
-        }
-        dl_comp[j] = (key << 14) | (uint32_t)j;
-    }
-    __syncthreads();
-    for (int j = t; j < n; j += 1024) {
-        const uint32_t mine = dl_comp[j];
-        int rank = 0;
-        for (int k = 0; k < n; k++) rank += dl_comp[k] < mine ? 1 : 0;
-        out[8 * rank + x] = S[8 * j + x];
-    }
-}
-hipError_t launch_deadline_order(const uint32_t* d_static, int grid, uint32_t* d_cost, float beta, uint32_t* d_order, hipStream_t s) {
-    const int n = grid / 8;
-    if (n <= 0 || (grid & 7) || n > DL_MAX_N) return hipErrorInvalidValue;
-    deadline_order_kernel<<<8, 1024, (size_t)n * sizeof(uint32_t), s>>>(d_static, n, d_cost, beta, d_order);
-    return hipGetLastError();
-}
-int deadline_order_max_grid() { return DL_MAX_N * 8; }
 
 static const char* const kVariantNames[] = {"lockstep", "queue", "queue-lds", "compact"};
 int cloud_variant_count() { return (int)(sizeof(kVariantNames) / sizeof(kVariantNames[0])); }

@@ -70,22 +70,33 @@ CSKY_HD Coeffs atmosphere_collision_coefficients(float h) {
     return c;
 }
 
-// T:157-196 main() for texel (px,py) of a w x h LUT.
-CSKY_HD F4 transmittance_texel(int px, int py, float w, float h) {
+// T:157-196 main() for texel (px,py) of a w x h LUT, split like the sky LUT below so that the 40 optical-depth steps of one texel can be
+// evaluated by 40 lanes in parallel: every step's extinction * dt is independent of the others, only the running sum (T:191) is
+// sequential, and it is replayed in the reference's order (bit-identical to the one-lane form).
+struct TransRay { float sdx, sdz, d, dt; };
+CSKY_HD TransRay transmittance_ray(int px, int py, float w, float h) {
+    TransRay r;
     const float uvx = (float)px / w, uvy = (float)py / h;
     const float c = uvx * 2.0f - 1.0f;
-    const float sdx = -sqrtf(1.0f - c * c), sdz = c;
-    const float d = EARTH_RADIUS * (1.0f - uvy) + ATMOSPHERE_RADIUS * uvy;  // mix()
-    const float t_d = ray_sphere_intersection(0.0f, 0.0f, d, sdx, 0.0f, sdz, ATMOSPHERE_RADIUS);
-    const float dt = t_d / (float)TRANSMITTANCE_STEPS;
+    r.sdx = -sqrtf(1.0f - c * c); r.sdz = c;
+    r.d = EARTH_RADIUS * (1.0f - uvy) + ATMOSPHERE_RADIUS * uvy;  // mix()
+    const float t_d = ray_sphere_intersection(0.0f, 0.0f, r.d, r.sdx, 0.0f, r.sdz, ATMOSPHERE_RADIUS);
+    r.dt = t_d / (float)TRANSMITTANCE_STEPS;
+    return r;
+}
+CSKY_HD F4 transmittance_step(const TransRay& r, int i) {            // one term of the sum at T:186-192
+    const float t = ((float)i + 0.5f) * r.dt;
+    const float x = 0.0f + r.sdx * t, y = 0.0f + 0.0f * t, z = r.d + r.sdz * t;
+    const float altitude = sqrtf(x * x + y * y + z * z) - EARTH_RADIUS;
+    return atmosphere_collision_coefficients(altitude).extinction * r.dt;
+}
+CSKY_HD F4 transmittance_finish(const F4& result) { return exp4(f4(-result.x, -result.y, -result.z, -result.w)); }   // T:194
+// the whole texel on one lane (host-compiled unit test; the kernel spreads the steps over lanes)
+CSKY_HD F4 transmittance_texel(int px, int py, float w, float h) {
+    const TransRay r = transmittance_ray(px, py, w, h);
     F4 result = f4(0, 0, 0, 0);
-    for (int i = 0; i < TRANSMITTANCE_STEPS; ++i) {
-        const float t = ((float)i + 0.5f) * dt;
-        const float x = 0.0f + sdx * t, y = 0.0f + 0.0f * t, z = d + sdz * t;
-        const float altitude = sqrtf(x * x + y * y + z * z) - EARTH_RADIUS;
-        result = result + atmosphere_collision_coefficients(altitude).extinction * dt;
-    }
-    return exp4(f4(-result.x, -result.y, -result.z, -result.w));
+    for (int i = 0; i < TRANSMITTANCE_STEPS; ++i) result = result + transmittance_step(r, i);
+    return transmittance_finish(result);
 }
 
 // CLAMP + LINEAR tap of the transmittance LUT (fp16-rounded values widened to float), sky_lut.gd:62-68

@@ -89,4 +89,22 @@ CSKY_HD void shape_voxel(uint32_t seed, int n, int x, int y, int z, uint8_t o[4]
     o[0] = unorm8(r); o[1] = unorm8(g); o[2] = unorm8(b); o[3] = unorm8(a);
 }
 
+// One voxel of a generated 32^3 RGB detail volume in the role of cloud_sky/worlnoise.bmp (README.md:30 TODO 3: "generate the noise on
+// the GPU"): three tileable inverted-Worley fBm channels of rising frequency.  Calibrated against the shipped worlnoise.bmp (SURVEY A.8;
+// tests/test_assets.py compares against the asset itself): channel means 0.71, std 0.11 / 0.11 / 0.14, maxima at 1.0, dominant
+// |k| = 2.4 / 4.6 / 7.0 cycles per 32 texels (generated: 2.1 / 4.8 / 6.6), tileable in x, y, z.  Same arithmetic rules as shape_voxel:
+// bit-identical on the host and on the GPU.
+CSKY_HD void detail_voxel(uint32_t seed, int n, int x, int y, int z, uint8_t o[3]) {
+    const float inv = 1.0f / (float)n;
+    const float u = ((float)x + 0.5f) * inv, v = ((float)y + 0.5f) * inv, w = ((float)z + 0.5f) * inv;
+    const int freq[3] = {2, 5, 7};
+    const float centre[3] = {0.4928f, 0.4795f, 0.4801f}, gain[3] = {1.0f, 0.95f, 1.2f};
+    for (int c = 0; c < 3; c++) {
+        const uint32_t salt = seed * 211U + 7U + (uint32_t)c;
+        const float d = (1.0f - worley(u, v, w, freq[c], salt)) * 0.625f + (1.0f - worley(u, v, w, freq[c] * 2, salt + 10U)) * 0.25f +
+                        (1.0f - worley(u, v, w, freq[c] * 4, salt + 20U)) * 0.125f;       // fBm of the nearest-feature distance (worley() is 1 - distance, clamped)
+        o[c] = unorm8(((1.0f - d) - centre[c]) * gain[c] + 0.712f);
+    }
+}
+
 }  // namespace csky

@@ -183,10 +183,9 @@ int csky_variant_count(void);
  * 5 = slab rows round-robin over the XCDs; 1 = contiguous eighths; 2 = natural order (all three written on the device);
  * 7 = cost feedback: every launch records a cost per workgroup (in-cloud samples) and the next launch of the same geometry
  *     and view starts its workgroups heaviest first (the first launch runs in a static order);
- * 8 = deadline feedback: order 5, except that workgroups whose previous-launch cost says they would finish after everybody
- *     else are moved forward just far enough (kernels.hip::deadline_order_kernel): removes the launch tail of a lone frame
- *     without breaking up neighbours.  Under 7 and 8 only the ORDER comes from the previous launch; every sample is recomputed.
- * (0, 3, 4, 6 were azimuth-wedge / horizon-first orders of round 1, measured slower and removed.) */
+ *     Only the ORDER comes from the previous launch; every sample is recomputed.
+ * (0, 3, 4, 6 were azimuth-wedge / horizon-first orders of round 1; 8 / 9 the 'deadline' reorder and per-workgroup adaptive ray
+ *  segments of round 2: all measured, no gain, removed -- kernels.hip keeps the numbers.) */
 int csky_set_schedule(csky_ctx* ctx, int mode);
 /* Ray segments: the primary march of every ray is cut into `segments` pieces marched by different wavefronts of one
  * workgroup and composited front to back (T and L are associative).  0 = auto (whole rays for large launches, 2 or 4
@@ -237,8 +236,19 @@ int csky_strip_to_volume(const uint8_t* strip, int n, int ch, uint8_t* vol);
 int csky_generate_shape_noise(uint32_t seed, int n, uint8_t* out_rgba8);
 /* The same generator as a HIP kernel (one voxel per lane): byte-identical output, ~1 ms for 128^3 (README.md:30 TODO 3). */
 int csky_generate_shape_noise_device(csky_ctx* ctx, uint32_t seed, int n, uint8_t* out_rgba8);
+/* A generated 32^3 RGB detail volume in the role of worlnoise.bmp (three tileable inverted-Worley fBm channels calibrated on the asset's
+ * statistics, noise_core.h), host and GPU (byte-identical): README.md:30 TODO 3 "generate the noise on the GPU". */
+int csky_generate_detail_noise(uint32_t seed, int n, uint8_t* out_rgb8);
+int csky_generate_detail_noise_device(csky_ctx* ctx, uint32_t seed, int n, uint8_t* out_rgb8);
 size_t csky_mip_offset(int n, int level, int ch);
+/* 3-D mip chain (mipmaps/generate=true of the .import files): 2x2x2 box, (sum + 4) >> 3.  `vol` holds level 0 on entry and has room for
+ * csky_mip_offset(n, levels, ch) bytes.  csky_build_mips runs on the host, csky_build_mips_device on the GPU (byte-identical); since round 2
+ * csky_set_noise builds its chains and its device layouts on the GPU itself (kernels.hip::launch_mip_chain / launch_bake). */
 int csky_build_mips(uint8_t* vol, int n, int ch, int levels);
+int csky_build_mips_device(csky_ctx* ctx, uint8_t* vol, int n, int ch, int levels);
+/* Test hook: read back what csky_set_noise built on the device.  which: 0 shape layout, 1 detail layout, 2 weather layout (csky_common.h),
+ * 3 / 4 the 8-bit mip chains of the large / small volume.  out may be NULL to query the size. */
+int csky_read_baked_texture(csky_ctx* ctx, int which, void* out, size_t capacity, size_t* bytes);
 const char* csky_assets_last_error(void);
 
 #ifdef __cplusplus

@@ -1,0 +1,203 @@
+/* A mock GDExtension host: just enough of Godot's extension interface to load gdext/libcloudsky_gdext.so the way the engine
+ * would (entry symbol -> initialize(SCENE) -> class + method registration), instantiate `CloudSkyHIP` and call its methods
+ * through BOTH binding forms the engine uses (ptrcall and Variant call).  TEST INFRASTRUCTURE: Godot is on neither box.
+ *   gdext_mock_host <libcloudsky_gdext.so>                          registration + error paths (no GPU needed)
+ *   gdext_mock_host <libcloudsky_gdext.so> <asset_dir> <fixture>    + create / set_noise / LUTs / a 64x32 cloud frame vs the fixture
+ * Mock object model: StringName = const char*, String = char*, Packed*Array = {data, size}, Variant = {type, payload}. */
+#include <dlfcn.h>
+#include "../gdext/gdextension_min.h"
+#include "c_test_util.h"
+
+typedef struct { uint8_t *data; int64_t size; } MockPacked;                 /* 16 bytes, like the engine's */
+typedef struct { int32_t type; int32_t pad; union { int64_t i; MockPacked arr; char *s; } u; } MockVariant;   /* 24 bytes */
+
+typedef void (*builtin_method)(GDExtensionTypePtr, const GDExtensionConstTypePtr *, GDExtensionTypePtr, int);
+typedef void (*ptr_constructor)(GDExtensionTypePtr, const GDExtensionConstTypePtr *);
+
+static struct {
+    char class_name[64], parent[64];
+    GDExtensionClassCreationInfo2 ci;
+    struct { char name[64]; GDExtensionClassMethodInfo mi; } methods[16];
+    int n_methods;
+    void *instance;
+} R;
+
+/* ---- interface functions ------------------------------------------------------------------------------------------------- */
+static void *i_mem_alloc(size_t n) { return malloc(n); }
+static void i_mem_free(void *p) { free(p); }
+static void i_string_name_new(GDExtensionStringNamePtr dst, const char *s, GDExtensionBool is_static) { (void)is_static; *(const char **)dst = s; }
+static void i_string_new(GDExtensionStringPtr dst, const char *s) { *(char **)dst = strdup(s); }
+static uint8_t *i_pba_index(GDExtensionTypePtr self, GDExtensionInt i) { return ((MockPacked *)self)->data + i; }
+static const uint8_t *i_pba_index_const(GDExtensionConstTypePtr self, GDExtensionInt i) { return ((const MockPacked *)self)->data + i; }
+static const float *i_pfa_index_const(GDExtensionConstTypePtr self, GDExtensionInt i) { return (const float *)((const MockPacked *)self)->data + i; }
+static GDExtensionObjectPtr i_construct_object(GDExtensionConstStringNamePtr name) { (void)name; return malloc(8); }
+static void i_object_set_instance(GDExtensionObjectPtr o, GDExtensionConstStringNamePtr cls, GDExtensionClassInstancePtr inst) { (void)o; (void)cls; R.instance = inst; }
+static void i_register_class(GDExtensionClassLibraryPtr lib, GDExtensionConstStringNamePtr name, GDExtensionConstStringNamePtr parent, const GDExtensionClassCreationInfo2 *ci) {
+    (void)lib;
+    snprintf(R.class_name, sizeof R.class_name, "%s", *(const char *const *)name);
+    snprintf(R.parent, sizeof R.parent, "%s", *(const char *const *)parent);
+    R.ci = *ci;
+}
+static void i_register_method(GDExtensionClassLibraryPtr lib, GDExtensionConstStringNamePtr cls, const GDExtensionClassMethodInfo *mi) {
+    (void)lib; (void)cls;
+    snprintf(R.methods[R.n_methods].name, 64, "%s", *(const char *const *)mi->name);
+    R.methods[R.n_methods].mi = *mi;
+    R.n_methods++;
+}
+static void i_unregister_class(GDExtensionClassLibraryPtr lib, GDExtensionConstStringNamePtr name) { (void)lib; (void)name; R.class_name[0] = 0; }
+/* Variant <-> native */
+static void v2t_int(GDExtensionTypePtr dst, GDExtensionVariantPtr v) { *(int64_t *)dst = ((MockVariant *)v)->u.i; }
+static void v2t_packed(GDExtensionTypePtr dst, GDExtensionVariantPtr v) {   /* the engine shares the buffer; the mock copies it */
+    const MockPacked *s = &((MockVariant *)v)->u.arr; MockPacked *d = (MockPacked *)dst;
+    d->size = s->size; d->data = (uint8_t *)malloc((size_t)(s->size ? s->size : 1) * 4); memcpy(d->data, s->data, (size_t)s->size * (((MockVariant *)v)->type == GDEXTENSION_VARIANT_TYPE_PACKED_FLOAT32_ARRAY ? 4 : 1));
+}
+static GDExtensionTypeFromVariantConstructorFunc i_to_type(GDExtensionVariantType t) { return t == GDEXTENSION_VARIANT_TYPE_INT ? v2t_int : v2t_packed; }
+static void t2v_int(GDExtensionVariantPtr v, GDExtensionTypePtr src) { MockVariant *m = (MockVariant *)v; m->type = GDEXTENSION_VARIANT_TYPE_INT; m->u.i = *(int64_t *)src; }
+static void t2v_pba(GDExtensionVariantPtr v, GDExtensionTypePtr src) {
+    MockVariant *m = (MockVariant *)v; const MockPacked *s = (const MockPacked *)src;
+    m->type = GDEXTENSION_VARIANT_TYPE_PACKED_BYTE_ARRAY; m->u.arr.size = s->size; m->u.arr.data = (uint8_t *)malloc((size_t)(s->size ? s->size : 1)); memcpy(m->u.arr.data, s->data, (size_t)s->size);
+}
+static void t2v_str(GDExtensionVariantPtr v, GDExtensionTypePtr src) { MockVariant *m = (MockVariant *)v; m->type = GDEXTENSION_VARIANT_TYPE_STRING; m->u.s = strdup(*(char **)src); }
+static GDExtensionVariantFromTypeConstructorFunc i_from_type(GDExtensionVariantType t) {
+    return t == GDEXTENSION_VARIANT_TYPE_INT ? t2v_int : (t == GDEXTENSION_VARIANT_TYPE_STRING ? t2v_str : t2v_pba);
+}
+static void d_packed(GDExtensionTypePtr p) { free(((MockPacked *)p)->data); ((MockPacked *)p)->data = NULL; ((MockPacked *)p)->size = 0; }
+static void d_string(GDExtensionTypePtr p) { free(*(char **)p); *(char **)p = NULL; }
+static GDExtensionPtrDestructor i_get_destructor(GDExtensionVariantType t) { return t == GDEXTENSION_VARIANT_TYPE_STRING ? d_string : d_packed; }
+static void b_size(GDExtensionTypePtr self, const GDExtensionConstTypePtr *a, GDExtensionTypePtr r, int n) { (void)a; (void)n; *(int64_t *)r = ((MockPacked *)self)->size; }
+static void b_resize(GDExtensionTypePtr self, const GDExtensionConstTypePtr *a, GDExtensionTypePtr r, int n) {
+    MockPacked *p = (MockPacked *)self; (void)n;
+    p->size = *(const int64_t *)a[0]; p->data = (uint8_t *)realloc(p->data, (size_t)(p->size ? p->size : 1)); *(int64_t *)r = 0;
+}
+static builtin_method i_get_builtin(GDExtensionVariantType t, GDExtensionConstStringNamePtr name, GDExtensionInt hash) {
+    const char *n = *(const char *const *)name; (void)t;
+    if (!strcmp(n, "size") && hash == 3173160232LL) return b_size;
+    if (!strcmp(n, "resize") && hash == 848867239LL) return b_resize;
+    return NULL;
+}
+static void c_default(GDExtensionTypePtr self, const GDExtensionConstTypePtr *a) { (void)a; memset(self, 0, sizeof(MockPacked)); }
+static ptr_constructor i_get_ctor(GDExtensionVariantType t, int32_t idx) { (void)t; return idx == 0 ? c_default : NULL; }
+
+static GDExtensionInterfaceFunctionPtr get_proc(const char *name) {
+#define F(n, f) if (!strcmp(name, n)) return (GDExtensionInterfaceFunctionPtr)f
+    F("mem_alloc", i_mem_alloc); F("mem_free", i_mem_free);
+    F("string_name_new_with_latin1_chars", i_string_name_new); F("string_new_with_utf8_chars", i_string_new);
+    F("packed_byte_array_operator_index", i_pba_index); F("packed_byte_array_operator_index_const", i_pba_index_const);
+    F("packed_float32_array_operator_index_const", i_pfa_index_const);
+    F("classdb_construct_object", i_construct_object); F("object_set_instance", i_object_set_instance);
+    F("classdb_register_extension_class2", i_register_class); F("classdb_register_extension_class_method", i_register_method);
+    F("classdb_unregister_extension_class", i_unregister_class);
+    F("get_variant_to_type_constructor", i_to_type); F("get_variant_from_type_constructor", i_from_type);
+    F("variant_get_ptr_destructor", i_get_destructor); F("variant_get_ptr_builtin_method", i_get_builtin);
+    F("variant_get_ptr_constructor", i_get_ctor);
+#undef F
+    return NULL;
+}
+
+static const GDExtensionClassMethodInfo *method(const char *name) {
+    int i;
+    for (i = 0; i < R.n_methods; i++) if (!strcmp(R.methods[i].name, name)) return &R.methods[i].mi;
+    return NULL;
+}
+static int64_t ptrcall_int(const char *name, const GDExtensionConstTypePtr *args) {
+    int64_t r = -999;
+    method(name)->ptrcall_func(method(name)->method_userdata, R.instance, args, &r);
+    return r;
+}
+static MockPacked ptrcall_bytes(const char *name, const GDExtensionConstTypePtr *args) {
+    MockPacked r = {NULL, -1};
+    method(name)->ptrcall_func(method(name)->method_userdata, R.instance, args, &r);
+    return r;
+}
+
+int main(int argc, char **argv) {
+    GDExtensionInitialization init;
+    GDExtensionInitializationFunction entry;
+    void *so;
+    static const char *expect[] = {"create", "set_noise", "set_march", "render_transmittance", "render_sky_lut", "render_clouds", "get_status", "get_last_error"};
+    static const int expect_argc[] = {1, 3, 2, 1, 1, 3, 0, 0};
+    int i;
+    if (argc < 2) return 2;
+    so = dlopen(argv[1], RTLD_NOW);
+    if (!so) { fprintf(stderr, "%s\n", dlerror()); return 3; }
+    entry = (GDExtensionInitializationFunction)dlsym(so, "csky_gdextension_init");     /* entry_symbol of gdext/cloudsky.gdextension */
+    if (!entry) return 4;
+    memset(&init, 0, sizeof init);
+    if (!entry(get_proc, (GDExtensionClassLibraryPtr)&R, &init)) return 5;
+    if (init.minimum_initialization_level != GDEXTENSION_INITIALIZATION_SCENE || !init.initialize || !init.deinitialize) return 6;
+    init.initialize(init.userdata, GDEXTENSION_INITIALIZATION_CORE);
+    if (R.class_name[0]) return 7;                                  /* nothing may register before the SCENE level */
+    init.initialize(init.userdata, GDEXTENSION_INITIALIZATION_SCENE);
+    if (strcmp(R.class_name, "CloudSkyHIP") || strcmp(R.parent, "RefCounted") || !R.ci.create_instance_func || !R.ci.free_instance_func || !R.ci.is_exposed) return 8;
+    if (R.n_methods != 8) return 9;
+    for (i = 0; i < 8; i++) {
+        const GDExtensionClassMethodInfo *mi = method(expect[i]);
+        if (!mi || (int)mi->argument_count != expect_argc[i] || !mi->ptrcall_func || !mi->call_func || !mi->has_return_value) return 10 + i;
+    }
+    free(R.ci.create_instance_func(R.ci.class_userdata));
+    if (!R.instance) return 20;
+    {   /* error paths before create(): ERR_STATE, empty image; through ptrcall and through the Variant trampoline */
+        float pcf[28]; MockPacked pc = {(uint8_t *)pcf, 28}; int64_t w = 64, h = 32;
+        GDExtensionConstTypePtr a[3] = {&pc, &w, &h};
+        MockPacked img;
+        MockVariant va[3], vr; const GDExtensionConstVariantPtr vp[3] = {&va[0], &va[1], &va[2]}; GDExtensionCallError ce;
+        ctu_default_push_constant(pcf, 64.0f, 32.0f);
+        img = ptrcall_bytes("render_clouds", a);
+        if (img.size != 0 || ptrcall_int("get_status", NULL) != CSKY_ERR_STATE) return 21;
+        memset(va, 0, sizeof va); memset(&vr, 0, sizeof vr);
+        va[0].type = GDEXTENSION_VARIANT_TYPE_PACKED_FLOAT32_ARRAY; va[0].u.arr = pc;
+        va[1].type = va[2].type = GDEXTENSION_VARIANT_TYPE_INT; va[1].u.i = 64; va[2].u.i = 32;
+        ce.error = GDEXTENSION_CALL_ERROR_INVALID_METHOD;
+        method("render_clouds")->call_func(method("render_clouds")->method_userdata, R.instance, vp, 3, &vr, &ce);
+        if (ce.error != GDEXTENSION_CALL_OK || vr.type != GDEXTENSION_VARIANT_TYPE_PACKED_BYTE_ARRAY || vr.u.arr.size != 0) return 22;
+        method("render_clouds")->call_func(method("render_clouds")->method_userdata, R.instance, vp, 2, &vr, &ce);
+        if (ce.error != GDEXTENSION_CALL_ERROR_TOO_FEW_ARGUMENTS) return 23;
+        memset(&vr, 0, sizeof vr);
+        method("get_last_error")->call_func(method("get_last_error")->method_userdata, R.instance, NULL, 0, &vr, &ce);
+        if (vr.type != GDEXTENSION_VARIANT_TYPE_STRING || !strstr(vr.u.s, "create()")) return 24;
+    }
+    if (argc >= 4) {   /* the whole chain on the GPU through the shim */
+        uint8_t *large, *small, *weather;
+        uint16_t *ref = (uint16_t *)ctu_read_file(argv[3], (size_t)64 * 32 * 8);
+        int64_t dev = 0, prim = 128, light = 6, w = 64, h = 32;
+        float pcf[28], tpc[4] = {256, 64, 0, 0}, spc[8] = {200, 100, 0, 0, 0, 0, 0, 0};
+        MockPacked pl, ps, pw, pc = {(uint8_t *)pcf, 28}, ptc = {(uint8_t *)tpc, 4}, psc = {(uint8_t *)spc, 8}, img, lut;
+        GDExtensionConstTypePtr a[3];
+        int bad;
+        if (!ref || ctu_default_noise(argv[2], &large, &small, &weather) != 0) return 30;
+        a[0] = &dev;
+        if (ptrcall_int("create", a) != CSKY_OK) return 31;                           /* exit 31 = no usable GPU */
+        pl.data = large; pl.size = 128 * 128 * 128 * 4; ps.data = small; ps.size = 32 * 32 * 32 * 3; pw.data = weather; pw.size = 512 * 512 * 3;
+        a[0] = &pl; a[1] = &ps; a[2] = &pw;
+        if (ptrcall_int("set_noise", a) != CSKY_OK) return 32;
+        ps.size -= 1;
+        if (ptrcall_int("set_noise", a) != CSKY_ERR_INVALID) return 33;               /* wrong array size is refused, not read */
+        a[0] = &prim; a[1] = &light;
+        if (ptrcall_int("set_march", a) != CSKY_OK) return 34;
+        a[0] = &ptc; lut = ptrcall_bytes("render_transmittance", a);
+        if (lut.size != 256 * 64 * 8) return 35;
+        ctu_default_push_constant(pcf, 64.0f, 32.0f);
+        spc[4] = pcf[16]; spc[5] = pcf[17]; spc[6] = pcf[18];                          /* sky_lut.gd:123-132 */
+        a[0] = &psc; lut = ptrcall_bytes("render_sky_lut", a);
+        if (lut.size != 200 * 100 * 8) return 36;
+        a[0] = &pc; a[1] = &w; a[2] = &h;
+        img = ptrcall_bytes("render_clouds", a);
+        if (img.size != 64 * 32 * 8 || ptrcall_int("get_status", NULL) != CSKY_OK) return 37;
+        bad = ctu_bad_pixels((const uint16_t *)img.data, ref, 64 * 32);
+        printf("shim frame vs fixture: %d pixels beyond 2 fp16 ulp\n", bad);
+        if (bad < 0 || bad > 2) return 38;
+        {   /* the same frame through the Variant call: byte-identical */
+            MockVariant va[3], vr; const GDExtensionConstVariantPtr vp[3] = {&va[0], &va[1], &va[2]}; GDExtensionCallError ce;
+            memset(va, 0, sizeof va); memset(&vr, 0, sizeof vr);
+            va[0].type = GDEXTENSION_VARIANT_TYPE_PACKED_FLOAT32_ARRAY; va[0].u.arr = pc;
+            va[1].type = va[2].type = GDEXTENSION_VARIANT_TYPE_INT; va[1].u.i = 64; va[2].u.i = 32;
+            method("render_clouds")->call_func(method("render_clouds")->method_userdata, R.instance, vp, 3, &vr, &ce);
+            if (ce.error != GDEXTENSION_CALL_OK || vr.u.arr.size != img.size || memcmp(vr.u.arr.data, img.data, (size_t)img.size)) return 39;
+        }
+    }
+    R.ci.free_instance_func(R.ci.class_userdata, R.instance);
+    init.deinitialize(init.userdata, GDEXTENSION_INITIALIZATION_SCENE);
+    if (R.class_name[0]) return 40;
+    printf("gdext mock host ok\n");
+    return 0;
+}

@@ -49,6 +49,20 @@ unsigned long long hostsim_inexact_coeffs(const uint8_t* large_chain, const uint
     return n;
 }
 int hostsim_shape_poly() { return CSKY_SHAPE_POLY; }
+// the HOST bake of the three device layouts (bake.h), for the byte comparison with what csky_set_noise bakes on the GPU.
+// which: 0 shape, 1 detail, 2 weather.  Returns the byte count; out may be NULL to query it.
+size_t hostsim_bake(const uint8_t* large_chain, const uint8_t* small_chain, const uint8_t* weather_rgb8, int which, uint8_t* out) {
+    std::vector<uint8_t> lc(large_chain, large_chain + csky_mip_offset(SHAPE_N, SHAPE_LEVELS, 4));
+    std::vector<uint8_t> sc(small_chain, small_chain + csky_mip_offset(DETAIL_N, DETAIL_LEVELS, 3));
+    std::vector<ShapeTexel> shape; std::vector<uint4> detail, weather;
+    uint32_t so[SHAPE_LEVELS], dof[DETAIL_LEVELS];
+    const void* src; size_t n;
+    if (which == 0) { bake_shape(lc, shape, so); src = shape.data(); n = shape.size() * sizeof(ShapeTexel); }
+    else if (which == 1) { bake_detail(sc, detail, dof); src = detail.data(); n = detail.size() * sizeof(uint4); }
+    else { bake_weather(weather_rgb8, weather); src = weather.data(); n = weather.size() * sizeof(uint4); }
+    if (out) memcpy(out, src, n);
+    return n;
+}
 
 void hostsim_clouds(const uint8_t* large_chain, const uint8_t* small_chain, const uint8_t* weather_rgb8, const float params[28],
                     int primary_steps, int light_steps, float early_eps, const uint16_t* sky_h, int sw, int sh, int tile_w,

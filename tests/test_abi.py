@@ -68,8 +68,8 @@ def test_header_is_plain_c_and_links(pkg, tmp_path):
     import subprocess
     exe = str(tmp_path / "c_abi_check")
     lib_dir = os.path.dirname(pkg.library_path())
-    subprocess.check_call(["gcc", "-std=c99", "-Wall", "-Werror", "-pedantic", "-I", os.path.join(ROOT, "include"),
-                           os.path.join(ROOT, "tests", "c_abi_check.c"), "-o", exe, "-L", lib_dir, "-l:libcloudsky.so",
+    subprocess.check_call(["gcc", "-std=c99", "-Wall", "-Werror", "-pedantic", "-I", os.path.join(ROOT, "include"), "-I", os.path.join(ROOT, "tests"),
+                           os.path.join(ROOT, "tests", "c_abi_check.c"), "-o", exe, "-lm", "-L", lib_dir, "-l:libcloudsky.so",
                            "-Wl,-rpath," + lib_dir, "-Wl,-rpath,/opt/rocm/lib"])
     out = subprocess.run([exe], capture_output=True, text=True)
     assert out.returncode == 0 and "c abi ok" in out.stdout, (out.returncode, out.stdout, out.stderr)

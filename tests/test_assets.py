@@ -62,6 +62,36 @@ def test_generator_small_and_bad_args(pkg):
         pkg.assets.generate_shape_noise(1, 12)
 
 
+def _spectral_centroid(ch):
+    F = np.abs(np.fft.fftn(ch - ch.mean())) ** 2
+    k = np.fft.fftfreq(ch.shape[0]) * ch.shape[0]
+    K = np.sqrt(k[:, None, None] ** 2 + k[None, :, None] ** 2 + k[None, None, :] ** 2)
+    return float((K * F).sum() / F.sum())
+
+
+def test_generated_detail_noise_matches_the_shipped_asset_statistics(pkg, noise):
+    """SURVEY §8f row 2 / README.md:30 TODO 3: the generated 32^3 Worley detail volume is compared with worlnoise.bmp ITSELF (not with
+    another run of the generator): per-channel mean, spread, range, dominant spatial frequency and 3-D tileability."""
+    asset = noise[1].astype(np.float64) / 255.0
+    gen8 = pkg.assets.generate_detail_noise(1, 32)
+    assert gen8.shape == (32, 32, 32, 3) and (gen8 == pkg.assets.generate_detail_noise(1, 32)).all()       # deterministic
+    assert (gen8 != pkg.assets.generate_detail_noise(2, 32)).any()
+    gen = gen8.astype(np.float64) / 255.0
+    for c in range(3):
+        a, g = asset[..., c], gen[..., c]
+        assert abs(g.mean() - a.mean()) < 0.03, (c, g.mean(), a.mean())          # asset: 0.711 / 0.706 / 0.708
+        assert abs(g.std() - a.std()) < 0.03, (c, g.std(), a.std())              # asset: 0.112 / 0.112 / 0.140
+        assert g.max() > 0.97 and a.max() > 0.97 and g.min() < 0.45              # full bright range, dark cell borders
+        assert abs(_spectral_centroid(g) - _spectral_centroid(a)) < 0.8, (c, _spectral_centroid(g), _spectral_centroid(a))   # asset: 2.4 / 4.6 / 7.0
+        for ax in range(3):   # REPEAT sampler (cloud_sky.gd:302-304): the wrap seam looks like an interior step, as in the asset
+            seam = np.abs(np.take(g, 0, ax) - np.take(g, 31, ax)).mean()
+            inner = np.abs(np.diff(g, axis=ax)).mean()
+            assert seam < 1.5 * inner + 0.01, (c, ax, seam, inner)
+    import pytest
+    with pytest.raises(pkg.CloudSkyError):
+        pkg.assets.generate_detail_noise(1, 12)
+
+
 def test_mips_match_oracle_and_numpy(pkg, oracle, noise):
     from oracle import numpy_restatement as NR
     large, small, _ = noise

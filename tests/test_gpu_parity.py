@@ -75,7 +75,7 @@ def test_variants_and_schedules_agree(gpu_ctx, oracle):
     p = oracle.default_params(256, 128, (1, 1, 0))
     imgs = {}
     for v in (0, 1):
-        for sch in (1, 2, 5, 7, 7, 8, 8):                          # 7 / 8 twice: the second launch runs in the feedback order
+        for sch in (1, 2, 5, 7, 7):                                # 7 twice: the second launch runs in the feedback order
             gpu_ctx.set_variant(v); gpu_ctx.set_schedule(sch)
             img = gpu_ctx.render_clouds(p)
             st = gpu_ctx.cloud_stats()
@@ -97,7 +97,7 @@ def test_variants_and_schedules_agree(gpu_ctx, oracle):
     gpu_ctx.set_variant(3)
     for seg in (1, 2, 4):
         gpu_ctx.set_segments(seg)
-        for sch in (5, 2, 7, 7, 8, 8, 9):                       # 9: mixed-segment launch (whole rays, then 2- and 4-segment workgroups)
+        for sch in (5, 2, 7, 7):
             gpu_ctx.set_schedule(sch)
             img = gpu_ctx.render_clouds(p)
             ok, info = cloud_close(img, imgs[1][0], frac=0.9999, atol=5e-4, rtol=2e-3)
@@ -259,7 +259,7 @@ def test_error_behaviour(pkg, noise):
     with pytest.raises(pkg.CloudSkyError) as e:                      # no textures bound yet: nothing to report on
         ctx.noise_inexact_coeffs()
     assert e.value.code == pkg._lib.ERR_STATE
-    for bad in (-2, 0, 3, 4, 6, 10):                               # 0/3/4/6: round-1 wedge orders, removed
+    for bad in (-2, 0, 3, 4, 6, 8, 9):                               # 0/3/4/6: round-1 wedge orders, removed
         with pytest.raises(pkg.CloudSkyError) as e:
             ctx.set_schedule(bad)
         assert e.value.code == pkg._lib.ERR_INVALID

@@ -17,11 +17,11 @@ pool = [torch.cuda.Stream() for _ in range(3)]
 for share in [int(a) for a in sys.argv[1:]] or (2, 4, 8):
     bands = (8, 0, share, H // 8 // share)
     outs = [torch.zeros((bands[3] * 8, W, 4), dtype=torch.int16, device="cuda") for _ in range(3)]
-    for seg in (1, 2, 4, 5):
+    for seg in (0, 1, 2, 4):                                   # 0 = the library's automatic choice
         row = []
-        for sched in (5, 7):
-            for ns in (1, 2, 3):
-                ctx.set_segments(seg); ctx.set_schedule(sched)
+        for sched in ((-1,) if seg == 0 else (5, 7)):
+            for ns in (1, 2):
+                ctx.set_segments(seg); ctx.set_schedule(sched); ctx.set_frames_in_flight(ns)
                 def step(k):
                     i = k % ns
                     ctx.render_sky_lut_device(s, 200, 100, pool[i].cuda_stream)
@@ -34,4 +34,4 @@ for share in [int(a) for a in sys.argv[1:]] or (2, 4, 8):
                     step(k)
                 torch.cuda.synchronize()
                 row.append("s%d/x%d %.3f" % (sched, ns, (time.perf_counter() - t0) / 60 * 1e3))
-        print("1/%d frame, seg %d: %s" % (share, seg, "  ".join(row)), flush=True)
+        print("%s1/%d frame, seg %d: %s" % (os.environ.get("TAG", ""), share, seg, "  ".join(row)), flush=True)

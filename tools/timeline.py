@@ -47,5 +47,11 @@ for x in range(8):
     if m.any():
         print("XCD %d: %5d waves, events %8d, busy wave-ms %.1f, last end %.3f ms" % (x, m.sum(), ev[m].sum(), (t1[m] - t0[m]).sum() * tick, t1[m].max() * tick))
 dur = (t1 - t0) * tick
+order = np.argsort(t0)
+last = order[-len(order) // 10:]
+print("last dispatch at %.3f ms (%.0f %% of the span); the 10 %% of wavefronts that start last: start >= %.3f ms, duration mean %.3f max %.3f ms" % (
+    t0.max() * tick, 100.0 * t0.max() / end, t0[last].min() * tick, dur[last].mean(), dur[last].max()))
+for q in (0.5, 0.75, 0.9, 0.99):
+    print("  %2.0f %% of the wavefronts have finished by %.3f ms" % (100 * q, np.quantile(t1, q) * tick))
 c = np.corrcoef(dur, ev)[0, 1]
 print("corr(wave duration, in-cloud events) = %.3f; duration ~ %.4f + %.6f * events ms" % (c, *np.polyfit(ev, dur, 1)[::-1]))
