@@ -14,9 +14,16 @@ is fixed, each rank renders 1/N of it).
 
 Consecutive frames are independent, so by default every rank keeps two frames in flight (alternating streams): the tail of
 frame k's launch overlaps the head of frame k+1's and, at N > 1, frame k's gather (`--frames-in-flight 1` = strictly one frame
-at a time; both are whole-job rates of the same K frames).  `roofline.kernel_ms` is the mean duration of the cloud-kernel
-launches OF THE TIMED REGION (HIP event pairs on each launch's stream, recorded inside libcloudsky), the quantity rocprofv3
---kernel-trace --stats reports for this command.
+at a time).  `value` is the pipelined whole-job rate; the same K frames strictly one at a time are timed right after it and
+reported next to it (`value_one_frame_at_a_time`): quote both.
+
+`roofline` (round 2): the path is not HBM-bound (82 MB of baked inputs live in L2 / Infinity Cache) and has no contraction, so
+neither "hbm" nor "mfma" bounds it; the binding units are VALU issue and the vector-L1 gather path.  Their fractions are computed
+from hardware counters collected LIVE by this run (tools/pmc_collect.py: rocprofv3 --pmc passes over the same workload in child
+processes, after the timed region) and priced with issue costs MEASURED on gfx950 (profiles/r02/issue_cost_calibration.json);
+all durations are of the kernel with the GPU to itself (HIP event pairs on the launch's stream).  Nothing is read from a committed
+counter file: without rocprofv3 the fractions are null.  The contract's algorithmic-bytes figure is kept as `hbm_algorithmic`
+with its ratio to the HBM peak (> 1: the taps are served by L1/L2, it stopped discriminating in round 1).
 
 Prints ONE JSON line on rank 0.
 """
@@ -116,6 +123,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--also-early-out", action="store_true", help="add a secondary measurement with the wave early-out (eps = 1e-3) to the JSON line")
     ap.add_argument("--kernel-iters", type=int, default=1, help="solo (one launch in flight) cloud-kernel launches timed after the timed region")
+    ap.add_argument("--no-pmc", action="store_true", help="skip the live rocprofv3 counter passes (roofline fractions become null)")
     ap.add_argument("--frames-in-flight", type=int, default=None,
                     help="consecutive frames alternate between this many streams per rank (default 2: the tail of frame k overlaps the head "
                          "of frame k+1 and, at N > 1, its gather; 1 = strictly one frame at a time)")
@@ -159,7 +167,9 @@ def main():
     large, small, weather = gvcd_amd.assets.load_default_noise()
 
     ctx = gvcd_amd.Context(local_rank)
-    ctx.set_noise(large, small, weather)            # inputs -> HBM (device layouts baked once)
+    ctx.set_noise(large, small, weather)            # inputs -> HBM (mip chains + device layouts baked on the GPU, once)
+    if ctx.noise_inexact_coeffs() != 0:
+        raise SystemExit("bench.py: the benchmark textures must bake exactly (fp16 finite differences)")
     ctx.set_march(primary, light)
     ctx.set_early_out(args.early_out)
     if args.variant is not None:
@@ -174,8 +184,8 @@ def main():
     if os.environ.get("CSKY_BENCH_SYNC_GATHER") == "1":
         fif = 1                                      # debugging aid: gather-then-render, one frame at a time
     ctx.set_frames_in_flight(fif)
-    streams = [torch.cuda.Stream(device=dev) for _ in range(fif)] if fif > 1 else [torch.cuda.current_stream()]
-    stream = streams[0].cuda_stream
+    streams = [torch.cuda.Stream(device=dev) for _ in range(fif)]   # always real streams: handle 0 (torch's default stream) would select the
+    stream = streams[0].cuda_stream                                  # library's own non-blocking stream, unordered against the gather
     bands = tiling.bands_for_rank(H, rank, world)
     mb = tiling.max_bands(H, world)
     # N > 1: the gather of frame k (RCCL, its own stream, ordered behind the stream of frame k at the call) overlaps the march of
@@ -247,18 +257,37 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
-    # dominant kernel (clouds_kernel): average launch duration over the timed region (event pairs on the launch's stream, inside
-    # libcloudsky).  With two frames in flight a launch shares the GPU with its neighbour, so it lasts ~2 frame times; the same
-    # kernel alone (one frame at a time) is timed afterwards over --kernel-iters launches, which also reads the sample counters.
-    k_ms = k_total / max(1, k_launches)
-    k_solo, st = ctx.time_clouds(params, W, bands, warmup=0, iters=max(1, args.kernel_iters))     # (also reads the sample counters)
-    if fif == 1:
-        k_solo = k_ms                                    # one frame at a time: the timed region already is the solo measurement
+    # dominant kernel (clouds_kernel): with two frames in flight a launch shares the GPU with its neighbour and lasts ~2 frame times, which
+    # measures nothing: the roofline uses the kernel ALONE.  k_inflight = mean launch duration over the timed region (event pairs
+    # on each launch's stream, inside libcloudsky; what rocprofv3 --kernel-trace reports for this command); k_solo = the same kernel with the
+    # GPU to itself, timed over solo launches right here (also reads the sample counters).
+    k_inflight = k_total / max(1, k_launches)
+    k_solo, st = ctx.time_clouds(params, W, bands, warmup=1, iters=max(3, args.kernel_iters))
     rays_launch = bands[3] * bands[0] * W
     f_incloud = st["incloud_samples"] / max(1, st["primary_samples"])
     floor_bytes = rays_launch * (8 + BYTES_PER_SAMPLE * primary)                           # 10 248 B/ray at 128 steps
     total_bytes = rays_launch * 8 + BYTES_PER_SAMPLE * (st["primary_samples"] + (light + 1) * st["incloud_samples"])
-    achieved = floor_bytes / (k_ms * 1e-3) / 1e9
+
+    # the same K frames strictly one at a time (sky LUT + set-up + march [+ gather] per frame, nothing overlapped): N = 1 only
+    one_at_a_time = None
+    if world == 1 and fif > 1:
+        ctx.set_frames_in_flight(1)
+        s0 = streams[0]
+        def step1(k):
+            fp, fs = (params, sun_n) if sweep is None else sweep[k % len(sweep)]
+            ctx.render_sky_lut_device(fs, 200, 100, s0.cuda_stream)
+            ctx.render_clouds_device(fp, W, bands, local[0].data_ptr(), W * 8, s0.cuda_stream)
+        for k in range(max(2, args.warmup)):
+            step1(k)
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        for k in range(args.steps):
+            step1(k)
+        torch.cuda.synchronize()
+        e1 = time.perf_counter() - t1
+        one_at_a_time = {"value": W * H * args.steps / e1 / 1e6, "ms_per_step": e1 / args.steps * 1e3, "hemisphere_fps": args.steps / e1}
+        ctx.set_frames_in_flight(fif)
+        frame[0] = local[0]
 
     # secondary figure, N = 1 only: the same frames with the wave early-out the north star describes (T < 1e-3; bounded error
     # <= 1e-3, within the stated parity tolerance).  NOT the headline: the reference has no early-out, so `value` keeps eps = 0.
@@ -293,19 +322,23 @@ def main():
                   "(segmented small launches re-associate the compositing sums)" % (world, float(err.max().item()), ok), file=sys.stderr, flush=True)
             if ok < 0.9999:
                 raise SystemExit("bench.py: multi-rank frame differs from the single-rank frame")
-        traffic = None
-        valu_insts = None
-        pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")   # written from the committed rocprofv3 --pmc passes (tools/summarize_prof.py)
-        traffic_note = "not collected in this run"
-        if os.path.exists(pmc):
+        # ---- hardware counters of the cloud kernel, collected now (child processes; the timed region is over)
+        pmc, pmc_note = None, "not collected: N > 1 or --no-pmc"
+        pmc_cfg = "C5frame" if args.config == "C5" else args.config          # the sweep's frames cost the same: profile one of them
+        if world == 1 and not args.no_pmc:
+            sys.path.insert(0, os.path.join(ROOT, "tools"))
+            import pmc_collect
+            t_p = time.perf_counter()
             try:
-                j = json.load(open(pmc))
-                if j.get("workload") == args.config and world == 1:
-                    traffic = j.get("hbm_bytes_per_launch")
-                    traffic_note = j.get("note", "")
-                    valu_insts = j.get("valu_insts_per_launch")
-            except Exception:
-                pass
+                keep = os.path.join(ROOT, "gpurun_out", "bench_pmc_%s.json" % args.config) if os.path.isdir(os.path.join(ROOT, "gpurun_out")) else None
+                pmc, pmc_note = pmc_collect.collect(pmc_cfg, frames=6, keep=keep)
+            except Exception as e:   # the bench line is still valid without the fractions
+                pmc, pmc_note = None, "pmc collection failed: %s" % str(e)[:200]
+            pmc_s = time.perf_counter() - t_p
+        vi = (pmc or {}).get("valu_issue") or {}
+        l1 = (pmc or {}).get("l1_gather") or {}
+        hb = (pmc or {}).get("hbm_traffic") or {}
+        traffic = hb.get("bytes")
         out = {
             "metric": "Mrays/s + hemisphere fps, 2048x1024 @ 128x6 steps, 1/2/4/8 MI355X",
             "value": W * H * args.steps / elapsed / 1e6,
@@ -315,6 +348,7 @@ def main():
             "ms_per_step": elapsed / args.steps * 1e3,
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
+            "value_one_frame_at_a_time": one_at_a_time,
             "config": {"workload": "%s: %dx%d hemisphere, %d primary x %d light steps, sun (%.4f,%.4f,%.4f), clouds_sky.tres defaults, "
                                    "weather.bmp + worlnoise.bmp + generated 128^3 shape noise (seed 1), wind frozen"
                                    % (args.config, W, H, primary, light, sun_n[0], sun_n[1], sun_n[2]),
@@ -322,26 +356,32 @@ def main():
                        "variant": gvcd_amd.lib().csky_variant_name(args.variant if args.variant is not None else gvcd_amd._lib.DEFAULT_VARIANT).decode(),
                        "parallelism": "bands%d%s" % (world, "+overlapped-gather" if overlap else ""), "frames_in_flight": fif,
                        "alpha_mean": alpha_mean, "finite": finite},
-            "roofline": {"bound": "hbm", "kernel": "clouds_kernel", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_note": traffic_note,
-                         "kernel_ms": k_ms, "kernel_launches_timed": k_launches, "frames_in_flight": fif,
-                         "kernel_ms_solo": k_solo, "frac_solo": floor_bytes / (k_solo * 1e-3) / 1e9 / HBM_PEAK_GBS,
-                         "frac_per_frame_time": floor_bytes / (elapsed / args.steps) / 1e9 / HBM_PEAK_GBS if world == 1 else None,
-                         "rays_per_launch": rays_launch,
-                         "algorithmic_bytes_per_launch": floor_bytes,
-                         "algorithmic_bytes_incl_light_march": total_bytes,
-                         "achieved_incl_light_march_GBps": total_bytes / (k_ms * 1e-3) / 1e9,
-                         "incloud_fraction": f_incloud,
-                         # the unit that actually binds: VALU issue.  cycles each SIMD had per VALU instruction it issued (live kernel
-                         # time x 2.4 GHz x 1024 SIMDs / committed SQ_INSTS_VALU); the instruction kinds cost 2.5 - 4.4 cycles to issue
-                         "valu_issue": None if not valu_insts else {"insts_per_launch": valu_insts, "simd_cycles_per_inst": k_solo * 1e-3 * 2.4e9 * 1024 / valu_insts,
-                                                                    "issue_cost_range_cycles": [2.5, 4.4]},
-                         "note": "algorithmic tap bytes (80 B/sample x 128 + 8 B/ray = 10 248 B/ray), not DRAM bytes: the "
-                                 "unique inputs (~82 MB of baked textures) live in L2/Infinity Cache, so frac may exceed what HBM could deliver.  "
-                                 "achieved/frac use kernel_ms = the mean launch duration over the timed region (what rocprofv3 reports for the "
-                                 "same command); with frames_in_flight = 2 each launch overlaps its neighbour and lasts about two frame "
-                                 "times, so frac_solo (the kernel with the GPU to itself) and frac_per_frame_time (bytes per launch / "
-                                 "ms_per_step) bracket it"},
+            "roofline": {
+                # neither "hbm" nor "mfma" binds this path (docstring): the top-level fields are the VALU-issue roof, the one closest to 1
+                "bound": "valu", "kernel": "clouds_kernel<3,1> (compact march), one launch with the GPU to itself",
+                "achieved": vi.get("issue_cycles_per_simd"), "peak": vi.get("kernel_cycles"), "unit": "SIMD issue cycles per launch",
+                "frac": vi.get("frac"), "frac_bounds": [vi.get("frac_lower"), vi.get("frac_upper")] if vi else None,
+                "traffic": traffic,
+                "kernel_ms_solo": k_solo, "kernel_ms_in_flight": k_inflight, "kernel_launches_timed": k_launches, "frames_in_flight": fif,
+                "valu_issue": vi or None,
+                "l1_gather": l1 or None,
+                "hbm": None if traffic is None else {"bytes_per_launch": traffic, "achieved_GBps": traffic / (k_solo * 1e-3) / 1e9, "peak_GBps": HBM_PEAK_GBS,
+                                                     "frac": traffic / (k_solo * 1e-3) / 1e9 / HBM_PEAK_GBS, "l2_hit": hb.get("l2_hit"),
+                                                     "note": "memory-side bytes of the L2 (FETCH_SIZE + WRITE_SIZE, KiB -> bytes, Infinity-Cache hits included; the guide's x2 "
+                                                             "FETCH_SIZE correction is for wide streaming reads and is not applied to these 16-byte gathers)"},
+                "hbm_algorithmic": {"bytes_per_sample": BYTES_PER_SAMPLE, "rays_per_launch": rays_launch, "bytes_per_launch": floor_bytes,
+                                    "bytes_per_launch_incl_light_march": total_bytes, "incloud_fraction": f_incloud,
+                                    "achieved_GBps": floor_bytes / (k_solo * 1e-3) / 1e9, "ratio_to_hbm_peak": floor_bytes / (k_solo * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                                    "note": "SURVEY 8(d)'s contractual figure: 80 B/sample x primary steps + 8 B/ray against the 8 TB/s HBM peak, solo launch.  It exceeds 1 "
+                                            "(taps are served by L1/L2, 44 % of the primary samples are rejected before the shape tap) and therefore measures nothing: kept "
+                                            "for continuity with round 1 only"},
+                "pmc": {"collected": "live in this run (tools/pmc_collect.py)" if pmc else None, "note": pmc_note, "source_hash": (pmc or {}).get("source_hash"),
+                        "calibration": (pmc or {}).get("calibration"), "seconds": pmc_s if pmc else None},
+                "note": "fractions are per launch of the cloud kernel ALONE, in cycles of the SQ's own clock (SQ_BUSY_CYCLES / 32 of the same counter pass): "
+                        "valu = wave64 VALU instructions x issue cost measured on gfx950 (full rate 2.29, half rate 4.11, transcendental 8.08 cycles per SIMD) / "
+                        "(1024 SIMDs x kernel cycles), bracketed because the class counters do not see every kind; l1_gather = TA_TA_BUSY / (256 CUs x kernel "
+                        "cycles), ~1.0 in every saturated pattern of tools/ubench/gather_rates.hip.  With two frames in flight (the headline `value`) the next "
+                        "frame fills this launch's tail and the VALU fraction per frame time approaches 1"},
         }
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(large, small, weather, params, sun_n, W, H, primary, light)

@@ -1,0 +1,152 @@
+#!/usr/bin/env python
+"""Hardware counters of the cloud kernel, collected LIVE (rocprofv3 --pmc, separate passes, kernel-trace only: the combination the GPU pool
+allows) by running tools/prof_kernel.py on the SAME workload in child processes, and priced with the measured gfx950 issue costs of
+profiles/r02/issue_cost_calibration.json.  Used by bench.py (the `roofline` object of its JSON line) and runnable by hand:
+    python tools/pmc_collect.py --config C3 [--out profiles/r02/clouds_C3_pmc.json]
+Nothing here is read from a committed counter file: if rocprofv3 is missing or a pass fails the caller gets None for that quantity."""
+import argparse
+import csv
+import glob
+import json
+import os
+import shutil
+import subprocess
+import sys
+import tempfile
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+CALIBRATION = os.path.join(ROOT, "profiles", "r02", "issue_cost_calibration.json")
+N_SE, N_SIMD, N_CU = 32, 1024, 256
+PASSES = {
+    "valu": ["SQ_INSTS_VALU", "SQ_INSTS_VALU_TRANS_F32", "SQ_INSTS_VALU_FMA_F32", "SQ_INSTS_VALU_ADD_F32", "SQ_INSTS_VALU_MUL_F32", "SQ_INSTS_VALU_CVT",
+             "SQ_INSTS_VALU_INT32", "SQ_BUSY_CYCLES"],
+    "mem": ["TCP_TOTAL_CACHE_ACCESSES_sum", "TCP_TCC_READ_REQ_sum", "TA_TA_BUSY_sum", "SQ_INSTS_VMEM_RD", "SQ_BUSY_CYCLES", "SQ_WAVE_CYCLES", "SQ_WAIT_INST_ANY",
+            "SQ_INSTS_SALU"],
+    "fetch": ["FETCH_SIZE", "TCC_HIT_sum"],
+    "write": ["WRITE_SIZE", "TCC_MISS_sum", "TCC_REQ_sum"],
+}
+
+
+def source_hash():
+    """sha256 over the kernel sources the profiled library is built from (the GPU box has no .git): recorded with the counters."""
+    import hashlib
+    h = hashlib.sha256()
+    d = os.path.join(ROOT, "godot-volumetric-cloud-demo-v2_amd", "csrc")
+    for f in sorted(os.listdir(d)):
+        if f.endswith((".h", ".hip", ".cpp")) or f == "Makefile":
+            h.update(f.encode()); h.update(open(os.path.join(d, f), "rb").read())
+    return h.hexdigest()[:16]
+
+
+def run_pass(name, counters, config, frames, workdir, kernel, timeout):
+    out = os.path.join(workdir, name)
+    cmd = ["rocprofv3", "--pmc"] + counters + ["--kernel-trace", "-f", "csv", "-d", out, "-o", "p", "--", sys.executable, os.path.join(ROOT, "tools", "prof_kernel.py"),
+           "--config", config, "--frames", str(frames)]
+    env = dict(os.environ, TMPDIR="/tmp")
+    r = subprocess.run(cmd, cwd="/tmp", env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=timeout)
+    if r.returncode != 0:
+        raise RuntimeError("rocprofv3 pass %s failed (%d): %s" % (name, r.returncode, r.stdout.decode(errors="replace")[-400:]))
+    vals = {}
+    for f in glob.glob(os.path.join(out, "**", "*counter_collection.csv"), recursive=True):
+        for row in csv.DictReader(open(f)):
+            if kernel in row.get("Kernel_Name", ""):
+                v = vals.setdefault(row["Counter_Name"], [0.0, 0])
+                v[0] += float(row["Counter_Value"]); v[1] += 1
+    dur = []
+    for f in glob.glob(os.path.join(out, "**", "*kernel_trace.csv"), recursive=True):
+        for row in csv.DictReader(open(f)):
+            if kernel in row.get("Kernel_Name", ""):
+                dur.append(int(row["End_Timestamp"]) - int(row["Start_Timestamp"]))
+    if not vals:
+        raise RuntimeError("rocprofv3 pass %s: no dispatch of %s found" % (name, kernel))
+    return {k: v[0] / v[1] for k, v in vals.items()}, (sum(dur) / len(dur) if dur else None), max(v[1] for v in vals.values())
+
+
+def price(c):
+    """Counters (per launch) -> fractions of the two measured roofs.  All cycles are SQ_BUSY_CYCLES / 32 of the SAME pass."""
+    cal = json.load(open(CALIBRATION))
+    full, half, trans = cal["valu"]["full_rate_cycles"], cal["valu"]["half_rate_cycles"], cal["valu"]["transcendental_cycles"]
+    out = {"calibration": {"full_rate_cycles": full, "half_rate_cycles": half, "transcendental_cycles": trans,
+                           "tcp_cycles_per_access": cal["tcp"]["cycles_per_access_distinct_lines"], "source": "profiles/r02/issue_cost_calibration.json"}}
+    v = c.get("valu")
+    if v:
+        cyc = v["SQ_BUSY_CYCLES"] / N_SE
+        n, tr = v["SQ_INSTS_VALU"], v["SQ_INSTS_VALU_TRANS_F32"]
+        add, mul, fma, cvt, i32 = (v["SQ_INSTS_VALU_ADD_F32"], v["SQ_INSTS_VALU_MUL_F32"], v["SQ_INSTS_VALU_FMA_F32"], v["SQ_INSTS_VALU_CVT"], v["SQ_INSTS_VALU_INT32"])
+        # The class counters do not separate every kind: FMA_F32 also counts the half-rate v_fma_mix_f32, INT32 mixes v_add_u32 (full) with
+        # shifts / bit-field ops (half), and moves, selects, compares, fract/floor, min/max are in no class counter.  One of these can be
+        # recovered exactly: every 16-byte texel-cell load of this kernel feeds exactly four v_fma_mix_f32 (cloud_core.h: weather 1 load + 4,
+        # shape 2 + 8, detail 1 + 4), so mix <= 4 x SQ_INSTS_VMEM_RD (collected in the `mem` pass).  The rest is bracketed:
+        #   lower: every unclassified / INT32 instruction issues at full rate;  upper: every one of them at half rate.
+        # `frac` prices them with the static mix of the light-march loop body (9 full-rate : 25 half-rate).
+        loads = (c.get("mem") or {}).get("SQ_INSTS_VMEM_RD")
+        mix = min(fma, 4.0 * loads) if loads else None
+        rest = n - tr - add - mul - fma - cvt                                       # INT32 + kinds no class counter sees
+        if mix is None:
+            lo = tr * trans + cvt * half + (n - tr - cvt) * full
+            hi = tr * trans + (add + mul) * full + (n - tr - add - mul) * half
+            est = None
+        else:
+            known = tr * trans + (add + mul + fma - mix) * full + (mix + cvt) * half
+            lo, hi = known + rest * full, known + rest * half
+            est = known + rest * (9.0 * full + 25.0 * half) / 34.0
+        out["valu_issue"] = {"insts": n, "trans": tr, "add_f32": add, "mul_f32": mul, "fma_f32_incl_mix": fma, "fma_mix_from_loads": mix, "cvt": cvt, "int32": i32,
+                             "unclassified_incl_int32": rest, "kernel_cycles": cyc,
+                             "issue_cycles_per_simd": None if est is None else est / N_SIMD,
+                             "issue_cycles_per_simd_lower": lo / N_SIMD, "issue_cycles_per_simd_upper": hi / N_SIMD,
+                             "frac": None if est is None else min(1.0, est / N_SIMD / cyc),
+                             "frac_lower": lo / N_SIMD / cyc, "frac_upper": min(1.0, hi / N_SIMD / cyc), "mean_cycles_per_inst_available": cyc * N_SIMD / n}
+    m = c.get("mem")
+    if m:
+        cyc = m["SQ_BUSY_CYCLES"] / N_SE
+        acc = m["TCP_TOTAL_CACHE_ACCESSES_sum"]
+        out["l1_gather"] = {"tcp_accesses": acc, "vmem_rd_insts": m["SQ_INSTS_VMEM_RD"], "accesses_per_load": acc / max(1.0, m["SQ_INSTS_VMEM_RD"]), "kernel_cycles": cyc,
+                            # TA_TA_BUSY is ~1.0 of the kernel cycles in every saturated gather pattern of tools/ubench/gather_rates.hip: the direct
+                            # measure of how busy the vector-memory front end is; the access count priced at 1 cycle per access is the cross-check
+                            "frac": m["TA_TA_BUSY_sum"] / N_CU / cyc, "tcp_access_frac": acc * cal["tcp"]["cycles_per_access_distinct_lines"] / N_CU / cyc,
+                            "l1_hit": 1.0 - m["TCP_TCC_READ_REQ_sum"] / max(1.0, acc),
+                            "wave_cycles_waiting_on_issue_frac": m["SQ_WAIT_INST_ANY"] / max(1.0, m["SQ_WAVE_CYCLES"])}
+    f, w = c.get("fetch"), c.get("write")
+    if f and w:
+        # FETCH_SIZE / WRITE_SIZE are in KiB; the guide's x2 gfx950 correction applies to wide coalesced streaming reads only, these are 16-byte
+        # gathers (uncalibrated width: left as counted); Infinity-Cache hits are included, so true DRAM bytes are lower
+        out["hbm_traffic"] = {"fetch_bytes": f["FETCH_SIZE"] * 1024.0, "write_bytes": w["WRITE_SIZE"] * 1024.0, "bytes": (f["FETCH_SIZE"] + w["WRITE_SIZE"]) * 1024.0,
+                              "l2_hit": f["TCC_HIT_sum"] / max(1.0, f["TCC_HIT_sum"] + w["TCC_MISS_sum"]) if "TCC_MISS_sum" in w else None}
+    return out
+
+
+def collect(config="C3", frames=6, kernel="clouds_kernel", timeout=120, keep=None):
+    if shutil.which("rocprofv3") is None:
+        return None, "rocprofv3 not found"
+    work = tempfile.mkdtemp(prefix="csky_pmc_", dir="/tmp")
+    counters, notes = {}, []
+    try:
+        for name, cs in PASSES.items():
+            try:
+                vals, dur_ns, n = run_pass(name, cs, config, frames, work, kernel, timeout)
+                counters[name] = vals
+                counters[name]["_kernel_ns"] = dur_ns
+                counters[name]["_dispatches"] = n
+            except Exception as e:   # a failed pass leaves its quantities out; never silently replaced by stale numbers
+                notes.append(str(e)[:300])
+        res = price(counters)
+        res["counters_per_launch"] = counters
+        res["source_hash"] = source_hash()
+        res["workload"] = config
+        res["notes"] = notes
+        if keep:
+            os.makedirs(os.path.dirname(os.path.abspath(keep)), exist_ok=True)
+            json.dump(res, open(keep, "w"), indent=1)
+        return res, "; ".join(notes)
+    finally:
+        shutil.rmtree(work, ignore_errors=True)
+
+
+if __name__ == "__main__":
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--config", default="C3")
+    ap.add_argument("--frames", type=int, default=6)
+    ap.add_argument("--out", default=None)
+    a = ap.parse_args()
+    res, note = collect(a.config, a.frames, keep=a.out)
+    print(json.dumps(res, indent=1) if res else note)
