@@ -94,6 +94,7 @@ SYMBOLS = [
     ("csky_generate_detail_noise_device", C.c_int, [C.c_void_p, C.c_uint32, C.c_int, C.c_void_p]),
     ("csky_build_mips_device", C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int]),
     ("csky_read_baked_texture", C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_size_t, C.POINTER(C.c_size_t)]),
+    ("csky_test_sqrt_shell", C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t]),
     ("csky_mip_offset", C.c_size_t, [C.c_int, C.c_int, C.c_int]),
     ("csky_build_mips", C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int]),
     ("csky_assets_last_error", C.c_char_p, []),
@@ -300,6 +301,13 @@ class Context:
         buf[: level0.size] = level0.reshape(-1)
         self._chk(self._L.csky_build_mips_device(self._h, _ptr(buf), n, ch, levels))
         return buf
+
+    def test_sqrt_shell(self, x):
+        """Test hook: cloud_core.h::sqrt_shell on the device over a float32 array."""
+        x = np.ascontiguousarray(x, np.float32)
+        out = np.zeros_like(x)
+        self._chk(self._L.csky_test_sqrt_shell(self._h, _ptr(x), _ptr(out), x.size))
+        return out
 
     def read_baked_texture(self, which):
         """Test hook: the device layouts / mip chains csky_set_noise built, as raw bytes (0 shape, 1 detail, 2 weather, 3 / 4 8-bit chains)."""

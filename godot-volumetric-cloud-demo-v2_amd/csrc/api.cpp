@@ -407,6 +407,20 @@ int csky_read_baked_texture(csky_ctx* c, int which, void* out, size_t capacity, 
     return CSKY_OK;
 }
 
+int csky_test_sqrt_shell(csky_ctx* c, const float* in, float* out, size_t n) {
+    if (!c || !in || !out) return fail(c, CSKY_ERR_INVALID, "csky_test_sqrt_shell: NULL argument");
+    int rc; if ((rc = bind(c))) return rc;
+    float* d = nullptr;
+    HIPCHK(c, hipMalloc(reinterpret_cast<void**>(&d), 2 * n * sizeof(float) + 16));
+    hipError_t e = hipMemcpyAsync(d, in, n * sizeof(float), hipMemcpyHostToDevice, c->stream);
+    if (e == hipSuccess) e = launch_sqrt_shell(d, d + n, n, c->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(out, d + n, n * sizeof(float), hipMemcpyDeviceToHost, c->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+    (void)hipFree(d);
+    if (e != hipSuccess) return fail(c, CSKY_ERR_HIP, "csky_test_sqrt_shell: %s", hipGetErrorString(e));
+    return CSKY_OK;
+}
+
 int csky_build_mips_device(csky_ctx* c, uint8_t* vol, int n, int ch, int levels) {
     if (!c) return fail(nullptr, CSKY_ERR_INVALID, "csky_build_mips_device: ctx is NULL");
     if (!vol || n < 1 || n > 1024 || (n & (n - 1)) || ch < 1 || ch > 4 || levels < 1 || (n >> (levels - 1)) < 1) return fail(c, CSKY_ERR_INVALID, "csky_build_mips_device: bad arguments");

@@ -58,6 +58,27 @@ CSKY_HD float sqrt_exact(float x) {
 }
 CSKY_HD float length3_exact(float x, float y, float z) { return sqrt_exact(x * x + y * y + z * z); }
 
+// Correctly rounded sqrt for |p|^2 of SAMPLE positions, which only ever lie between the two cloud shells plus the light march's reach:
+// |p| in [5 997 500, 6 008 000] m, i.e. x in [3.597e13, 3.6097e13] -- 30 067 consecutive floats.  On that range the two-FMA Newton step
+//     y = rsq(x); g = x*y; h = y/2; d = fma(-g, g, x); r = fma(d, h, g)
+// returns exactly the IEEE sqrt: checked EXHAUSTIVELY on the MI355X against the host's sqrtf by tests/test_gpu_round2.py
+// (csky_test_sqrt_shell; v_rsq_f32 is a fixed hardware function).  In general this short form is only "almost always" correctly rounded
+// (Markstein's proof needs one more refinement), hence the restriction to the verified range; sqrt_exact above stays for everything else.
+// 8.1 + 2 x 2.3 + 2 x 2.3 = 17 issue cycles instead of 34 (v_sqrt + two neighbour residuals + two compare/select pairs, half-rate kinds):
+// the march evaluates it once per primary AND per light sample, 8 % of the kernel's VALU time before.
+constexpr float SHELL_SQRT_LO = 3.597e13f, SHELL_SQRT_HI = 3.6097e13f;
+CSKY_HD float sqrt_shell(float x) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    const float y = __builtin_amdgcn_rsqf(x);
+    const float g = x * y, h = 0.5f * y;
+    const float d = __builtin_fmaf(-g, g, x);
+    return __builtin_fmaf(d, h, g);
+#else
+    return sqrtf(x);
+#endif
+}
+CSKY_HD float length3_shell(float x, float y, float z) { return sqrt_shell(x * x + y * y + z * z); }
+
 // clouds.glsl:97-105 with pos = camPos = (0, g_radius, 0)
 CSKY_HD float intersect_sphere_cam(float dx, float dy, float dz, float r) {
     const float a = dx * dx + dy * dy + dz * dz;
@@ -239,6 +260,9 @@ CSKY_HD void weather_tap(const uint4* __restrict__ w, float sx, float sy, float&
     weather_filter(q, ax, ay, wr, wb);
 }
 
+// (float)(1 << e) built from the exponent field: integer SALU work when e is wave-uniform (the light march's LOD), where a cast costs a
+// half-rate v_cvt per tap
+CSKY_HD float pow2f(int e) { const uint32_t b = (uint32_t)(127 + e) << 23; float f; memcpy(&f, &b, 4); return f; }
 // texel offset of mip level l inside the packed chains: sum_{i<l} (N>>i)^3 = (N^3*8 - (N>>l)^3*8) / 7, computed
 // arithmetically so a per-lane level needs no table (api.cpp checks it against the baked offsets)
 CSKY_HD uint32_t shape_level_offset(int l) { return ((1u << 24) - (1u << (24 - 3 * l))) / 7u; }
@@ -247,7 +271,7 @@ CSKY_HD uint32_t detail_level_offset(int l) { return ((1u << 18) - (1u << (18 - 
 // Returns r = n.r and fbm = n.g*0.625 + n.b*0.25 + n.a*0.125 (clouds.glsl:118; exact integer numerators, filtered linearly).
 CSKY_HD void shape_tap(const TexSet& T, int lvl, float sx, float sy, float sz, float& r, float& fbm) {
     const int n = SHAPE_N >> lvl, m = n - 1;
-    const float fn = (float)n;
+    const float fn = pow2f(7 - lvl);
     int ix, iy, iz; float ax, ay, az;
     split_coord(sx * fn - 0.5f, ix, ax); split_coord(sy * fn - 0.5f, iy, ay); split_coord(sz * fn - 0.5f, iz, az);
     const int x0 = ix & m, y0 = iy & m, z0 = iz & m;
@@ -282,7 +306,7 @@ CSKY_HD float detail_tap(const TexSet& T, int lvl, float sx, float sy, float sz)
     // sampler returns), so light samples j = 5 and the distant sample (clouds.glsl:190,198: textureLod(.., 5.0)) need no tap
     if (lvl == 5) return T.detail_lod5;
     const int n = DETAIL_N >> lvl, m = n - 1;
-    const float fn = (float)n;
+    const float fn = pow2f(5 - lvl);
     int ix, iy, iz; float ax, ay, az;
     split_coord(sx * fn - 0.5f, ix, ax); split_coord(sy * fn - 0.5f, iy, ay); split_coord(sz * fn - 0.5f, iz, az);
     const int x0 = ix & m, y0 = iy & m, z0 = iz & m;
@@ -403,7 +427,7 @@ CSKY_HD float sample_density_eager(const TexSet& T, const FrameConsts& fc, float
     float qx, qy, qz, sx, sy, sz;
     shape_coord(fc, px, py, pz, qx, qy, qz, sx, sy, sz);
     const int sn = SHAPE_N >> lod_shape, sm = sn - 1;
-    const float sfn = (float)sn;
+    const float sfn = pow2f(7 - lod_shape);
     int six, siy, siz; float sax, say, saz;
     split_coord(sx * sfn - 0.5f, six, sax); split_coord(sy * sfn - 0.5f, siy, say); split_coord(sz * sfn - 0.5f, siz, saz);
     const uint32_t ssh = (uint32_t)(7 - lod_shape);
@@ -416,7 +440,7 @@ CSKY_HD float sample_density_eager(const TexSet& T, const FrameConsts& fc, float
     float dax = 0.0f, day = 0.0f, daz = 0.0f;
     if (EAGER_DETAIL && lod_detail != 5) {                    // wave-uniform; LOD 5 is one texel (detail_tap)
         const int dn = DETAIL_N >> lod_detail, dm = dn - 1;
-        const float dfn = (float)dn;
+        const float dfn = pow2f(5 - lod_detail);
         int dix, diy, diz;
         split_coord(dsx * dfn - 0.5f, dix, dax); split_coord(dsy * dfn - 0.5f, diy, day); split_coord(dsz * dfn - 0.5f, diz, daz);
         const uint32_t dsh = (uint32_t)(5 - lod_detail);
@@ -457,8 +481,9 @@ CSKY_HD float sample_density_eager(const TexSet& T, const FrameConsts& fc, float
 }
 #endif
 
-CSKY_HD float henyey_greenstein(float c, float g) {                         // clouds.glsl:72-75 (once per ray: accurate powf)
-    return 0.0795774715459f * (1.0f - g * g) / powf(1.0f + g * g - 2.0f * g * c, 1.5f);
+CSKY_HD float henyey_greenstein(float c, float g) {                         // clouds.glsl:72-75, once per ray
+    const float x = 1.0f + g * g - 2.0f * g * c;                            // >= (1 - |g|)^2 >= 0
+    return 0.0795774715459f * (1.0f - g * g) / (x * sqrtf(x));             // pow(x, 1.5) = x sqrt(x): ~15 instructions instead of powf's ~80, within 2 fp32 ulp of it
 }
 
 // clouds.glsl:202-210: shade one in-cloud sample (density t, height fraction hf, step transmittance dt, summed light-march
@@ -500,7 +525,7 @@ CSKY_HD MarchOut march(const TexSet& T, const FrameConsts& fc, Ray ray) {
         if (fc.early_eps > 0.0f && CSKY_WAVE_ALL(!ray.above || Tr < fc.early_eps)) break;    // build-side early-out
         if (!ray.above) continue;
         advance(px, py, pz, ray.sx, ray.sy, ray.sz);                                         // :173
-        const float hf = height_fraction(length3_exact(px, py, pz));                         // :175
+        const float hf = height_fraction(length3_shell(px, py, pz));                         // :175
         const float t = sample_density(T, fc, px, py, pz, hf, fc.wpos_x, fc.wpos_y, 0, 0);   // :174,:177
         if (t > 0.0f) {                                                                      // :184
             o.incloud++;
@@ -508,13 +533,13 @@ CSKY_HD MarchOut march(const TexSet& T, const FrameConsts& fc, Ray ray) {
             float lx = px, ly = py, lz = pz, cd = 0.0f;
             for (int j = 0; j < ls; j++) {                                                   // :186
                 advance(lx, ly, lz, fc.linc[j][0], fc.linc[j][1], fc.linc[j][2]);            // :187
-                const float lhf = height_fraction(length3_exact(lx, ly, lz));                // :188
+                const float lhf = height_fraction(length3_shell(lx, ly, lz));                // :188
                 cd += sample_density(T, fc, lx, ly, lz, lhf, fc.wpos_x, fc.wpos_y, j > 2 ? j - 2 : 0, j);   // :189-191 (LOD mip-2 clamps at 0)
             }
             {   // distant sample, :195-199
                 lx = px; ly = py; lz = pz;
                 advance(lx, ly, lz, fc.ldist[0], fc.ldist[1], fc.ldist[2]);
-                const float lhf = height_fraction(length3_exact(lx, ly, lz));
+                const float lhf = height_fraction(length3_shell(lx, ly, lz));
                 const float ld = sample_density(T, fc, lx, ly, lz, lhf, 0.0f, 0.0f, 3, 5);   // :197 has no weather_pos
                 cd += fast_pow(ld, (1.0f - lhf) * 0.8f + 0.5f);                              // :198 (second pow)
             }

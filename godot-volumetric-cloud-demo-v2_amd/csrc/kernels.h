@@ -42,6 +42,9 @@ hipError_t launch_mip_chain(uint8_t* d_chain, int n, int ch, int levels, hipStre
 hipError_t launch_bake(const uint8_t* d_large_chain, const uint8_t* d_small_chain, const uint8_t* d_weather, ShapeTexel* d_shape, uint4* d_detail, uint16_t* d_detail_h,
                        uint4* d_weather_out, unsigned long long* d_inexact, int* d_range, hipStream_t s);
 
+// test hook: cloud_core.h::sqrt_shell over an array
+hipError_t launch_sqrt_shell(const float* d_in, float* d_out, size_t n, hipStream_t s);
+
 int cloud_variant_count();
 const char* cloud_variant_name(int v);
 

@@ -189,6 +189,17 @@ hipError_t launch_bake(const uint8_t* d_large_chain, const uint8_t* d_small_chai
     return hipGetLastError();
 }
 
+// test hook (csky_test_sqrt_shell): cloud_core.h::sqrt_shell over an array, for the exhaustive check against the host's sqrtf
+__global__ __launch_bounds__(256) void sqrt_shell_kernel(const float* __restrict__ in, float* __restrict__ out, size_t n) {
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < n) out[i] = sqrt_shell(in[i]);
+}
+hipError_t launch_sqrt_shell(const float* d_in, float* d_out, size_t n, hipStream_t s) {
+    if (n == 0) return hipSuccess;
+    sqrt_shell_kernel<<<(unsigned)((n + 255) / 256), 256, 0, s>>>(d_in, d_out, n);
+    return hipGetLastError();
+}
+
 // ------------------------------------------------------------------------------------------------ compositor
 // clouds.gdshader sky() on an equirectangular panorama, one pixel per lane
 __global__ __launch_bounds__(256) void composite_kernel(CompositeArgs A, uint2* __restrict__ out) {
@@ -276,7 +287,7 @@ __device__ __forceinline__ MarchOut march_queue(const TexSet& T, const FrameCons
         float t = 0.0f, hf = 0.0f;
         if (live) {
             advance(px, py, pz, ray.sx, ray.sy, ray.sz);                                                       // :173
-            hf = height_fraction(length3_exact(px, py, pz));                                                   // :175
+            hf = height_fraction(length3_shell(px, py, pz));                                                   // :175
             t = sample_density(T, fc, px, py, pz, hf, fc.wpos_x, fc.wpos_y, 0, 0);                             // :174, :177
         }
         const bool have = t > 0.0f;                                                                            // :184
@@ -314,7 +325,7 @@ __device__ __forceinline__ MarchOut march_queue(const TexSet& T, const FrameCons
                         else if (jj <= j) advance(lx, ly, lz, fc.linc[jj][0], fc.linc[jj][1], fc.linc[jj][2]);
                     }
                 }
-                const float lhf = height_fraction(length3_exact(lx, ly, lz));                                  // :188 / :196
+                const float lhf = height_fraction(length3_shell(lx, ly, lz));                                  // :188 / :196
                 const int lod_s = distant ? 3 : (j > 2 ? j - 2 : 0), lod_d = distant ? 5 : j;                  // textureLod(.., mip-2) / (.., mip)
                 float d = sample_density(T, fc, lx, ly, lz, lhf, distant ? 0.0f : fc.wpos_x, distant ? 0.0f : fc.wpos_y, lod_s, lod_d);  // :189-190 / :197-198
                 if (distant) d = fast_pow(d, (1.0f - lhf) * 0.8f + 0.5f);                                      // :198 second pow
@@ -410,7 +421,7 @@ __device__ __forceinline__ MarchOut march_compact(const TexSet& T, const FrameCo
             float t = 0.0f, hf = 0.0f;
             if (live) {
                 advance(px, py, pz, ray.sx, ray.sy, ray.sz);                                                   // :173
-                hf = height_fraction(length3_exact(px, py, pz));                                               // :175
+                hf = height_fraction(length3_shell(px, py, pz));                                               // :175
                 t = CSKY_PRIMARY_SAMPLE(T, fc, px, py, pz, hf, fc.wpos_x, fc.wpos_y, 0, 0);                    // :174, :177
             }
             const bool have = t > 0.0f;                                                                        // :184
@@ -437,13 +448,13 @@ __device__ __forceinline__ MarchOut march_compact(const TexSet& T, const FrameCo
             for (int j = 0; j < 6; j++) {                                                                      // :186 (light_steps <= 6)
                 if (j >= ls) break;
                 advance(lx, ly, lz, fc.linc[j][0], fc.linc[j][1], fc.linc[j][2]);                              // :187
-                const float lhf = height_fraction(length3_exact(lx, ly, lz));                                  // :188
+                const float lhf = height_fraction(length3_shell(lx, ly, lz));                                  // :188
                 cd += CSKY_LIGHT_SAMPLE(T, fc, lx, ly, lz, lhf, fc.wpos_x, fc.wpos_y, j > 2 ? j - 2 : 0, j);   // :189-191
             }
             {   // distant sample, :195-199
                 lx = ex; ly = ey; lz = ez;
                 advance(lx, ly, lz, fc.ldist[0], fc.ldist[1], fc.ldist[2]);
-                const float lhf = height_fraction(length3_exact(lx, ly, lz));
+                const float lhf = height_fraction(length3_shell(lx, ly, lz));
                 const float ld = CSKY_LIGHT_SAMPLE(T, fc, lx, ly, lz, lhf, 0.0f, 0.0f, 3, 5);                  // :197 has no weather_pos
                 cd += fast_pow(ld, (1.0f - lhf) * 0.8f + 0.5f);                                                // :198 (second pow)
             }
@@ -539,7 +550,7 @@ __device__ __forceinline__ void march_interleaved(const TexSet& T, const FrameCo
             float t = 0.0f, hf = 0.0f;
             if (ray.above && i < steps) {
                 for (int a = 0; a < replay; a++) advance(px, py, pz, ray.sx, ray.sy, ray.sz);     // clouds.glsl:173, one add per step
-                hf = height_fraction(length3_exact(px, py, pz));
+                hf = height_fraction(length3_shell(px, py, pz));
                 t = sample_density(T, fc, px, py, pz, hf, fc.wpos_x, fc.wpos_y, 0, 0);
             }
             replay = 4;
@@ -577,7 +588,7 @@ __device__ __forceinline__ void march_interleaved(const TexSet& T, const FrameCo
                             else if (jj <= j) advance(lx, ly, lz, fc.linc[jj][0], fc.linc[jj][1], fc.linc[jj][2]);
                         }
                     }
-                    const float lhf = height_fraction(length3_exact(lx, ly, lz));
+                    const float lhf = height_fraction(length3_shell(lx, ly, lz));
                     const int lod_s = distant ? 3 : (j > 2 ? j - 2 : 0), lod_d = distant ? 5 : j;
                     float d = sample_density(T, fc, lx, ly, lz, lhf, distant ? 0.0f : fc.wpos_x, distant ? 0.0f : fc.wpos_y, lod_s, lod_d);
                     if (distant) d = fast_pow(d, (1.0f - lhf) * 0.8f + 0.5f);

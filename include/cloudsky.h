@@ -249,6 +249,9 @@ int csky_build_mips_device(csky_ctx* ctx, uint8_t* vol, int n, int ch, int level
 /* Test hook: read back what csky_set_noise built on the device.  which: 0 shape layout, 1 detail layout, 2 weather layout (csky_common.h),
  * 3 / 4 the 8-bit mip chains of the large / small volume.  out may be NULL to query the size. */
 int csky_read_baked_texture(csky_ctx* ctx, int which, void* out, size_t capacity, size_t* bytes);
+/* Test hook: the march's range-restricted exact square root (cloud_core.h::sqrt_shell, |p|^2 of sample positions) over an array, so that
+ * a test can check it EXHAUSTIVELY against IEEE sqrtf on the range it is used on (all 30 067 floats in [3.597e13, 3.6097e13]). */
+int csky_test_sqrt_shell(csky_ctx* ctx, const float* in, float* out, size_t n);
 const char* csky_assets_last_error(void);
 
 #ifdef __cplusplus

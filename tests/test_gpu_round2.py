@@ -232,3 +232,17 @@ def test_gpu_detail_noise_mips_and_bake_are_byte_identical_to_the_host(pkg, host
         assert np.isfinite(img).all() and 0.2 < img[..., 3].mean() < 0.8
     finally:
         ctx.close()
+
+
+def test_shell_sqrt_is_ieee_exact_on_its_whole_range(gpu_ctx):
+    """cloud_core.h::sqrt_shell (one Newton step on v_rsq_f32, 17 issue cycles instead of 34) replaces the correctly rounded sqrt for |p|^2 of
+    sample positions.  It is only used on x in [3.597e13, 3.6097e13] (|p| between the cloud shells +- the light march's reach): EVERY float32
+    in that interval, plus a margin on both sides, must give exactly the IEEE result (numpy's float32 sqrt is correctly rounded)."""
+    lo, hi = np.float32(3.59e13), np.float32(3.62e13)
+    bits = np.arange(lo.view(np.uint32), hi.view(np.uint32) + 1, dtype=np.uint32)
+    x = bits.view(np.float32)
+    assert x.size > 60000 and x[0] <= 3.597e13 and x[-1] >= 3.6097e13
+    got = gpu_ctx.test_sqrt_shell(x)
+    ref = np.sqrt(x)                                             # IEEE-754 correctly rounded
+    bad = int((got.view(np.uint32) != ref.view(np.uint32)).sum())
+    assert bad == 0, (bad, x.size)
