@@ -18,7 +18,7 @@ inline void bake_shape(const std::vector<uint8_t>& chain, std::vector<ShapeTexel
     for (int l = 0; l < SHAPE_LEVELS; l++) {
         const int n = SHAPE_N >> l;
         const uint8_t* src = chain.data() + chain_offset(SHAPE_N, l, 4);
-        for (int z = 0; z < n; z++) for (int y = 0; y < n; y++) for (int x = 0; x < n; x++) out[off[l] + ((size_t)z * n + y) * n + x] = bake_shape_texel(src, n, x, y, z, bad);
+        for (int z = 0; z < n; z++) for (int y = 0; y < n; y++) for (int x = 0; x < n; x++) out[off[l] + shape_cell_index(n, x, y, z)] = bake_shape_texel(src, n, x, y, z, bad);
     }
     if (inexact) *inexact += bad;
 }

@@ -34,6 +34,8 @@ CSKY_HD void cell_coeffs(const int v[8], int c[8]) {
     c[7] = v[7] - v[6] - v[5] + v[4] - v[3] + v[2] + v[1] - v[0];
 }
 
+// where the cell (x,y,z) of an n^3 level is stored inside the level (csky_common.h: x fastest, then y, then z)
+CSKY_HD size_t shape_cell_index(int n, int x, int y, int z) { return ((size_t)z * n + y) * n + x; }
 // shape texel (x,y,z) of a level with n^3 RGBA8 texels at `src` (REPEAT addressing)
 CSKY_HD ShapeTexel bake_shape_texel(const uint8_t* __restrict__ src, int n, int x, int y, int z, unsigned& inexact) {
     int vr[8], vf[8], cr[8], cf[8];

@@ -183,7 +183,7 @@ CSKY_HD void frame_setup(const CloudParams& P, const float4* sky, int sky_w, int
     for (int k = 0; k < 3; k++) s[k] = s[k] * 5.0f * 0.05f;
     len = length3_exact(s[0], s[1], s[2]);
     for (int k = 0; k < 3; k++) fc.gnd_c[k] = s[k] * (1.0f - 0.5f) + (P.ground_color[k] * len) * 0.5f;  // clouds.glsl:167
-    fc.density = P.density; fc.coverage = P.cloud_coverage;
+    fc.density = P.density; fc.coverage = P.cloud_coverage; fc.cov255 = P.cloud_coverage * (1.0f / 255.0f);
     fc.primary_steps = primary_steps; fc.light_steps = light_steps; fc.steps_f = (float)primary_steps;
     fc.early_eps = early_eps;
     fc.hf_lo = hf_lo; fc.hf_hi = hf_hi;
@@ -243,7 +243,8 @@ CSKY_HD void split_coord(float u, int& i, float& f) {
 #endif
 }
 
-// REPEAT + LINEAR bilinear tap of the quad-packed weather map (clouds.glsl:174).  Returns r (cloud type), b (coverage).
+// REPEAT + LINEAR bilinear tap of the quad-packed weather map (clouds.glsl:174).  Returns r (cloud type), b (coverage) ON THE TEXEL SCALE
+// 0..255: the UNORM 1/255 is folded into the two consumers (coverage / 255 in FrameConsts, the gradient's slopes), two multiplies less per sample.
 CSKY_HD void weather_fetch(const uint4* __restrict__ w, float sx, float sy, uint4& q, float& ax, float& ay) {
     int ix, iy;
     split_coord(sx * 512.0f - 0.5f, ix, ax); split_coord(sy * 512.0f - 0.5f, iy, ay);
@@ -251,8 +252,8 @@ CSKY_HD void weather_fetch(const uint4* __restrict__ w, float sx, float sy, uint
     q = *reinterpret_cast<const uint4*>(reinterpret_cast<const char*>(w) + ((((uint32_t)y0 << 9) | (uint32_t)x0) << 4));
 }
 CSKY_HD void weather_filter(const uint4& q, float ax, float ay, float& wr, float& wb) {
-    wr = fmaf(ay, lerp_h(q.y, ax), lerp_h(q.x, ax)) * (1.0f / 255.0f);      // polynomial cell: (c0 + c1 fx) + fy (c2 + c3 fx)
-    wb = fmaf(ay, lerp_h(q.w, ax), lerp_h(q.z, ax)) * (1.0f / 255.0f);
+    wr = fmaf(ay, lerp_h(q.y, ax), lerp_h(q.x, ax));                        // polynomial cell: (c0 + c1 fx) + fy (c2 + c3 fx)
+    wb = fmaf(ay, lerp_h(q.w, ax), lerp_h(q.z, ax));
 }
 CSKY_HD void weather_tap(const uint4* __restrict__ w, float sx, float sy, float& wr, float& wb) {
     uint4 q; float ax, ay;
@@ -263,6 +264,8 @@ CSKY_HD void weather_tap(const uint4* __restrict__ w, float sx, float sy, float&
 // (float)(1 << e) built from the exponent field: integer SALU work when e is wave-uniform (the light march's LOD), where a cast costs a
 // half-rate v_cvt per tap
 CSKY_HD float pow2f(int e) { const uint32_t b = (uint32_t)(127 + e) << 23; float f; memcpy(&f, &b, 4); return f; }
+// index of cell (x0,y0,z0) inside a shape level with n = 1 << sh cells per side (== bake_core.h::shape_cell_index)
+CSKY_HD uint32_t shape_cell_offset(uint32_t x0, uint32_t y0, uint32_t z0, uint32_t sh) { return (((z0 << sh) | y0) << sh) | x0; }
 // texel offset of mip level l inside the packed chains: sum_{i<l} (N>>i)^3 = (N^3*8 - (N>>l)^3*8) / 7, computed
 // arithmetically so a per-lane level needs no table (api.cpp checks it against the baked offsets)
 CSKY_HD uint32_t shape_level_offset(int l) { return ((1u << 24) - (1u << (24 - 3 * l))) / 7u; }
@@ -292,8 +295,8 @@ CSKY_HD void shape_tap(const TexSet& T, int lvl, float sx, float sy, float sz, f
     r = lerpf(fmaf(ay, lerp_h(t0.y, ax), lerp_h(t0.x, ax)), fmaf(ay, lerp_h(t1.y, ax), lerp_h(t1.x, ax)), az) * (1.0f / 255.0f);
     fbm = lerpf(fmaf(ay, lerp_h(t0.w, ax), lerp_h(t0.z, ax)), fmaf(ay, lerp_h(t1.w, ax), lerp_h(t1.z, ax)), az) * (1.0f / (8.0f * 255.0f));
 #else
-    const uint32_t r0 = ((((uint32_t)z0 << sh) | (uint32_t)y0) << sh);
-    const uint4* __restrict__ t = reinterpret_cast<const uint4*>(sb + ((base + r0) << 5));
+    (void)base;
+    const uint4* __restrict__ t = reinterpret_cast<const uint4*>(sb + ((shape_level_offset(lvl) + shape_cell_offset((uint32_t)x0, (uint32_t)y0, (uint32_t)z0, sh)) << 5));
     const uint4 tr = t[0], tf = t[1];
     r = fmaf(az, fmaf(ay, lerp_h(tr.w, ax), lerp_h(tr.z, ax)), fmaf(ay, lerp_h(tr.y, ax), lerp_h(tr.x, ax))) * (1.0f / 255.0f);
     fbm = fmaf(az, fmaf(ay, lerp_h(tf.w, ax), lerp_h(tf.z, ax)), fmaf(ay, lerp_h(tf.y, ax), lerp_h(tf.x, ax))) * (1.0f / (8.0f * 255.0f));
@@ -337,21 +340,22 @@ CSKY_HD float smoothstep_fast(float e0, float e1, float x) {
 // stratocumulus (2ct) are non-zero, above 0.5 only stratocumulus (2-2ct) and cumulus (2ct-1), so each of the four
 // gradient corners is A + ct*B with (A,B) picked by the branch (8 selects + 4 FMA instead of 3 weights x 4 x 2 FMA).
 CSKY_HD float density_height_gradient(const FrameConsts& fc, float hf, float ct) {
-    const float c = ct;                                       // ct is a filtered UNORM8 texel: always in [0,1]
+    const float c = ct;                                       // ct is a filtered UNORM8 texel ON THE TEXEL SCALE 0..255 (weather_filter): slopes carry the 1/255
+    constexpr float K = 1.0f / 255.0f;
     // ct < 0.5 : STRATUS + ct*2*(STRATOCUMULUS - STRATUS)   ; ct >= 0.5 : (2*STRATOCUMULUS - CUMULUS) + ct*2*(CUMULUS - STRATOCUMULUS)
     float gx, gy, gz, gw;
     if (fc.ct_mode == 1) {
         // every texel of the bound weather map is >= 128/255, and bilinear filtering stays inside the texel range: the branch of
         // the piecewise form is known for the whole frame (a scalar test) and its 8 selects + compare disappear.  Same arithmetic.
-        gx = 0.03f + c * -0.02f; gy = 0.3375f + c * -0.275f; gz = 0.18f + c * 0.6f; gw = 0.25f + c * 0.75f;
+        gx = 0.03f + c * (-0.02f * K); gy = 0.3375f + c * (-0.275f * K); gz = 0.18f + c * (0.6f * K); gw = 0.25f + c * (0.75f * K);
     } else if (fc.ct_mode == 2) {
-        gx = 0.02f + c * 0.0f; gy = 0.05f + c * 0.3f; gz = 0.09f + c * 0.78f; gw = 0.11f + c * 1.03f;
+        gx = 0.02f + c * 0.0f; gy = 0.05f + c * (0.3f * K); gz = 0.09f + c * (0.78f * K); gw = 0.11f + c * (1.03f * K);
     } else {
-        const bool hi = ct >= 0.5f;
-        gx = (hi ? 0.03f : 0.02f) + c * (hi ? -0.02f : 0.0f);
-        gy = (hi ? 0.3375f : 0.05f) + c * (hi ? -0.275f : 0.3f);
-        gz = (hi ? 0.18f : 0.09f) + c * (hi ? 0.6f : 0.78f);
-        gw = (hi ? 0.25f : 0.11f) + c * (hi ? 0.75f : 1.03f);
+        const bool hi = ct >= 127.5f;
+        gx = (hi ? 0.03f : 0.02f) + c * (hi ? -0.02f * K : 0.0f);
+        gy = (hi ? 0.3375f : 0.05f) + c * (hi ? -0.275f * K : 0.3f * K);
+        gz = (hi ? 0.18f : 0.09f) + c * (hi ? 0.6f * K : 0.78f * K);
+        gw = (hi ? 0.25f : 0.11f) + c * (hi ? 0.75f * K : 1.03f * K);
     }
     return smoothstep_fast(gx, gy, hf) - smoothstep_fast(gz, gw, hf);
 }
@@ -365,7 +369,7 @@ CSKY_HD float density_height_gradient(const FrameConsts& fc, float hf, float ct)
 //  (2) after :125, base_cloud <= 0 makes :135-136 return 0 for the same reason: the detail tap is dead.
 CSKY_HD float density(const TexSet& T, const FrameConsts& fc, float px, float py, float pz, float hf, float wr, float wb,
                       int lod_shape, int lod_detail) {
-    const float wc = fc.coverage * wb;                                       // :123
+    const float wc = fc.cov255 * wb;                                         // :123 (wb on the texel scale)
     const float g = density_height_gradient(fc, hf, wr);                    // :121
     const float omw = 1.0f - wc;
     if (!(g > omw)) return 0.0f;                                             // exact reject (1)
@@ -406,6 +410,9 @@ CSKY_HD float sample_density(const TexSet& T, const FrameConsts& fc, float px, f
     return density(T, fc, px, py, pz, hf, wr, wb, lod_shape, lod_detail);
 }
 
+// (Round-2 experiment, measured and removed: the cells of detail LODs 2..4 / 3..4 staged in LDS per workgroup and served to the light march
+// with one ds_read_b128 per tap: frames bit-identical, C3 2.16 / 2.08 ms against 2.05 ms (LODs 2..4 need 9.3 KB and cost a wavefront per SIMD;
+// LODs 3..4 remove 2 of 28 gathers per in-cloud sample and add a workgroup barrier + staging): profiles/r02/layout_lds_ab.txt.)
 // sample_density() with all of a sample's texture fetches issued up front ("eager"): the addresses of the weather, shape and detail
 // cells depend only on the sample position, not on each other's results, so the three gathers can be in flight together instead of
 // one after the other (one memory latency per sample instead of three; the kernel is as sensitive to latency as to VALU issue:
@@ -431,7 +438,7 @@ CSKY_HD float sample_density_eager(const TexSet& T, const FrameConsts& fc, float
     int six, siy, siz; float sax, say, saz;
     split_coord(sx * sfn - 0.5f, six, sax); split_coord(sy * sfn - 0.5f, siy, say); split_coord(sz * sfn - 0.5f, siz, saz);
     const uint32_t ssh = (uint32_t)(7 - lod_shape);
-    const uint32_t sidx = shape_level_offset(lod_shape) + ((((((uint32_t)(siz & sm)) << ssh) | (uint32_t)(siy & sm)) << ssh) | (uint32_t)(six & sm));
+    const uint32_t sidx = shape_level_offset(lod_shape) + shape_cell_offset((uint32_t)(six & sm), (uint32_t)(siy & sm), (uint32_t)(siz & sm), ssh);
     const uint4* __restrict__ sp = reinterpret_cast<const uint4*>(reinterpret_cast<const char*>(T.shape) + (sidx << 5));
     const uint4 tr = sp[0], tf = sp[1];
     float dsx, dsy, dsz;
@@ -448,9 +455,9 @@ CSKY_HD float sample_density_eager(const TexSet& T, const FrameConsts& fc, float
         dq = *reinterpret_cast<const uint4*>(reinterpret_cast<const char*>(T.detail) + (didx << 4));
     }
     // ---- the arithmetic of density() (clouds.glsl:109-137) on the fetched cells
-    const float wr = fmaf(way, lerp_h(wq.y, wax), lerp_h(wq.x, wax)) * (1.0f / 255.0f);
-    const float wb = fmaf(way, lerp_h(wq.w, wax), lerp_h(wq.z, wax)) * (1.0f / 255.0f);
-    const float wc = fc.coverage * wb;                                       // :123
+    const float wr = fmaf(way, lerp_h(wq.y, wax), lerp_h(wq.x, wax));       // texel scale 0..255 (weather_filter)
+    const float wb = fmaf(way, lerp_h(wq.w, wax), lerp_h(wq.z, wax));
+    const float wc = fc.cov255 * wb;                                         // :123 (wb on the texel scale)
     const float g = density_height_gradient(fc, hf, wr);                    // :121
     const float omw = 1.0f - wc;
     if (!(g > omw)) return 0.0f;                                             // exact reject (1)

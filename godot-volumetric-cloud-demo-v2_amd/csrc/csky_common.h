@@ -50,6 +50,14 @@ constexpr int DETAIL_CHAIN_TEXELS = 32768 + 4096 + 512 + 64 + 8 + 1;   // all si
 #ifndef CSKY_SHAPE_POLY
 #define CSKY_SHAPE_POLY 3   // measured on MI355X, C3 frame: rank 1 2.89 ms, rank 2 2.56 ms, rank 3 2.52 ms (profiles/r01/texture_cell_rank_ab.txt)
 #endif
+// Cells of a level are stored x fastest, then y, then z (the texture's own slice order).  Round 2 measured two alternatives on MI355X with
+// TCP / TCC counters (profiles/r02/shape_layout_ab.txt), frames bit-identical in all three:
+//   x, then z, then y (a wavefront's rays sit at one altitude = texture v, and spread over u / w)   2.031 / 1.792 ms vs 2.040 / 1.795: no difference,
+//                                                                                                 L1 hit 72.6 % and L2 hit 78.0 % unchanged
+//   4x4x4-cell bricks (2 KB, what texture hardware does)                                          2.081 / 1.819 ms: L1 hit unchanged (72.6 %), L2 hit
+//                                                                                                 77.9 -> 78.2 %, fabric bytes -1.5 %, VALU +5.2 %
+// The L1 hit rate is set by the 4 cells a 128-byte line holds and by how far apart a quad's rays land, not by the slice strides; the kernel
+// is VALU-issue bound (bench.py roofline), so the bricks' six extra half-rate integer instructions per tap cost more than they save.
 #if CSKY_SHAPE_POLY == 1
 typedef uint2 ShapeTexel;
 #elif CSKY_SHAPE_POLY == 2
@@ -81,6 +89,7 @@ struct FrameConsts {
     float hg_g2;                      // 0.4 - 1.4*ldir.y, clouds.glsl:160
     float sun_c[3], amb_c[3], gnd_c[3];  // clouds.glsl:163-167
     float density, coverage;          // clouds.glsl:37-38
+    float cov255;                     // coverage / 255: weather taps stay on the texel scale 0..255, the 1/255 is folded into their consumers
     int primary_steps, light_steps;   // clouds.glsl:228 (128), :186 (6)
     float steps_f;
     float early_eps;                  // wave early-out threshold on T (0 = off; not in the reference)

@@ -151,8 +151,10 @@ template <int N, int LEVELS> __device__ __forceinline__ bool level_of(size_t i, 
 __global__ __launch_bounds__(256) void bake_shape_kernel(const uint8_t* __restrict__ chain, ShapeTexel* __restrict__ out, unsigned long long* __restrict__ inexact) {
     const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
     int l, n; size_t local; unsigned bad = 0;
-    if (level_of<SHAPE_N, SHAPE_LEVELS>(i, l, n, local))
-        out[i] = bake_shape_texel(chain + chain_offset(SHAPE_N, l, 4), n, (int)(local % n), (int)((local / n) % n), (int)(local / ((size_t)n * n)), bad);
+    if (level_of<SHAPE_N, SHAPE_LEVELS>(i, l, n, local)) {
+        const int x = (int)(local % n), y = (int)((local / n) % n), z = (int)(local / ((size_t)n * n));
+        out[(i - local) + shape_cell_index(n, x, y, z)] = bake_shape_texel(chain + chain_offset(SHAPE_N, l, 4), n, x, y, z, bad);
+    }
     bake_tally(bad, inexact);
 }
 __global__ __launch_bounds__(256) void bake_detail_kernel(const uint8_t* __restrict__ chain, uint4* __restrict__ out, uint16_t* __restrict__ out_h, unsigned long long* __restrict__ inexact) {

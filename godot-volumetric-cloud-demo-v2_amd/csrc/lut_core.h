@@ -27,20 +27,29 @@ CSKY_HD F4 operator*(F4 a, float s) { return f4(a.x * s, a.y * s, a.z * s, a.w *
 // cases; OCML's float versions are 1-ulp functions, and the Hillaire integration S - S*exp(-dt*ext) (S:270) cancels and amplifies
 // that ulp to 3-4 fp16 ulp of the sky LUT.  On the device they are therefore evaluated in double and rounded once (correctly
 // rounded except ~1e-8 of the cases): these kernels are 16 384 + 20 000 x 30 lanes, the fp64 rate is irrelevant (25 us).
+// Measured on MI355X over 75 suns (tools/lut_time.py): all through double (3, the default) transmittance LUT bit-identical, sky LUT worst 1 ulp,
+// 0.09 % of texels off, 33.0 us per back-to-back launch; every exp only (2) or the step exps only (1) worst 3 ulp, 0.8 % off, 27 us; none (0)
+// worst 3 ulp, 1.5 % off, 25.6 us: the log / pow / sin / cos matter as much as the exps, and exactness costs 7 us of a kernel that runs on the
+// prologue stream beside the march.
+#ifndef CSKY_LUT_CR
+#define CSKY_LUT_CR 3
+#endif
 #if defined(__HIP_DEVICE_COMPILE__)
-CSKY_HD float exp_cr(float x) { return (float)exp((double)x); }
-CSKY_HD float log_cr(float x) { return (float)log((double)x); }
-CSKY_HD float pow_cr(float x, float y) { return (float)pow((double)x, (double)y); }
-CSKY_HD float sin_cr(float x) { return (float)sin((double)x); }
-CSKY_HD float cos_cr(float x) { return (float)cos((double)x); }
+CSKY_HD float exp_step(float x) { return CSKY_LUT_CR >= 1 ? (float)exp((double)x) : expf(x); }
+CSKY_HD float exp_cr(float x) { return CSKY_LUT_CR >= 2 ? (float)exp((double)x) : expf(x); }
+CSKY_HD float log_cr(float x) { return CSKY_LUT_CR >= 3 ? (float)log((double)x) : logf(x); }
+CSKY_HD float pow_cr(float x, float y) { return CSKY_LUT_CR >= 3 ? (float)pow((double)x, (double)y) : powf(x, y); }
+CSKY_HD float sin_cr(float x) { return CSKY_LUT_CR >= 3 ? (float)sin((double)x) : sinf(x); }
+CSKY_HD float cos_cr(float x) { return CSKY_LUT_CR >= 3 ? (float)cos((double)x) : cosf(x); }
 #else
+CSKY_HD float exp_step(float x) { return expf(x); }
 CSKY_HD float exp_cr(float x) { return expf(x); }
 CSKY_HD float log_cr(float x) { return logf(x); }
 CSKY_HD float pow_cr(float x, float y) { return powf(x, y); }
 CSKY_HD float sin_cr(float x) { return sinf(x); }
 CSKY_HD float cos_cr(float x) { return cosf(x); }
 #endif
-CSKY_HD F4 exp4(F4 a) { return f4(exp_cr(a.x), exp_cr(a.y), exp_cr(a.z), exp_cr(a.w)); }
+CSKY_HD F4 exp4(F4 a) { return f4(exp_step(a.x), exp_step(a.y), exp_step(a.z), exp_step(a.w)); }
 
 // T:89-98 / S:100-109
 CSKY_HD float ray_sphere_intersection(float ox, float oy, float oz, float dx, float dy, float dz, float radius) {
