@@ -1,0 +1,60 @@
+"""-m gpu: bench.py's output contract on the GPU box (one JSON line with the metric of BASELINE.json, `roofline` from live counters with every
+fraction <= 1, `cpu_baseline`), and its N > 1 code path exercised end to end with two ranks sharing GPU 0 through gloo (RCCL refuses two ranks on
+one device; the 8-GPU run is the driver's)."""
+import json
+import os
+import socket
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+pytestmark = pytest.mark.gpu
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _last_json(text):
+    lines = [l for l in text.splitlines() if l.startswith("{")]
+    assert lines, text[-2000:]
+    return json.loads(lines[-1])
+
+
+def test_bench_line_contract_single_gpu():
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "6", "--warmup", "2"], capture_output=True, text=True,
+                         cwd=ROOT, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    d = _last_json(out.stdout)
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data", "config",
+              "roofline", "cpu_baseline", "value_one_frame_at_a_time"):
+        assert k in d, k
+    assert d["unit"] == "Mrays/s" and d["n_gpus"] == 1 and d["steps"] == 6 and d["warmup"] == 2 and d["dtype"] == "f32" and d["vs_baseline"] is None
+    assert d["config"]["workload"].startswith("C3: 2048x1024") and d["config"]["finite"] is True
+    assert abs(d["value"] - 2048 * 1024 / d["ms_per_step"] / 1e3) < 1e-6 * d["value"]
+    assert 100.0 < d["value"] < 1e5 and d["value_one_frame_at_a_time"]["value"] <= d["value"] * 1.05
+    r = d["roofline"]
+    assert r["pmc"]["collected"], r["pmc"]                                     # the counters were collected in THIS run
+    assert 0.3 < r["frac"] <= 1.0 and r["frac_bounds"][0] <= r["frac"] <= r["frac_bounds"][1] <= 1.0
+    assert 0.2 < r["l1_gather"]["frac"] <= 1.0 and 0.0 < r["hbm"]["frac"] <= 1.0
+    assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-9 and r["traffic"] > 1e8
+    assert 0.5 < r["kernel_ms_solo"] < 20.0 and r["kernel_ms_in_flight"] >= 0.9 * r["kernel_ms_solo"]
+    c = d["cpu_baseline"]
+    assert c["kind"] == "port" and c["cores"] >= 1 and c["value"] > 0 and "sample" in c
+
+
+def test_bench_two_ranks_on_one_gpu_through_gloo():
+    env = dict(os.environ, CSKY_BENCH_ONE_GPU_DEBUG="1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", str(_free_port()),
+           os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "4", "--warmup", "1", "--no-cpu-baseline"]
+    out = subprocess.run(cmd, capture_output=True, text=True, cwd=ROOT, env=env, timeout=600)
+    assert out.returncode == 0, (out.stdout[-1500:], out.stderr[-2500:])
+    d = _last_json(out.stdout)
+    assert d["n_gpus"] == 2 and d["scaling"] == "strong" and d["config"]["finite"] is True and d["config"]["parallelism"].startswith("bands2")
+    assert "gathered 2-rank frame vs single-rank frame" in out.stderr             # bench.py compared the gathered frame with a single-context render
