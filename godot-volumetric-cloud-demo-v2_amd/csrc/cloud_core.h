@@ -230,25 +230,18 @@ CSKY_HD float lerp_h2(uint32_t a_lo_b_hi, float f) {
 #endif
 }
 
-// Texel coordinate u = s*n - 0.5 (n a power of two, so s*n is exact) -> (cell index, fraction) with FULL-RATE instructions only.
-// v_cvt_flr_i32_f32 + v_fract_f32 are half-rate on gfx950 (4.1 issue cycles each, profiles/r02/issue_cost_calibration_tables.txt); two FMAs
-// and two subtractions are 4 x 2.3 - 2.3 (the u FMA was there anyway) = 1.3 cycles less per axis, eight axes per density sample:
-//     u = fma(s, n, -0.5)               t = fma(s, n, M - 1),  M = 1.5 * 2^23      (t = M + round-to-nearest-even(u - 0.5): an integer)
-//     i = bits(t)                       (low 22 mantissa bits = that integer in two's complement; callers mask with n - 1: REPEAT)
-//     f = u - (t - M)                   (exact)
-// round(u - 0.5) == floor(u) except when u is exactly an integer k (a tie): then t may land on k - 1 with f = 1 instead of k with f = 0.
-// Both address the same sample point, and the polynomial cells make it the same NUMBER: at f = 1 a cell evaluates sums of its integer
-// coefficients, c0 + c1 = the neighbour's c0, c2 + c3 = the neighbour's c2, ... exactly.  Frames are bit-identical to the floor/fract form
-// (tools/ab_frame.py frame hash; the -m gpu parity tests run on this path).  Valid for |u| < 2^22 (texel coordinates stay below 2^17).
-CSKY_HD void split_coord(float s, float n, int& i, float& f) {
+// Texel coordinate -> (floor as int, fraction).  gfx950 has v_cvt_flr_i32_f32 (float -> int with floor rounding) and
+// v_fract_f32, so the pair costs 2 instructions instead of floor + cvt + sub; u - floor(u) is exact in fp32 and v_fract returns
+// the same value (it only clamps the one-in-2^25 case u = -tiny to 1 - 2^-24 instead of 1.0).
+// (Round 2 tried the full-rate alternative t = fma(s, n, 1.5*2^23 - 1), i = bits(t), f = u - (t - 1.5*2^23): four full-rate instead of one
+// full + two half-rate instructions per axis.  It is NOT bit-identical -- when u is an exact integer, round-to-nearest-even lands on the cell
+// below with f = 1 for half of them, which is the same sample point but three roundings instead of one in the y / z lerps -- and it measured
+// SLOWER, 2.20 vs 2.04 ms: u and t are both live per axis and the kernel sits at its 72-VGPR budget, 5 -> 11 spilled registers.  Dropped.)
+CSKY_HD void split_coord(float u, int& i, float& f) {
 #if defined(__HIP_DEVICE_COMPILE__)
-    constexpr float M = 12582912.0f;
-    const float u = __builtin_fmaf(s, n, -0.5f);
-    const float t = __builtin_fmaf(s, n, M - 1.0f);
-    i = (int)__float_as_uint(t);
-    f = u - (t - M);
+    asm("v_cvt_flr_i32_f32 %0, %1" : "=v"(i) : "v"(u));
+    f = __builtin_amdgcn_fractf(u);
 #else
-    const float u = s * n - 0.5f;
     const float fl = floorf(u);
     i = (int)fl; f = u - fl;
 #endif
@@ -258,7 +251,7 @@ CSKY_HD void split_coord(float s, float n, int& i, float& f) {
 // 0..255: the UNORM 1/255 is folded into the two consumers (coverage / 255 in FrameConsts, the gradient's slopes), two multiplies less per sample.
 CSKY_HD void weather_fetch(const uint4* __restrict__ w, float sx, float sy, uint4& q, float& ax, float& ay) {
     int ix, iy;
-    split_coord(sx, 512.0f, ix, ax); split_coord(sy, 512.0f, iy, ay);
+    split_coord(sx * 512.0f - 0.5f, ix, ax); split_coord(sy * 512.0f - 0.5f, iy, ay);
     const int x0 = ix & 511, y0 = iy & 511;
     q = *reinterpret_cast<const uint4*>(reinterpret_cast<const char*>(w) + ((((uint32_t)y0 << 9) | (uint32_t)x0) << 4));
 }
@@ -287,7 +280,7 @@ CSKY_HD void shape_tap(const TexSet& T, int lvl, float sx, float sy, float sz, f
     const int n = SHAPE_N >> lvl, m = n - 1;
     const float fn = pow2f(7 - lvl);
     int ix, iy, iz; float ax, ay, az;
-    split_coord(sx, fn, ix, ax); split_coord(sy, fn, iy, ay); split_coord(sz, fn, iz, az);
+    split_coord(sx * fn - 0.5f, ix, ax); split_coord(sy * fn - 0.5f, iy, ay); split_coord(sz * fn - 0.5f, iz, az);
     const int x0 = ix & m, y0 = iy & m, z0 = iz & m;
     const uint32_t sh = (uint32_t)(7 - lvl), base = shape_level_offset(lvl) + (uint32_t)x0;   // n = 1 << sh: shifts, not v_mul_lo_u32 (quarter rate)
     const char* __restrict__ sb = reinterpret_cast<const char*>(T.shape);
@@ -322,7 +315,7 @@ CSKY_HD float detail_tap(const TexSet& T, int lvl, float sx, float sy, float sz)
     const int n = DETAIL_N >> lvl, m = n - 1;
     const float fn = pow2f(5 - lvl);
     int ix, iy, iz; float ax, ay, az;
-    split_coord(sx, fn, ix, ax); split_coord(sy, fn, iy, ay); split_coord(sz, fn, iz, az);
+    split_coord(sx * fn - 0.5f, ix, ax); split_coord(sy * fn - 0.5f, iy, ay); split_coord(sz * fn - 0.5f, iz, az);
     const int x0 = ix & m, y0 = iy & m, z0 = iz & m;
     if (T.detail_lds) {
         // "lds" variant (north star: noise bricks staged in LDS): the whole detail chain sits in LDS as unpacked fp16 texels, so
@@ -440,14 +433,14 @@ CSKY_HD float sample_density_eager(const TexSet& T, const FrameConsts& fc, float
     float wsx, wsy;
     weather_coord(px, pz, wx, wy, wsx, wsy);
     int wix, wiy; float wax, way;
-    split_coord(wsx, 512.0f, wix, wax); split_coord(wsy, 512.0f, wiy, way);
+    split_coord(wsx * 512.0f - 0.5f, wix, wax); split_coord(wsy * 512.0f - 0.5f, wiy, way);
     const uint4 wq = *reinterpret_cast<const uint4*>(reinterpret_cast<const char*>(T.weather) + (((((uint32_t)(wiy & 511)) << 9) | (uint32_t)(wix & 511)) << 4));
     float qx, qy, qz, sx, sy, sz;
     shape_coord(fc, px, py, pz, qx, qy, qz, sx, sy, sz);
     const int sn = SHAPE_N >> lod_shape, sm = sn - 1;
     const float sfn = pow2f(7 - lod_shape);
     int six, siy, siz; float sax, say, saz;
-    split_coord(sx, sfn, six, sax); split_coord(sy, sfn, siy, say); split_coord(sz, sfn, siz, saz);
+    split_coord(sx * sfn - 0.5f, six, sax); split_coord(sy * sfn - 0.5f, siy, say); split_coord(sz * sfn - 0.5f, siz, saz);
     const uint32_t ssh = (uint32_t)(7 - lod_shape);
     const uint32_t sidx = shape_level_offset(lod_shape) + shape_cell_offset((uint32_t)(six & sm), (uint32_t)(siy & sm), (uint32_t)(siz & sm), ssh);
     const uint4* __restrict__ sp = reinterpret_cast<const uint4*>(reinterpret_cast<const char*>(T.shape) + (sidx << 5));
@@ -460,7 +453,7 @@ CSKY_HD float sample_density_eager(const TexSet& T, const FrameConsts& fc, float
         const int dn = DETAIL_N >> lod_detail, dm = dn - 1;
         const float dfn = pow2f(5 - lod_detail);
         int dix, diy, diz;
-        split_coord(dsx, dfn, dix, dax); split_coord(dsy, dfn, diy, day); split_coord(dsz, dfn, diz, daz);
+        split_coord(dsx * dfn - 0.5f, dix, dax); split_coord(dsy * dfn - 0.5f, diy, day); split_coord(dsz * dfn - 0.5f, diz, daz);
         const uint32_t dsh = (uint32_t)(5 - lod_detail);
         const uint32_t didx = detail_level_offset(lod_detail) + ((((((uint32_t)(diz & dm)) << dsh) | (uint32_t)(diy & dm)) << dsh) | (uint32_t)(dix & dm));
         dq = *reinterpret_cast<const uint4*>(reinterpret_cast<const char*>(T.detail) + (didx << 4));
