@@ -19,6 +19,13 @@
 
 using namespace csky;
 
+// Two frames in flight (csky_set_frames_in_flight) need the caller's two streams on DIFFERENT hardware queues.  The HIP runtime
+// multiplexes a process's streams onto GPU_MAX_HW_QUEUES queues (default 4) in first-use order, and with the library's two internal streams
+// plus a host's own, four are not enough (measured: no overlap at 4, overlap at 8).  The runtime reads the variable when it initialises, at
+// the first HIP call; this runs when libcloudsky.so is loaded, so a host that cannot set environment variables (a GDExtension inside Godot)
+// still gets the overlap as long as it has not used HIP before loading the library.  An existing value is never overwritten.
+__attribute__((constructor)) static void csky_runtime_defaults() { setenv("GPU_MAX_HW_QUEUES", "8", /*overwrite=*/0); }
+
 static_assert(sizeof(csky_cloud_params) == sizeof(CloudParams), "ABI struct mismatch");
 
 struct csky_ctx {

@@ -194,7 +194,9 @@ int csky_set_schedule(csky_ctx* ctx, int mode);
 int csky_set_segments(csky_ctx* ctx, int segments);
 /* Policy hint for the automatic segment / schedule choice: 2 = the caller keeps two frames in flight by alternating two streams
  * between consecutive csky_render_*_device calls (always safe: per-frame state lives in two-deep rings ordered by events); the
- * next frame then fills the tail of this one and fewer, longer wavefronts are the better choice for partial frames.  Default 1. */
+ * next frame then fills the tail of this one and fewer, longer wavefronts are the better choice for partial frames.  Default 1.
+ * The two streams must map to different hardware queues: the library sets GPU_MAX_HW_QUEUES=8 at load time unless the host already set it
+ * (the HIP runtime's default of 4 loses part of the overlap); that works when the library is loaded before the process's first HIP call. */
 int csky_set_frames_in_flight(csky_ctx* ctx, int frames);
 const char* csky_variant_name(int variant);
 

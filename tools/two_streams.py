@@ -2,7 +2,8 @@
 """Throughput with several frames in flight: consecutive renders alternate between caller streams (the library's rings + events
 keep them independent), so the tail of frame k overlaps the head of frame k+1.  Whole frame and one rank's share at N = 2, 4, 8."""
 import os, sys, time
-os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")   # frame streams must land on different hardware queues (see bench.py)
+if os.environ.get("CSKY_TOOLS_NO_QUEUE_ENV") != "1":   # =1: leave it to libcloudsky's load-time default (api.cpp::csky_runtime_defaults)
+    os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")   # frame streams must land on different hardware queues (see bench.py)
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
