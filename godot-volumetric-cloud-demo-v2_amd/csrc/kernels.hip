@@ -732,17 +732,16 @@ __global__ __launch_bounds__(1024) void clouds_kernel_lds(TexSet T, const FrameC
 #define CSKY_COMPACT_WAVES 7   // waves/SIMD asked of the "compact" variant.  With the eager light-march fetches (three gathers of a sample in flight
                                // together) 7 waves x 72 VGPRs beat 8 waves x 64 VGPRs + spills: whole frame 1.83 -> 1.80 ms, 1/4 frame 0.49 -> 0.48
 #endif
+// One workgroup's footprint (4 tiles / SEG): `logical` = slab * tiles_x + bx, `rec` = its position in the launch order (timeline build).
 template <int VARIANT, int SEG>
-__global__ __launch_bounds__(256, VARIANT == 3 ? CSKY_COMPACT_WAVES : 7) void clouds_kernel(TexSet T, const FrameConsts* __restrict__ fcp, RenderGeom G, const uint32_t* __restrict__ order,
-                                                     uint2* __restrict__ out, unsigned long long* __restrict__ stats, uint32_t* __restrict__ wg_cost) {
+__device__ __forceinline__ void render_block(TexSet T, const FrameConsts* __restrict__ fcp, const RenderGeom& G, const uint32_t logical, const uint32_t rec,
+                                             uint2* __restrict__ out, unsigned long long* __restrict__ stats, uint32_t* __restrict__ wg_cost, const int tile_of_wave = -1) {
     constexpr int BW = 32 / SEG;                               // workgroup footprint width in pixels
     const int tiles_x = (G.tile_w + BW - 1) / BW;
     const int local_rows = G.n_bands * G.band_rows;
-    const uint32_t logical = order[blockIdx.x];
-    if (logical == 0xffffffffu) return;                        // workgroup-uniform
     const int slab = (int)logical / tiles_x, bx = (int)logical - slab * tiles_x;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const int tile = wave / SEG, seg = wave - tile * SEG;
+    const int tile = tile_of_wave >= 0 ? tile_of_wave : wave / SEG, seg = tile_of_wave >= 0 ? 0 : wave - tile * SEG;   // tile_of_wave: SEG == 1 only
     const int gx = bx * BW + tile * 8 + (lane & 7);
     const int lr = slab * 8 + (lane >> 3);
     const bool valid = gx < G.tile_w && lr < local_rows;
@@ -790,7 +789,7 @@ __global__ __launch_bounds__(256, VARIANT == 3 ? CSKY_COMPACT_WAVES : 7) void cl
         unsigned xcc, hwid;
         asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
         asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid));
-        unsigned long long* tl = stats + 2 + 4 * ((size_t)blockIdx.x * 4 + wave);
+        unsigned long long* tl = stats + 2 + 4 * ((size_t)rec * 4 + (tile_of_wave >= 0 ? tile : wave));
         tl[0] = tl0; tl[1] = wall_clock64(); tl[2] = ((unsigned long long)xcc << 32) | hwid; tl[3] = ((unsigned long long)logical << 32) | o.incloud;
     }
 #endif
@@ -804,6 +803,61 @@ __global__ __launch_bounds__(256, VARIANT == 3 ? CSKY_COMPACT_WAVES : 7) void cl
     }
 }
 
+template <int VARIANT, int SEG>
+__global__ __launch_bounds__(256, VARIANT == 3 ? CSKY_COMPACT_WAVES : 7) void clouds_kernel(TexSet T, const FrameConsts* __restrict__ fcp, RenderGeom G, const uint32_t* __restrict__ order,
+                                                     uint2* __restrict__ out, unsigned long long* __restrict__ stats, uint32_t* __restrict__ wg_cost) {
+    const uint32_t logical = order[blockIdx.x];
+    if (logical == 0xffffffffu) return;                        // workgroup-uniform
+    render_block<VARIANT, SEG>(T, fcp, G, logical, blockIdx.x, out, stats, wg_cost);
+}
+
+// Persistent form: the launch is only as large as the chip holds (CUs x resident workgroups) and every workgroup pulls footprints
+// from the launch order until it is empty.  The order is read as eight interleaved sequences (entry 8j + x belongs to XCD x, the
+// same assignment the hardware's round-robin gives a plain launch, so the per-XCD L2 locality of mode 5 is kept); a workgroup
+// pops from its own XCD's sequence (one returning device-scope atomic per footprint) and, when that is empty, from the others
+// in turn, so that XCDs that finish early take over work of the ones that run late.  heads[0..7] = the sequences' pop counters,
+// heads[8] = workgroups that have left; all nine are zero at launch and the kernel leaves them zero.
+// Used for whole-ray launches while two frames are in flight (api.cpp::clouds_dev has the policy and the numbers: 1.767 -> 1.743
+// ms per C3 frame, 0.936 -> 0.884 for a half frame).  The pop is per WORKGROUP on purpose: popping single tiles per wavefront
+// scatters the four tiles of a footprint over CUs and loses their shared L1 lines (2.12 -> 2.34 ms); the price is that the four
+// wavefronts wait for each other at every pop, which is why launches with nothing else in flight, ray-segment launches and
+// frames too large to have a tail stay plain (profiles/r02/persistent_launch_ab.txt).  The popped entry is made wave-uniform
+// with readfirstlane so that the loop stays scalar control flow.
+template <int VARIANT, int SEG>
+__global__ __launch_bounds__(256, VARIANT == 3 ? CSKY_COMPACT_WAVES : 7) void clouds_kernel_persistent(TexSet T, const FrameConsts* __restrict__ fcp, RenderGeom G,
+        const uint32_t* __restrict__ order, const uint32_t n_items, uint32_t* __restrict__ heads, uint2* __restrict__ out, unsigned long long* __restrict__ stats,
+        uint32_t* __restrict__ wg_cost) {
+    unsigned xcc;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+    xcc &= 7u;
+    const uint32_t per_xcd = (n_items + 7u) >> 3;
+    __shared__ uint32_t next_item[2];
+    for (;;) {
+        if (threadIdx.x == 0) {
+            uint32_t e = 0xfffffffeu, pos = 0;
+            for (unsigned k = 0; k < 8u; k++) {
+                const unsigned y = (xcc + k) & 7u;
+                const uint32_t j = atomicAdd(&heads[y], 1u);
+                const uint32_t i = 8u * j + y;
+                if (j < per_xcd && i < n_items) { e = order[i]; pos = i; break; }
+            }
+            next_item[0] = e; next_item[1] = pos;
+        }
+        __syncthreads();
+        const uint32_t logical = (uint32_t)__builtin_amdgcn_readfirstlane((int)next_item[0]), rec = (uint32_t)__builtin_amdgcn_readfirstlane((int)next_item[1]);
+        __syncthreads();                                   // everyone has read the slot before lane 0 of the next round rewrites it
+        if (logical == 0xfffffffeu) {
+            // the last workgroup to leave re-arms the heads for the next launch on this ring slot (nobody pops any more): no memset
+            // node in front of every launch (it cost 46 us on a busy chip)
+            if (threadIdx.x == 0 && atomicAdd(&heads[8], 1u) == gridDim.x - 1u) {
+                for (unsigned k = 0; k < 9u; k++) atomicExch(&heads[k], 0u);
+            }
+            return;
+        }
+        if (logical != 0xffffffffu) render_block<VARIANT, SEG>(T, fcp, G, logical, rec, out, stats, wg_cost);
+    }
+}
+
 // ---- launch-tail / share experiments of round 2 (measured, removed; evidence under profiles/r02/) -----------------------------
 // A whole-frame launch drains for the last ~27 % of its span with the chip 3/4 empty (time-integral of occupancy 72-76 %).  Three
 // ways of filling that tail were built and measured on MI355X, none made the frame faster, and the code was removed again:
@@ -811,7 +865,8 @@ __global__ __launch_bounds__(256, VARIANT == 3 ? CSKY_COMPACT_WAVES : 7) void cl
 //   * mixed-segment launch: the order's last 10-25 % as 2-/4-segment workgroups in the SAME launch: occupancy integral 72 -> 85-87 %,
 //     frame 2.06-2.28 vs 2.09 ms: segments add 17 % wave-time and the launch is VALU/L1-throughput bound     (timeline_static_vs_mixed_segment_tail.txt)
 //   * adaptive segments per workgroup from previous-frame costs, for one GPU's 1/4..1/16 share             0.446 vs 0.434 ms at 1/8 (share_matrix_adaptive_segments.txt)
-// What does fill the tail is the NEXT frame's workgroups (two frames in flight, api.cpp): 2.12 -> 1.80 ms per frame.
+// What does fill the tail is the NEXT frame's workgroups (two frames in flight, api.cpp): 2.12 -> 1.80 ms per frame, and with them
+// in flight the persistent form above (cross-XCD stealing at the end of a launch): 1.80 -> 1.75 (share_matrix) / 1.767 -> 1.743 (bench).
 
 // ---- cost-feedback schedule (api.cpp, schedule mode 7) -----------------------------------------------------------------
 // Workgroups differ 10x in cost (in-cloud samples per tile) and a C3 frame is only ~4 waves of resident workgroups deep, so
@@ -887,12 +942,20 @@ hipError_t launch_static_order(int mode, int tiles_x, int slabs, int grid, uint3
 }
 
 static const char* const kVariantNames[] = {"lockstep", "queue", "queue-lds", "compact"};
+int cloud_resident_workgroups_per_cu() { return CSKY_COMPACT_WAVES; }
 int cloud_variant_count() { return (int)(sizeof(kVariantNames) / sizeof(kVariantNames[0])); }
 const char* cloud_variant_name(int v) { return (v >= 0 && v < cloud_variant_count()) ? kVariantNames[v] : nullptr; }
 
 hipError_t launch_clouds(int variant, int seg, const TexSet& t, const FrameConsts* d_fc, const RenderGeom& g, const uint32_t* d_order, int grid,
-                         uint2* d_out, unsigned long long* d_stats, uint32_t* d_wg_cost, hipStream_t s) {
+                         uint2* d_out, unsigned long long* d_stats, uint32_t* d_wg_cost, hipStream_t s, uint32_t* d_heads, int resident) {
     if (grid <= 0) return hipSuccess;
+    if (d_heads && variant == 3 && (seg == 1 || seg == 2 || seg == 4)) {       // persistent form, see clouds_kernel_persistent
+        const int pg = grid < resident ? grid : resident;
+        if (seg == 1) clouds_kernel_persistent<3, 1><<<pg, 256, 0, s>>>(t, d_fc, g, d_order, (uint32_t)grid, d_heads, d_out, d_stats, d_wg_cost);
+        else if (seg == 2) clouds_kernel_persistent<3, 2><<<pg, 256, 0, s>>>(t, d_fc, g, d_order, (uint32_t)grid, d_heads, d_out, d_stats, d_wg_cost);
+        else clouds_kernel_persistent<3, 4><<<pg, 256, 0, s>>>(t, d_fc, g, d_order, (uint32_t)grid, d_heads, d_out, d_stats, d_wg_cost);
+        return hipGetLastError();
+    }
     if (variant == 0 && seg == 1) clouds_kernel<0, 1><<<grid, 256, 0, s>>>(t, d_fc, g, d_order, d_out, d_stats, d_wg_cost);
     else if (variant == 1 && seg == 1) clouds_kernel<1, 1><<<grid, 256, 0, s>>>(t, d_fc, g, d_order, d_out, d_stats, d_wg_cost);
     else if (variant == 1 && seg == 2) clouds_kernel<1, 2><<<grid, 256, 0, s>>>(t, d_fc, g, d_order, d_out, d_stats, d_wg_cost);

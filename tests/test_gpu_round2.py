@@ -246,3 +246,50 @@ def test_shell_sqrt_is_ieee_exact_on_its_whole_range(gpu_ctx):
     ref = np.sqrt(x)                                             # IEEE-754 correctly rounded
     bad = int((got.view(np.uint32) != ref.view(np.uint32)).sum())
     assert bad == 0, (bad, x.size)
+
+
+@pytest.mark.parametrize("size", [(2048, 1024), (520, 200), (96, 24)])
+def test_persistent_launch_form_matches_plain_launches(pkg, noise, gpu_ctx, oracle, size, monkeypatch):
+    """Whole-ray launches of 12 Ki - 64 Ki wavefronts with two frames in flight run in the persistent form
+    (kernels.hip::clouds_kernel_persistent: workgroups pop footprints from per-XCD sequences and steal from the other XCDs at the
+    end; the last workgroup out re-arms the pop counters).  CSKY_PERSISTENT=2 forces it for every whole-ray launch so that a ragged
+    frame and one smaller than the resident grid are covered too.  Same rays, same arithmetic: frames must be byte-identical to
+    plain launches, under the static and the cost-feedback order, with both ring slots in use and launch after launch."""
+    import torch
+    W, H = size
+    sun = (1, 1, 0)
+    p = oracle.default_params(W, H, sun)
+    gpu_ctx.set_march(128, 6); gpu_ctx.set_segments(1)
+    gpu_ctx.render_sky_lut(norm(sun), 200, 100)
+    ref = gpu_ctx.render_clouds(p).view(np.uint16).copy()                      # plain launch (one frame in flight)
+    ref_stats = gpu_ctx.cloud_stats()
+    gpu_ctx.set_segments(0)
+    assert ref.any()
+    monkeypatch.setenv("CSKY_PERSISTENT", "2")
+    ctx = pkg.Context(0)
+    try:
+        ctx.set_noise(*noise); ctx.set_march(128, 6); ctx.set_segments(1)
+        ctx.render_transmittance(256, 64)
+        ctx.render_sky_lut(norm(sun), 200, 100)
+        assert (ctx.render_clouds(p).view(np.uint16) == ref).all()             # persistent, one frame in flight
+        bands = (8, 0, 1, (H + 7) // 8)
+        streams = [torch.cuda.Stream() for _ in range(2)]
+        outs = [torch.zeros((bands[3] * 8, W, 4), dtype=torch.int16, device="cuda") for _ in range(2)]
+        ctx.set_frames_in_flight(2)
+        for sched in (5, 7, -1):
+            ctx.set_schedule(sched)
+            for k in range(6):                                                 # alternate the two streams / ring slots; mode 7 re-sorts from the 2nd launch of a slot
+                i = k & 1
+                outs[i].zero_()
+                torch.cuda.current_stream().synchronize()
+                ctx.render_sky_lut_device(norm(sun), 200, 100, streams[i].cuda_stream)
+                ctx.render_clouds_device(p, W, bands, outs[i].data_ptr(), W * 8, streams[i].cuda_stream)
+                if k >= 1:
+                    streams[i ^ 1].synchronize()
+                    got = outs[i ^ 1].cpu().numpy().view(np.uint16)[:H]
+                    assert (got == ref).all(), (size, sched, k, int((got != ref).sum()))
+            torch.cuda.synchronize()
+        ms, st = ctx.time_clouds(p, W, bands, warmup=1, iters=3)               # back-to-back launches on one ring slot: the counters re-arm
+        assert st["primary_samples"] == ref_stats["primary_samples"] and st["incloud_samples"] == ref_stats["incloud_samples"]
+    finally:
+        ctx.close()

@@ -1,28 +1,28 @@
 #!/bin/bash
 # Round-2 validation + evidence run (GPU box).  usage: bash tools/gpu_full_r02.sh   -> everything lands under gpurun_out/r02final/
 R=$PWD; O=$R/gpurun_out/r02final; mkdir -p $O
-timeout 600 python -m pytest tests -m gpu -q 2>&1 | tail -5 | tee $O/pytest_gpu.log
-timeout 200 python __graft_entry__.py smoke 2>&1 | tail -1 | tee $O/smoke.log
-timeout 300 python bench.py > $O/bench_C3_n1.json 2> $O/bench_C3_n1.err
+timeout -s KILL 300 python -m pytest tests -m gpu -q 2>&1 | tail -5 | tee $O/pytest_gpu.log
+timeout -s KILL 200 python __graft_entry__.py smoke 2>&1 | tail -1 | tee $O/smoke.log
+timeout -s KILL 300 python bench.py > $O/bench_C3_n1.json 2> $O/bench_C3_n1.err
 cp gpurun_out/bench_pmc_C3.json $O/clouds_C3_pmc_live_from_bench.json 2>/dev/null
-timeout 300 python bench.py --frames-in-flight 1 --no-cpu-baseline --no-pmc > $O/bench_C3_n1_one_frame_at_a_time.json 2>/dev/null
-(cd /tmp && export TMPDIR=/tmp && timeout 300 rocprofv3 --kernel-trace --stats -f csv -d $O/bench_trace -o b -- python $R/bench.py --no-cpu-baseline --no-pmc > $O/bench_trace.log 2>&1)
-(cd /tmp && export TMPDIR=/tmp && timeout 300 rocprofv3 --kernel-trace --stats -f csv -d $O/bench_trace_fif1 -o b -- python $R/bench.py --no-cpu-baseline --no-pmc --frames-in-flight 1 > $O/bench_trace_fif1.log 2>&1)
+timeout -s KILL 300 python bench.py --frames-in-flight 1 --no-cpu-baseline --no-pmc > $O/bench_C3_n1_one_frame_at_a_time.json 2>/dev/null
+(cd /tmp && export TMPDIR=/tmp && timeout -s KILL 300 rocprofv3 --kernel-trace --stats -f csv -d $O/bench_trace -o b -- python $R/bench.py --no-cpu-baseline --no-pmc > $O/bench_trace.log 2>&1)
+(cd /tmp && export TMPDIR=/tmp && timeout -s KILL 300 rocprofv3 --kernel-trace --stats -f csv -d $O/bench_trace_fif1 -o b -- python $R/bench.py --no-cpu-baseline --no-pmc --frames-in-flight 1 > $O/bench_trace_fif1.log 2>&1)
 cp $O/bench_trace/b_kernel_stats.csv $O/bench_py_C3_n1_kernel_stats.csv 2>/dev/null
 cp $O/bench_trace_fif1/b_kernel_stats.csv $O/bench_py_C3_n1_one_frame_at_a_time_kernel_stats.csv 2>/dev/null
 {
-for C in C2 C5frame C5; do echo "== bench $C"; timeout 300 python bench.py --config $C --no-cpu-baseline 2>/dev/null; done
-echo "== bench C3 --also-early-out"; timeout 300 python bench.py --also-early-out --no-cpu-baseline --no-pmc 2>/dev/null
-echo "== tiny_launch"; timeout 120 python tools/tiny_launch.py 2>/dev/null
-echo "== variants"; timeout 120 python tools/prof_kernel.py --time --frames 20 2>/dev/null
-echo "== lut_time"; timeout 120 python tools/lut_time.py 2>/dev/null
-echo "== frame_overhead"; timeout 120 python tools/frame_overhead.py 2>/dev/null
+for C in C2 C5frame C5; do echo "== bench $C"; timeout -s KILL 300 python bench.py --config $C --no-cpu-baseline 2>/dev/null; done
+echo "== bench C3 --also-early-out"; timeout -s KILL 300 python bench.py --also-early-out --no-cpu-baseline --no-pmc 2>/dev/null
+echo "== tiny_launch"; timeout -s KILL 120 python tools/tiny_launch.py 2>/dev/null
+echo "== variants"; timeout -s KILL 120 python tools/prof_kernel.py --time --frames 20 2>/dev/null
+echo "== lut_time"; timeout -s KILL 120 python tools/lut_time.py 2>/dev/null
+echo "== frame_overhead"; timeout -s KILL 120 python tools/frame_overhead.py 2>/dev/null
 } > $O/secondary_numbers.log
 make -C godot-volumetric-cloud-demo-v2_amd/csrc timeline -s > /dev/null 2>&1
 ( echo "== whole frame, static XCD-row schedule (mode 5)"; CSKY_LIBRARY=$R/godot-volumetric-cloud-demo-v2_amd/libcloudsky_timeline.so python tools/timeline.py 1 5
   echo "== one rank's 1/8 of the frame (automatic policy)"; CSKY_LIBRARY=$R/godot-volumetric-cloud-demo-v2_amd/libcloudsky_timeline.so python tools/timeline.py 8 -1 ) 2>&1 | grep -v amdgpu.ids > $O/occupancy_timeline.txt
 rm -f godot-volumetric-cloud-demo-v2_amd/libcloudsky_timeline.so
-python tools/share_matrix.py 2 4 8 2>/dev/null > $O/share_matrix.txt
-python tools/two_streams.py -1 2>/dev/null > $O/two_streams.txt
+timeout -s KILL 200 python tools/share_matrix.py 1 2 4 8 2>/dev/null > $O/share_matrix.txt
+timeout -s KILL 120 python tools/two_streams.py -1 2>/dev/null > $O/two_streams.txt
 rm -rf $O/bench_trace $O/bench_trace_fif1
 ls -la $O
