@@ -66,7 +66,7 @@ struct csky_ctx {
     long long order_key_ring[2][4] = {{-1, -1, -1, -1}, {-1, -1, -1, -1}};
     // cost-feedback schedule (mode 7): per-workgroup costs of the last launch -> heaviest-first order of the next one
     uint32_t* d_wg_cost = nullptr; uint32_t* d_lpt_order = nullptr; uint32_t* d_lpt_hist = nullptr; size_t lpt_cap = 0;
-    uint32_t* d_heads = nullptr; int persistent = 1; int resident_wgs = 0;   // persistent launches: 2 ring slots x (8 per-XCD queue heads + exit counter)
+    uint32_t* d_heads = nullptr; int persistent = 1; int resident_wgs = 0;   // persistent launches: 2 ring slots x (8 per-XCD pop counters + exit counter)
     bool lpt_valid[2] = {false, false}; long long lpt_key[2][11] = {{-1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1}, {-1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1}};
     // optional per-launch timing of the cloud kernel (csky_set_kernel_timing): HIP event pairs recorded around the launch on ITS stream
     bool kt_on = false; std::vector<hipEvent_t> kt_ev; int kt_count = 0;   // the event pool grows on demand (clouds_dev)
@@ -230,15 +230,14 @@ int clouds_dev(csky_ctx* c, const csky_cloud_params* p, int tile_w, const csky_b
     if (mode == 7 && !feedback) mode = waves >= 12288 ? 5 : 2;
     const int static_mode = mode == 7 ? (waves >= 12288 ? 5 : 2) : mode;   // order of the first launch of a geometry under feedback
     const int slot = c->fc_cur;
-    // Persistent launch form (kernels.hip::clouds_kernel_persistent): as many workgroups as the chip holds, each popping footprints
-    // from per-XCD sequences of the launch order and, at the end, from the other XCDs' sequences.  Measured (tools/persistent_ab.sh,
-    // profiles/r02/persistent_launch_ab.txt), ms per frame plain -> persistent: whole frame, two frames in flight 1.767 -> 1.743
-    // (bench.py, three alternating pairs) / 1.807 -> 1.745 (share_matrix.py), 1/2 frame 0.936 -> 0.884; one frame at a time
-    // 2.10 -> 2.18 (the four wavefronts of a workgroup wait for each other before the next pop and nothing else fills their
-    // slots), 4096x2048 6.14 -> 6.20 (no tail to fill), ray segments 0.33 -> 0.40 (segments of a ray cost very different
-    // amounts), 1/4 frame as whole rays 0.477 -> 0.516 (barely deeper than the resident grid).  So: whole-ray launches of 12 Ki to
-    // 64 Ki wavefronts while the caller keeps two frames in flight.
-    const bool persist = c->persistent == 3 || (seg == 1 && c->variant == 3 && (c->persistent == 2 || (c->persistent == 1 && c->frames_in_flight >= 2 && waves >= 12288 && waves <= 65536)));
+    // Persistent launch form (kernels.hip::clouds_kernel_persistent): as many workgroups as the chip holds, their wavefronts pop
+    // footprints from per-XCD sequences of the launch order and, at the end, from the other XCDs' sequences.  Measured
+    // (tools/persistent_ab.sh, profiles/r02/persistent_launch_ab.txt), ms per frame plain -> persistent: whole frame with two frames
+    // in flight 1.806 -> 1.724 (bench.py, alternating runs), 1/2 frame 0.938 -> 0.882; one frame at a time 2.12 -> 2.17 (plain
+    // launches refill freed slots at least as well when nothing else is in flight), 1/4 frame 0.477 -> 0.539 (barely deeper than
+    // the resident grid), 4096x2048 6.13 -> 6.19 (no tail to fill), cost-feedback order 1.90 -> 2.09.  So: whole-ray launches of
+    // 12 Ki to 64 Ki wavefronts (they run in the static XCD-row order) while the caller keeps two frames in flight.
+    const bool persist = seg == 1 && c->variant == 3 && (c->persistent == 2 || (c->persistent == 1 && !feedback && c->frames_in_flight >= 2 && waves >= 12288 && waves <= 65536));
     uint32_t* const heads = persist ? c->d_heads + slot * 16 : nullptr;
     const int resident = c->resident_wgs;
     hipEvent_t* kt = nullptr;                                    // timing pair of this launch (csky_set_kernel_timing)
@@ -342,7 +341,7 @@ int csky_create(csky_ctx** out, int device_id) {
     if ((e = hipMalloc(reinterpret_cast<void**>(&c->d_heads), 32 * sizeof(uint32_t))) != hipSuccess) return bail("hipMalloc", e);
     if ((e = hipMemset(c->d_heads, 0, 32 * sizeof(uint32_t))) != hipSuccess) return bail("hipMemset", e);   // persistent launches leave them zero
     { int cus = 0; (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device_id); c->resident_wgs = (cus > 0 ? cus : 256) * cloud_resident_workgroups_per_cu(); }
-    // A/B switches of tools/persistent_ab.sh: 0 = never, 1 = the policy of clouds_dev (default), 2 = every whole-ray launch, 3 = every launch
+    // A/B switch of tools/persistent_ab.sh: 0 = never, 1 = the policy of clouds_dev (default), 2 = every whole-ray launch
     if (const char* pe = getenv("CSKY_PERSISTENT")) c->persistent = atoi(pe);
     if (const char* pe = getenv("CSKY_PERSISTENT_WGS")) { const int n = atoi(pe); if (n > 0) c->resident_wgs = n; }
     *out = c;

@@ -811,19 +811,24 @@ __global__ __launch_bounds__(256, VARIANT == 3 ? CSKY_COMPACT_WAVES : 7) void cl
     render_block<VARIANT, SEG>(T, fcp, G, logical, blockIdx.x, out, stats, wg_cost);
 }
 
-// Persistent form: the launch is only as large as the chip holds (CUs x resident workgroups) and every workgroup pulls footprints
-// from the launch order until it is empty.  The order is read as eight interleaved sequences (entry 8j + x belongs to XCD x, the
-// same assignment the hardware's round-robin gives a plain launch, so the per-XCD L2 locality of mode 5 is kept); a workgroup
-// pops from its own XCD's sequence (one returning device-scope atomic per footprint) and, when that is empty, from the others
-// in turn, so that XCDs that finish early take over work of the ones that run late.  heads[0..7] = the sequences' pop counters,
-// heads[8] = workgroups that have left; all nine are zero at launch and the kernel leaves them zero.
-// Used for whole-ray launches while two frames are in flight (api.cpp::clouds_dev has the policy and the numbers: 1.767 -> 1.743
-// ms per C3 frame, 0.936 -> 0.884 for a half frame).  The pop is per WORKGROUP on purpose: popping single tiles per wavefront
-// scatters the four tiles of a footprint over CUs and loses their shared L1 lines (2.12 -> 2.34 ms); the price is that the four
-// wavefronts wait for each other at every pop, which is why launches with nothing else in flight, ray-segment launches and
-// frames too large to have a tail stay plain (profiles/r02/persistent_launch_ab.txt).  The popped entry is made wave-uniform
-// with readfirstlane so that the loop stays scalar control flow.
-template <int VARIANT, int SEG>
+// Persistent form of the whole-ray kernel: the launch is only as large as the chip holds (CUs x resident workgroups) and its
+// wavefronts pull work from the launch order until it is empty.  The order is read as eight interleaved sequences (entry 8j + x
+// belongs to XCD x, the same assignment the hardware's round-robin gives a plain launch, so the per-XCD L2 locality of mode 5 is
+// kept); a footprint is popped from the workgroup's own XCD's sequence (one returning device-scope atomic) and, when that is
+// empty, from the others in turn, so that XCDs that finish early take over work of the ones that run late.
+//   * The four wavefronts of a workgroup never meet at a barrier: each draws a workgroup-local ticket t from LDS = tile t & 3 of
+//     the workgroup's footprint number t >> 2.  The drawer of tile 0 pops that footprint and publishes it in one of two LDS slots;
+//     the others wait for the publication (a global atomic's latency at most).  A slot is rewritten only after the three readers
+//     of its previous footprint are through (slot_reads).  So a workgroup's wavefronts stay on neighbouring tiles (shared L1
+//     lines) without waiting for each other.  Measured alternatives: one pop per workgroup behind a barrier 1.757 ms per C3
+//     frame (tickets: 1.724; plain launches 1.806); popping single tiles globally per wavefront scatters a footprint over CUs
+//     (2.12 -> 2.34 ms).  Everything that steers the loop is made wave-uniform with readfirstlane: with per-lane values the
+//     structurizer wrapped the body in a lane loop that re-entered with ticket 0.
+//   * heads[0..7] = the sequences' pop counters, heads[8] = wavefronts that have left; all nine are zero at launch and the last
+//     wavefront out zeroes them again (a memset node in front of every launch cost 46 us on a busy chip).
+// Used for launches of 12 Ki - 64 Ki wavefronts while two frames are in flight (api.cpp::clouds_dev has the policy and the
+// numbers; profiles/r02/persistent_launch_ab.txt).
+template <int VARIANT>
 __global__ __launch_bounds__(256, VARIANT == 3 ? CSKY_COMPACT_WAVES : 7) void clouds_kernel_persistent(TexSet T, const FrameConsts* __restrict__ fcp, RenderGeom G,
         const uint32_t* __restrict__ order, const uint32_t n_items, uint32_t* __restrict__ heads, uint2* __restrict__ out, unsigned long long* __restrict__ stats,
         uint32_t* __restrict__ wg_cost) {
@@ -831,30 +836,52 @@ __global__ __launch_bounds__(256, VARIANT == 3 ? CSKY_COMPACT_WAVES : 7) void cl
     asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
     xcc &= 7u;
     const uint32_t per_xcd = (n_items + 7u) >> 3;
-    __shared__ uint32_t next_item[2];
+    __shared__ uint32_t ticket, slot_ready[2], slot_reads[2], slot_entry[2], slot_rec[2];
+    if (threadIdx.x == 0) { ticket = 0; slot_ready[0] = slot_ready[1] = 0; slot_reads[0] = slot_reads[1] = 0; }
+    __syncthreads();
+    const bool lane0 = (threadIdx.x & 63) == 0;
     for (;;) {
-        if (threadIdx.x == 0) {
-            uint32_t e = 0xfffffffeu, pos = 0;
+        uint32_t tv = 0;
+        if (lane0) tv = __hip_atomic_fetch_add(&ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        const uint32_t t = (uint32_t)__builtin_amdgcn_readfirstlane((int)tv);
+        const uint32_t f = t >> 2, sl = f & 1u;
+        const int tile = (int)(t & 3u);
+        uint32_t logical = 0xfffffffeu, rec = 0;               // 0xfffffffe: every sequence is empty
+        if (tile == 0) {
             for (unsigned k = 0; k < 8u; k++) {
                 const unsigned y = (xcc + k) & 7u;
-                const uint32_t j = atomicAdd(&heads[y], 1u);
+                uint32_t jv = 0;
+                if (lane0) jv = atomicAdd(&heads[y], 1u);
+                const uint32_t j = (uint32_t)__builtin_amdgcn_readfirstlane((int)jv);
                 const uint32_t i = 8u * j + y;
-                if (j < per_xcd && i < n_items) { e = order[i]; pos = i; break; }
+                if (j < per_xcd && i < n_items) { logical = order[i]; rec = i; break; }
             }
-            next_item[0] = e; next_item[1] = pos;
+            for (;;) {                                         // the slot's previous footprint (f - 2) had three readers
+                const uint32_t r = (uint32_t)__builtin_amdgcn_readfirstlane((int)__hip_atomic_load(&slot_reads[sl], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP));
+                if (r == 3u * (f >> 1)) break;
+                __builtin_amdgcn_s_sleep(1);
+            }
+            if (lane0) {
+                slot_entry[sl] = logical; slot_rec[sl] = rec;
+                __hip_atomic_store(&slot_ready[sl], f + 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+            }
+        } else {
+            for (;;) {
+                const uint32_t r = (uint32_t)__builtin_amdgcn_readfirstlane((int)__hip_atomic_load(&slot_ready[sl], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP));
+                if (r == f + 1u) break;
+                __builtin_amdgcn_s_sleep(1);
+            }
+            logical = (uint32_t)__builtin_amdgcn_readfirstlane((int)slot_entry[sl]);
+            rec = (uint32_t)__builtin_amdgcn_readfirstlane((int)slot_rec[sl]);
+            if (lane0) __hip_atomic_fetch_add(&slot_reads[sl], 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
         }
-        __syncthreads();
-        const uint32_t logical = (uint32_t)__builtin_amdgcn_readfirstlane((int)next_item[0]), rec = (uint32_t)__builtin_amdgcn_readfirstlane((int)next_item[1]);
-        __syncthreads();                                   // everyone has read the slot before lane 0 of the next round rewrites it
         if (logical == 0xfffffffeu) {
-            // the last workgroup to leave re-arms the heads for the next launch on this ring slot (nobody pops any more): no memset
-            // node in front of every launch (it cost 46 us on a busy chip)
-            if (threadIdx.x == 0 && atomicAdd(&heads[8], 1u) == gridDim.x - 1u) {
+            if (lane0 && atomicAdd(&heads[8], 1u) == gridDim.x * 4u - 1u) {
                 for (unsigned k = 0; k < 9u; k++) atomicExch(&heads[k], 0u);
             }
             return;
         }
-        if (logical != 0xffffffffu) render_block<VARIANT, SEG>(T, fcp, G, logical, rec, out, stats, wg_cost);
+        if (logical != 0xffffffffu) render_block<VARIANT, 1>(T, fcp, G, logical, rec, out, stats, wg_cost, tile);
     }
 }
 
@@ -866,7 +893,7 @@ __global__ __launch_bounds__(256, VARIANT == 3 ? CSKY_COMPACT_WAVES : 7) void cl
 //     frame 2.06-2.28 vs 2.09 ms: segments add 17 % wave-time and the launch is VALU/L1-throughput bound     (timeline_static_vs_mixed_segment_tail.txt)
 //   * adaptive segments per workgroup from previous-frame costs, for one GPU's 1/4..1/16 share             0.446 vs 0.434 ms at 1/8 (share_matrix_adaptive_segments.txt)
 // What does fill the tail is the NEXT frame's workgroups (two frames in flight, api.cpp): 2.12 -> 1.80 ms per frame, and with them
-// in flight the persistent form above (cross-XCD stealing at the end of a launch): 1.80 -> 1.75 (share_matrix) / 1.767 -> 1.743 (bench).
+// in flight the persistent form above (cross-XCD stealing at the end of a launch): 1.81 -> 1.72 ms per frame.
 
 // ---- cost-feedback schedule (api.cpp, schedule mode 7) -----------------------------------------------------------------
 // Workgroups differ 10x in cost (in-cloud samples per tile) and a C3 frame is only ~4 waves of resident workgroups deep, so
@@ -949,11 +976,8 @@ const char* cloud_variant_name(int v) { return (v >= 0 && v < cloud_variant_coun
 hipError_t launch_clouds(int variant, int seg, const TexSet& t, const FrameConsts* d_fc, const RenderGeom& g, const uint32_t* d_order, int grid,
                          uint2* d_out, unsigned long long* d_stats, uint32_t* d_wg_cost, hipStream_t s, uint32_t* d_heads, int resident) {
     if (grid <= 0) return hipSuccess;
-    if (d_heads && variant == 3 && (seg == 1 || seg == 2 || seg == 4)) {       // persistent form, see clouds_kernel_persistent
-        const int pg = grid < resident ? grid : resident;
-        if (seg == 1) clouds_kernel_persistent<3, 1><<<pg, 256, 0, s>>>(t, d_fc, g, d_order, (uint32_t)grid, d_heads, d_out, d_stats, d_wg_cost);
-        else if (seg == 2) clouds_kernel_persistent<3, 2><<<pg, 256, 0, s>>>(t, d_fc, g, d_order, (uint32_t)grid, d_heads, d_out, d_stats, d_wg_cost);
-        else clouds_kernel_persistent<3, 4><<<pg, 256, 0, s>>>(t, d_fc, g, d_order, (uint32_t)grid, d_heads, d_out, d_stats, d_wg_cost);
+    if (d_heads && variant == 3 && seg == 1) {                 // persistent form, see clouds_kernel_persistent
+        clouds_kernel_persistent<3><<<grid < resident ? grid : resident, 256, 0, s>>>(t, d_fc, g, d_order, (uint32_t)grid, d_heads, d_out, d_stats, d_wg_cost);
         return hipGetLastError();
     }
     if (variant == 0 && seg == 1) clouds_kernel<0, 1><<<grid, 256, 0, s>>>(t, d_fc, g, d_order, d_out, d_stats, d_wg_cost);
