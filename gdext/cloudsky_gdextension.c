@@ -8,7 +8,7 @@
  * transmittance_lut.gd:44):
  *
  *   create(device_id: int) -> int                                   cloud_sky.gd:355-408 `_initialize_compute_code`
- *   set_noise(large, small, weather: PackedByteArray) -> int        cloud_sky.gd:298-341 `_create_noise_uniform_set`
+ *   set_noise(large, small, weather: PackedByteArray) -> int        cloud_sky.gd:298-341 `_create_noise_uniform_set` (level 0, or every mip level back to back)
  *   set_march(primary_steps, light_steps: int) -> int               clouds.glsl:228 / :186 (literals in the reference)
  *   render_transmittance(pc: PackedFloat32Array) -> PackedByteArray transmittance_lut.gd:66-77   (pc = its 4-float push constant)
  *   render_sky_lut(pc: PackedFloat32Array) -> PackedByteArray       sky_lut.gd:122-148           (pc = its 8-float push constant)
@@ -124,9 +124,15 @@ static void m_set_noise(void *ud, GDExtensionClassInstancePtr inst, const GDExte
     CloudSkyHIP *self = (CloudSkyHIP *)inst; (void)ud;
     int rc;
     if (!self->ctx) rc = fail(self, CSKY_ERR_STATE, "CloudSkyHIP: create() has not been called");
-    else if (packed_size(G.pba_size, a[0]) != 128 * 128 * 128 * 4 || packed_size(G.pba_size, a[1]) != 32 * 32 * 32 * 3 || packed_size(G.pba_size, a[2]) != 512 * 512 * 3)
-        rc = fail(self, CSKY_ERR_INVALID, "set_noise: expected 128^3 RGBA8, 32^3 RGB8 and 512^2 RGB8 byte arrays (level 0 only)");
-    else rc = pass(self, csky_set_noise(self->ctx, G.pba_index_const(a[0], 0), G.pba_index_const(a[1], 0), G.pba_index_const(a[2], 0)));
+    else if (packed_size(G.pba_size, a[2]) != 512 * 512 * 3)
+        rc = fail(self, CSKY_ERR_INVALID, "set_noise: the weather map must be 512^2 RGB8");
+    else if (packed_size(G.pba_size, a[0]) == 128 * 128 * 128 * 4 && packed_size(G.pba_size, a[1]) == 32 * 32 * 32 * 3)
+        rc = pass(self, csky_set_noise(self->ctx, G.pba_index_const(a[0], 0), G.pba_index_const(a[1], 0), G.pba_index_const(a[2], 0)));
+    /* all mip levels back to back (what Texture3D.get_data() holds after Image.decompress()): the importer's own chains are bound as they are */
+    else if ((size_t)packed_size(G.pba_size, a[0]) == csky_mip_offset(128, 8, 4) && (size_t)packed_size(G.pba_size, a[1]) == csky_mip_offset(32, 6, 3))
+        rc = pass(self, csky_set_noise_mips(self->ctx, G.pba_index_const(a[0], 0), G.pba_index_const(a[1], 0), G.pba_index_const(a[2], 0)));
+    else
+        rc = fail(self, CSKY_ERR_INVALID, "set_noise: expected 128^3 RGBA8 and 32^3 RGB8 byte arrays, level 0 only or all mip levels back to back");
     *(GDExtensionInt *)r = rc;
 }
 static void m_set_march(void *ud, GDExtensionClassInstancePtr inst, const GDExtensionConstTypePtr *a, GDExtensionTypePtr r) {

@@ -50,6 +50,7 @@ SYMBOLS = [
     ("csky_destroy", None, [C.c_void_p]),
     ("csky_last_error", C.c_char_p, [C.c_void_p]),
     ("csky_set_noise", C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    ("csky_set_noise_mips", C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     ("csky_noise_inexact_coeffs", C.c_int, [C.c_void_p, C.POINTER(C.c_uint64)]),
     ("csky_set_march", C.c_int, [C.c_void_p, C.c_int, C.c_int]),
     ("csky_set_early_out", C.c_int, [C.c_void_p, C.c_float]),
@@ -97,6 +98,9 @@ SYMBOLS = [
     ("csky_test_sqrt_shell", C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t]),
     ("csky_mip_offset", C.c_size_t, [C.c_int, C.c_int, C.c_int]),
     ("csky_build_mips", C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int]),
+    ("csky_decode_bc7", C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
+    ("csky_load_ctex", C.c_int, [C.c_char_p, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int), C.c_void_p, C.c_size_t]),
+    ("csky_load_ctex3d", C.c_int, [C.c_char_p, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int), C.c_void_p, C.c_size_t]),
     ("csky_assets_last_error", C.c_char_p, []),
 ]
 
@@ -188,6 +192,20 @@ class Context:
         if n:   # never silent.  The taps stay within the parity tolerance (test_white_noise_textures) but are no longer exact
             import warnings
             warnings.warn((self._L.csky_last_error(self._h) or b"").decode() or "csky_set_noise: %d inexact fp16 coefficients" % n, RuntimeWarning)
+
+    def set_noise_mips(self, large_chain_rgba8, small_chain_rgb8, weather_rgb8):
+        """csky_set_noise_mips: full mip chains supplied by the caller (all levels back to back), e.g. the importer's own from
+        assets.load_ctex3d; no box filter is applied by the library."""
+        a = np.ascontiguousarray(large_chain_rgba8, np.uint8)
+        b = np.ascontiguousarray(small_chain_rgb8, np.uint8)
+        c = np.ascontiguousarray(weather_rgb8, np.uint8)
+        if a.size != self._L.csky_mip_offset(128, 8, 4) or b.size != self._L.csky_mip_offset(32, 6, 3) or c.size != 512 * 512 * 3:
+            raise ValueError("set_noise_mips: expected the 8-level 128^3 RGBA8 chain, the 6-level 32^3 RGB8 chain, 512^2 RGB8")
+        self._chk(self._L.csky_set_noise_mips(self._h, _ptr(a), _ptr(b), _ptr(c)))
+        n = self.noise_inexact_coeffs()
+        if n:
+            import warnings
+            warnings.warn((self._L.csky_last_error(self._h) or b"").decode() or "csky_set_noise_mips: %d inexact fp16 coefficients" % n, RuntimeWarning)
 
     def noise_inexact_coeffs(self):
         """Finite-difference coefficients of the bound textures that fp16 could not hold exactly (0 for natural noise)."""

@@ -80,6 +80,57 @@ def build_mips(level0, levels):
     return buf
 
 
+def decode_bc7(blocks, w, h):
+    """BC7 / BPTC RGBA UNORM blocks (16 bytes per 4x4 pixels, row-major) -> [h, w, 4] uint8 (csky_decode_bc7)."""
+    blocks = np.ascontiguousarray(np.frombuffer(blocks, np.uint8) if isinstance(blocks, (bytes, bytearray)) else blocks, np.uint8)
+    need = ((w + 3) // 4) * ((h + 3) // 4) * 16
+    if blocks.size < need:
+        raise ValueError("decode_bc7: %d bytes of blocks, %d needed for %dx%d" % (blocks.size, need, w, h))
+    out = np.zeros((h, w, 4), np.uint8)
+    _chk(_lib.lib().csky_decode_bc7(blocks.ctypes.data_as(C.c_void_p), w, h, out.ctypes.data_as(C.c_void_p)))
+    return out
+
+
+def load_ctex(path):
+    """Godot CompressedTexture2D (.ctex, e.g. .godot/imported/weather.bmp-<md5>.bptc.ctex) -> list of [h, w, 4] uint8 levels."""
+    L = _lib.lib()
+    w, h, n = C.c_int(), C.c_int(), C.c_int()
+    _chk(L.csky_load_ctex(path.encode(), C.byref(w), C.byref(h), C.byref(n), None, 0))
+    dims = [(max(1, h.value >> l), max(1, w.value >> l)) for l in range(n.value)]
+    buf = np.zeros(sum(a * b * 4 for a, b in dims), np.uint8)
+    _chk(L.csky_load_ctex(path.encode(), C.byref(w), C.byref(h), C.byref(n), buf.ctypes.data_as(C.c_void_p), buf.nbytes))
+    out, o = [], 0
+    for a, b in dims:
+        out.append(buf[o:o + a * b * 4].reshape(a, b, 4)); o += a * b * 4
+    return out
+
+
+def load_ctex3d(path):
+    """Godot CompressedTexture3D (.ctex3d) -> list of [d, h, w, 4] uint8 levels (level 0 first, then the importer's own mips)."""
+    L = _lib.lib()
+    w, h, d, n = C.c_int(), C.c_int(), C.c_int(), C.c_int()
+    _chk(L.csky_load_ctex3d(path.encode(), C.byref(w), C.byref(h), C.byref(d), C.byref(n), None, 0))
+    dims = [(max(1, d.value >> l), max(1, h.value >> l), max(1, w.value >> l)) for l in range(n.value)]
+    buf = np.zeros(sum(a * b * c * 4 for a, b, c in dims), np.uint8)
+    _chk(L.csky_load_ctex3d(path.encode(), C.byref(w), C.byref(h), C.byref(d), C.byref(n), buf.ctypes.data_as(C.c_void_p), buf.nbytes))
+    out, o = [], 0
+    for a, b, c in dims:
+        out.append(buf[o:o + a * b * c * 4].reshape(a, b, c, 4)); o += a * b * c * 4
+    return out
+
+
+def chains_from_godot_import(large_ctex3d, small_ctex3d, weather_ctex):
+    """The three imported files of a Godot project (.godot/imported/perlworlnoise.tga-*.bptc.ctex3d, worlnoise.bmp-*.bptc.ctex3d,
+    weather.bmp-*.bptc.ctex) -> (large chain RGBA8, small chain RGB8, weather RGB8) for Context.set_noise_mips: the texels the
+    reference's samplers see (decoded BC7 blocks, the importer's mip chains)."""
+    large = load_ctex3d(large_ctex3d)
+    small = load_ctex3d(small_ctex3d)
+    weather = load_ctex(weather_ctex)[0]
+    if large[0].shape[:3] != (128, 128, 128) or len(large) != 8 or small[0].shape[:3] != (32, 32, 32) or len(small) != 6 or weather.shape[:2] != (512, 512):
+        raise ValueError("unexpected sizes: large %s x%d, small %s x%d, weather %s" % (large[0].shape, len(large), small[0].shape, len(small), weather.shape))
+    return (np.concatenate([l.reshape(-1) for l in large]), np.concatenate([l[..., :3].reshape(-1) for l in small]), np.ascontiguousarray(weather[..., :3]))
+
+
 _CACHE = {}
 
 

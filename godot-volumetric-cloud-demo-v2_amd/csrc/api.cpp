@@ -363,7 +363,7 @@ void csky_destroy(csky_ctx* c) {
     delete c;
 }
 
-int csky_set_noise(csky_ctx* c, const uint8_t* large_rgba8, const uint8_t* small_rgb8, const uint8_t* weather_rgb8) {
+static int set_noise_impl(csky_ctx* c, const uint8_t* large_rgba8, const uint8_t* small_rgb8, const uint8_t* weather_rgb8, bool chains_given) {
     if (!c) return fail(nullptr, CSKY_ERR_INVALID, "csky_set_noise: ctx is NULL");
     if (!large_rgba8 || !small_rgb8 || !weather_rgb8) return fail(c, CSKY_ERR_INVALID, "csky_set_noise: NULL texture pointer");
     int rc; if ((rc = bind(c))) return rc;
@@ -389,11 +389,13 @@ int csky_set_noise(csky_ctx* c, const uint8_t* large_rgba8, const uint8_t* small
     struct { unsigned long long inexact; int range[3]; int pad; } meta = {0ull, {255, 0, 0}, 0};
     hipStream_t s = c->stream;
     HIPCHK(c, hipMemcpyAsync(c->d_bake_meta, &meta, sizeof meta, hipMemcpyHostToDevice, s));
-    HIPCHK(c, hipMemcpyAsync(c->d_raw_large, large_rgba8, large_l0, hipMemcpyHostToDevice, s));
-    HIPCHK(c, hipMemcpyAsync(c->d_raw_small, small_rgb8, small_l0, hipMemcpyHostToDevice, s));
+    HIPCHK(c, hipMemcpyAsync(c->d_raw_large, large_rgba8, chains_given ? large_chain : large_l0, hipMemcpyHostToDevice, s));
+    HIPCHK(c, hipMemcpyAsync(c->d_raw_small, small_rgb8, chains_given ? small_chain : small_l0, hipMemcpyHostToDevice, s));
     HIPCHK(c, hipMemcpyAsync(c->d_raw_weather, weather_rgb8, weather_b, hipMemcpyHostToDevice, s));
-    HIPCHK(c, launch_mip_chain(c->d_raw_large, SHAPE_N, 4, SHAPE_LEVELS, s));
-    HIPCHK(c, launch_mip_chain(c->d_raw_small, DETAIL_N, 3, DETAIL_LEVELS, s));
+    if (!chains_given) {                                      // csky_set_noise_mips: the caller's chains (e.g. the importer's own, csky_load_ctex3d) are used as they are
+        HIPCHK(c, launch_mip_chain(c->d_raw_large, SHAPE_N, 4, SHAPE_LEVELS, s));
+        HIPCHK(c, launch_mip_chain(c->d_raw_small, DETAIL_N, 3, DETAIL_LEVELS, s));
+    }
     HIPCHK(c, launch_bake(c->d_raw_large, c->d_raw_small, c->d_raw_weather, c->d_shape, c->d_detail, c->d_detail_h, c->d_weather,
                           reinterpret_cast<unsigned long long*>(c->d_bake_meta), reinterpret_cast<int*>(c->d_bake_meta + 8), s));
     uint8_t t5[3] = {0, 0, 0};                                // detail LOD 5 is one texel: every tap at that level returns it (cloud_core.h::detail_tap)
@@ -409,6 +411,13 @@ int csky_set_noise(csky_ctx* c, const uint8_t* large_rgba8, const uint8_t* small
         snprintf(c->err, sizeof c->err, "csky_set_noise: warning: %llu finite-difference coefficients of these textures are not exact in fp16 "
                  "(|coefficient| > 2048); taps through them carry a relative 2^-11 error", c->inexact_coeffs);
     return CSKY_OK;
+}
+
+int csky_set_noise(csky_ctx* c, const uint8_t* large_rgba8, const uint8_t* small_rgb8, const uint8_t* weather_rgb8) {
+    return set_noise_impl(c, large_rgba8, small_rgb8, weather_rgb8, false);
+}
+int csky_set_noise_mips(csky_ctx* c, const uint8_t* large_chain_rgba8, const uint8_t* small_chain_rgb8, const uint8_t* weather_rgb8) {
+    return set_noise_impl(c, large_chain_rgba8, small_chain_rgb8, weather_rgb8, true);
 }
 
 int csky_read_baked_texture(csky_ctx* c, int which, void* out, size_t capacity, size_t* bytes) {

@@ -27,8 +27,9 @@ void shape_rows(uint32_t seed, int n, int z0, int z1, uint8_t* out) {
         csky::shape_voxel(seed, n, x, y, z, out + ((((size_t)z * n + y) * n + x) * 4));
 }
 
-thread_local char g_asset_err[256];
 }  // namespace
+namespace csky { thread_local char g_asset_err[256]; }   // shared with godot_import.cpp
+using csky::g_asset_err;
 
 extern "C" {
 

@@ -88,6 +88,11 @@ const char* csky_last_error(const csky_ctx* ctx); /* ctx may be NULL: last creat
  * weather_rgb8: 512x512 RGB8, row 0 = top row of the bitmap                  (weather.bmp)
  * Level-0 data only; the library builds the mip chains (2x2x2 box) and its device layouts. */
 int csky_set_noise(csky_ctx* ctx, const uint8_t* large_rgba8, const uint8_t* small_rgb8, const uint8_t* weather_rgb8);
+/* The same with caller-supplied mip chains: large_chain_rgba8 / small_chain_rgb8 hold ALL levels back to back (level l of an n^3 volume
+ * at byte csky_mip_offset(n, l, channels), 8 levels for 128^3, 6 for 32^3).  For hosts that have the importer's own chains, e.g. read
+ * from the project's .godot/imported/ files with csky_load_ctex3d (perlworlnoise.tga.import:24, worlnoise.bmp.import:24:
+ * mipmaps/generate=true): the sampler of the reference sees exactly those texels, not a re-derived box filter. */
+int csky_set_noise_mips(csky_ctx* ctx, const uint8_t* large_chain_rgba8, const uint8_t* small_chain_rgb8, const uint8_t* weather_rgb8);
 /* The device layouts store finite differences of neighbouring texels as fp16 (exact for integers up to 2048).  Returns how
  * many coefficients of the textures bound by the last csky_set_noise did NOT fit exactly (0 for natural noise; only
  * adversarial checkerboards of extreme values exceed the range and then carry a relative 2^-11 error on that term).
@@ -254,6 +259,21 @@ int csky_read_baked_texture(csky_ctx* ctx, int which, void* out, size_t capacity
 /* Test hook: the march's range-restricted exact square root (cloud_core.h::sqrt_shell, |p|^2 of sample positions) over an array, so that
  * a test can check it EXHAUSTIVELY against IEEE sqrtf on the range it is used on (all 30 067 floats in [3.597e13, 3.6097e13]). */
 int csky_test_sqrt_shell(csky_ctx* ctx, const float* in, float* out, size_t n);
+/* ---- what Godot's importer wrote (godot_import.cpp; host only) ------------------------------------
+ * The reference's noise textures are imported with compress/mode=2, compress/high_quality=true (weather.bmp.import:19-20,
+ * worlnoise.bmp.import:19-20, perlworlnoise.tga.import:19-20), i.e. as BPTC (BC7) blocks in .godot/imported/<name>-<md5>.bptc.ctex
+ * / .ctex3d: what the reference's samplers return are the DECODED blocks.  Decoding is fixed by the format (all 8 block modes,
+ * checked against an independent decoder in tests/test_godot_import.py); the engine's encoder is not reproduced, so a host that
+ * wants the reference's exact texels loads the imported files:
+ *   csky_decode_bc7   w x h pixels from ceil(w/4) x ceil(h/4) 16-byte blocks (row-major) -> RGBA8
+ *   csky_load_ctex    CompressedTexture2D ("GST2"): *levels images (level 0 first, then the stored mips) back to back as RGBA8
+ *   csky_load_ctex3d  CompressedTexture3D ("GSTL"): the d slices of level 0, then the slices of every stored mip level, as RGBA8
+ * Raw (uncompressed R8/RGB8/RGBA8) and BPTC_RGBA payloads are read; PNG/WebP/Basis payloads are refused.  out may be NULL to query the
+ * sizes.  The container layout follows the engine's loader (Godot 4.2 scene/resources/compressed_texture.cpp); no imported file
+ * ships with the reference, so only the BC7 decoder is pinned by an outside implementation. */
+int csky_decode_bc7(const uint8_t* blocks, int w, int h, uint8_t* out_rgba8);
+int csky_load_ctex(const char* path, int* w, int* h, int* levels, uint8_t* out_rgba8, size_t out_capacity);
+int csky_load_ctex3d(const char* path, int* w, int* h, int* d, int* levels, uint8_t* out_rgba8, size_t out_capacity);
 const char* csky_assets_last_error(void);
 
 #ifdef __cplusplus

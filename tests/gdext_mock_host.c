@@ -172,6 +172,18 @@ int main(int argc, char **argv) {
         if (ptrcall_int("set_noise", a) != CSKY_OK) return 32;
         ps.size -= 1;
         if (ptrcall_int("set_noise", a) != CSKY_ERR_INVALID) return 33;               /* wrong array size is refused, not read */
+        {   /* every mip level back to back (the importer's chains): routed to csky_set_noise_mips; here the library's own box chains, so the frame below is unchanged */
+            const size_t nl = csky_mip_offset(128, 8, 4), ns = csky_mip_offset(32, 6, 3);
+            uint8_t *lc = (uint8_t *)calloc(nl, 1), *sc = (uint8_t *)calloc(ns, 1);
+            int rc_chain;
+            if (!lc || !sc) return 30;
+            memcpy(lc, large, (size_t)128 * 128 * 128 * 4); memcpy(sc, small, (size_t)32 * 32 * 32 * 3);
+            if (csky_build_mips(lc, 128, 4, 8) != CSKY_OK || csky_build_mips(sc, 32, 3, 6) != CSKY_OK) return 30;
+            pl.data = lc; pl.size = (int64_t)nl; ps.data = sc; ps.size = (int64_t)ns;
+            rc_chain = ptrcall_int("set_noise", a);
+            free(lc); free(sc);
+            if (rc_chain != CSKY_OK) return 39;
+        }
         a[0] = &prim; a[1] = &light;
         if (ptrcall_int("set_march", a) != CSKY_OK) return 34;
         a[0] = &ptc; lut = ptrcall_bytes("render_transmittance", a);
