@@ -358,7 +358,7 @@ def main():
                        "alpha_mean": alpha_mean, "finite": finite},
             "roofline": {
                 # neither "hbm" nor "mfma" binds this path (docstring): the top-level fields are the VALU-issue roof, the one closest to 1
-                "bound": "valu", "kernel": "clouds_kernel<3,1> (compact march), one launch with the GPU to itself",
+                "bound": "valu", "kernel": "clouds_kernel<3,1> (compact march), one launch with the GPU to itself; with two frames in flight the timed region runs the same body in its persistent form, clouds_kernel_persistent<3>",
                 "achieved": vi.get("issue_cycles_per_simd"), "peak": vi.get("kernel_cycles"), "unit": "SIMD issue cycles per launch",
                 "frac": vi.get("frac"), "frac_bounds": [vi.get("frac_lower"), vi.get("frac_upper")] if vi else None,
                 "traffic": traffic,
