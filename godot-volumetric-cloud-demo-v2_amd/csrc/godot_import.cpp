@@ -17,6 +17,7 @@
 #include <cstdint>
 #include <cstdio>
 #include <cstring>
+#include <exception>
 #include <vector>
 
 namespace csky { extern thread_local char g_asset_err[256]; }
@@ -97,6 +98,7 @@ void decode_block(const uint8_t* blk, uint8_t out[16][4]) {
     }
 }
 
+struct FileCloser { FILE* f; ~FileCloser() { if (f) fclose(f); } };
 struct Reader {
     FILE* f; bool ok = true;
     uint32_t u32() { uint8_t b[4]; if (fread(b, 1, 4, f) != 4) { ok = false; return 0; } return b[0] | (b[1] << 8) | (b[2] << 16) | ((uint32_t)b[3] << 24); }
@@ -126,7 +128,7 @@ int read_image_record(Reader& r, const char* what, int& w, int& h, std::vector<s
     const int fmt = (int)r.u32();
     if (!r.ok) { snprintf(g_asset_err, sizeof g_asset_err, "%s: truncated image header", what); return CSKY_ERR_IO; }
     if (data_format != GD_DATA_FORMAT_IMAGE) { snprintf(g_asset_err, sizeof g_asset_err, "%s: data format %u (PNG/WebP/Basis) is not supported, only raw image data", what, data_format); return CSKY_ERR_IO; }
-    if (w < 1 || h < 1 || mips > 16 || !level_bytes(fmt, 4, 4)) { snprintf(g_asset_err, sizeof g_asset_err, "%s: unsupported image (%dx%d, %u mips, format %d)", what, w, h, mips, fmt); return CSKY_ERR_IO; }
+    if (w < 1 || h < 1 || w > 16384 || h > 16384 || mips > 16 || !level_bytes(fmt, 4, 4)) { snprintf(g_asset_err, sizeof g_asset_err, "%s: unsupported image (%dx%d, %u mips, format %d)", what, w, h, mips, fmt); return CSKY_ERR_IO; }
     int lw = w, lh = h;
     for (uint32_t l = 0; l <= mips; l++) {
         const size_t nb = level_bytes(fmt, lw, lh);
@@ -165,22 +167,22 @@ int csky_decode_bc7(const uint8_t* blocks, int w, int h, uint8_t* out_rgba8) {
     return CSKY_OK;
 }
 
-int csky_load_ctex(const char* path, int* w, int* h, int* levels, uint8_t* out_rgba8, size_t out_capacity) {
+static int load_ctex_impl(const char* path, int* w, int* h, int* levels, uint8_t* out_rgba8, size_t out_capacity) {
     FILE* f = path ? fopen(path, "rb") : nullptr;
     if (!f) { snprintf(g_asset_err, sizeof g_asset_err, "load_ctex: cannot open %s", path ? path : "(null)"); return CSKY_ERR_IO; }
+    FileCloser closer{f};                                      // every return path (and an exception) closes the file
     Reader r{f};
     uint8_t magic[4];
-    if (fread(magic, 1, 4, f) != 4 || memcmp(magic, "GST2", 4) != 0) { fclose(f); snprintf(g_asset_err, sizeof g_asset_err, "load_ctex: %s is not a CompressedTexture2D (GST2)", path); return CSKY_ERR_IO; }
+    if (fread(magic, 1, 4, f) != 4 || memcmp(magic, "GST2", 4) != 0) { snprintf(g_asset_err, sizeof g_asset_err, "load_ctex: %s is not a CompressedTexture2D (GST2)", path); return CSKY_ERR_IO; }
     const uint32_t version = r.u32();
     r.u32(); r.u32();                                          // custom width / height
     r.u32();                                                   // flags
     r.u32();                                                   // mipmap limit
     r.u32(); r.u32(); r.u32();                                 // reserved
-    if (!r.ok || version > 1) { fclose(f); snprintf(g_asset_err, sizeof g_asset_err, "load_ctex: %s: unsupported version %u", path, version); return CSKY_ERR_IO; }
+    if (!r.ok || version > 1) { snprintf(g_asset_err, sizeof g_asset_err, "load_ctex: %s: unsupported version %u", path, version); return CSKY_ERR_IO; }
     int iw = 0, ih = 0;
     std::vector<std::vector<uint8_t>> lv;
     const int rc = read_image_record(r, "load_ctex", iw, ih, lv);
-    fclose(f);
     if (rc != CSKY_OK) return rc;
     if (w) *w = iw; if (h) *h = ih; if (levels) *levels = (int)lv.size();
     if (!out_rgba8) return CSKY_OK;                            // size query
@@ -190,19 +192,25 @@ int csky_load_ctex(const char* path, int* w, int* h, int* levels, uint8_t* out_r
     return CSKY_OK;
 }
 
-int csky_load_ctex3d(const char* path, int* w, int* h, int* d, int* levels, uint8_t* out_rgba8, size_t out_capacity) {
+int csky_load_ctex(const char* path, int* w, int* h, int* levels, uint8_t* out_rgba8, size_t out_capacity) {
+    try { return load_ctex_impl(path, w, h, levels, out_rgba8, out_capacity); }
+    catch (const std::exception&) { snprintf(g_asset_err, sizeof g_asset_err, "load_ctex: out of memory"); return CSKY_ERR_IO; }   // nothing throws across the ABI
+}
+
+static int load_ctex3d_impl(const char* path, int* w, int* h, int* d, int* levels, uint8_t* out_rgba8, size_t out_capacity) {
     FILE* f = path ? fopen(path, "rb") : nullptr;
     if (!f) { snprintf(g_asset_err, sizeof g_asset_err, "load_ctex3d: cannot open %s", path ? path : "(null)"); return CSKY_ERR_IO; }
+    FileCloser closer{f};                                      // every return path (and an exception) closes the file
     Reader r{f};
     uint8_t magic[4];
-    if (fread(magic, 1, 4, f) != 4 || memcmp(magic, "GSTL", 4) != 0) { fclose(f); snprintf(g_asset_err, sizeof g_asset_err, "load_ctex3d: %s is not a CompressedTexture3D (GSTL)", path); return CSKY_ERR_IO; }
+    if (fread(magic, 1, 4, f) != 4 || memcmp(magic, "GSTL", 4) != 0) { snprintf(g_asset_err, sizeof g_asset_err, "load_ctex3d: %s is not a CompressedTexture3D (GSTL)", path); return CSKY_ERR_IO; }
     const uint32_t version = r.u32();
     const int depth = (int)r.u32();
     r.u32();                                                   // layer type
     r.u32();                                                   // data format flags
     const int mip_images = (int)r.u32();                       // number of mip SLICES that follow the level-0 slices
     r.u32(); r.u32();                                          // reserved
-    if (!r.ok || version > 1 || depth < 1 || depth > 4096 || mip_images < 0 || mip_images > 8192) { fclose(f); snprintf(g_asset_err, sizeof g_asset_err, "load_ctex3d: %s: bad header", path); return CSKY_ERR_IO; }
+    if (!r.ok || version > 1 || depth < 1 || depth > 4096 || mip_images < 0 || mip_images > 8192) { snprintf(g_asset_err, sizeof g_asset_err, "load_ctex3d: %s: bad header", path); return CSKY_ERR_IO; }
     // slices of level 0, then the slices of level 1 (depth/2 of them), level 2, ...: every slice is one image record without 2-D mips
     std::vector<std::vector<uint8_t>> slices;
     int iw = 0, ih = 0, lw = 0, lh = 0, ld = depth, n_levels = 0, left_in_level = depth;
@@ -210,16 +218,15 @@ int csky_load_ctex3d(const char* path, int* w, int* h, int* d, int* levels, uint
         int sw = 0, sh = 0;
         std::vector<std::vector<uint8_t>> one;
         const int rc = read_image_record(r, "load_ctex3d", sw, sh, one);
-        if (rc != CSKY_OK) { fclose(f); return rc; }
+        if (rc != CSKY_OK) return rc;
         if (i == 0) { iw = lw = sw; ih = lh = sh; n_levels = 1; }
         if (left_in_level == 0) {                              // next mip level
             lw = lw > 1 ? lw >> 1 : 1; lh = lh > 1 ? lh >> 1 : 1; ld = ld > 1 ? ld >> 1 : 1; left_in_level = ld; n_levels++;
         }
-        if (sw != lw || sh != lh) { fclose(f); snprintf(g_asset_err, sizeof g_asset_err, "load_ctex3d: slice %d is %dx%d, expected %dx%d", i, sw, sh, lw, lh); return CSKY_ERR_IO; }
+        if (sw != lw || sh != lh) { snprintf(g_asset_err, sizeof g_asset_err, "load_ctex3d: slice %d is %dx%d, expected %dx%d", i, sw, sh, lw, lh); return CSKY_ERR_IO; }
         slices.push_back(std::move(one[0]));
         left_in_level--;
     }
-    fclose(f);
     if (left_in_level != 0) { snprintf(g_asset_err, sizeof g_asset_err, "load_ctex3d: the last mip level is incomplete"); return CSKY_ERR_IO; }
     if (w) *w = iw; if (h) *h = ih; if (d) *d = depth; if (levels) *levels = n_levels;
     if (!out_rgba8) return CSKY_OK;
@@ -227,6 +234,11 @@ int csky_load_ctex3d(const char* path, int* w, int* h, int* d, int* levels, uint
     if (out_capacity < total) { snprintf(g_asset_err, sizeof g_asset_err, "load_ctex3d: output buffer too small (%zu needed)", total); return CSKY_ERR_INVALID; }
     size_t o = 0; for (auto& s : slices) { memcpy(out_rgba8 + o, s.data(), s.size()); o += s.size(); }
     return CSKY_OK;
+}
+
+int csky_load_ctex3d(const char* path, int* w, int* h, int* d, int* levels, uint8_t* out_rgba8, size_t out_capacity) {
+    try { return load_ctex3d_impl(path, w, h, d, levels, out_rgba8, out_capacity); }
+    catch (const std::exception&) { snprintf(g_asset_err, sizeof g_asset_err, "load_ctex3d: out of memory"); return CSKY_ERR_IO; }
 }
 
 }  // extern "C"

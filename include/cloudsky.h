@@ -201,7 +201,11 @@ int csky_set_segments(csky_ctx* ctx, int segments);
  * between consecutive csky_render_*_device calls (always safe: per-frame state lives in two-deep rings ordered by events); the
  * next frame then fills the tail of this one and fewer, longer wavefronts are the better choice for partial frames.  Default 1.
  * The two streams must map to different hardware queues: the library sets GPU_MAX_HW_QUEUES=8 at load time unless the host already set it
- * (the HIP runtime's default of 4 loses part of the overlap); that works when the library is loaded before the process's first HIP call. */
+ * (the HIP runtime's default of 4 loses part of the overlap); that works when the library is loaded before the process's first HIP call.
+ * With 2, whole-ray launches of 12 Ki - 64 Ki wavefronts (a 2048x1024 frame, half of it) run in the persistent form: one workgroup per
+ * resident slot, wavefronts pop tiles from per-XCD sequences of the schedule and steal from the other XCDs at the end (kernels.hip,
+ * clouds_kernel_persistent); frames are byte-identical either way.  Environment variable CSKY_PERSISTENT, read by csky_create, is the A/B
+ * switch: 0 = never, 1 = this policy (default), 2 = every whole-ray launch. */
 int csky_set_frames_in_flight(csky_ctx* ctx, int frames);
 const char* csky_variant_name(int variant);
 
