@@ -849,7 +849,7 @@ __global__ __launch_bounds__(256, VARIANT == 3 ? CSKY_COMPACT_WAVES : 7) void cl
         uint32_t logical = 0xfffffffeu, rec = 0;               // 0xfffffffe: every sequence is empty
         if (tile == 0) {
             for (unsigned k = 0; k < 8u; k++) {
-                const unsigned y = (xcc + k) & 7u;
+                const unsigned y = (xcc + k) & 7u;             // (own, then xcc ^ k = the XCD on the same IO die first: 0.3 % slower)
                 uint32_t jv = 0;
                 if (lane0) jv = atomicAdd(&heads[y], 1u);
                 const uint32_t j = (uint32_t)__builtin_amdgcn_readfirstlane((int)jv);
