@@ -10,6 +10,7 @@
 #include <new>
 #include <algorithm>
 #include <cmath>
+#include <string>
 #include <vector>
 #include "../../include/cloudsky.h"
 #include "kernels.h"
@@ -675,6 +676,30 @@ int csky_time_clouds(csky_ctx* c, const csky_cloud_params* p, int tile_w, const 
         std::vector<unsigned long long> h(n);
         HIPCHK(c, hipMemcpy(h.data(), c->d_stats + 2, n * 8, hipMemcpyDeviceToHost));
         if (FILE* f = fopen(path, "wb")) { fwrite(h.data(), 8, n, f); fclose(f); }
+        // CSKY_TIMELINE_PAIR=K: K frames, two in flight on two streams (what bench.py's timed region does), every launch with its own
+        // timestamp region -> <path>.pair (K regions of 16 * grid words; tools/timeline_pair.py)
+        if (const char* pk = getenv("CSKY_TIMELINE_PAIR")) {
+            const int K = atoi(pk) > 0 ? atoi(pk) : 8;
+            const int fif_saved = c->frames_in_flight;
+            c->frames_in_flight = 2;
+            hipStream_t ss[2];
+            for (int i = 0; i < 2; i++) HIPCHK(c, hipStreamCreateWithFlags(&ss[i], hipStreamNonBlocking));
+            if ((rc = clouds_dev(c, p, tile_w, bands, c->d_frame, pitch, ss[0], nullptr, true))) return rc;      // settles the geometry: grid of the two-in-flight policy
+            HIPCHK(c, hipDeviceSynchronize());
+            const size_t grid = (size_t)c->order_grid_ring[c->fc_cur], per = 2 + 16 * grid;
+            unsigned long long* big = nullptr;
+            HIPCHK(c, hipMalloc(reinterpret_cast<void**>(&big), (size_t)K * per * 8));
+            HIPCHK(c, hipMemset(big, 0, (size_t)K * per * 8));
+            for (int k = 0; k < K; k++)
+                if ((rc = clouds_dev(c, p, tile_w, bands, c->d_frame, pitch, ss[k & 1], big + (size_t)k * per, true))) return rc;
+            HIPCHK(c, hipDeviceSynchronize());
+            std::vector<unsigned long long> hb((size_t)K * per);
+            HIPCHK(c, hipMemcpy(hb.data(), big, hb.size() * 8, hipMemcpyDeviceToHost));
+            const std::string pp = std::string(path) + ".pair";
+            if (FILE* f = fopen(pp.c_str(), "wb")) { unsigned long long hd[2] = {(unsigned long long)K, (unsigned long long)per}; fwrite(hd, 8, 2, f); fwrite(hb.data(), 8, hb.size(), f); fclose(f); }
+            (void)hipFree(big); for (int i = 0; i < 2; i++) (void)hipStreamDestroy(ss[i]);
+            c->frames_in_flight = fif_saved;
+        }
     }
 #endif
     return CSKY_OK;
