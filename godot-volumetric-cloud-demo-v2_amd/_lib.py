@@ -106,7 +106,7 @@ SYMBOLS = [
 
 
 DEFAULT_VARIANT = 3   # include/cloudsky.h CSKY_DEFAULT_VARIANT ("compact"); set_variant(-1) selects it
-ABI_VERSION = 2       # include/cloudsky.h CSKY_ABI_VERSION
+ABI_VERSION = 3       # include/cloudsky.h CSKY_ABI_VERSION
 
 
 def library_path():

@@ -30,7 +30,7 @@ extern "C" {
 #define CSKY_ERR_IO (-4)         /* asset file problem                                       */
 #define CSKY_ERR_STATE (-5)      /* e.g. clouds requested before noise / LUTs exist          */
 
-#define CSKY_ABI_VERSION 2
+#define CSKY_ABI_VERSION 3  /* 3: csky_set_noise_mips, csky_decode_bc7, csky_load_ctex[3d]; 2: csky_multi_*, device asset builders */
 
 typedef struct csky_ctx csky_ctx; /* opaque: owns every device allocation, the HIP stream and events */
 
