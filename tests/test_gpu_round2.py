@@ -41,6 +41,26 @@ def test_full_frame_c3_vs_oracle_tight(gpu_ctx, oracle, otex, o_skies, sun_name)
     print("C3 %s: %s, in-cloud branch flips %d" % (sun_name, info, flips))
 
 
+def test_full_frame_c5_vs_oracle_tight(gpu_ctx, oracle, otex, o_skies):
+    """BASELINE configs[4]'s frame: the WHOLE 4096x2048 @ 128x6 hemisphere (8.4 M rays, ~20 s of oracle on 16 host threads) at the
+    tightened gate.  Three quarters of these rays exist in no smaller configuration (the rest: test_full_size_c5_subsamples_to_c3)."""
+    from bench import usable_cores
+    sun = SUNS["deg45"]
+    gpu_ctx.set_variant(-1); gpu_ctx.set_schedule(-1); gpu_ctx.set_segments(0); gpu_ctx.set_early_out(0.0)
+    gpu_ctx.set_march(128, 6)
+    gpu_ctx.render_sky_lut(norm(sun), 200, 100)
+    W, H = 4096, 2048
+    p = oracle.default_params(W, H, sun)
+    img = gpu_ctx.render_clouds(p)
+    st = gpu_ctx.cloud_stats()
+    ref, st_o = oracle.clouds(otex, p, o_skies["deg45"], nthreads=max(1, min(oracle.max_threads(), usable_cores())), return_stats=True)
+    ok, info = cloud_tight(img, ref)
+    assert ok, info
+    assert info["within1"] >= 0.9998 and info["beyond2_pixels"] <= 1e-4 * W * H, info
+    flips = _count_gate(st, st_o)
+    print("C5 frame: %s, in-cloud branch flips %d" % (info, flips))
+
+
 def test_full_frame_c2_vs_oracle_tight(gpu_ctx, oracle, otex, o_skies):
     """BASELINE configs[1]: the whole 512x256 @ 64x4 frame, sun at zenith, tightened gate, equal sample counts."""
     gpu_ctx.set_march(64, 4)
