@@ -81,6 +81,8 @@ SYMBOLS = [
     ("csky_multi_ctx", C.c_void_p, [C.c_void_p, C.c_int]),
     ("csky_multi_last_error", C.c_char_p, [C.c_void_p]),
     ("csky_multi_set_noise", C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    ("csky_multi_set_noise_mips", C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    ("csky_multi_set_frames_in_flight", C.c_int, [C.c_void_p, C.c_int]),
     ("csky_multi_set_march", C.c_int, [C.c_void_p, C.c_int, C.c_int]),
     ("csky_multi_render_sky_lut", C.c_int, [C.c_void_p, C.POINTER(SkyParams)]),
     ("csky_multi_render_clouds_device", C.c_int, [C.c_void_p, C.POINTER(CloudParams), C.c_int, C.c_int, C.c_void_p, C.c_size_t, C.c_void_p]),
@@ -403,8 +405,18 @@ class MultiContext:
             raise ValueError("set_noise: expected 128^3 RGBA8, 32^3 RGB8, 512^2 RGB8")
         self._chk(self._L.csky_multi_set_noise(self._h, _ptr(a), _ptr(b), _ptr(c)))
 
+    def set_noise_mips(self, large_chain_rgba8, small_chain_rgb8, weather_rgb8):
+        a, b, c = (np.ascontiguousarray(x, np.uint8) for x in (large_chain_rgba8, small_chain_rgb8, weather_rgb8))
+        if a.size != self._L.csky_mip_offset(128, 8, 4) or b.size != self._L.csky_mip_offset(32, 6, 3) or c.size != 512 * 512 * 3:
+            raise ValueError("set_noise_mips: expected the 8-level 128^3 RGBA8 chain, the 6-level 32^3 RGB8 chain, 512^2 RGB8")
+        self._chk(self._L.csky_multi_set_noise_mips(self._h, _ptr(a), _ptr(b), _ptr(c)))
+
     def set_march(self, primary_steps=128, light_steps=6):
         self._chk(self._L.csky_multi_set_march(self._h, primary_steps, light_steps))
+
+    def set_frames_in_flight(self, frames):
+        """2: consecutive render_clouds_device calls alternate two consumer streams; every device alternates two streams too."""
+        self._chk(self._L.csky_multi_set_frames_in_flight(self._h, int(frames)))
 
     def render_sky_lut(self, sun_dir, w=200, h=100):
         p = SkyParams()

@@ -777,8 +777,10 @@ int csky_copy_sky_lut_device(csky_ctx* c, void* d_out, void* hip_stream) {
 // ---- multi-GPU: n contexts, one frame on the first device written by peer stores (cloudsky.h) ----------------------------
 struct csky_multi {
     std::vector<csky_ctx*> ctx;
-    std::vector<hipEvent_t> ev_done;      // one per device: its march of the current frame has finished
-    hipEvent_t ev_begin = nullptr;        // on the first device: the consumer stream's position when the frame was requested
+    std::vector<hipEvent_t> ev_done[2];   // [frame parity][device]: its march of that frame has finished
+    hipEvent_t ev_begin[2] = {nullptr, nullptr};   // on the first device: the consumer stream's position when the frame was requested
+    std::vector<hipStream_t> side;        // two frames in flight: the stream of the odd frames on device i > 0 (even frames: the context's own)
+    int fif = 1, parity = 0;
     uint2* d_frame = nullptr; size_t frame_px = 0;   // host-buffer form: internal frame on the first device
     char err[512] = {0};
 };
@@ -812,9 +814,14 @@ int csky_multi_create(csky_multi** out, const int* device_ids, int n) {
     for (int i = 0; i < n; i++) {
         const int di = device_ids[i];
         if ((e = hipSetDevice(di)) != hipSuccess) return bail(CSKY_ERR_HIP, "hipSetDevice", e);
-        hipEvent_t ev = nullptr;
-        if ((e = hipEventCreateWithFlags(&ev, hipEventDisableTiming)) != hipSuccess) return bail(CSKY_ERR_HIP, "hipEventCreate", e);
-        m->ev_done.push_back(ev);
+        for (int par = 0; par < 2; par++) {
+            hipEvent_t ev = nullptr;
+            if ((e = hipEventCreateWithFlags(&ev, hipEventDisableTiming)) != hipSuccess) return bail(CSKY_ERR_HIP, "hipEventCreate", e);
+            m->ev_done[par].push_back(ev);
+        }
+        hipStream_t st = nullptr;
+        if ((e = hipStreamCreateWithFlags(&st, hipStreamNonBlocking)) != hipSuccess) return bail(CSKY_ERR_HIP, "hipStreamCreate", e);
+        m->side.push_back(st);
         if (di != d0) {                                          // the march on device di stores into the frame on d0: xGMI peer access
             int can = 0;
             if ((e = hipDeviceCanAccessPeer(&can, di, d0)) != hipSuccess) return bail(CSKY_ERR_HIP, "hipDeviceCanAccessPeer", e);
@@ -825,7 +832,8 @@ int csky_multi_create(csky_multi** out, const int* device_ids, int n) {
         }
     }
     if ((e = hipSetDevice(d0)) != hipSuccess) return bail(CSKY_ERR_HIP, "hipSetDevice", e);
-    if ((e = hipEventCreateWithFlags(&m->ev_begin, hipEventDisableTiming)) != hipSuccess) return bail(CSKY_ERR_HIP, "hipEventCreate", e);
+    for (int par = 0; par < 2; par++)
+        if ((e = hipEventCreateWithFlags(&m->ev_begin[par], hipEventDisableTiming)) != hipSuccess) return bail(CSKY_ERR_HIP, "hipEventCreate", e);
     *out = m;
     return CSKY_OK;
 }
@@ -835,11 +843,12 @@ void csky_multi_destroy(csky_multi* m) {
     for (size_t i = 0; i < m->ctx.size(); i++) {
         (void)hipSetDevice(m->ctx[i]->device);
         (void)hipDeviceSynchronize();
-        if (i < m->ev_done.size() && m->ev_done[i]) (void)hipEventDestroy(m->ev_done[i]);
+        for (int par = 0; par < 2; par++) if (i < m->ev_done[par].size() && m->ev_done[par][i]) (void)hipEventDestroy(m->ev_done[par][i]);
+        if (i < m->side.size() && m->side[i]) (void)hipStreamDestroy(m->side[i]);
     }
     if (!m->ctx.empty()) {
         (void)hipSetDevice(m->ctx[0]->device);
-        if (m->ev_begin) (void)hipEventDestroy(m->ev_begin);
+        for (int par = 0; par < 2; par++) if (m->ev_begin[par]) (void)hipEventDestroy(m->ev_begin[par]);
         if (m->d_frame) (void)hipFree(m->d_frame);
     }
     for (csky_ctx* c : m->ctx) csky_destroy(c);
@@ -855,9 +864,21 @@ int csky_multi_set_noise(csky_multi* m, const uint8_t* large, const uint8_t* sma
     for (size_t i = 0; i < m->ctx.size(); i++) { const int rc = csky_set_noise(m->ctx[i], large, small, weather); if (rc) return mpass(m, (int)i, rc); }
     return CSKY_OK;
 }
+int csky_multi_set_noise_mips(csky_multi* m, const uint8_t* large_chain, const uint8_t* small_chain, const uint8_t* weather) {
+    if (!m) return mfail(nullptr, CSKY_ERR_INVALID, "csky_multi_set_noise_mips: handle is NULL");
+    for (size_t i = 0; i < m->ctx.size(); i++) { const int rc = csky_set_noise_mips(m->ctx[i], large_chain, small_chain, weather); if (rc) return mpass(m, (int)i, rc); }
+    return CSKY_OK;
+}
 int csky_multi_set_march(csky_multi* m, int primary_steps, int light_steps) {
     if (!m) return mfail(nullptr, CSKY_ERR_INVALID, "csky_multi_set_march: handle is NULL");
     for (size_t i = 0; i < m->ctx.size(); i++) { const int rc = csky_set_march(m->ctx[i], primary_steps, light_steps); if (rc) return mpass(m, (int)i, rc); }
+    return CSKY_OK;
+}
+int csky_multi_set_frames_in_flight(csky_multi* m, int frames) {
+    if (!m) return mfail(nullptr, CSKY_ERR_INVALID, "csky_multi_set_frames_in_flight: handle is NULL");
+    if (frames < 1 || frames > 2) return mfail(m, CSKY_ERR_INVALID, "csky_multi_set_frames_in_flight: 1 or 2");
+    for (size_t i = 0; i < m->ctx.size(); i++) { const int rc = csky_set_frames_in_flight(m->ctx[i], frames); if (rc) return mpass(m, (int)i, rc); }
+    m->fif = frames;
     return CSKY_OK;
 }
 int csky_multi_render_sky_lut(csky_multi* m, const csky_sky_params* p) {
@@ -874,23 +895,26 @@ int csky_multi_render_clouds_device(csky_multi* m, const csky_cloud_params* p, i
     csky_ctx* c0 = m->ctx[0];
     int rc; if ((rc = bind(c0))) return mpass(m, 0, rc);
     hipStream_t consumer = hip_stream ? (hipStream_t)hip_stream : c0->stream;
+    // two frames in flight (csky_multi_set_frames_in_flight): consecutive frames alternate between two sets of streams and events on
+    // every device, like a caller of the single-device entry points alternates two streams
+    const int par = m->fif >= 2 ? (m->parity ^= 1) : 0;
     // no device may store into the frame before the consumer's earlier work on it (reads of the previous frame) is done
-    if (hipEventRecord(m->ev_begin, consumer) != hipSuccess) return mfail(m, CSKY_ERR_HIP, "csky_multi_render_clouds_device: hipEventRecord failed");
+    if (hipEventRecord(m->ev_begin[par], consumer) != hipSuccess) return mfail(m, CSKY_ERR_HIP, "csky_multi_render_clouds_device: hipEventRecord failed");
     for (int i = 0; i < n; i++) {
         csky_ctx* c = m->ctx[i];
         if ((rc = bind(c))) return mpass(m, i, rc);
         const int nb = i < total ? (total - i + n - 1) / n : 0;
         if (nb == 0) continue;
-        hipStream_t s = (i == 0) ? consumer : c->stream;
-        if (i != 0 && hipStreamWaitEvent(s, m->ev_begin, 0) != hipSuccess) return mfail(m, CSKY_ERR_HIP, "csky_multi_render_clouds_device: hipStreamWaitEvent failed");
+        hipStream_t s = (i == 0) ? consumer : (par ? m->side[i] : c->stream);
+        if (i != 0 && hipStreamWaitEvent(s, m->ev_begin[par], 0) != hipSuccess) return mfail(m, CSKY_ERR_HIP, "csky_multi_render_clouds_device: hipStreamWaitEvent failed");
         const csky_bands b = {8, i, n, nb};
         if ((rc = clouds_dev(c, p, tile_w, &b, (uint2*)d_out, pitch, s, nullptr, true, /*out_full=*/true))) return mpass(m, i, rc);
-        if (i != 0 && hipEventRecord(m->ev_done[i], s) != hipSuccess) return mfail(m, CSKY_ERR_HIP, "csky_multi_render_clouds_device: hipEventRecord failed");
+        if (i != 0 && hipEventRecord(m->ev_done[par][i], s) != hipSuccess) return mfail(m, CSKY_ERR_HIP, "csky_multi_render_clouds_device: hipEventRecord failed");
     }
     if ((rc = bind(c0))) return mpass(m, 0, rc);
     for (int i = 1; i < n; i++) {
         if (i >= total) continue;
-        if (hipStreamWaitEvent(consumer, m->ev_done[i], 0) != hipSuccess) return mfail(m, CSKY_ERR_HIP, "csky_multi_render_clouds_device: hipStreamWaitEvent failed");
+        if (hipStreamWaitEvent(consumer, m->ev_done[par][i], 0) != hipSuccess) return mfail(m, CSKY_ERR_HIP, "csky_multi_render_clouds_device: hipStreamWaitEvent failed");
     }
     return CSKY_OK;
 }

@@ -226,6 +226,10 @@ int csky_multi_device_count(const csky_multi* m);
 csky_ctx* csky_multi_ctx(csky_multi* m, int i);
 const char* csky_multi_last_error(const csky_multi* m);
 int csky_multi_set_noise(csky_multi* m, const uint8_t* large_rgba8, const uint8_t* small_rgb8, const uint8_t* weather_rgb8);
+int csky_multi_set_noise_mips(csky_multi* m, const uint8_t* large_chain_rgba8, const uint8_t* small_chain_rgb8, const uint8_t* weather_rgb8);
+/* 2 = the caller keeps two frames in flight by alternating two consumer streams between consecutive csky_multi_render_clouds_device
+ * calls: every device then alternates two streams / event sets as well (csky_set_frames_in_flight on every context).  Default 1. */
+int csky_multi_set_frames_in_flight(csky_multi* m, int frames);
 int csky_multi_set_march(csky_multi* m, int primary_steps, int light_steps);
 int csky_multi_render_sky_lut(csky_multi* m, const csky_sky_params* p);
 /* Whole tile [0,tile_w) x [0,tile_h) into d_out on the FIRST device (row pitch in bytes), asynchronously: `hip_stream` (a stream of

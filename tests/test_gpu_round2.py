@@ -126,6 +126,24 @@ def test_multi_device_handle_matches_single_context(pkg, noise, gpu_ctx, oracle)
                 s.synchronize()
                 got = buf.cpu().numpy().view(np.uint16)
                 assert (got[:, :W] == ref).all() and (got[:, W:] == 0).all(), ids
+            # two frames in flight through the handle: consecutive frames on two consumer streams into two buffers; every device
+            # alternates its own two streams and event sets (csky_multi_set_frames_in_flight)
+            with torch.cuda.device(ids[0]):
+                m.set_frames_in_flight(2)
+                cs = [torch.cuda.Stream() for _ in range(2)]
+                bufs = [torch.zeros((H, W, 4), dtype=torch.int16, device="cuda:%d" % ids[0]) for _ in range(2)]
+                for k in range(6):
+                    bufs[k & 1].zero_()
+                    torch.cuda.current_stream().synchronize()
+                    m.render_clouds_device(p, W, H, bufs[k & 1].data_ptr(), W * 8, cs[k & 1].cuda_stream)
+                    if k >= 1:
+                        cs[(k - 1) & 1].synchronize()
+                        assert (bufs[(k - 1) & 1].cpu().numpy().view(np.uint16) == ref).all(), (ids, k)
+                torch.cuda.synchronize()
+                assert (bufs[1].cpu().numpy().view(np.uint16) == ref).all(), ids
+                m.set_frames_in_flight(1)
+                with pytest.raises(pkg.CloudSkyError):
+                    m.set_frames_in_flight(3)
             with pytest.raises(pkg.CloudSkyError):
                 m.render_clouds(p, W, 12)            # bands are 8 rows
         finally:
