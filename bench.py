@@ -125,8 +125,8 @@ def main():
     ap.add_argument("--kernel-iters", type=int, default=1, help="solo (one launch in flight) cloud-kernel launches timed after the timed region")
     ap.add_argument("--no-pmc", action="store_true", help="skip the live rocprofv3 counter passes (roofline fractions become null)")
     ap.add_argument("--frames-in-flight", type=int, default=None,
-                    help="consecutive frames alternate between this many streams per rank (default 2: the tail of frame k overlaps the head "
-                         "of frame k+1 and, at N > 1, its gather; 1 = strictly one frame at a time)")
+                    help="consecutive frames rotate over this many streams per rank, 1..4 (default 2: the tail of frame k overlaps the head of "
+                         "frame k+1 and, at N > 1, its gather; 4 for rank shares of 3072..6143 tiles; 1 = strictly one frame at a time)")
     args = ap.parse_args()
 
     import torch
@@ -177,19 +177,23 @@ def main():
     ctx.render_transmittance(256, 64)               # once at load, transmittance_lut.gd:15-18
 
     # Frames are independent and a launch ends in a tail of few, long wavefronts; with two frames in flight on two streams the next
-    # frame's workgroups fill that tail (the library keeps per-frame state in two-deep rings ordered by events).  Measured on one
+    # frame's workgroups fill that tail (the library keeps per-frame state in four-deep rings ordered by events).  Measured on one
     # GPU: whole frame 2.19 -> 1.90 ms; one rank's 1/2, 1/4, 1/8 share 1.09 -> 0.96, 0.67 -> 0.52, 0.43 -> 0.34 ms per frame
-    # (tools/share_matrix.py).  Buffer set b = frame parity: band buffer, stream, gather target.
-    fif = max(1, min(2, args.frames_in_flight if args.frames_in_flight is not None else 2))
+    # (tools/share_matrix.py).  Buffer set b = frame number mod frames in flight: band buffer, stream, gather target.
+    # The rings are four deep; more than two frames in flight only pay for small rank shares (a 1/8 share of C3: 0.32 -> 0.28 ms per
+    # frame as whole rays), so the default is 4 for 3072..6143 tiles per rank at N > 1 and 2 everywhere else.
+    bands = tiling.bands_for_rank(H, rank, world)
+    tiles_per_rank = ((W + 7) // 8) * bands[3]
+    fif_default = 4 if (world > 1 and 3072 <= tiles_per_rank < 6144) else 2    # measured per frame, x2 / x4: 1/4 share 0.485 / 0.512, 1/8 share 0.316 / 0.283, 1/16 share 0.191 / 0.250
+    fif = max(1, min(4, args.frames_in_flight if args.frames_in_flight is not None else fif_default))
     if os.environ.get("CSKY_BENCH_SYNC_GATHER") == "1":
         fif = 1                                      # debugging aid: gather-then-render, one frame at a time
     ctx.set_frames_in_flight(fif)
     streams = [torch.cuda.Stream(device=dev) for _ in range(fif)]   # always real streams: handle 0 (torch's default stream) would select the
     stream = streams[0].cuda_stream                                  # library's own non-blocking stream, unordered against the gather
-    bands = tiling.bands_for_rank(H, rank, world)
     mb = tiling.max_bands(H, world)
     # N > 1: the gather of frame k (RCCL, its own stream, ordered behind the stream of frame k at the call) overlaps the march of
-    # frame k+1 on the other stream; wait() orders frame k's stream behind its collective before that buffer set is reused.
+    # the following frames on the other streams; wait() orders frame k's stream behind its collective before that buffer set is reused.
     overlap = world > 1 and fif > 1
     nbuf = fif
     local = [torch.zeros((mb * tiling.BAND_ROWS, W, 4), dtype=torch.int16, device=dev) for _ in range(nbuf)]
@@ -224,14 +228,15 @@ def main():
             src = local_b[bset].cpu() if debug_one_gpu else local_b[bset]
             pending[bset] = dist.gather(src, gather_list=parts[bset], dst=0, async_op=True)
         if overlap:
-            o = 1 - bset
-            if pending[o] is not None:
-                finish(o)                  # frame k-1: its gather ran while frame k was marching
+            o = (bset + 1) % nbuf          # the oldest frame in flight (its buffer set is the next one to be reused):
+            if pending[o] is not None:     # its gather ran while the younger frames were marching
+                finish(o)
         else:
             finish(bset)
 
     def drain():
-        for o in range(nbuf):
+        for i in range(1, nbuf + 1):       # oldest first
+            o = (counter[0] - 1 + i) % nbuf
             if pending[o] is not None:
                 finish(o)
 

@@ -29,6 +29,10 @@ __attribute__((constructor)) static void csky_runtime_defaults() { setenv("GPU_M
 
 static_assert(sizeof(csky_cloud_params) == sizeof(CloudParams), "ABI struct mismatch");
 
+// Depth of the per-frame rings (frame constants, launch order, cost feedback, pop counters, events): the number of frames a caller may keep
+// in flight on as many streams (csky_set_frames_in_flight).  The slots rotate over all RING entries whatever that number is.
+constexpr int RING = 4;
+
 struct csky_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
@@ -46,13 +50,14 @@ struct csky_ctx {
     FrameConsts* d_fc = nullptr;                                                                          // = ring slot fc_cur
     // Frame prologue pipeline.  The sky LUT and the frame set-up of frame k+1 are small dependent kernels; enqueued behind the
     // cloud kernel of frame k they cost their run time plus two launch gaps per frame (6 % of one GPU's 1/8-frame share).  They
-    // run on the context's own prologue stream instead, into the other slot of a two-deep ring (the reference keeps three-deep
+    // run on the context's own prologue stream instead, into the next slot of a ring (the sky LUT two deep: every reader of it runs on `pro`;
+    // the frame constants RING deep: the marches of up to RING frames in flight read them) (the reference keeps three-deep
     // texture rings for the same reason, sky_lut.gd:143-146), so they overlap the march of the previous frame; events order
     // set-up -> clouds (ev_setup) and clouds -> the next writer of that slot (ev_clouds).  All sky-LUT readers run on `pro`.
     hipStream_t pro = nullptr;
     uint16_t* sky_h_ring[2] = {nullptr, nullptr}; float4* sky_f_ring[2] = {nullptr, nullptr}; int sky_cur = 0;
-    FrameConsts* fc_ring[2] = {nullptr, nullptr}; int fc_cur = 0;
-    hipEvent_t ev_setup[2] = {nullptr, nullptr}, ev_clouds[2] = {nullptr, nullptr}; bool clouds_pending[2] = {false, false};
+    FrameConsts* fc_ring[RING] = {}; int fc_cur = 0;
+    hipEvent_t ev_setup[RING] = {}, ev_clouds[RING] = {}; bool clouds_pending[RING] = {};
     unsigned long long* d_stats = nullptr;
     uint2* d_frame = nullptr; size_t frame_px = 0;  // internal frame for the host-buffer form / timing
     int primary_steps = 128, light_steps = 6;        // clouds.glsl:228, :186
@@ -60,15 +65,15 @@ struct csky_ctx {
     int variant = CSKY_DEFAULT_VARIANT;
     int sched_mode = -1;                              // -1 = auto (5 for large launches, 2 for small ones)
     int segments = 0;                                 // ray segments per ray: 0 = auto, 1, 2, 4
-    int frames_in_flight = 1;                         // policy hint (csky_set_frames_in_flight): the caller alternates two streams
+    int frames_in_flight = 1;                         // policy hint (csky_set_frames_in_flight): the caller alternates that many streams
     // static workgroup order (physical workgroup -> slab), written on the device, one table per ring slot (= frame parity, so two
     // frames in flight with different geometries never share one), cached per launch geometry
-    uint32_t* d_order_ring[2] = {nullptr, nullptr}; size_t order_cap[2] = {0, 0}; int order_grid_ring[2] = {0, 0};
-    long long order_key_ring[2][4] = {{-1, -1, -1, -1}, {-1, -1, -1, -1}};
+    uint32_t* d_order_ring[RING] = {}; size_t order_cap[RING] = {}; int order_grid_ring[RING] = {};
+    long long order_key_ring[RING][4];     // csky_create fills them with -1
     // cost-feedback schedule (mode 7): per-workgroup costs of the last launch -> heaviest-first order of the next one
     uint32_t* d_wg_cost = nullptr; uint32_t* d_lpt_order = nullptr; uint32_t* d_lpt_hist = nullptr; size_t lpt_cap = 0;
     uint32_t* d_heads = nullptr; int persistent = 1; int resident_wgs = 0;   // persistent launches: 2 ring slots x (8 per-XCD pop counters + exit counter)
-    bool lpt_valid[2] = {false, false}; long long lpt_key[2][11] = {{-1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1}, {-1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1}};
+    bool lpt_valid[RING] = {}; long long lpt_key[RING][11];   // csky_create fills the keys with -1
     // optional per-launch timing of the cloud kernel (csky_set_kernel_timing): HIP event pairs recorded around the launch on ITS stream
     bool kt_on = false; std::vector<hipEvent_t> kt_ev; int kt_count = 0;   // the event pool grows on demand (clouds_dev)
     uint8_t* d_composite = nullptr; size_t composite_cap = 0;              // grow-only scratch of csky_composite_sky
@@ -183,7 +188,7 @@ int clouds_dev(csky_ctx* c, const csky_cloud_params* p, int tile_w, const csky_b
         }
         const float lo = c->use_window ? c->win_lo : -1.0f, hi = c->use_window ? c->win_hi : 2.0f;
         // frame set-up on the prologue stream into the other constants slot (its last reader, the march two frames ago, must be done)
-        const int f = c->fc_cur ^ 1;
+        const int f = (c->fc_cur + 1) % RING;
         if (c->clouds_pending[f]) HIPCHK(c, hipStreamWaitEvent(c->pro, c->ev_clouds[f], 0));
         // cloud-type range of the weather map (texel values 0..255): all >= 128 or all <= 127 fixes the branch of the height gradient
         const int ctm = !c->use_window ? 0 : (c->w_rmin * 255.0 >= 127.5 ? 1 : (c->w_rmax * 255.0 <= 127.5 ? 2 : 0));
@@ -214,7 +219,10 @@ int clouds_dev(csky_ctx* c, const csky_cloud_params* p, int tile_w, const csky_b
         // the caller keeps two frames in flight on two streams (csky_set_frames_in_flight): the next frame's workgroups fill this
         // launch's tail, so fewer, longer wavefronts win (tools/share_matrix.py, ms per frame at 1/2, 1/4, 1/8, 1/16 of the frame):
         //   seg 1: 0.96 (s5) 0.52 (s7) 0.42 0.35    seg 2: 1.18 0.61 0.34 (s7) 0.29    seg 4: 1.27 0.75 0.39 0.22 (s7)
-        if (queued && seg == 0) seg = waves >= 6144 ? 1 : (waves >= 3072 ? 2 : (waves >= 768 ? 4 : 5));
+        // With three or four frames in flight (the rings are four deep) a 1/8 share is best marched as whole rays:
+        //   1/8 frame, cost feedback, x2 / x3 / x4:  seg 1 0.330 0.284 0.279   seg 2 0.313 0.352 0.355   (1/4 frame and larger: no gain over x2)
+        const int whole_from = c->frames_in_flight >= 3 ? 3072 : 6144;
+        if (queued && seg == 0) seg = waves >= whole_from ? 1 : (waves >= 3072 ? 2 : (waves >= 768 ? 4 : 5));
         auto_mode = waves >= 12288 ? 5 : (waves >= 768 ? 7 : 2);
     } else if (c->variant == 3) {
         if (queued && seg == 0) seg = waves >= 12288 ? 1 : (waves >= 6144 ? 2 : (waves >= 768 ? 4 : 5));
@@ -268,14 +276,14 @@ int clouds_dev(csky_ctx* c, const csky_cloud_params* p, int tile_w, const csky_b
     if (c->lpt_cap < need) {
         HIPCHK(c, hipDeviceSynchronize());                   // (re)allocation is rare; frames may be in flight on other streams
         (void)hipFree(c->d_wg_cost); (void)hipFree(c->d_lpt_order); c->d_wg_cost = c->d_lpt_order = nullptr; c->lpt_cap = 0;
-        c->lpt_valid[0] = c->lpt_valid[1] = false;
-        HIPCHK(c, hipMalloc(reinterpret_cast<void**>(&c->d_wg_cost), 2 * need * sizeof(uint32_t)));
-        HIPCHK(c, hipMalloc(reinterpret_cast<void**>(&c->d_lpt_order), 2 * need * sizeof(uint32_t)));
+        for (int k = 0; k < RING; k++) c->lpt_valid[k] = false;
+        HIPCHK(c, hipMalloc(reinterpret_cast<void**>(&c->d_wg_cost), RING * need * sizeof(uint32_t)));
+        HIPCHK(c, hipMalloc(reinterpret_cast<void**>(&c->d_lpt_order), RING * need * sizeof(uint32_t)));
         if (!c->d_lpt_hist) {
-            HIPCHK(c, hipMalloc(reinterpret_cast<void**>(&c->d_lpt_hist), 2 * 2048 * sizeof(uint32_t)));
-            HIPCHK(c, hipMemset(c->d_lpt_hist, 0, 2 * 2048 * sizeof(uint32_t)));
+            HIPCHK(c, hipMalloc(reinterpret_cast<void**>(&c->d_lpt_hist), RING * 2048 * sizeof(uint32_t)));
+            HIPCHK(c, hipMemset(c->d_lpt_hist, 0, RING * 2048 * sizeof(uint32_t)));
         }
-        HIPCHK(c, hipMemset(c->d_wg_cost, 0, 2 * need * sizeof(uint32_t)));       // the sort kernels leave both zeroed afterwards
+        HIPCHK(c, hipMemset(c->d_wg_cost, 0, RING * need * sizeof(uint32_t)));       // the sort kernels leave both zeroed afterwards
         c->lpt_cap = need;
     }
     uint32_t* const cost = c->d_wg_cost + (size_t)slot * c->lpt_cap;
@@ -332,15 +340,17 @@ int csky_create(csky_ctx** out, int device_id) {
     // (a HIGH-PRIORITY prologue stream was measured in round 2: whole frames with two frames in flight 1.78 -> 2.02 ms, one rank's 1/8 share
     // 0.329 -> 0.335 ms: the priority queue breaks the overlap of the two frame streams.  Plain stream.)
     if ((e = hipStreamCreateWithFlags(&c->pro, hipStreamNonBlocking)) != hipSuccess) return bail("hipStreamCreate", e);
-    for (int k = 0; k < 2; k++) {
+    for (int k = 0; k < RING; k++) {
+        for (long long& v : c->order_key_ring[k]) v = -1;
+        for (long long& v : c->lpt_key[k]) v = -1;
         if ((e = hipEventCreateWithFlags(&c->ev_setup[k], hipEventDisableTiming)) != hipSuccess) return bail("hipEventCreate", e);
         if ((e = hipEventCreateWithFlags(&c->ev_clouds[k], hipEventDisableTiming)) != hipSuccess) return bail("hipEventCreate", e);
         if ((e = hipMalloc(reinterpret_cast<void**>(&c->fc_ring[k]), sizeof(FrameConsts))) != hipSuccess) return bail("hipMalloc", e);
     }
     c->d_fc = c->fc_ring[0];
     if ((e = hipMalloc(reinterpret_cast<void**>(&c->d_stats), CSKY_STATS_WORDS * sizeof(unsigned long long))) != hipSuccess) return bail("hipMalloc", e);
-    if ((e = hipMalloc(reinterpret_cast<void**>(&c->d_heads), 32 * sizeof(uint32_t))) != hipSuccess) return bail("hipMalloc", e);
-    if ((e = hipMemset(c->d_heads, 0, 32 * sizeof(uint32_t))) != hipSuccess) return bail("hipMemset", e);   // persistent launches leave them zero
+    if ((e = hipMalloc(reinterpret_cast<void**>(&c->d_heads), RING * 16 * sizeof(uint32_t))) != hipSuccess) return bail("hipMalloc", e);
+    if ((e = hipMemset(c->d_heads, 0, RING * 16 * sizeof(uint32_t))) != hipSuccess) return bail("hipMemset", e);   // persistent launches leave them zero
     { int cus = 0; (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device_id); c->resident_wgs = (cus > 0 ? cus : 256) * cloud_resident_workgroups_per_cu(); }
     // A/B switch of tools/persistent_ab.sh: 0 = never, 1 = the policy of clouds_dev (default), 2 = every whole-ray launch
     if (const char* pe = getenv("CSKY_PERSISTENT")) c->persistent = atoi(pe);
@@ -354,9 +364,15 @@ void csky_destroy(csky_ctx* c) {
     (void)hipSetDevice(c->device);
     (void)hipDeviceSynchronize();                              // launches may sit on caller streams too
     void* ptrs[] = {c->d_shape, c->d_detail, c->d_weather, c->d_trans_h, c->d_trans_f, c->sky_h_ring[0], c->sky_h_ring[1], c->sky_f_ring[0], c->sky_f_ring[1],
-                    c->fc_ring[0], c->fc_ring[1], c->d_stats, c->d_frame, c->d_order_ring[0], c->d_order_ring[1], c->d_composite, c->d_raw_large, c->d_raw_small, c->d_raw_weather, c->d_bake_meta, c->d_detail_h, c->d_wg_cost, c->d_lpt_order, c->d_lpt_hist, c->d_heads};
+                    c->d_stats, c->d_frame, c->d_composite, c->d_raw_large, c->d_raw_small, c->d_raw_weather, c->d_bake_meta, c->d_detail_h, c->d_wg_cost, c->d_lpt_order, c->d_lpt_hist, c->d_heads};
     for (void* p : ptrs) if (p) (void)hipFree(p);
-    hipEvent_t evs[] = {c->ev0, c->ev1, c->ev_copy, c->ev_setup[0], c->ev_setup[1], c->ev_clouds[0], c->ev_clouds[1]};
+    for (int k = 0; k < RING; k++) {
+        if (c->fc_ring[k]) (void)hipFree(c->fc_ring[k]);
+        if (c->d_order_ring[k]) (void)hipFree(c->d_order_ring[k]);
+        if (c->ev_setup[k]) (void)hipEventDestroy(c->ev_setup[k]);
+        if (c->ev_clouds[k]) (void)hipEventDestroy(c->ev_clouds[k]);
+    }
+    hipEvent_t evs[] = {c->ev0, c->ev1, c->ev_copy};
     for (hipEvent_t ev : evs) if (ev) (void)hipEventDestroy(ev);
     for (hipEvent_t ev : c->kt_ev) if (ev) (void)hipEventDestroy(ev);
     if (c->pro) (void)hipStreamDestroy(c->pro);
@@ -521,7 +537,7 @@ int csky_set_schedule(csky_ctx* c, int mode) {
 }
 int csky_set_frames_in_flight(csky_ctx* c, int frames) {
     if (!c) return fail(nullptr, CSKY_ERR_INVALID, "csky_set_frames_in_flight: ctx is NULL");
-    if (frames < 1 || frames > 2) return fail(c, CSKY_ERR_INVALID, "csky_set_frames_in_flight: 1 or 2 (the rings are two deep)");
+    if (frames < 1 || frames > RING) return fail(c, CSKY_ERR_INVALID, "csky_set_frames_in_flight: 1 .. 4 (the rings are four deep)");
     c->frames_in_flight = frames; return CSKY_OK;
 }
 int csky_set_segments(csky_ctx* c, int segments) {

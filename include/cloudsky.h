@@ -129,8 +129,8 @@ int csky_render_clouds(csky_ctx* ctx, const csky_cloud_params* p, int tile_w, in
  * side.wait_stream(default) / default.wait_stream(side): the Python host class does exactly that (cloud_sky.py::_march_stream).
  * The LUT inputs of later calls are
  * always the context's internal copies, so the chain transmittance -> sky -> clouds needs no host hop.
- * The sky LUT and the per-frame constants derived from it are rendered on an internal "prologue" stream into two-deep
- * rings (like the reference's texture rings, sky_lut.gd:143-146): when frames are enqueued back to back, the prologue of
+ * The sky LUT and the per-frame constants derived from it are rendered on an internal "prologue" stream into rings (the
+ * LUT two deep: all its readers run on that stream; the per-frame constants four deep; like the reference's texture rings, sky_lut.gd:143-146): when frames are enqueued back to back, the prologue of
  * frame k+1 overlaps the march of frame k.  The library orders prologue -> march -> reuse of a ring slot with events, so a
  * caller only has to order its own reads of d_out behind `hip_stream`; csky_render_sky_lut_device ignores `hip_stream`. */
 int csky_render_sky_lut_device(csky_ctx* ctx, const csky_sky_params* p, void* hip_stream);
@@ -197,9 +197,10 @@ int csky_set_schedule(csky_ctx* ctx, int mode);
  * step ranges for one GPU's share of a split frame, 4 interleaved step sets for tile-sized launches such as the
  * reference's 96x96 temporal tiles), 1, 2, 4 (step ranges) or 5 (4 interleaved). */
 int csky_set_segments(csky_ctx* ctx, int segments);
-/* Policy hint for the automatic segment / schedule choice: 2 = the caller keeps two frames in flight by alternating two streams
- * between consecutive csky_render_*_device calls (always safe: per-frame state lives in two-deep rings ordered by events); the
- * next frame then fills the tail of this one and fewer, longer wavefronts are the better choice for partial frames.  Default 1.
+/* Policy hint for the automatic segment / schedule choice: n = 2..4: the caller keeps n frames in flight by rotating n streams
+ * between consecutive csky_render_*_device calls (always safe: per-frame state lives in four-deep rings ordered by events); the
+ * next frame then fills the tail of this one and fewer, longer wavefronts are the better choice for partial frames.  Default 1;
+ * 2 is the best choice for whole frames down to quarter frames, 3-4 only pay for one GPU's 1/8 share (0.32 -> 0.28 ms per frame).
  * The two streams must map to different hardware queues: the library sets GPU_MAX_HW_QUEUES=8 at load time unless the host already set it
  * (the HIP runtime's default of 4 loses part of the overlap); that works when the library is loaded before the process's first HIP call.
  * With 2, whole-ray launches of 12 Ki - 64 Ki wavefronts (a 2048x1024 frame, half of it) run in the persistent form: one workgroup per

@@ -49,12 +49,17 @@ def test_bench_line_contract_single_gpu():
     assert c["kind"] == "port" and c["cores"] >= 1 and c["value"] > 0 and "sample" in c
 
 
-def test_bench_two_ranks_on_one_gpu_through_gloo():
+@pytest.mark.parametrize("fif", [None, 4])
+def test_bench_two_ranks_on_one_gpu_through_gloo(fif):
+    """fif = 4: the buffer-set rotation of small rank shares (the default at N = 8), steps chosen so that the drain starts mid-rotation."""
     env = dict(os.environ, CSKY_BENCH_ONE_GPU_DEBUG="1")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", str(_free_port()),
-           os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "4", "--warmup", "1", "--no-cpu-baseline"]
+           os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "4" if fif is None else "7", "--warmup", "1", "--no-cpu-baseline"]
+    if fif is not None:
+        cmd += ["--frames-in-flight", str(fif)]
     out = subprocess.run(cmd, capture_output=True, text=True, cwd=ROOT, env=env, timeout=600)
     assert out.returncode == 0, (out.stdout[-1500:], out.stderr[-2500:])
     d = _last_json(out.stdout)
     assert d["n_gpus"] == 2 and d["scaling"] == "strong" and d["config"]["finite"] is True and d["config"]["parallelism"].startswith("bands2")
+    assert d["config"]["frames_in_flight"] == (2 if fif is None else fif)
     assert "gathered 2-rank frame vs single-rank frame" in out.stderr             # bench.py compared the gathered frame with a single-context render

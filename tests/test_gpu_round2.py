@@ -331,3 +331,50 @@ def test_persistent_launch_form_matches_plain_launches(pkg, noise, gpu_ctx, orac
         assert st["primary_samples"] == ref_stats["primary_samples"] and st["incloud_samples"] == ref_stats["incloud_samples"]
     finally:
         ctx.close()
+
+
+@pytest.mark.parametrize("share", [1, 8])
+def test_four_frames_in_flight_rotate_the_four_deep_rings(pkg, noise, gpu_ctx, oracle, share):
+    """csky_set_frames_in_flight(3 / 4): consecutive frames on 3 / 4 rotating streams (what bench.py does for a 1/8 rank share).  Frame
+    constants, launch orders, cost feedback and pop counters live in four-deep rings ordered by events: every frame must be byte-identical
+    to the one-frame-at-a-time render, with DIFFERENT suns in flight at once (a slot reused too early would mix them up)."""
+    import torch
+    W, H = 2048, 1024
+    suns = [(1, 1, 0), (0.2, 1, 0.3), (-1, 0.4, 0.5), (0.1, 0.3, -1), (0.7, 0.2, 0.1)]
+    bands = (8, 3 % share, share, H // 8 // share)
+    rows = bands[3] * 8
+    gpu_ctx.set_march(128, 6); gpu_ctx.set_segments(0); gpu_ctx.set_schedule(-1); gpu_ctx.set_frames_in_flight(1)
+    s0 = torch.cuda.Stream()
+    refs = []
+    for sun in suns:
+        o = torch.zeros((rows, W, 4), dtype=torch.int16, device="cuda")
+        torch.cuda.synchronize()
+        gpu_ctx.set_segments(1)                                               # whole rays: the segment count must not differ between the two regimes
+        gpu_ctx.render_sky_lut_device(norm(sun), 200, 100, s0.cuda_stream)
+        gpu_ctx.render_clouds_device(oracle.default_params(W, H, sun), W, bands, o.data_ptr(), W * 8, s0.cuda_stream)
+        s0.synchronize()
+        refs.append(o.cpu().numpy().view(np.uint16).copy())
+    assert all(r.any() for r in refs) and (refs[0] != refs[1]).any()
+    try:
+        for fif in (3, 4):
+            gpu_ctx.set_frames_in_flight(fif)
+            streams = [torch.cuda.Stream() for _ in range(fif)]
+            outs = [torch.zeros((rows, W, 4), dtype=torch.int16, device="cuda") for _ in range(fif)]
+            torch.cuda.synchronize()
+            which = [None] * fif
+            for k in range(3 * fif + 2):
+                i = k % fif
+                if which[i] is not None:                                      # the frame that used this buffer set fif frames ago
+                    streams[i].synchronize()
+                    assert (outs[i].cpu().numpy().view(np.uint16) == refs[which[i]]).all(), (share, fif, k)
+                sun = suns[k % len(suns)]
+                gpu_ctx.render_sky_lut_device(norm(sun), 200, 100, streams[i].cuda_stream)
+                gpu_ctx.render_clouds_device(oracle.default_params(W, H, sun), W, bands, outs[i].data_ptr(), W * 8, streams[i].cuda_stream)
+                which[i] = k % len(suns)
+            torch.cuda.synchronize()
+            for i in range(fif):
+                assert (outs[i].cpu().numpy().view(np.uint16) == refs[which[i]]).all(), (share, fif, "drain", i)
+        with pytest.raises(pkg.CloudSkyError):
+            gpu_ctx.set_frames_in_flight(5)
+    finally:
+        gpu_ctx.set_frames_in_flight(1); gpu_ctx.set_segments(0)

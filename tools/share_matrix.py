@@ -13,20 +13,21 @@ p = np.array([W, H, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0.270588, 0.188235, 0.027451, 
 ctx = gvcd_amd.Context(0)
 ctx.set_noise(*gvcd_amd.assets.load_default_noise())
 ctx.render_transmittance(256, 64)
-pool = [torch.cuda.Stream() for _ in range(3)]
+NS = [int(a) for a in os.environ.get("NS", "1,2").split(",")]   # frames in flight to try (the rings are four deep)
+pool = [torch.cuda.Stream() for _ in range(max(NS))]
 for share in [int(a) for a in sys.argv[1:]] or (2, 4, 8):
     bands = (8, 0, share, H // 8 // share)
-    outs = [torch.zeros((bands[3] * 8, W, 4), dtype=torch.int16, device="cuda") for _ in range(3)]
+    outs = [torch.zeros((bands[3] * 8, W, 4), dtype=torch.int16, device="cuda") for _ in range(max(NS))]
     for seg in (0, 1, 2, 4):                                   # 0 = the library's automatic choice
         row = []
         for sched in ((-1,) if seg == 0 else (5, 7)):
-            for ns in (1, 2):
+            for ns in NS:
                 ctx.set_segments(seg); ctx.set_schedule(sched); ctx.set_frames_in_flight(ns)
                 def step(k):
                     i = k % ns
                     ctx.render_sky_lut_device(s, 200, 100, pool[i].cuda_stream)
                     ctx.render_clouds_device(p, W, bands, outs[i].data_ptr(), W * 8, pool[i].cuda_stream)
-                for k in range(9):
+                for k in range(12):
                     step(k)
                 torch.cuda.synchronize()
                 t0 = time.perf_counter()
