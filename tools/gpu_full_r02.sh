@@ -22,7 +22,7 @@ make -C godot-volumetric-cloud-demo-v2_amd/csrc timeline -s > /dev/null 2>&1
 ( echo "== whole frame, static XCD-row schedule (mode 5)"; CSKY_LIBRARY=$R/godot-volumetric-cloud-demo-v2_amd/libcloudsky_timeline.so python tools/timeline.py 1 5
   echo "== one rank's 1/8 of the frame (automatic policy)"; CSKY_LIBRARY=$R/godot-volumetric-cloud-demo-v2_amd/libcloudsky_timeline.so python tools/timeline.py 8 -1 ) 2>&1 | grep -v amdgpu.ids > $O/occupancy_timeline.txt
 rm -f godot-volumetric-cloud-demo-v2_amd/libcloudsky_timeline.so
-timeout -s KILL 200 python tools/share_matrix.py 1 2 4 8 2>/dev/null > $O/share_matrix.txt
+NS=1,2,3,4 timeout -s KILL 300 python tools/share_matrix.py 1 2 4 8 2>/dev/null > $O/share_matrix.txt
 timeout -s KILL 120 python tools/two_streams.py -1 2>/dev/null > $O/two_streams.txt
 rm -rf $O/bench_trace $O/bench_trace_fif1
 ls -la $O
