@@ -417,15 +417,21 @@ __device__ __forceinline__ MarchOut march_compact(const TexSet& T, const FrameCo
     int count = 0, cs = 0;                                    // queued samples / steps owning them (uniform)
     if (!__any(live)) return o;
     for (int i = 0; i < step_begin; i++) advance(px, py, pz, ray.sx, ray.sy, ray.sz);   // segment start: replay the fp32 additions (:173)
+    int end = step_end;                                       // shrinks when the whole wavefront has left the height window
     for (int i = step_begin;;) {
         // ---- A: one primary sample per lane (none once the segment is exhausted and only carried samples remain)
-        if (i < step_end) {
+        if (i < end) {
             float t = 0.0f, hf = 0.0f;
             if (live) {
                 advance(px, py, pz, ray.sx, ray.sy, ray.sz);                                                   // :173
                 hf = height_fraction(length3_shell(px, py, pz));                                               // :175
                 t = CSKY_PRIMARY_SAMPLE(T, fc, px, py, pz, hf, fc.wpos_x, fc.wpos_y, 0, 0);                    // :174, :177
             }
+            // Exact early end of the march: a ray starts on the inner shell and |p| only grows along it (>= 20 m per step even for a
+            // grazing ray, against 0.5 m of fp32 noise), so once EVERY live ray of the wavefront is above the height window
+            // (density() == 0 there, cloud_core.h) all remaining samples are 0 too.  Checked every 4th step: one compare + ballot.
+            // 21 % of the wave-steps of the headline view lie above the window (tools/stage_trace).
+            if ((i & 3) == 3 && !__any(live && !(hf >= fc.hf_hi))) end = i + 1;
             const bool have = t > 0.0f;                                                                        // :184
             const unsigned long long m = __ballot(have);
             if (m != 0ull) {
@@ -437,7 +443,7 @@ __device__ __forceinline__ MarchOut march_compact(const TexSet& T, const FrameCo
             }
             i++;
         }
-        const bool last = i >= step_end;
+        const bool last = i >= end;
         if (count == 0) { if (last) break; continue; }
         if (count < 64 && !last) continue;
         // ---- B: the light march of the first n = min(count, 64) queued samples, one per lane
