@@ -173,3 +173,28 @@ def test_set_noise_mips_uses_the_callers_chains(pkg, noise, gpu_ctx):
             ctx.set_noise_mips(large, small, weather)                        # level-0 arrays are not chains
     finally:
         ctx.close()
+
+
+def test_import_entry_points_refuse_bad_arguments_without_a_gpu(pkg, tmp_path):
+    """Error behaviour of the new C-ABI entry points (no compute): codes, not crashes; texts through csky_assets_last_error."""
+    import ctypes as C
+    L = pkg.lib()
+    buf = (C.c_uint8 * 64)()
+    assert L.csky_decode_bc7(None, 4, 4, buf) == -1 and L.csky_decode_bc7(buf, 0, 4, buf) == -1 and L.csky_decode_bc7(buf, 4, 4, None) == -1
+    assert b"decode_bc7" in L.csky_assets_last_error()
+    w, h, d, n = C.c_int(), C.c_int(), C.c_int(), C.c_int()
+    assert L.csky_load_ctex(None, C.byref(w), C.byref(h), C.byref(n), None, 0) == -4
+    assert L.csky_load_ctex3d(b"/nonexistent/x.ctex3d", C.byref(w), C.byref(h), C.byref(d), C.byref(n), None, 0) == -4
+    p = str(tmp_path / "huge.ctex")                                          # absurd dimensions / mip counts are refused before any allocation
+    write_ctex(p, struct.pack("<IHHII", 0, 65535, 65535, 0, FMT_RGBA8))
+    assert L.csky_load_ctex(p.encode(), C.byref(w), C.byref(h), C.byref(n), None, 0) == -4 and b"unsupported image" in L.csky_assets_last_error()
+    write_ctex(p, struct.pack("<IHHII", 0, 8, 8, 40, FMT_RGBA8))
+    assert L.csky_load_ctex(p.encode(), C.byref(w), C.byref(h), C.byref(n), None, 0) == -4
+    write_ctex3d(p, 0, [], 0)
+    assert L.csky_load_ctex3d(p.encode(), C.byref(w), C.byref(h), C.byref(d), C.byref(n), None, 0) == -4 and b"bad header" in L.csky_assets_last_error()
+    small = np.zeros(16, np.uint8)                                          # caller buffer too small: refused, nothing written past it
+    write_ctex(p, image_record(4, 4, FMT_RGBA8, [bytes(range(64))]))
+    assert L.csky_load_ctex(p.encode(), C.byref(w), C.byref(h), C.byref(n), small.ctypes.data_as(C.c_void_p), small.nbytes) == -1
+    assert not small.any() and (w.value, h.value, n.value) == (4, 4, 1)
+    assert L.csky_set_noise_mips(None, buf, buf, buf) == -1                   # NULL context
+    assert L.csky_multi_set_noise_mips(None, buf, buf, buf) == -1 and L.csky_multi_set_frames_in_flight(None, 2) == -1
