@@ -301,7 +301,7 @@ CSKY_HD void shape_tap(const TexSet& T, int lvl, float sx, float sy, float sz, f
 #else
     (void)base;
     const uint4* __restrict__ t = reinterpret_cast<const uint4*>(sb + ((shape_level_offset(lvl) + shape_cell_offset((uint32_t)x0, (uint32_t)y0, (uint32_t)z0, sh)) << 5));
-    const uint4 tr = t[0], tf = t[1];
+    const uint4 tr = t[0], tf = t[1];             // (marking these loads non-temporal to spare the L1 for the other textures: 1.70 -> 2.48 ms; the cells ARE re-used)
     r = fmaf(az, fmaf(ay, lerp_h(tr.w, ax), lerp_h(tr.z, ax)), fmaf(ay, lerp_h(tr.y, ax), lerp_h(tr.x, ax))) * (1.0f / 255.0f);
     fbm = fmaf(az, fmaf(ay, lerp_h(tf.w, ax), lerp_h(tf.z, ax)), fmaf(ay, lerp_h(tf.y, ax), lerp_h(tf.x, ax))) * (1.0f / (8.0f * 255.0f));
 #endif
