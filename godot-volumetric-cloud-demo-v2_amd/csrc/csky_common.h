@@ -56,6 +56,9 @@ constexpr int DETAIL_CHAIN_TEXELS = 32768 + 4096 + 512 + 64 + 8 + 1;   // all si
 //                                                                                                 L1 hit 72.6 % and L2 hit 78.0 % unchanged
 //   4x4x4-cell bricks (2 KB, what texture hardware does)                                          2.081 / 1.819 ms: L1 hit unchanged (72.6 %), L2 hit
 //                                                                                                 77.9 -> 78.2 %, fabric bytes -1.5 %, VALU +5.2 %
+//   the two channels' cells in two planes of dense 16-byte cells instead of one 32-byte texel                2.22 / 1.97 ms vs 2.03 / 1.71: a tap then
+//                                                                                                 touches two cache lines instead of one
+//   (and marking the shape loads non-temporal to spare the L1 for the other textures: 2.48 ms per frame: the cells ARE re-used)
 // The L1 hit rate is set by the 4 cells a 128-byte line holds and by how far apart a quad's rays land, not by the slice strides; the kernel
 // is VALU-issue bound (bench.py roofline), so the bricks' six extra half-rate integer instructions per tap cost more than they save.
 #if CSKY_SHAPE_POLY == 1
