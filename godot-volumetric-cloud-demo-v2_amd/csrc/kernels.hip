@@ -748,6 +748,7 @@ __device__ __forceinline__ void render_block(TexSet T, const FrameConsts* __rest
     const int slab = (int)logical / tiles_x, bx = (int)logical - slab * tiles_x;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int tile = tile_of_wave >= 0 ? tile_of_wave : wave / SEG, seg = tile_of_wave >= 0 ? 0 : wave - tile * SEG;   // tile_of_wave: SEG == 1 only
+    // (lanes in Morton order or in 2x2 quads inside the tile instead of rows of 8: 1.701 / 1.700 vs 1.702 ms per frame, no difference)
     const int gx = bx * BW + tile * 8 + (lane & 7);
     const int lr = slab * 8 + (lane >> 3);
     const bool valid = gx < G.tile_w && lr < local_rows;
