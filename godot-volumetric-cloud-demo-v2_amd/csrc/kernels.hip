@@ -427,8 +427,9 @@ __device__ __forceinline__ MarchOut march_compact(const TexSet& T, const FrameCo
                 hf = height_fraction(length3_shell(px, py, pz));                                               // :175
                 t = CSKY_PRIMARY_SAMPLE(T, fc, px, py, pz, hf, fc.wpos_x, fc.wpos_y, 0, 0);                    // :174, :177
             }
-            // Exact early end of the march: a ray starts on the inner shell and |p| only grows along it (>= 20 m per step even for a
-            // grazing ray, against 0.5 m of fp32 noise), so once EVERY live ray of the wavefront is above the height window
+            // Exact early end of the march: a ray starts on the inner shell and |p| only grows along it (>= 14 m per step at 128 steps even
+            // for a grazing ray, 1.7 m at 1024 steps, against 0.5 m of fp32 noise; every ray of the C3 / C5 frames is walked by
+            // tests/test_hostsim_core.py), so once EVERY live ray of the wavefront is above the height window
             // (density() == 0 there, cloud_core.h) all remaining samples are 0 too.  Checked every 4th step: one compare + ballot.
             // 21 % of the wave-steps of the headline view lie above the window (tools/stage_trace).
             if ((i & 3) == 3 && !__any(live && !(hf >= fc.hf_hi))) end = i + 1;

@@ -4,6 +4,7 @@
 // never a render fallback: the product has no CPU path.
 #include <cstdint>
 #include <cstring>
+#include <cmath>
 #include <vector>
 #include "../../godot-volumetric-cloud-demo-v2_amd/csrc/cloud_core.h"
 #include "../../godot-volumetric-cloud-demo-v2_amd/csrc/lut_core.h"
@@ -108,6 +109,38 @@ void hostsim_clouds(const uint8_t* large_chain, const uint8_t* small_chain, cons
         }
     }
     if (incloud) *incloud = ic;
+}
+
+// Precondition of the march's exact early end (kernels.hip::march_compact): a ray starts on the inner shell and its radius only grows, so once
+// a sample is at or above the top of the height window every later sample of that ray is too.  Walks every ray of a W x H frame with the
+// kernel's own ray set-up and fp32 position updates.  out[0] = above-horizon rays, out[1] = rays whose height-fraction sequence ever
+// decreases, out[2] = samples with hf < hi AFTER a sample with hf >= hi, out[3] = smallest radius gain of a step in metres (unclamped).
+void hostsim_march_monotonic(const float params[28], int primary_steps, int W, int H, float hi, double out[4]) {
+    CloudParams P; memcpy(&P, params, sizeof P);
+    FrameConsts fc;
+    const float4 sky1 = {0.0f, 0.0f, 0.0f, 0.0f};
+    frame_setup(P, &sky1, 1, 1, primary_steps, 6, 0.0f, -1.0f, 2.0f, fc);
+    double rays = 0, nonmono = 0, back = 0, min_gain = 1e30;
+    for (int gy = 0; gy < H; gy++) for (int gx = 0; gx < W; gx++) {
+        Ray ray = ray_setup(fc, gx, gy);
+        if (!ray.above) continue;
+        rays++;
+        float px = ray.px, py = ray.py, pz = ray.pz, prev_hf = -1.0f;
+        double prev_r = std::sqrt((double)px * px + (double)py * py + (double)pz * pz);
+        bool seen = false, bad = false;
+        for (int i = 0; i < primary_steps; i++) {
+            advance(px, py, pz, ray.sx, ray.sy, ray.sz);
+            const float hf = height_fraction(length3_shell(px, py, pz));
+            const double r = std::sqrt((double)px * px + (double)py * py + (double)pz * pz);
+            if (r - prev_r < min_gain) min_gain = r - prev_r;
+            if (hf < prev_hf) bad = true;
+            if (seen && hf < hi) back++;
+            if (hf >= hi) seen = true;
+            prev_hf = hf; prev_r = r;
+        }
+        if (bad) nonmono++;
+    }
+    out[0] = rays; out[1] = nonmono; out[2] = back; out[3] = min_gain;
 }
 
 // sample_density() vs sample_density_eager() (all fetches of a sample issued up front) on n sample points of the default frame set-up:

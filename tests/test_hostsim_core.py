@@ -100,6 +100,24 @@ def test_height_window_reject_is_exact(hostsim, pkg, oracle, noise, o_skies):
             assert ia == 0
 
 
+def test_radius_only_grows_along_a_ray_precondition_of_the_early_march_end(hostsim, oracle):
+    """kernels.hip::march_compact ends a wavefront's march once every live ray is at or above the top of the height window.  That is exact
+    iff no ray ever comes back below a height fraction it has reached.  Every above-horizon ray of the headline frame (2048x1024, 128 steps),
+    of the 4096x2048 frame and of a small frame, walked with the kernel's own ray set-up and fp32 position updates: the height fraction
+    never decreases, no sample falls back below the window top (default 0.788, and other levels), and the smallest radius gain of any step
+    (a grazing ray's first step) is 14.6 m at 128 steps (1.7 m at the 1024-step maximum) against ~0.5 m of fp32 position noise."""
+    out = np.zeros(4, np.float64)
+    for (W, H, steps) in ((2048, 1024, 128), (4096, 2048, 128), (96, 48, 64), (512, 256, 64), (512, 256, 1024)):   # 1024 = csky_set_march's maximum
+        p = np.ascontiguousarray(oracle.default_params(W, H, (1, 1, 0)), np.float32)
+        for hi in (0.788, 0.5, 0.95, 0.1):
+            if W > 2048 and hi != 0.788:
+                continue
+            hostsim.hostsim_march_monotonic(P(p), steps, W, H, C.c_float(hi), P(out))
+            rays, nonmono, back, gain = out
+            assert rays == (W - 1) * (H - 1) and nonmono == 0 and back == 0, (W, H, hi, out.tolist())
+            assert gain > (10.0 if steps <= 128 else 1.0), (W, H, gain)     # 14.6 m at 128 steps, 1.7 m at 1024
+
+
 def test_lds_detail_tap_path_matches(hostsim, pkg, oracle, noise, o_skies):
     """The detail tap of the "lds" kernel variant (eight unpacked fp16 reads, a*(1-f) + b*f) agrees with the pre-differenced
     oct-packed gather (a + f*(b-a)) to rounding: same in-cloud decisions, images within 1 fp16 ulp."""
