@@ -1,0 +1,233 @@
+#!/usr/bin/env python
+"""isa_census.py -- static census of a gfx950 kernel's ISA: basic blocks, loops, instruction kinds per block, scratch traffic.
+
+    python tools/isa_census.py [--kernel SUBSTR] [--asm FILE.s] [--blocks] [--json OUT]
+
+Without --asm the device assembly of csrc/kernels.hip is produced with the Makefile's flags (hipcc -save-temps, gfx950, with
+-gline-tables-only so that every instruction carries the source line it came from).  The census is STATIC: one entry per basic
+block with the histogram of its instructions by issue class and the loop nest it sits in.  tools/census_weights.py combines it
+with the dynamic block counts measured on the GPU (the census build of the kernel) into the VALU-issue roofline of bench.py.
+
+Issue classes (cycles per wave64 instruction per SIMD, measured on gfx950: profiles/r02/issue_cost_calibration.json):
+  full  : v_fma_f32 v_fmac v_mul v_add v_sub v_mov v_and v_or v_xor v_add_u32 v_sub_u32 ...
+  half  : v_fma_mix, v_max/min/med3, shifts, v_lshl_or/v_and_or/v_bfe/v_bfi/v_lshl_add, v_cvt_*, v_fract/floor, v_cmp_*, v_cndmask,
+          v_mul_lo_u32, v_mad_u32_u24, v_pk_*
+  trans : v_rcp v_exp v_log v_sqrt v_rsq v_sin v_cos
+  other kinds: salu, smem, vmem_load, vmem_store, scratch, lds, branch, wait (s_waitcnt / s_nop / s_sleep), misc
+"""
+import argparse
+import collections
+import json
+import os
+import re
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+CSRC = os.path.join(ROOT, "godot-volumetric-cloud-demo-v2_amd", "csrc")
+
+FULL = ("v_fma_f32", "v_fmac_f32", "v_mul_f32", "v_add_f32", "v_sub_f32", "v_subrev_f32", "v_mov_b32", "v_and_b32", "v_or_b32", "v_xor_b32",
+        "v_add_u32", "v_sub_u32", "v_subrev_u32", "v_add_co_u32", "v_addc_co_u32", "v_sub_co_u32", "v_subb_co_u32", "v_not_b32", "v_mac_f32", "v_madak_f32", "v_madmk_f32",
+        "v_fmaak_f32", "v_fmamk_f32", "v_add3_u32", "v_or3_b32", "v_xad_u32", "v_mul_legacy_f32", "v_accvgpr_write_b32", "v_accvgpr_read_b32",
+        "v_mov_b64", "v_add_i32", "v_sub_i32", "v_bfrev_b32", "v_ldexp_f32", "v_mul_u32_u24", "v_mul_i32_i24", "v_mad_f32", "v_xnor_b32")
+TRANS = ("v_rcp_f32", "v_exp_f32", "v_log_f32", "v_sqrt_f32", "v_rsq_f32", "v_sin_f32", "v_cos_f32", "v_rcp_iflag_f32", "v_rcp_f64", "v_rsq_f64", "v_sqrt_f64")
+
+
+def classify(mn):
+    if mn.startswith("v_"):
+        base = mn
+        for suf in ("_e32", "_e64", "_dpp", "_sdwa", "_e64_dpp"):
+            if base.endswith(suf):
+                base = base[: -len(suf)]
+        if base in TRANS:
+            return "trans"
+        if base in FULL:
+            return "full"
+        if base in ("v_readfirstlane_b32", "v_readlane_b32", "v_writelane_b32"):
+            return "lane"
+        if base.endswith("_f64") or base.startswith("v_mul_hi") or base in ("v_mad_u64_u32", "v_mad_i64_i32"):
+            return "quarter"
+        return "half"          # everything else measured at 4.1 cycles: v_fma_mix, min/max/med3, shifts, bit-field ops, cvt, fract, cmp, cndmask, mul_lo, pk
+    if mn.startswith("s_load") or mn.startswith("s_buffer_load") or mn.startswith("s_store") or mn.startswith("s_dcache") or mn.startswith("s_memtime") or mn.startswith("s_memrealtime"):
+        return "smem"
+    if mn.startswith("s_cbranch") or mn in ("s_branch", "s_setpc_b64", "s_swappc_b64", "s_endpgm", "s_call_b64"):
+        return "branch"
+    if mn in ("s_waitcnt", "s_nop", "s_sleep", "s_barrier", "s_waitcnt_vscnt", "s_waitcnt_depctr", "s_setprio", "s_sethalt"):
+        return "wait"
+    if mn.startswith("s_"):
+        return "salu"
+    if mn.startswith("scratch_"):
+        return "scratch"
+    if mn.startswith("global_load") or mn.startswith("buffer_load") or mn.startswith("flat_load"):
+        return "vmem_load"
+    if mn.startswith("global_store") or mn.startswith("buffer_store") or mn.startswith("flat_store"):
+        return "vmem_store"
+    if mn.startswith("global_atomic") or mn.startswith("buffer_atomic") or mn.startswith("flat_atomic"):
+        return "vmem_atomic"
+    if mn.startswith("ds_"):
+        return "lds"
+    if mn.startswith("buffer_") or mn.startswith("global_"):
+        return "misc"
+    return "misc"
+
+
+def build_asm(out_dir, extra=()):
+    os.makedirs(out_dir, exist_ok=True)
+    flags = ["-O3", "-std=c++17", "-fPIC", "-fno-slp-vectorize", "--offload-arch=gfx950", "-Wno-unused-function", "-Wno-unknown-pragmas", "-Wno-pass-failed",
+             "-gline-tables-only", "-save-temps", "-c", os.path.join(CSRC, "kernels.hip"), "-o", os.path.join(out_dir, "kernels.o")]
+    subprocess.check_call(["/opt/rocm/bin/hipcc"] + list(extra) + flags, cwd=out_dir, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+    return os.path.join(out_dir, "kernels-hip-amdgcn-amd-amdhsa-gfx950.s")
+
+
+LABEL = re.compile(r"^([.\w$]+):")
+LOC = re.compile(r"^\s*\.loc\s+(\d+)\s+(\d+)")
+FILE_RE = re.compile(r'^\s*\.file\s+(\d+)\s+"([^"]*)"(?:\s+"([^"]*)")?')
+INSN = re.compile(r"^\s+([a-z_][a-z0-9_]*)\b(.*)$")
+
+
+def parse_kernel(asm_path, want):
+    """-> (name, blocks).  blocks: list of dicts {label, insns: [(mnemonic, operands, file, line)], succ: [labels], falls: bool}"""
+    files = {}
+    lines = open(asm_path).read().split("\n")
+    start = None
+    name = None
+    for i, ln in enumerate(lines):
+        m = FILE_RE.match(ln)
+        if m:
+            files[int(m.group(1))] = os.path.basename(m.group(3) or m.group(2))
+        m = LABEL.match(ln)
+        if m and start is None and want in m.group(1) and not m.group(1).startswith("."):
+            start, name = i, m.group(1)
+    if start is None:
+        raise SystemExit("kernel containing %r not found in %s" % (want, asm_path))
+    blocks = []
+    cur = {"label": name, "insns": [], "succ": [], "falls": True}
+    loc = (None, None)
+    for ln in lines[start + 1:]:
+        if ln.startswith(".Lfunc_end") or ln.lstrip().startswith(".end_amdhsa_kernel"):
+            break
+        m = LABEL.match(ln)
+        if m:
+            lab = m.group(1)
+            if lab.startswith(".LBB") or lab.startswith("BB") or lab.startswith(".LBB"):
+                if cur["insns"] or cur["label"] == name:
+                    blocks.append(cur)
+                cur = {"label": lab, "insns": [], "succ": [], "falls": True}
+            continue
+        m = LOC.match(ln)
+        if m:
+            loc = (files.get(int(m.group(1)), m.group(1)), int(m.group(2)))
+            continue
+        if ln.lstrip().startswith(".") or ln.lstrip().startswith(";") or not ln.strip():
+            continue
+        m = INSN.match(ln)
+        if not m:
+            continue
+        mn, ops = m.group(1), m.group(2).split(";")[0].strip()
+        cur["insns"].append((mn, ops, loc[0], loc[1]))
+        if mn.startswith("s_cbranch"):
+            cur["succ"].append(ops.strip())
+            # a conditional branch ends the block: what follows is a new (fall-through) block
+            blocks.append(cur)
+            cur = {"label": cur["label"] + "+%d" % len(blocks), "insns": [], "succ": [], "falls": True}
+        elif mn == "s_branch":
+            cur["succ"].append(ops.strip()); cur["falls"] = False
+            blocks.append(cur)
+            cur = {"label": cur["label"] + "+%d" % len(blocks), "insns": [], "succ": [], "falls": True}
+        elif mn == "s_endpgm":
+            cur["falls"] = False
+            blocks.append(cur)
+            cur = {"label": cur["label"] + "+%d" % len(blocks), "insns": [], "succ": [], "falls": True}
+    if cur["insns"]:
+        blocks.append(cur)
+    blocks = [b for b in blocks if b["insns"] or b["succ"]]
+    return name, blocks
+
+
+def loops_of(blocks):
+    """natural loops from back edges in layout order (a branch to a label at or before the branching block).  -> depth per block index,
+    list of (head index, tail index)"""
+    index = {}
+    for i, b in enumerate(blocks):
+        index.setdefault(b["label"], i)
+    back = []
+    for i, b in enumerate(blocks):
+        for s in b["succ"]:
+            j = index.get(s)
+            if j is not None and j <= i:
+                back.append((j, i))
+    depth = [0] * len(blocks)
+    for h, t in back:
+        for k in range(h, t + 1):
+            depth[k] += 1
+    # merged loops with the same head count once
+    heads = collections.defaultdict(int)
+    for h, t in back:
+        heads[h] = max(heads[h], t)
+    depth = [0] * len(blocks)
+    for h, t in heads.items():
+        for k in range(h, t + 1):
+            depth[k] += 1
+    return depth, sorted(heads.items())
+
+
+def census(blocks):
+    depth, loops = loops_of(blocks)
+    out = []
+    for i, b in enumerate(blocks):
+        hist = collections.Counter()
+        kinds = collections.Counter()
+        lines = collections.Counter()
+        for mn, ops, f, l in b["insns"]:
+            c = classify(mn)
+            hist[c] += 1
+            base = re.sub(r"_(e32|e64|dpp|sdwa)$", "", mn)
+            kinds[base] += 1
+            if f:
+                lines[(f, l)] += 1
+        out.append({"index": i, "label": b["label"], "depth": depth[i], "n": len(b["insns"]), "classes": dict(hist), "kinds": dict(kinds),
+                    "lines": sorted(("%s:%d" % k, v) for k, v in lines.items()), "succ": b["succ"], "falls": b["falls"]})
+    return out, loops
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--kernel", default="clouds_kernelILi3ELi1E")
+    ap.add_argument("--asm", default=None)
+    ap.add_argument("--blocks", action="store_true", help="print every basic block")
+    ap.add_argument("--json", default=None)
+    ap.add_argument("--define", action="append", default=[])
+    args = ap.parse_args()
+    asm = args.asm or build_asm("/tmp/isa_census", ["-D" + d for d in args.define])
+    name, blocks = parse_kernel(asm, args.kernel)
+    cen, loops = census(blocks)
+    tot = collections.Counter()
+    for b in cen:
+        for k, v in b["classes"].items():
+            tot[k] += v
+    print("kernel %s: %d basic blocks, %d instructions, %d loops" % (name[:60], len(cen), sum(b["n"] for b in cen), len(loops)))
+    print("static totals:", dict(tot))
+    print("loops (head..tail block, depth of head, instructions inside):")
+    for h, t in loops:
+        n = sum(cen[k]["n"] for k in range(h, t + 1))
+        sc = sum(cen[k]["classes"].get("scratch", 0) for k in range(h, t + 1))
+        print("  blocks %4d..%4d depth %d  %5d instructions  scratch %d   first line %s" % (h, t, cen[h]["depth"], n, sc, cen[h]["lines"][0][0] if cen[h]["lines"] else "?"))
+    print("scratch instructions by loop depth:")
+    sd = collections.Counter()
+    for b in cen:
+        if b["classes"].get("scratch"):
+            sd[b["depth"]] += b["classes"]["scratch"]
+    print("  ", dict(sd))
+    for b in cen:
+        if b["classes"].get("scratch"):
+            ops = [(mn, ops, l) for (mn, ops, f, l) in blocks[b["index"]]["insns"] if mn.startswith("scratch_")]
+            print("   block %4d depth %d: %s" % (b["index"], b["depth"], ", ".join("%s %s @%s" % (m.replace("scratch_", ""), o.split(",")[0 if m.startswith("scratch_load") else 1].strip(), l) for m, o, l in ops)))
+    if args.blocks:
+        for b in cen:
+            print("%4d %-16s d%d n%4d %s  lines %s" % (b["index"], b["label"][-16:], b["depth"], b["n"], b["classes"], ",".join(k for k, _ in b["lines"][:6])))
+    if args.json:
+        json.dump({"kernel": name, "blocks": cen, "loops": loops}, open(args.json, "w"))
+
+
+if __name__ == "__main__":
+    main()
