@@ -112,6 +112,139 @@ def cpu_baseline(large, small, weather, params, sun, W, H, primary, light, every
                               "sample": "every 16th 8-row band, columns 0..%d (%d rays, %.2f s)" % (w1 - 1, nb1 * 8 * w1, dt1)}}
 
 
+def free_port():
+    import socket
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as so:
+        so.bind(("127.0.0.1", 0))
+        return so.getsockname()[1]
+
+
+def self_launch(n):
+    """`python bench.py --gpus N` without a launcher around it: start the N ranks ourselves (one process per GPU, torch.distributed.run on
+    127.0.0.1) with the same arguments and pass rank 0's JSON line through.  The driver's own `python -m torch.distributed.run ... bench.py`
+    command sets WORLD_SIZE and never comes here."""
+    import subprocess
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n), "--master-addr", "127.0.0.1",
+           "--master-port", str(free_port()), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    r = subprocess.run(cmd, env=env)
+    raise SystemExit(r.returncode)
+
+
+def main_single_process(args):
+    """N devices behind ONE handle (csky_multi_*, include/cloudsky.h): the same step (sky LUT + march of every device's bands into the frame on
+    device 0) timed by the same loop; `frames in flight` consumer streams rotate per frame group.  CSKY_BENCH_ONE_GPU_DEBUG=1 puts all N contexts
+    on device 0 (exercises the path on a one-GPU box; its number is meaningless)."""
+    import torch
+
+    import gvcd_amd
+
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py: no GPU visible; the cloud path has no CPU fallback")
+    debug_one_gpu = os.environ.get("CSKY_BENCH_ONE_GPU_DEBUG") == "1"
+    n = args.gpus
+    if not debug_one_gpu and torch.cuda.device_count() < n:
+        raise SystemExit("bench.py --single-process: %d devices requested, %d visible" % (n, torch.cuda.device_count()))
+    G = args.groups
+    if G < 1 or n % G:
+        raise SystemExit("bench.py: --groups must divide --gpus")
+    W, H, primary, light, sun = CONFIGS[args.config]
+    sweep = None
+    if isinstance(sun, str):
+        th = np.radians(np.linspace(2.0, 178.0, 64))
+        sweep = [default_params(W, H, (np.cos(t), np.sin(t), 0.0)) for t in th]
+        sun = (np.cos(th[16]), np.sin(th[16]), 0.0)
+    params, sun_n = default_params(W, H, sun)
+    large, small, weather = gvcd_amd.assets.load_default_noise()
+    ids = [0] * n if debug_one_gpu else list(range(n))
+    m = gvcd_amd.MultiContext(ids)
+    m.set_noise(large, small, weather)
+    m.set_march(primary, light)
+    for i in range(n):
+        c = m.ctx(i)
+        if c.noise_inexact_coeffs() != 0:
+            raise SystemExit("bench.py: the benchmark textures must bake exactly")
+        c.set_early_out(args.early_out)
+        c.render_transmittance(256, 64)
+    per = n // G
+    tiles_per_dev = ((W + 7) // 8) * ((H // 8 + per - 1) // per)
+    fif_default = 4 if (per > 1 and 3072 <= tiles_per_dev < 6144) else 2
+    fif = max(1, min(4, args.frames_in_flight if args.frames_in_flight is not None else fif_default))
+    m.set_groups(G)
+    m.set_frames_in_flight(fif)
+    if args.staged:
+        m.set_staged(True)
+    torch.cuda.set_device(0)
+    dev = torch.device("cuda", 0)
+    slots = fif * G
+    streams = [torch.cuda.Stream(device=dev) for _ in range(slots)]
+    frames = [torch.zeros((H, W, 4), dtype=torch.int16, device=dev) for _ in range(slots)]
+    counter = [0]
+
+    def step():
+        k = counter[0]
+        counter[0] += 1
+        fp, fs = (params, sun_n) if sweep is None else sweep[k % len(sweep)]
+        b = k % slots
+        m.render_sky_lut(fs, 200, 100)                                                            # sky_lut.gd:122-148 (on the devices of this frame's group)
+        m.render_clouds_device(fp, W, H, frames[b].data_ptr(), W * 8, streams[b].cuda_stream)     # cloud_sky.gd:234-248, every device of the group
+
+    def sync_all():
+        m.sync()
+        for i in range(1 if debug_one_gpu else n):
+            torch.cuda.synchronize(i)
+
+    for _ in range(max(args.warmup, slots)):
+        step()
+    sync_all()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    sync_all()
+    elapsed = time.perf_counter() - t0
+    # every device's share alone (one launch at a time on that device): what bounds the split
+    share_ms = []
+    for i in range(n):
+        k = i % per
+        total = H // 8
+        nb = (total - k + per - 1) // per
+        ms, _ = m.ctx(i).time_clouds(params, W, (8, k, per, nb), warmup=1, iters=3)
+        share_ms.append(ms)
+    fr = frames[(counter[0] - 1) % slots].view(torch.float16)
+    alpha_mean = float(fr[..., 3].float().mean().item())
+    finite = bool(torch.isfinite(fr.float()).all().item())
+    if debug_one_gpu or os.environ.get("CSKY_BENCH_CHECK") == "1":       # the assembled frame must equal a single-context render of the same frame
+        c0 = m.ctx(0)
+        full = torch.zeros((H, W, 4), dtype=torch.int16, device=dev)
+        k_last = counter[0] - 1
+        fp, fs = (params, sun_n) if sweep is None else sweep[k_last % len(sweep)]
+        c0.set_segments(1); c0.set_frames_in_flight(1)
+        c0.render_sky_lut_device(fs, 200, 100, streams[0].cuda_stream)
+        c0.render_clouds_device(fp, W, (H, 0, 1, 1), full.data_ptr(), W * 8, streams[0].cuda_stream)
+        torch.cuda.synchronize(0)
+        a, b = full.view(torch.float16).float(), fr.float()
+        err = (a - b).abs()
+        ok = float((err <= 5e-4 + 2e-3 * a.abs()).float().mean().item())
+        print("check: %d-device frame vs single-context frame: max|d| = %.3g, within 1 fp16 ulp-ish: %.6f" % (n, float(err.max().item()), ok), file=sys.stderr, flush=True)
+        if ok < 0.9999:
+            raise SystemExit("bench.py: multi-device frame differs from the single-context frame")
+    out = {
+        "metric": "Mrays/s + hemisphere fps, 2048x1024 @ 128x6 steps, 1/2/4/8 MI355X",
+        "value": W * H * args.steps / elapsed / 1e6, "unit": "Mrays/s", "hemisphere_fps": args.steps / elapsed,
+        "n_gpus": n, "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
+        "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "ranks_seen": len(m), "per_rank_share_ms": share_ms,
+        "config": {"workload": "%s: %dx%d hemisphere, %d primary x %d light steps, sun (%.4f,%.4f,%.4f), clouds_sky.tres defaults, weather.bmp + worlnoise.bmp "
+                               "+ generated 128^3 shape noise (seed 1), wind frozen" % (args.config, W, H, primary, light, sun_n[0], sun_n[1], sun_n[2]),
+                   "texture_size": [W, H], "primary_steps": primary, "light_steps": light, "early_out_eps": args.early_out,
+                   "parallelism": "single-process csky_multi: %d group(s) x %d-way bands, %s" % (G, per, "staged peer copies" if args.staged else "in-place xGMI peer stores"),
+                   "frames_in_flight": fif, "frame_groups": G, "device_ids": ids, "alpha_mean": alpha_mean, "finite": finite},
+        "roofline": None, "note": "roofline and cpu_baseline are reported by the N = 1 run (same kernel); this line times the multi-device step only",
+    }
+    print(json.dumps(out), flush=True)
+    m.close()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -127,7 +260,19 @@ def main():
     ap.add_argument("--frames-in-flight", type=int, default=None,
                     help="consecutive frames rotate over this many streams per rank, 1..4 (default 2: the tail of frame k overlaps the head of "
                          "frame k+1 and, at N > 1, its gather; 4 for rank shares of 3072..6143 tiles; 1 = strictly one frame at a time)")
+    ap.add_argument("--single-process", action="store_true",
+                    help="N > 1 behind the C ABI: ONE process, one host thread, csky_multi_* over the N devices (every device stores its bands straight "
+                         "into the frame on device 0 over xGMI; no torch.distributed, no RCCL): the form a GDExtension host can use")
+    ap.add_argument("--groups", type=int, default=1,
+                    help="frame groups for throughput workloads (single-process form): consecutive frames go to G groups of N/G devices in turn, each "
+                         "group splits its frame (N/G)-way; 1 = every device works on every frame (the C4 split)")
+    ap.add_argument("--staged", action="store_true", help="single-process form: local band buffers + strided peer copies instead of in-place peer stores")
     args = ap.parse_args()
+
+    if args.gpus > 1 and not args.single_process and "WORLD_SIZE" not in os.environ:
+        return self_launch(args.gpus)
+    if args.single_process:
+        return main_single_process(args)
 
     import torch
 
@@ -268,6 +413,15 @@ def main():
     # GPU to itself, timed over solo launches right here (also reads the sample counters).
     k_inflight = k_total / max(1, k_launches)
     k_solo, st = ctx.time_clouds(params, W, bands, warmup=1, iters=max(3, args.kernel_iters))
+    # every rank's share alone (solo launches): what bounds the split; gathered so that rank 0 can print them
+    share_ms = [k_solo]
+    ranks_seen = 1
+    if world > 1:
+        ranks_seen = dist.get_world_size()
+        t = torch.zeros(world, dtype=torch.float64, device="cpu" if debug_one_gpu else dev)
+        t[rank] = k_solo
+        dist.all_reduce(t, op=dist.ReduceOp.SUM)
+        share_ms = [float(x) for x in t.tolist()]
     rays_launch = bands[3] * bands[0] * W
     f_incloud = st["incloud_samples"] / max(1, st["primary_samples"])
     floor_bytes = rays_launch * (8 + BYTES_PER_SAMPLE * primary)                           # 10 248 B/ray at 128 steps
@@ -354,6 +508,7 @@ def main():
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
             "value_one_frame_at_a_time": one_at_a_time,
+            "ranks_seen": ranks_seen, "per_rank_share_ms": share_ms,
             "config": {"workload": "%s: %dx%d hemisphere, %d primary x %d light steps, sun (%.4f,%.4f,%.4f), clouds_sky.tres defaults, "
                                    "weather.bmp + worlnoise.bmp + generated 128^3 shape noise (seed 1), wind frozen"
                                    % (args.config, W, H, primary, light, sun_n[0], sun_n[1], sun_n[2]),

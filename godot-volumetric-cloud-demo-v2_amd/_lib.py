@@ -83,6 +83,8 @@ SYMBOLS = [
     ("csky_multi_set_noise", C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     ("csky_multi_set_noise_mips", C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     ("csky_multi_set_frames_in_flight", C.c_int, [C.c_void_p, C.c_int]),
+    ("csky_multi_set_groups", C.c_int, [C.c_void_p, C.c_int]),
+    ("csky_multi_set_staged", C.c_int, [C.c_void_p, C.c_int]),
     ("csky_multi_set_march", C.c_int, [C.c_void_p, C.c_int, C.c_int]),
     ("csky_multi_render_sky_lut", C.c_int, [C.c_void_p, C.POINTER(SkyParams)]),
     ("csky_multi_render_clouds_device", C.c_int, [C.c_void_p, C.POINTER(CloudParams), C.c_int, C.c_int, C.c_void_p, C.c_size_t, C.c_void_p]),
@@ -108,7 +110,7 @@ SYMBOLS = [
 
 
 DEFAULT_VARIANT = 3   # include/cloudsky.h CSKY_DEFAULT_VARIANT ("compact"); set_variant(-1) selects it
-ABI_VERSION = 3       # include/cloudsky.h CSKY_ABI_VERSION
+ABI_VERSION = 4       # include/cloudsky.h CSKY_ABI_VERSION
 
 
 def library_path():
@@ -415,8 +417,16 @@ class MultiContext:
         self._chk(self._L.csky_multi_set_march(self._h, primary_steps, light_steps))
 
     def set_frames_in_flight(self, frames):
-        """2: consecutive render_clouds_device calls alternate two consumer streams; every device alternates two streams too."""
+        """2..4: consecutive render_clouds_device calls rotate that many consumer streams (per frame group); every device does too."""
         self._chk(self._L.csky_multi_set_frames_in_flight(self._h, int(frames)))
+
+    def set_groups(self, groups):
+        """Frame groups for throughput workloads: consecutive frames go to `groups` groups of len(self)/groups devices in turn."""
+        self._chk(self._L.csky_multi_set_groups(self._h, int(groups)))
+
+    def set_staged(self, staged):
+        """True: local band buffers + one strided peer copy per device instead of in-place peer stores from inside the march."""
+        self._chk(self._L.csky_multi_set_staged(self._h, 1 if staged else 0))
 
     def render_sky_lut(self, sun_dir, w=200, h=100):
         p = SkyParams()

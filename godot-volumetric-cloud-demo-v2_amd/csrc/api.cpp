@@ -801,12 +801,17 @@ int csky_copy_sky_lut_device(csky_ctx* c, void* d_out, void* hip_stream) {
 }
 
 // ---- multi-GPU: n contexts, one frame on the first device written by peer stores (cloudsky.h) ----------------------------
+constexpr int MULTI_SLOTS = 8;            // frames in flight over all groups (csky_multi_set_frames_in_flight x csky_multi_set_groups)
 struct csky_multi {
     std::vector<csky_ctx*> ctx;
-    std::vector<hipEvent_t> ev_done[2];   // [frame parity][device]: its march of that frame has finished
-    hipEvent_t ev_begin[2] = {nullptr, nullptr};   // on the first device: the consumer stream's position when the frame was requested
-    std::vector<hipStream_t> side;        // two frames in flight: the stream of the odd frames on device i > 0 (even frames: the context's own)
-    int fif = 1, parity = 0;
+    std::vector<hipEvent_t> ev_done[MULTI_SLOTS];   // [frame slot][device]: its march (and staged copy) of that frame has finished
+    hipEvent_t ev_begin[MULTI_SLOTS] = {};          // on the first device: the consumer stream's position when the frame was requested
+    std::vector<hipStream_t> side[RING - 1];        // frames in flight: the streams of a device's 2nd..4th frame in flight (the 1st: the context's own)
+    int fif = 1, groups = 1;              // frames in flight PER GROUP, frame groups (csky_multi_set_groups)
+    unsigned long long frame_no = 0;
+    bool staged = false;                  // CSKY_MULTI_STAGED=1 / csky_multi_set_staged: local band buffer + peer copy instead of in-place peer stores
+    std::vector<uint2*> d_stage[RING];    // [per-device frame slot][device]: compact band buffer on that device (staged form)
+    std::vector<size_t> stage_px[RING];
     uint2* d_frame = nullptr; size_t frame_px = 0;   // host-buffer form: internal frame on the first device
     char err[512] = {0};
 };
@@ -840,14 +845,17 @@ int csky_multi_create(csky_multi** out, const int* device_ids, int n) {
     for (int i = 0; i < n; i++) {
         const int di = device_ids[i];
         if ((e = hipSetDevice(di)) != hipSuccess) return bail(CSKY_ERR_HIP, "hipSetDevice", e);
-        for (int par = 0; par < 2; par++) {
+        for (int sl = 0; sl < MULTI_SLOTS; sl++) {
             hipEvent_t ev = nullptr;
             if ((e = hipEventCreateWithFlags(&ev, hipEventDisableTiming)) != hipSuccess) return bail(CSKY_ERR_HIP, "hipEventCreate", e);
-            m->ev_done[par].push_back(ev);
+            m->ev_done[sl].push_back(ev);
         }
-        hipStream_t st = nullptr;
-        if ((e = hipStreamCreateWithFlags(&st, hipStreamNonBlocking)) != hipSuccess) return bail(CSKY_ERR_HIP, "hipStreamCreate", e);
-        m->side.push_back(st);
+        for (int k = 0; k < RING - 1; k++) {
+            hipStream_t st = nullptr;
+            if ((e = hipStreamCreateWithFlags(&st, hipStreamNonBlocking)) != hipSuccess) return bail(CSKY_ERR_HIP, "hipStreamCreate", e);
+            m->side[k].push_back(st);
+        }
+        for (int k = 0; k < RING; k++) { m->d_stage[k].push_back(nullptr); m->stage_px[k].push_back(0); }
         if (di != d0) {                                          // the march on device di stores into the frame on d0: xGMI peer access
             int can = 0;
             if ((e = hipDeviceCanAccessPeer(&can, di, d0)) != hipSuccess) return bail(CSKY_ERR_HIP, "hipDeviceCanAccessPeer", e);
@@ -858,8 +866,9 @@ int csky_multi_create(csky_multi** out, const int* device_ids, int n) {
         }
     }
     if ((e = hipSetDevice(d0)) != hipSuccess) return bail(CSKY_ERR_HIP, "hipSetDevice", e);
-    for (int par = 0; par < 2; par++)
-        if ((e = hipEventCreateWithFlags(&m->ev_begin[par], hipEventDisableTiming)) != hipSuccess) return bail(CSKY_ERR_HIP, "hipEventCreate", e);
+    for (int sl = 0; sl < MULTI_SLOTS; sl++)
+        if ((e = hipEventCreateWithFlags(&m->ev_begin[sl], hipEventDisableTiming)) != hipSuccess) return bail(CSKY_ERR_HIP, "hipEventCreate", e);
+    if (const char* se = getenv("CSKY_MULTI_STAGED")) m->staged = atoi(se) != 0;   // A/B switch for the driver's 8-GPU node
     *out = m;
     return CSKY_OK;
 }
@@ -869,12 +878,13 @@ void csky_multi_destroy(csky_multi* m) {
     for (size_t i = 0; i < m->ctx.size(); i++) {
         (void)hipSetDevice(m->ctx[i]->device);
         (void)hipDeviceSynchronize();
-        for (int par = 0; par < 2; par++) if (i < m->ev_done[par].size() && m->ev_done[par][i]) (void)hipEventDestroy(m->ev_done[par][i]);
-        if (i < m->side.size() && m->side[i]) (void)hipStreamDestroy(m->side[i]);
+        for (int sl = 0; sl < MULTI_SLOTS; sl++) if (i < m->ev_done[sl].size() && m->ev_done[sl][i]) (void)hipEventDestroy(m->ev_done[sl][i]);
+        for (int k = 0; k < RING - 1; k++) if (i < m->side[k].size() && m->side[k][i]) (void)hipStreamDestroy(m->side[k][i]);
+        for (int k = 0; k < RING; k++) if (i < m->d_stage[k].size() && m->d_stage[k][i]) (void)hipFree(m->d_stage[k][i]);
     }
     if (!m->ctx.empty()) {
         (void)hipSetDevice(m->ctx[0]->device);
-        for (int par = 0; par < 2; par++) if (m->ev_begin[par]) (void)hipEventDestroy(m->ev_begin[par]);
+        for (int sl = 0; sl < MULTI_SLOTS; sl++) if (m->ev_begin[sl]) (void)hipEventDestroy(m->ev_begin[sl]);
         if (m->d_frame) (void)hipFree(m->d_frame);
     }
     for (csky_ctx* c : m->ctx) csky_destroy(c);
@@ -902,14 +912,33 @@ int csky_multi_set_march(csky_multi* m, int primary_steps, int light_steps) {
 }
 int csky_multi_set_frames_in_flight(csky_multi* m, int frames) {
     if (!m) return mfail(nullptr, CSKY_ERR_INVALID, "csky_multi_set_frames_in_flight: handle is NULL");
-    if (frames < 1 || frames > 2) return mfail(m, CSKY_ERR_INVALID, "csky_multi_set_frames_in_flight: 1 or 2");
+    if (frames < 1 || frames > RING) return mfail(m, CSKY_ERR_INVALID, "csky_multi_set_frames_in_flight: 1 .. 4 per frame group (the per-device rings are four deep)");
+    if (frames * m->groups > MULTI_SLOTS) return mfail(m, CSKY_ERR_INVALID, "csky_multi_set_frames_in_flight: frames x groups must be <= %d", MULTI_SLOTS);
     for (size_t i = 0; i < m->ctx.size(); i++) { const int rc = csky_set_frames_in_flight(m->ctx[i], frames); if (rc) return mpass(m, (int)i, rc); }
     m->fif = frames;
     return CSKY_OK;
 }
+int csky_multi_set_groups(csky_multi* m, int groups) {
+    if (!m) return mfail(nullptr, CSKY_ERR_INVALID, "csky_multi_set_groups: handle is NULL");
+    const int n = (int)m->ctx.size();
+    if (groups < 1 || groups > n || n % groups) return mfail(m, CSKY_ERR_INVALID, "csky_multi_set_groups: the group count must divide the %d devices", n);
+    if (groups * m->fif > MULTI_SLOTS) return mfail(m, CSKY_ERR_INVALID, "csky_multi_set_groups: frames in flight x groups must be <= %d", MULTI_SLOTS);
+    const int rc = csky_multi_sync(m); if (rc) return rc;       // frames of the old partition may be in flight
+    m->groups = groups; m->frame_no = 0;
+    return CSKY_OK;
+}
+int csky_multi_set_staged(csky_multi* m, int staged) {
+    if (!m) return mfail(nullptr, CSKY_ERR_INVALID, "csky_multi_set_staged: handle is NULL");
+    const int rc = csky_multi_sync(m); if (rc) return rc;
+    m->staged = staged != 0;
+    return CSKY_OK;
+}
 int csky_multi_render_sky_lut(csky_multi* m, const csky_sky_params* p) {
     if (!m) return mfail(nullptr, CSKY_ERR_INVALID, "csky_multi_render_sky_lut: handle is NULL");
-    for (size_t i = 0; i < m->ctx.size(); i++) { const int rc = csky_render_sky_lut_device(m->ctx[i], p, nullptr); if (rc) return mpass(m, (int)i, rc); }
+    // every device of the group that renders the NEXT frame needs the LUT; with one group that is every device.  With several groups the
+    // LUT is rendered on the devices of the next frame's group only (sky_lut.gd:43-52 is called once per frame, cloud_sky.gd:187).
+    const int n = (int)m->ctx.size(), per = n / m->groups, g = (int)(m->frame_no % (unsigned long long)m->groups);
+    for (int i = g * per; i < (g + 1) * per; i++) { const int rc = csky_render_sky_lut_device(m->ctx[i], p, nullptr); if (rc) return mpass(m, i, rc); }
     return CSKY_OK;
 }
 
@@ -917,42 +946,73 @@ int csky_multi_render_clouds_device(csky_multi* m, const csky_cloud_params* p, i
     if (!m) return mfail(nullptr, CSKY_ERR_INVALID, "csky_multi_render_clouds_device: handle is NULL");
     if (!d_out || !p) return mfail(m, CSKY_ERR_INVALID, "csky_multi_render_clouds_device: NULL argument");
     if (tile_w < 1 || tile_h < 8 || (tile_h & 7)) return mfail(m, CSKY_ERR_INVALID, "csky_multi_render_clouds_device: tile_h must be a positive multiple of 8 (bands are 8 rows)");
-    const int n = (int)m->ctx.size(), total = tile_h / 8;
+    if (pitch % 8 || pitch < (size_t)tile_w * 8) return mfail(m, CSKY_ERR_INVALID, "csky_multi_render_clouds_device: row pitch must be a multiple of 8 and >= tile_w*8");
+    const int n_all = (int)m->ctx.size(), total = tile_h / 8;
+    // Frame groups (csky_multi_set_groups): consecutive frames go to the G groups in turn; the n/G devices of a group split the frame's bands.
+    // Slot = frame number mod (groups x frames in flight): its events, and on every device of the group the stream / ring position
+    // slot / groups of that device's frames in flight.
+    const int G = m->groups, per = n_all / G, slots = G * m->fif;
+    const int slot = (int)(m->frame_no % (unsigned long long)slots), grp = slot % G, dslot = slot / G;
+    m->frame_no++;
     csky_ctx* c0 = m->ctx[0];
     int rc; if ((rc = bind(c0))) return mpass(m, 0, rc);
     hipStream_t consumer = hip_stream ? (hipStream_t)hip_stream : c0->stream;
-    // two frames in flight (csky_multi_set_frames_in_flight): consecutive frames alternate between two sets of streams and events on
-    // every device, like a caller of the single-device entry points alternates two streams
-    const int par = m->fif >= 2 ? (m->parity ^= 1) : 0;
     // no device may store into the frame before the consumer's earlier work on it (reads of the previous frame) is done
-    if (hipEventRecord(m->ev_begin[par], consumer) != hipSuccess) return mfail(m, CSKY_ERR_HIP, "csky_multi_render_clouds_device: hipEventRecord failed");
-    for (int i = 0; i < n; i++) {
+    if (hipEventRecord(m->ev_begin[slot], consumer) != hipSuccess) return mfail(m, CSKY_ERR_HIP, "csky_multi_render_clouds_device: hipEventRecord failed");
+    for (int k = 0; k < per; k++) {
+        const int i = grp * per + k;
         csky_ctx* c = m->ctx[i];
         if ((rc = bind(c))) return mpass(m, i, rc);
-        const int nb = i < total ? (total - i + n - 1) / n : 0;
+        const int nb = k < total ? (total - k + per - 1) / per : 0;
         if (nb == 0) continue;
-        hipStream_t s = (i == 0) ? consumer : (par ? m->side[i] : c->stream);
-        if (i != 0 && hipStreamWaitEvent(s, m->ev_begin[par], 0) != hipSuccess) return mfail(m, CSKY_ERR_HIP, "csky_multi_render_clouds_device: hipStreamWaitEvent failed");
-        const csky_bands b = {8, i, n, nb};
-        if ((rc = clouds_dev(c, p, tile_w, &b, (uint2*)d_out, pitch, s, nullptr, true, /*out_full=*/true))) return mpass(m, i, rc);
-        if (i != 0 && hipEventRecord(m->ev_done[par][i], s) != hipSuccess) return mfail(m, CSKY_ERR_HIP, "csky_multi_render_clouds_device: hipEventRecord failed");
+        hipStream_t s = (i == 0) ? consumer : (dslot ? m->side[dslot - 1][i] : c->stream);
+        if (i != 0 && hipStreamWaitEvent(s, m->ev_begin[slot], 0) != hipSuccess) return mfail(m, CSKY_ERR_HIP, "csky_multi_render_clouds_device: hipStreamWaitEvent failed");
+        const csky_bands b = {8, k, per, nb};
+        if (m->staged && i != 0) {
+            // Fallback for nodes where fine-grained remote stores from inside the march stall: the device renders its bands into a compact local
+            // buffer and one strided peer copy (a band = 8 rows, n bands apart in the frame) moves them over xGMI behind the march.
+            const size_t need = (size_t)nb * 8 * tile_w;
+            if (m->stage_px[dslot][i] < need) {
+                if (hipStreamSynchronize(s) != hipSuccess) return mfail(m, CSKY_ERR_HIP, "csky_multi_render_clouds_device: hipStreamSynchronize failed");
+                if (m->d_stage[dslot][i]) { (void)hipFree(m->d_stage[dslot][i]); m->d_stage[dslot][i] = nullptr; m->stage_px[dslot][i] = 0; }
+                if (hipMalloc(reinterpret_cast<void**>(&m->d_stage[dslot][i]), need * 8) != hipSuccess) return mfail(m, CSKY_ERR_HIP, "csky_multi_render_clouds_device: hipMalloc of the staging buffer failed");
+                m->stage_px[dslot][i] = need;
+            }
+            uint2* st = m->d_stage[dslot][i];
+            if ((rc = clouds_dev(c, p, tile_w, &b, st, (size_t)tile_w * 8, s, nullptr, true, /*out_full=*/false))) return mpass(m, i, rc);
+            const size_t band_bytes = (size_t)8 * tile_w * 8;
+            char* dst0 = (char*)d_out + (size_t)k * 8 * pitch;
+            hipError_t e;
+            if (pitch == (size_t)tile_w * 8) e = hipMemcpy2DAsync(dst0, (size_t)per * 8 * pitch, st, band_bytes, band_bytes, nb, hipMemcpyDeviceToDevice, s);
+            else {
+                e = hipSuccess;
+                for (int bnd = 0; bnd < nb && e == hipSuccess; bnd++)
+                    e = hipMemcpy2DAsync(dst0 + (size_t)bnd * per * 8 * pitch, pitch, (char*)st + (size_t)bnd * band_bytes, (size_t)tile_w * 8, (size_t)tile_w * 8, 8, hipMemcpyDeviceToDevice, s);
+            }
+            if (e != hipSuccess) return mfail(m, CSKY_ERR_HIP, "csky_multi_render_clouds_device: peer copy failed: %s", hipGetErrorString(e));
+        } else {
+            if ((rc = clouds_dev(c, p, tile_w, &b, (uint2*)d_out, pitch, s, nullptr, true, /*out_full=*/true))) return mpass(m, i, rc);
+        }
+        if (i != 0 && hipEventRecord(m->ev_done[slot][i], s) != hipSuccess) return mfail(m, CSKY_ERR_HIP, "csky_multi_render_clouds_device: hipEventRecord failed");
     }
     if ((rc = bind(c0))) return mpass(m, 0, rc);
-    for (int i = 1; i < n; i++) {
-        if (i >= total) continue;
-        if (hipStreamWaitEvent(consumer, m->ev_done[par][i], 0) != hipSuccess) return mfail(m, CSKY_ERR_HIP, "csky_multi_render_clouds_device: hipStreamWaitEvent failed");
+    for (int k = 0; k < per; k++) {
+        const int i = grp * per + k;
+        if (i == 0 || k >= total) continue;
+        if (hipStreamWaitEvent(consumer, m->ev_done[slot][i], 0) != hipSuccess) return mfail(m, CSKY_ERR_HIP, "csky_multi_render_clouds_device: hipStreamWaitEvent failed");
     }
     return CSKY_OK;
 }
 
 int csky_multi_render_clouds(csky_multi* m, const csky_cloud_params* p, int tile_w, int tile_h, uint16_t* out, size_t pitch) {
     if (!m) return mfail(nullptr, CSKY_ERR_INVALID, "csky_multi_render_clouds: handle is NULL");
-    if (tile_w < 1 || tile_h < 1) return mfail(m, CSKY_ERR_INVALID, "csky_multi_render_clouds: empty tile");
+    if (tile_w < 1 || tile_h < 8 || (tile_h & 7)) return mfail(m, CSKY_ERR_INVALID, "csky_multi_render_clouds: tile_h must be a positive multiple of 8 (bands are 8 rows; the single-device csky_render_clouds takes ragged tiles)");
     if (out && pitch < (size_t)tile_w * 8) return mfail(m, CSKY_ERR_INVALID, "csky_multi_render_clouds: row_pitch_bytes < tile_w*8");
     csky_ctx* c0 = m->ctx[0];
     int rc; if ((rc = bind(c0))) return mpass(m, 0, rc);
     const size_t px = (size_t)tile_w * tile_h;
     if (m->frame_px < px) {
+        if (hipStreamSynchronize(c0->stream) != hipSuccess) return mfail(m, CSKY_ERR_HIP, "csky_multi_render_clouds: hipStreamSynchronize failed");
         if (m->d_frame) { (void)hipFree(m->d_frame); m->d_frame = nullptr; m->frame_px = 0; }
         if (hipMalloc(reinterpret_cast<void**>(&m->d_frame), px * 8) != hipSuccess) return mfail(m, CSKY_ERR_HIP, "csky_multi_render_clouds: hipMalloc failed");
         m->frame_px = px;
@@ -967,7 +1027,11 @@ int csky_multi_render_clouds(csky_multi* m, const csky_cloud_params* p, int tile
 
 int csky_multi_sync(csky_multi* m) {
     if (!m) return mfail(nullptr, CSKY_ERR_INVALID, "csky_multi_sync: handle is NULL");
-    for (size_t i = 0; i < m->ctx.size(); i++) { const int rc = csky_sync(m->ctx[i]); if (rc) return mpass(m, (int)i, rc); }
+    for (size_t i = 0; i < m->ctx.size(); i++) {
+        const int rc = csky_sync(m->ctx[i]); if (rc) return mpass(m, (int)i, rc);
+        for (int k = 0; k < RING - 1; k++)                     // the streams of a device's 2nd..4th frame in flight
+            if (hipStreamSynchronize(m->side[k][i]) != hipSuccess) return mfail(m, CSKY_ERR_HIP, "csky_multi_sync: hipStreamSynchronize failed on device index %d", (int)i);
+    }
     return CSKY_OK;
 }
 

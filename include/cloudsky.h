@@ -30,7 +30,7 @@ extern "C" {
 #define CSKY_ERR_IO (-4)         /* asset file problem                                       */
 #define CSKY_ERR_STATE (-5)      /* e.g. clouds requested before noise / LUTs exist          */
 
-#define CSKY_ABI_VERSION 3  /* 3: csky_set_noise_mips, csky_decode_bc7, csky_load_ctex[3d]; 2: csky_multi_*, device asset builders */
+#define CSKY_ABI_VERSION 4  /* 4: csky_submit_* / csky_collect, csky_multi_set_groups / _set_staged, "compact-ilp" kernel; 3: csky_set_noise_mips, csky_decode_bc7, csky_load_ctex[3d]; 2: csky_multi_*, device asset builders */
 
 typedef struct csky_ctx csky_ctx; /* opaque: owns every device allocation, the HIP stream and events */
 
@@ -228,13 +228,29 @@ csky_ctx* csky_multi_ctx(csky_multi* m, int i);
 const char* csky_multi_last_error(const csky_multi* m);
 int csky_multi_set_noise(csky_multi* m, const uint8_t* large_rgba8, const uint8_t* small_rgb8, const uint8_t* weather_rgb8);
 int csky_multi_set_noise_mips(csky_multi* m, const uint8_t* large_chain_rgba8, const uint8_t* small_chain_rgb8, const uint8_t* weather_rgb8);
-/* 2 = the caller keeps two frames in flight by alternating two consumer streams between consecutive csky_multi_render_clouds_device
- * calls: every device then alternates two streams / event sets as well (csky_set_frames_in_flight on every context).  Default 1. */
+/* n = 2..4: the caller keeps n frames in flight (per frame group) by rotating n consumer streams between consecutive
+ * csky_multi_render_clouds_device calls: every device then rotates n streams / event sets as well (csky_set_frames_in_flight on every
+ * context; the per-device rings are four deep).  Default 1.  frames x groups <= 8. */
 int csky_multi_set_frames_in_flight(csky_multi* m, int frames);
+/* Frame groups, for THROUGHPUT workloads (a sequence of independent frames: BASELINE config 5's 64-frame sun sweep): the n devices are
+ * split into `groups` groups of n/groups devices; consecutive csky_multi_render_clouds_device calls go to the groups in turn and the
+ * devices of a group split that frame's bands (n/groups)-way.  A device's share is then `groups` times larger (fewer, fuller launches:
+ * one GPU's 1/8 share of a 2048x1024 frame is 4 wavefronts per SIMD and latency-bound), at the price of `groups` frames of latency:
+ * the caller keeps groups x frames_in_flight frames in flight on as many rotating streams and output buffers.  Every frame still lands
+ * in d_out on the FIRST device.  With groups > 1, csky_multi_render_sky_lut renders the LUT on the devices of the NEXT frame's group
+ * only: call it once per frame, before that frame's render call (the order of sky_lut.gd:43-52 / cloud_sky.gd:187).  Default 1 = every
+ * device works on every frame (the latency-optimal split, BASELINE config 4).  groups must divide the device count. */
+int csky_multi_set_groups(csky_multi* m, int groups);
+/* 1: devices other than the first render into a local band buffer and one strided peer copy per device moves the bands into the frame
+ * behind the march, instead of the march's wavefronts storing straight into the first device's memory over xGMI.  Same frame, one
+ * extra pass over 1/n of it; for nodes where fine-grained remote stores stall.  Also switched on by CSKY_MULTI_STAGED=1 in the
+ * environment at csky_multi_create.  Default 0. */
+int csky_multi_set_staged(csky_multi* m, int staged);
 int csky_multi_set_march(csky_multi* m, int primary_steps, int light_steps);
 int csky_multi_render_sky_lut(csky_multi* m, const csky_sky_params* p);
 /* Whole tile [0,tile_w) x [0,tile_h) into d_out on the FIRST device (row pitch in bytes), asynchronously: `hip_stream` (a stream of
- * the first device; NULL = that context's own stream) is ordered behind every device's march.  tile_h must be a multiple of 8. */
+ * the first device; NULL = that context's own stream) is ordered behind every device's march.  tile_h must be a multiple of 8 (bands are
+ * 8 rows; both forms reject other heights up front, unlike the single-device csky_render_clouds, which takes ragged tiles). */
 int csky_multi_render_clouds_device(csky_multi* m, const csky_cloud_params* p, int tile_w, int tile_h, void* d_out_rgba16f,
                                     size_t row_pitch_bytes, void* hip_stream);
 /* Host-buffer form: renders as above into an internal frame on the first device, copies it out, blocks. */

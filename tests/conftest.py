@@ -69,6 +69,22 @@ def o_skies(oracle, o_trans):
     return out
 
 
+@pytest.fixture(scope="session")
+def oracle_frames(oracle, otex, o_skies):
+    """Whole oracle frames of the default config, computed once per session and shared by the tests that gate against them
+    (a 2048x1024 @ 128x6 frame is ~10 s of oracle on 16 host threads): get(w, h, sun_name) -> (frame, stats)."""
+    cache = {}
+
+    def get(w, h, sun_name):
+        from bench import usable_cores
+        k = (w, h, sun_name)
+        if k not in cache:
+            p = oracle.default_params(w, h, SUNS[sun_name])
+            cache[k] = oracle.clouds(otex, p, o_skies[sun_name], nthreads=max(1, min(oracle.max_threads(), usable_cores())), return_stats=True)
+        return cache[k]
+    return get
+
+
 def norm(s):
     s = np.asarray(s, np.float64)
     return (s / np.linalg.norm(s)).astype(np.float32)

@@ -81,3 +81,108 @@ def test_ilp_variant_early_out_is_bounded(gpu_ctx, oracle):
         assert np.abs(img - ref).max() <= 4e-3
     finally:
         gpu_ctx.set_early_out(0.0); gpu_ctx.set_variant(-1)
+
+
+# ------------------------------------------------------------------------------------------------ BASELINE config 4 in its real shape
+@pytest.mark.parametrize("fif", [2, 4])
+def test_c4_eight_interleaved_shares_vs_oracle(pkg, noise, gpu_ctx, oracle, oracle_frames, fif):
+    """BASELINE configs[3] on one GPU (VERDICT r2 missing 3): the 2048x1024 @ 128x6 frame as EIGHT interleaved 8-row-band shares, each rendered
+    under the AUTOMATIC launch policy of a rank share (ray segments / whole rays by launch size and frames in flight, cost-feedback order)
+    exactly as bench.py's ranks and csky_multi's devices render them at N = 8, assembled and compared with the ORACLE at the tight gate.
+    (i) one process per GPU: tiling.bands_for_rank + tiling.interleave (what the RCCL gather feeds), consecutive shares on `fif` rotating
+    streams; (ii) behind the C ABI: csky_multi over eight contexts (all on device 0 here), frames in flight through the handle."""
+    import torch
+    from gvcd_amd import tiling
+    W, H, N = 2048, 1024, 8
+    sun = SUNS["deg45"]
+    p = oracle.default_params(W, H, sun)
+    ref, _ = oracle_frames(W, H, "deg45")
+    # (i) the per-rank form
+    ctx = pkg.Context(0)
+    try:
+        ctx.set_noise(*noise); ctx.set_march(128, 6); ctx.render_transmittance(256, 64)
+        ctx.set_frames_in_flight(fif)                                     # segments / schedule / variant stay automatic
+        streams = [torch.cuda.Stream() for _ in range(fif)]
+        mb = tiling.max_bands(H, N)
+        gathered = torch.zeros((N, mb * 8, W, 4), dtype=torch.int16, device="cuda")
+        for rep in range(2):                                              # twice: the second pass runs in the cost-feedback order of the first
+            for r in range(N):
+                b = tiling.bands_for_rank(H, r, N)
+                s = streams[r % fif]
+                ctx.render_sky_lut_device(norm(sun), 200, 100, s.cuda_stream)
+                ctx.render_clouds_device(p, W, b, gathered[r].data_ptr(), W * 8, s.cuda_stream)
+            torch.cuda.synchronize()
+        img = tiling.interleave(gathered, H, N).cpu().numpy().view(np.float16)
+        ok, info = cloud_tight(img, ref)
+        assert ok and info["within1"] >= 0.9998, ("per-rank form", fif, info)
+        print("C4 shape, per-rank form, %d frames in flight: %s" % (fif, info))
+    finally:
+        ctx.close()
+    # (ii) the single-handle form
+    m = pkg.MultiContext([0] * N)
+    try:
+        m.set_noise(*noise); m.set_march(128, 6)
+        m.set_frames_in_flight(fif)
+        cs = [torch.cuda.Stream() for _ in range(fif)]
+        bufs = [torch.zeros((H, W, 4), dtype=torch.int16, device="cuda") for _ in range(fif)]
+        for k in range(fif + 2):
+            m.render_sky_lut(norm(sun))
+            m.render_clouds_device(p, W, H, bufs[k % fif].data_ptr(), W * 8, cs[k % fif].cuda_stream)
+        torch.cuda.synchronize()
+        for k in range(fif):
+            ok, info = cloud_tight(bufs[k].cpu().numpy().view(np.float16), ref)
+            assert ok and info["within1"] >= 0.9998, ("single-handle form", fif, k, info)
+        print("C4 shape, single-handle form, %d frames in flight: %s" % (fif, info))
+    finally:
+        m.close()
+
+
+def test_multi_handle_groups_staged_and_four_frames_in_flight(pkg, noise, gpu_ctx, oracle):
+    """csky_multi round 3: frame groups (consecutive frames alternate between G groups of n/G devices, each group splitting its frame
+    (n/G)-way), up to four frames in flight per group, and the staged form (local band buffer + strided peer copy instead of in-place
+    peer stores).  Different suns in flight at once; every frame must equal the single-context render of ITS sun byte for byte
+    (whole rays everywhere), in every combination."""
+    import torch
+    W, H = 512, 256
+    suns = [(1, 1, 0), (0.2, 1, 0.3), (-1, 0.4, 0.5), (0.1, 0.3, -1), (0.7, 0.2, 0.1), (0.3, 0.9, -0.2)]
+    gpu_ctx.set_march(128, 6); gpu_ctx.set_segments(1)
+    refs = []
+    for sun in suns:
+        gpu_ctx.render_sky_lut(norm(sun), 200, 100)
+        refs.append(gpu_ctx.render_clouds(oracle.default_params(W, H, sun)).view(np.uint16).copy())
+    gpu_ctx.set_segments(0)
+    assert not (refs[0] == refs[1]).all()
+    for n, G, fif, staged in [(4, 2, 2, False), (4, 1, 4, False), (4, 4, 1, True), (6, 3, 2, True), (2, 1, 3, True), (8, 2, 4, False)]:
+        m = pkg.MultiContext([0] * n)
+        try:
+            m.set_noise(*noise); m.set_march(128, 6)
+            for i in range(n):
+                m.ctx(i).set_segments(1)
+            m.set_groups(G); m.set_frames_in_flight(fif); m.set_staged(staged)
+            slots = G * fif
+            cs = [torch.cuda.Stream() for _ in range(slots)]
+            bufs = [torch.zeros((H, W + 8, 4), dtype=torch.int16, device="cuda") for _ in range(slots)]     # ragged pitch: the per-band copy path of the staged form
+            K = 3 * slots + 1
+            for k in range(K):
+                sun = suns[k % len(suns)]
+                b = k % slots
+                if k >= slots:                                            # the frame that used this buffer set: check, then clear
+                    cs[b].synchronize()
+                    got = bufs[b].cpu().numpy().view(np.uint16)
+                    assert (got[:, :W] == refs[(k - slots) % len(suns)]).all(), (n, G, fif, staged, k)
+                    assert (got[:, W:] == 0).all()
+                    bufs[b].zero_(); torch.cuda.current_stream().synchronize()
+                m.render_sky_lut(norm(sun))
+                m.render_clouds_device(oracle.default_params(W, H, sun), W, H, bufs[b].data_ptr(), (W + 8) * 8, cs[b].cuda_stream)
+            m.sync(); torch.cuda.synchronize()
+            for k in range(K - slots, K):
+                assert (bufs[k % slots].cpu().numpy().view(np.uint16)[:, :W] == refs[k % len(suns)]).all(), (n, G, fif, staged, k, "drain")
+            with pytest.raises(pkg.CloudSkyError):
+                m.set_groups(n + 1)
+            if n % 3:
+                with pytest.raises(pkg.CloudSkyError):
+                    m.set_groups(3)
+            with pytest.raises(pkg.CloudSkyError):
+                m.render_clouds(oracle.default_params(W, H, suns[0]), W, 12)         # both forms reject heights that are not whole bands (ADVICE r2)
+        finally:
+            m.close()
