@@ -25,13 +25,21 @@ using namespace csky;
 // plus a host's own, four are not enough (measured: no overlap at 4, overlap at 8).  The runtime reads the variable when it initialises, at
 // the first HIP call; this runs when libcloudsky.so is loaded, so a host that cannot set environment variables (a GDExtension inside Godot)
 // still gets the overlap as long as it has not used HIP before loading the library.  An existing value is never overwritten.
-__attribute__((constructor)) static void csky_runtime_defaults() { setenv("GPU_MAX_HW_QUEUES", "8", /*overwrite=*/0); }
+// Opt-out: CSKY_NO_ENV=1 in the environment leaves the process's environment alone (a host that loads other HIP users and wants the runtime's
+// defaults); csky_set_frames_in_flight then warns through csky_last_error when the variable is not in effect.
+static bool g_env_set_by_us = false;
+__attribute__((constructor)) static void csky_runtime_defaults() {
+    const char* no = getenv("CSKY_NO_ENV");
+    if (no && no[0] && no[0] != '0') return;
+    if (!getenv("GPU_MAX_HW_QUEUES")) { setenv("GPU_MAX_HW_QUEUES", "8", /*overwrite=*/0); g_env_set_by_us = true; }
+}
 
 static_assert(sizeof(csky_cloud_params) == sizeof(CloudParams), "ABI struct mismatch");
 
 // Depth of the per-frame rings (frame constants, launch order, cost feedback, pop counters, events): the number of frames a caller may keep
 // in flight on as many streams (csky_set_frames_in_flight).  The slots rotate over all RING entries whatever that number is.
 constexpr int RING = 4;
+constexpr int HOST_RING = 8;   // pinned host frames of the asynchronous host form (a single context uses up to RING of them, csky_multi up to groups x frames in flight)
 
 struct csky_ctx {
     int device = 0;
@@ -79,6 +87,9 @@ struct csky_ctx {
     bool kt_on = false; std::vector<hipEvent_t> kt_ev; int kt_count = 0;   // the event pool grows on demand (clouds_dev)
     uint8_t* d_composite = nullptr; size_t composite_cap = 0;              // grow-only scratch of csky_composite_sky
     csky_cloud_stats last_stats = {0, 0, 0};
+    // asynchronous host form (csky_submit_clouds / csky_collect): a ring of pinned host frames + device frames on rotating internal streams
+    struct HostSlot { hipStream_t s = nullptr; hipEvent_t done = nullptr; uint2* d = nullptr; void* h = nullptr; size_t px = 0; long long ticket = -1; int w = 0, hh = 0; bool busy = false; };
+    HostSlot hring[HOST_RING]; int hslots = 2; long long next_ticket = 0;
     char err[512] = {0};
 };
 
@@ -382,6 +393,12 @@ void csky_destroy(csky_ctx* c) {
         if (c->ev_setup[k]) (void)hipEventDestroy(c->ev_setup[k]);
         if (c->ev_clouds[k]) (void)hipEventDestroy(c->ev_clouds[k]);
     }
+    for (auto& hs : c->hring) {
+        if (hs.d) (void)hipFree(hs.d);
+        if (hs.h) (void)hipHostFree(hs.h);
+        if (hs.done) (void)hipEventDestroy(hs.done);
+        if (hs.s) (void)hipStreamDestroy(hs.s);
+    }
     hipEvent_t evs[] = {c->ev0, c->ev1, c->ev_copy};
     for (hipEvent_t ev : evs) if (ev) (void)hipEventDestroy(ev);
     for (hipEvent_t ev : c->kt_ev) if (ev) (void)hipEventDestroy(ev);
@@ -405,6 +422,7 @@ static int set_noise_impl(csky_ctx* c, const uint8_t* large_rgba8, const uint8_t
     for (int l = 0; l < DETAIL_LEVELS; l++) if (c->detail_off[l] != detail_level_offset(l)) return fail(c, CSKY_ERR_INVALID, "internal: detail mip offset mismatch");
     if (detail_total != (size_t)DETAIL_CHAIN_TEXELS) return fail(c, CSKY_ERR_INVALID, "internal: detail chain size");
     HIPCHK(c, hipDeviceSynchronize());                        // frames reading the old textures may be in flight on caller streams
+    c->have_noise = false; c->win_cov = -1e30f;               // a failure below leaves freed / half-baked textures: no render until a later call succeeds
     if ((rc = dev_alloc(c, &c->d_raw_large, large_chain))) return rc;
     if ((rc = dev_alloc(c, &c->d_raw_small, small_chain))) return rc;
     if ((rc = dev_alloc(c, &c->d_raw_weather, weather_b))) return rc;
@@ -548,7 +566,15 @@ int csky_set_schedule(csky_ctx* c, int mode) {
 int csky_set_frames_in_flight(csky_ctx* c, int frames) {
     if (!c) return fail(nullptr, CSKY_ERR_INVALID, "csky_set_frames_in_flight: ctx is NULL");
     if (frames < 1 || frames > RING) return fail(c, CSKY_ERR_INVALID, "csky_set_frames_in_flight: 1 .. 4 (the rings are four deep)");
-    c->frames_in_flight = frames; return CSKY_OK;
+    c->frames_in_flight = frames;
+    c->err[0] = 0;
+    if (frames >= 2) {   // still CSKY_OK, but never silent: without enough hardware queues the frames' streams share one and do not overlap
+        const char* q = getenv("GPU_MAX_HW_QUEUES");
+        if (!q || atoi(q) < 8)
+            snprintf(c->err, sizeof c->err, "csky_set_frames_in_flight: warning: GPU_MAX_HW_QUEUES is %s (< 8): streams of consecutive frames may share a hardware "
+                     "queue and not overlap; set it to 8 before the process's first HIP call (libcloudsky does so at load time unless CSKY_NO_ENV=1)", q ? q : "unset");
+    }
+    return CSKY_OK;
 }
 int csky_set_segments(csky_ctx* c, int segments) {
     if (!c) return fail(nullptr, CSKY_ERR_INVALID, "csky_set_segments: ctx is NULL");
@@ -630,6 +656,78 @@ int csky_render_clouds(csky_ctx* c, const csky_cloud_params* p, int tile_w, int 
     HIPCHK(c, hipStreamSynchronize(c->stream));
     c->last_stats.rays = (uint64_t)tile_w * tile_h; c->last_stats.incloud_samples = st[0]; c->last_stats.primary_samples = st[1] * (uint64_t)c->primary_steps;
     return CSKY_OK;
+}
+
+// ---- asynchronous host form: submit / collect over a ring of pinned frames (cloudsky.h) -----------------------------------------
+namespace {
+int host_slot_prepare(csky_ctx* c, csky_ctx::HostSlot& hs, size_t px, bool need_device) {
+    if (!hs.s) HIPCHK(c, hipStreamCreateWithFlags(&hs.s, hipStreamNonBlocking));
+    if (!hs.done) HIPCHK(c, hipEventCreateWithFlags(&hs.done, hipEventDisableTiming));
+    if (hs.px < px) {
+        HIPCHK(c, hipStreamSynchronize(hs.s));
+        if (hs.d) { (void)hipFree(hs.d); hs.d = nullptr; }
+        if (hs.h) { (void)hipHostFree(hs.h); hs.h = nullptr; }
+        hs.px = 0;
+        if (need_device) HIPCHK(c, hipMalloc(reinterpret_cast<void**>(&hs.d), px * 8));
+        HIPCHK(c, hipHostMalloc(&hs.h, px * 8, hipHostMallocDefault));       // pinned: the device-to-host copy is a real asynchronous DMA
+        hs.px = px;
+    } else if (need_device && !hs.d) {
+        HIPCHK(c, hipMalloc(reinterpret_cast<void**>(&hs.d), hs.px * 8));
+    }
+    return CSKY_OK;
+}
+}  // namespace
+
+int csky_set_host_ring(csky_ctx* c, int slots) {
+    if (!c) return fail(nullptr, CSKY_ERR_INVALID, "csky_set_host_ring: ctx is NULL");
+    if (slots < 1 || slots > RING) return fail(c, CSKY_ERR_INVALID, "csky_set_host_ring: 1 .. 4 frames");
+    for (auto& hs : c->hring) if (hs.busy) return fail(c, CSKY_ERR_STATE, "csky_set_host_ring: collect the outstanding tickets first");
+    c->hslots = slots;
+    return csky_set_frames_in_flight(c, slots >= 2 ? 2 : 1);    // launch policy: two frames in flight is the best choice for whole frames (csky_set_frames_in_flight)
+}
+
+int csky_submit_clouds(csky_ctx* c, const csky_cloud_params* p, int tile_w, int tile_h, int64_t* ticket) {
+    if (!c) return fail(nullptr, CSKY_ERR_INVALID, "csky_submit_clouds: ctx is NULL");
+    if (!ticket) return fail(c, CSKY_ERR_INVALID, "csky_submit_clouds: ticket is NULL");
+    if (tile_w < 1 || tile_h < 1 || tile_w > 16384 || tile_h > 16384) return fail(c, CSKY_ERR_INVALID, "csky_submit_clouds: tile size out of range");
+    int rc; if ((rc = bind(c))) return rc;
+    csky_ctx::HostSlot& hs = c->hring[c->next_ticket % c->hslots];
+    if (hs.busy) return fail(c, CSKY_ERR_STATE, "csky_submit_clouds: %d frames are already in flight (csky_set_host_ring); collect ticket %lld first", c->hslots, hs.ticket);
+    const size_t px = (size_t)tile_w * tile_h;
+    if ((rc = host_slot_prepare(c, hs, px, true))) return rc;
+    const csky_bands b = {tile_h, 0, 1, 1};
+    if ((rc = clouds_dev(c, p, tile_w, &b, hs.d, (size_t)tile_w * 8, hs.s, nullptr, true))) return rc;
+    HIPCHK(c, hipMemcpyAsync(hs.h, hs.d, px * 8, hipMemcpyDeviceToHost, hs.s));
+    HIPCHK(c, hipEventRecord(hs.done, hs.s));
+    hs.busy = true; hs.ticket = c->next_ticket; hs.w = tile_w; hs.hh = tile_h;
+    *ticket = c->next_ticket++;
+    return CSKY_OK;
+}
+
+int csky_collect(csky_ctx* c, int64_t ticket, const uint16_t** frame, size_t* bytes) {
+    if (!c) return fail(nullptr, CSKY_ERR_INVALID, "csky_collect: ctx is NULL");
+    if (!frame) return fail(c, CSKY_ERR_INVALID, "csky_collect: frame is NULL");
+    csky_ctx::HostSlot* hs = nullptr;
+    for (auto& k : c->hring) if (k.busy && k.ticket == ticket) hs = &k;
+    if (!hs) return fail(c, CSKY_ERR_STATE, "csky_collect: ticket %lld is not outstanding (never submitted, or collected already)", (long long)ticket);
+    int rc; if ((rc = bind(c))) return rc;
+    HIPCHK(c, hipEventSynchronize(hs->done));
+    hs->busy = false;
+    *frame = reinterpret_cast<const uint16_t*>(hs->h);
+    if (bytes) *bytes = (size_t)hs->w * hs->hh * 8;
+    return CSKY_OK;
+}
+
+int csky_poll(csky_ctx* c, int64_t ticket) {
+    if (!c) return fail(nullptr, CSKY_ERR_INVALID, "csky_poll: ctx is NULL");
+    for (auto& k : c->hring)
+        if (k.busy && k.ticket == ticket) {
+            const hipError_t e = hipEventQuery(k.done);
+            if (e == hipSuccess) return 1;
+            if (e == hipErrorNotReady) { (void)hipGetLastError(); return 0; }
+            return fail(c, CSKY_ERR_HIP, "csky_poll: %s", hipGetErrorString(e));
+        }
+    return fail(c, CSKY_ERR_STATE, "csky_poll: ticket %lld is not outstanding", (long long)ticket);
 }
 
 int csky_read_transmittance(csky_ctx* c, uint16_t* out, int* w, int* h) {
@@ -1023,6 +1121,40 @@ int csky_multi_render_clouds(csky_multi* m, const csky_cloud_params* p, int tile
         return mfail(m, CSKY_ERR_HIP, "csky_multi_render_clouds: copy to host failed");
     if (hipStreamSynchronize(c0->stream) != hipSuccess) return mfail(m, CSKY_ERR_HIP, "csky_multi_render_clouds: hipStreamSynchronize failed");
     return CSKY_OK;
+}
+
+// asynchronous host form over the multi-device handle: the first context's pinned ring and streams serve as consumer streams
+int csky_multi_set_host_ring(csky_multi* m, int slots) {
+    if (!m) return mfail(nullptr, CSKY_ERR_INVALID, "csky_multi_set_host_ring: handle is NULL");
+    if (slots < 1 || slots > HOST_RING || slots > m->groups * RING || slots % m->groups) return mfail(m, CSKY_ERR_INVALID, "csky_multi_set_host_ring: 1 .. 8 frames, a multiple of the group count, at most 4 per group");
+    csky_ctx* c0 = m->ctx[0];
+    for (auto& hs : c0->hring) if (hs.busy) return mfail(m, CSKY_ERR_STATE, "csky_multi_set_host_ring: collect the outstanding tickets first");
+    const int rc = csky_multi_set_frames_in_flight(m, slots / m->groups); if (rc) return rc;
+    c0->hslots = slots;
+    return CSKY_OK;
+}
+int csky_multi_submit_clouds(csky_multi* m, const csky_cloud_params* p, int tile_w, int tile_h, int64_t* ticket) {
+    if (!m) return mfail(nullptr, CSKY_ERR_INVALID, "csky_multi_submit_clouds: handle is NULL");
+    if (!ticket || !p) return mfail(m, CSKY_ERR_INVALID, "csky_multi_submit_clouds: NULL argument");
+    if (tile_w < 1 || tile_h < 8 || (tile_h & 7) || tile_w > 16384 || tile_h > 16384) return mfail(m, CSKY_ERR_INVALID, "csky_multi_submit_clouds: tile_h must be a positive multiple of 8, sizes <= 16384");
+    csky_ctx* c0 = m->ctx[0];
+    if (c0->hslots != m->groups * m->fif) { const int rc = csky_multi_set_host_ring(m, m->groups * m->fif); if (rc) return rc; }
+    int rc; if ((rc = bind(c0))) return mpass(m, 0, rc);
+    csky_ctx::HostSlot& hs = c0->hring[c0->next_ticket % c0->hslots];
+    if (hs.busy) return mfail(m, CSKY_ERR_STATE, "csky_multi_submit_clouds: %d frames are already in flight; collect ticket %lld first", c0->hslots, hs.ticket);
+    const size_t px = (size_t)tile_w * tile_h;
+    if ((rc = host_slot_prepare(c0, hs, px, true))) return mpass(m, 0, rc);
+    if ((rc = csky_multi_render_clouds_device(m, p, tile_w, tile_h, hs.d, (size_t)tile_w * 8, hs.s))) return rc;
+    if ((rc = bind(c0))) return mpass(m, 0, rc);
+    if (hipMemcpyAsync(hs.h, hs.d, px * 8, hipMemcpyDeviceToHost, hs.s) != hipSuccess || hipEventRecord(hs.done, hs.s) != hipSuccess)
+        return mfail(m, CSKY_ERR_HIP, "csky_multi_submit_clouds: copy to the pinned frame failed");
+    hs.busy = true; hs.ticket = c0->next_ticket; hs.w = tile_w; hs.hh = tile_h;
+    *ticket = c0->next_ticket++;
+    return CSKY_OK;
+}
+int csky_multi_collect(csky_multi* m, int64_t ticket, const uint16_t** frame, size_t* bytes) {
+    if (!m) return mfail(nullptr, CSKY_ERR_INVALID, "csky_multi_collect: handle is NULL");
+    return mpass(m, 0, csky_collect(m->ctx[0], ticket, frame, bytes));
 }
 
 int csky_multi_sync(csky_multi* m) {

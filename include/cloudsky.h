@@ -12,6 +12,11 @@
  * every RenderingDevice call onto the single render thread: cloud_sky.gd:118,154).  There is NO CPU
  * fallback: without a usable HIP device csky_create fails with CSKY_ERR_NO_DEVICE.
  *
+ * Process environment: when libcloudsky.so is LOADED it sets GPU_MAX_HW_QUEUES=8 for the process unless the variable is already set (the HIP
+ * runtime reads it at its first call; with the default of 4 the streams of two frames in flight share hardware queues and do not overlap).
+ * CSKY_NO_ENV=1 in the environment disables that; csky_set_frames_in_flight(>= 2) then leaves a warning in csky_last_error when the
+ * variable is not in effect.  Other variables read (all optional, A/B switches): CSKY_PERSISTENT, CSKY_PERSISTENT_WGS, CSKY_MULTI_STAGED.
+ *
  * Images are tightly packed little-endian RGBA half floats (DATA_FORMAT_R16G16B16A16_SFLOAT,
  * cloud_sky.gd:369; sky_lut.gd:84; transmittance_lut.gd:37), row-major, row 0 = pixel y == 0.
  */
@@ -142,6 +147,22 @@ int csky_render_clouds_device(csky_ctx* ctx, const csky_cloud_params* p, int til
                               void* d_out_rgba16f, size_t row_pitch_bytes, void* hip_stream);
 int csky_sync(csky_ctx* ctx); /* wait for the context's own streams (work on caller streams is the caller's to wait for) */
 
+/* ---- asynchronous host form: submit / collect (the throughput path of a host that needs the frame in HOST memory) ---------------
+ * csky_render_clouds blocks for march + copy, one frame at a time.  These keep `slots` frames in flight instead: csky_submit_clouds enqueues
+ * the march of tile [0,tile_w) x [0,tile_h) (binding the sky LUT rendered last, like csky_render_clouds) and the copy of the frame into a
+ * PINNED host buffer of an internal ring, on that slot's own stream, and returns a ticket at once; csky_collect(ticket) blocks until that
+ * frame is in host memory and returns a pointer to it (tightly packed RGBA16F, tile_w*tile_h*8 bytes), valid until `slots` further
+ * submits.  Tickets count up from 0; at most `slots` may be outstanding (CSKY_ERR_STATE otherwise) and they may be collected in any order.
+ * csky_poll: 1 = ready, 0 = still in flight.  With 2 or more slots the march of frame k+1 overlaps the copy and the launch tail of
+ * frame k (the library sets its two-frames-in-flight launch policy, csky_set_frames_in_flight).  This is what the GDExtension's
+ * submit_clouds() / collect() wrap (gdext/cloudsky_gdextension.c): the reference's frame loop (cloud_sky.gd:129-187 on frame_pre_draw,
+ * rd.texture_update into the ring textures of :368-378) has a frame of slack by construction -- the cloud texture it draws with is the
+ * one finished in an EARLIER update pass (:137-148). */
+int csky_set_host_ring(csky_ctx* ctx, int slots);   /* 1..4, default 2 */
+int csky_submit_clouds(csky_ctx* ctx, const csky_cloud_params* p, int tile_w, int tile_h, int64_t* ticket);
+int csky_collect(csky_ctx* ctx, int64_t ticket, const uint16_t** frame_rgba16f, size_t* bytes);
+int csky_poll(csky_ctx* ctx, int64_t ticket);
+
 /* Read back the context's internal LUT copies (tests, the compositor, Texture2DRD.texture_update). */
 int csky_read_transmittance(csky_ctx* ctx, uint16_t* out_rgba16f, int* w, int* h);
 int csky_read_sky_lut(csky_ctx* ctx, uint16_t* out_rgba16f, int* w, int* h);
@@ -256,6 +277,11 @@ int csky_multi_render_clouds_device(csky_multi* m, const csky_cloud_params* p, i
 /* Host-buffer form: renders as above into an internal frame on the first device, copies it out, blocks. */
 int csky_multi_render_clouds(csky_multi* m, const csky_cloud_params* p, int tile_w, int tile_h, uint16_t* out_rgba16f, size_t row_pitch_bytes);
 int csky_multi_sync(csky_multi* m);
+/* Asynchronous host form over the handle (see csky_submit_clouds): frames land in pinned host memory of the first device's context.
+ * slots = groups x frames in flight per group (csky_multi_set_host_ring sets the latter). */
+int csky_multi_set_host_ring(csky_multi* m, int slots);
+int csky_multi_submit_clouds(csky_multi* m, const csky_cloud_params* p, int tile_w, int tile_h, int64_t* ticket);
+int csky_multi_collect(csky_multi* m, int64_t ticket, const uint16_t** frame_rgba16f, size_t* bytes);
 
 /* ---- asset layer (host only; usable without a GPU) ------------------------------------------------
  * What the reference gets from Godot's importers (weather.bmp.import, worlnoise.bmp.import,
