@@ -448,6 +448,36 @@ def main():
         ctx.set_frames_in_flight(fif)
         frame[0] = local[0]
 
+    # The host form (N = 1): frames delivered into PINNED HOST memory per second through csky_submit_clouds / csky_collect (what the GDExtension's
+    # submit_clouds() / collect() wrap), with 1 and 2 frames in flight.  PCIe-inclusive: never the headline `value` (frames resident in HBM).
+    host_form = None
+    if world == 1:
+        host_form = {}
+        nh = max(10, min(args.steps, 100))
+        for slots in (1, 2):
+            ctx.set_host_ring(slots)
+            tickets = []
+
+            def hstep(k):
+                fp, fs = (params, sun_n) if sweep is None else sweep[k % len(sweep)]
+                if len(tickets) == slots:
+                    ctx.collect(tickets.pop(0), copy=False)
+                ctx.render_sky_lut_device(fs, 200, 100, None)
+                tickets.append(ctx.submit_clouds(fp, W, H))
+            for k in range(4):
+                hstep(k)
+            while tickets:
+                ctx.collect(tickets.pop(0), copy=False)
+            t1 = time.perf_counter()
+            for k in range(nh):
+                hstep(k)
+            while tickets:
+                ctx.collect(tickets.pop(0), copy=False)
+            eh = time.perf_counter() - t1
+            host_form["%d_in_flight" % slots] = {"ms_per_frame": eh / nh * 1e3, "frames_per_s": nh / eh, "Mrays_per_s": W * H * nh / eh / 1e6, "frames": nh,
+                                                 "GB_per_s_to_host": W * H * 8 * nh / eh / 1e9}
+        ctx.set_frames_in_flight(fif)
+
     # secondary figure, N = 1 only: the same frames with the wave early-out the north star describes (T < 1e-3; bounded error
     # <= 1e-3, within the stated parity tolerance).  NOT the headline: the reference has no early-out, so `value` keeps eps = 0.
     early = None
@@ -508,6 +538,7 @@ def main():
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
             "value_one_frame_at_a_time": one_at_a_time,
+            "value_host_form": host_form,
             "ranks_seen": ranks_seen, "per_rank_share_ms": share_ms,
             "config": {"workload": "%s: %dx%d hemisphere, %d primary x %d light steps, sun (%.4f,%.4f,%.4f), clouds_sky.tres defaults, "
                                    "weather.bmp + worlnoise.bmp + generated 128^3 shape noise (seed 1), wind frozen"

@@ -16,6 +16,18 @@
  *                                                                   cloud_sky.gd:234-248         (pc = `_fill_push_constant()`, 28 floats)
  *   get_status() -> int                                             0 or the CSKY_ERR_* code of the last call
  *   get_last_error() -> String
+ * Throughput path (round 3): the blocking render_clouds() costs march + 16 MiB device-to-host copy per frame, one frame at a time.
+ *   create_multi(device_ids: PackedInt32Array) -> int               the GPUs of the node behind this one object (csky_multi_*): every device
+ *                                                                   renders its bands of each frame straight into the frame on the first one
+ *   set_noise_mips(large_chain, small_chain, weather) -> int        explicit form of set_noise() with all mip levels back to back (the importer's own chains)
+ *   set_frames(slots: int) -> int                                   frames kept in flight by submit/collect (1..4; default 2)
+ *   submit_clouds(pc: PackedFloat32Array, tile_w, tile_h: int) -> int   enqueue march + copy into a pinned ring slot, return a ticket (>= 0) at once, < 0 = error
+ *   collect(ticket: int) -> PackedByteArray                         wait for that frame, return its bytes for rd.texture_update()
+ *   is_ready(ticket: int) -> int                                    1 ready, 0 in flight, < 0 error
+ * cloud_sky.gd's loop already draws with the texture finished in an EARLIER pass (:137-148), so collect(ticket of the previous update) right
+ * before submit_clouds(this update) drops in without changing what is on screen when.
+ * A zero-copy design (the march writes into memory the engine's VkImage is bound to: no host hop at all) is in gdext/zero_copy_vulkan.c,
+ * compile-only here (no Vulkan headers / no engine in this image).
  *
  * The render methods return the image as tightly packed RGBA16F bytes (what texture_update takes); on error they
  * return an empty array and get_status() / get_last_error() say why.  Nothing here computes anything: every method is
@@ -59,6 +71,7 @@ static struct {
     GDExtensionInterfacePackedByteArrayOperatorIndex pba_index;
     GDExtensionInterfacePackedByteArrayOperatorIndexConst pba_index_const;
     GDExtensionInterfacePackedFloat32ArrayOperatorIndexConst pfa_index_const;
+    GDExtensionInterfacePackedInt32ArrayOperatorIndexConst pia_index_const;
     GDExtensionInterfaceClassdbConstructObject construct_object;
     GDExtensionInterfaceObjectSetInstance object_set_instance;
     GDExtensionInterfaceClassdbRegisterExtensionClass2 register_class;
@@ -68,13 +81,14 @@ static struct {
     GDExtensionInterfaceGetVariantFromTypeConstructor from_type;
     GDExtensionInterfaceVariantGetPtrDestructor get_destructor;
     csky_ptr_constructor pba_default_ctor;
-    csky_builtin_method pba_size, pba_resize, pfa_size;
-    GDExtensionPtrDestructor pba_destroy, pfa_destroy;
+    csky_builtin_method pba_size, pba_resize, pfa_size, pia_size;
+    GDExtensionPtrDestructor pba_destroy, pfa_destroy, pia_destroy;
     csky_name class_name, parent_name;
 } G;
 
 typedef struct {
-    csky_ctx *ctx;
+    csky_ctx *ctx;        /* the context every method talks to: the object's own, or the first device's context of `multi` */
+    csky_multi *multi;    /* create_multi(): the devices of the node behind this object (owns ctx then) */
     int status;
     char err[512];
 } CloudSkyHIP;
@@ -85,7 +99,9 @@ static GDExtensionInt packed_size(csky_builtin_method size_fn, GDExtensionConstT
     size_fn((GDExtensionTypePtr)arr, NULL, &n, 0);
     return n;
 }
-/* r_out = PackedByteArray(); r_out.resize(bytes); returns its writable data pointer (NULL if bytes == 0) */
+/* r_out = PackedByteArray(); r_out.resize(bytes); returns its writable data pointer, NULL if bytes == 0 OR the resize failed (the caller
+ * must tell the two apart).  The ptrcall return slot is UNINITIALISED memory by the GDExtension convention (the engine placement-constructs
+ * nothing there for builtin return types; godot-cpp's PtrToArg::encode does the same), so it is constructed, not assigned. */
 static uint8_t *packed_byte_array_new(csky_packed *r_out, GDExtensionInt bytes) {
     GDExtensionInt arg = bytes, ret = 0;
     GDExtensionConstTypePtr args[1];
@@ -93,7 +109,15 @@ static uint8_t *packed_byte_array_new(csky_packed *r_out, GDExtensionInt bytes) 
     if (bytes <= 0) return NULL;
     args[0] = &arg;
     G.pba_resize(r_out, args, &ret, 1);
+    if (ret != 0 || packed_size(G.pba_size, r_out) != bytes) return NULL;       /* resize() returns an Error; OK == 0 */
     return G.pba_index(r_out, 0);
+}
+/* LUT / tile sizes come from push-constant FLOATS the script controls: NaN, negative or huge values must never reach an integer cast or
+ * an allocation.  Returns 1 and the sizes when both are finite integers in [1, 8192] (the library's own limit). */
+static int lut_size_ok(const float ts[2], GDExtensionInt *w, GDExtensionInt *h) {
+    if (!(ts[0] >= 1.0f && ts[0] <= 8192.0f && ts[1] >= 1.0f && ts[1] <= 8192.0f)) return 0;   /* false for NaN too */
+    *w = (GDExtensionInt)ts[0]; *h = (GDExtensionInt)ts[1];
+    return 1;
 }
 static int fail(CloudSkyHIP *self, int code, const char *text) {
     self->status = code;
@@ -111,14 +135,36 @@ static const float *float_args(CloudSkyHIP *self, GDExtensionConstTypePtr arr, G
     return G.pfa_index_const(arr, 0);
 }
 
+static void release(CloudSkyHIP *self) {
+    if (self->multi) { csky_multi_destroy(self->multi); self->multi = NULL; self->ctx = NULL; }
+    if (self->ctx) { csky_destroy(self->ctx); self->ctx = NULL; }
+}
+static int mpass(CloudSkyHIP *self, int rc) { /* the same for calls through the multi-device handle */
+    if (rc != CSKY_OK) return fail(self, rc, csky_multi_last_error(self->multi));
+    self->status = CSKY_OK; self->err[0] = 0;
+    return rc;
+}
+
 /* ---- the methods (ptrcall form: p_args[i] points to the native value) --------------------------------------------------- */
 static void m_create(void *ud, GDExtensionClassInstancePtr inst, const GDExtensionConstTypePtr *a, GDExtensionTypePtr r) {
     CloudSkyHIP *self = (CloudSkyHIP *)inst; (void)ud;
     int rc;
-    if (self->ctx) { csky_destroy(self->ctx); self->ctx = NULL; }
+    release(self);
     rc = csky_create(&self->ctx, (int)*(const GDExtensionInt *)a[0]);
     if (rc != CSKY_OK) fail(self, rc, csky_last_error(NULL)); else pass(self, rc);
     *(GDExtensionInt *)r = rc;
+}
+static void m_create_multi(void *ud, GDExtensionClassInstancePtr inst, const GDExtensionConstTypePtr *a, GDExtensionTypePtr r) {
+    CloudSkyHIP *self = (CloudSkyHIP *)inst; (void)ud;
+    int ids[64], i, rc;
+    const GDExtensionInt n = packed_size(G.pia_size, a[0]);
+    release(self);
+    if (n < 1 || n > 64) { *(GDExtensionInt *)r = fail(self, CSKY_ERR_INVALID, "create_multi: 1 .. 64 device ids"); return; }
+    for (i = 0; i < (int)n; i++) ids[i] = (int)*G.pia_index_const(a[0], i);
+    rc = csky_multi_create(&self->multi, ids, (int)n);
+    if (rc != CSKY_OK) { fail(self, rc, csky_multi_last_error(NULL)); *(GDExtensionInt *)r = rc; return; }
+    self->ctx = csky_multi_ctx(self->multi, 0);      /* LUT reads, status texts; owned by `multi` */
+    *(GDExtensionInt *)r = pass(self, CSKY_OK);
 }
 static void m_set_noise(void *ud, GDExtensionClassInstancePtr inst, const GDExtensionConstTypePtr *a, GDExtensionTypePtr r) {
     CloudSkyHIP *self = (CloudSkyHIP *)inst; (void)ud;
@@ -127,42 +173,66 @@ static void m_set_noise(void *ud, GDExtensionClassInstancePtr inst, const GDExte
     else if (packed_size(G.pba_size, a[2]) != 512 * 512 * 3)
         rc = fail(self, CSKY_ERR_INVALID, "set_noise: the weather map must be 512^2 RGB8");
     else if (packed_size(G.pba_size, a[0]) == 128 * 128 * 128 * 4 && packed_size(G.pba_size, a[1]) == 32 * 32 * 32 * 3)
-        rc = pass(self, csky_set_noise(self->ctx, G.pba_index_const(a[0], 0), G.pba_index_const(a[1], 0), G.pba_index_const(a[2], 0)));
+        rc = self->multi ? mpass(self, csky_multi_set_noise(self->multi, G.pba_index_const(a[0], 0), G.pba_index_const(a[1], 0), G.pba_index_const(a[2], 0)))
+                         : pass(self, csky_set_noise(self->ctx, G.pba_index_const(a[0], 0), G.pba_index_const(a[1], 0), G.pba_index_const(a[2], 0)));
     /* all mip levels back to back (what Texture3D.get_data() holds after Image.decompress()): the importer's own chains are bound as they are */
     else if ((size_t)packed_size(G.pba_size, a[0]) == csky_mip_offset(128, 8, 4) && (size_t)packed_size(G.pba_size, a[1]) == csky_mip_offset(32, 6, 3))
-        rc = pass(self, csky_set_noise_mips(self->ctx, G.pba_index_const(a[0], 0), G.pba_index_const(a[1], 0), G.pba_index_const(a[2], 0)));
+        rc = self->multi ? mpass(self, csky_multi_set_noise_mips(self->multi, G.pba_index_const(a[0], 0), G.pba_index_const(a[1], 0), G.pba_index_const(a[2], 0)))
+                         : pass(self, csky_set_noise_mips(self->ctx, G.pba_index_const(a[0], 0), G.pba_index_const(a[1], 0), G.pba_index_const(a[2], 0)));
     else
         rc = fail(self, CSKY_ERR_INVALID, "set_noise: expected 128^3 RGBA8 and 32^3 RGB8 byte arrays, level 0 only or all mip levels back to back");
     *(GDExtensionInt *)r = rc;
 }
+/* the explicit form: ONLY the full chains are accepted (a host that decompressed the importer's .ctex3d files, perlworlnoise.tga.import:24) */
+static void m_set_noise_mips(void *ud, GDExtensionClassInstancePtr inst, const GDExtensionConstTypePtr *a, GDExtensionTypePtr r) {
+    CloudSkyHIP *self = (CloudSkyHIP *)inst; (void)ud;
+    int rc;
+    if (!self->ctx) rc = fail(self, CSKY_ERR_STATE, "CloudSkyHIP: create() has not been called");
+    else if (packed_size(G.pba_size, a[2]) != 512 * 512 * 3 || (size_t)packed_size(G.pba_size, a[0]) != csky_mip_offset(128, 8, 4) ||
+             (size_t)packed_size(G.pba_size, a[1]) != csky_mip_offset(32, 6, 3))
+        rc = fail(self, CSKY_ERR_INVALID, "set_noise_mips: expected the 8-level 128^3 RGBA8 chain, the 6-level 32^3 RGB8 chain and the 512^2 RGB8 weather map");
+    else
+        rc = self->multi ? mpass(self, csky_multi_set_noise_mips(self->multi, G.pba_index_const(a[0], 0), G.pba_index_const(a[1], 0), G.pba_index_const(a[2], 0)))
+                         : pass(self, csky_set_noise_mips(self->ctx, G.pba_index_const(a[0], 0), G.pba_index_const(a[1], 0), G.pba_index_const(a[2], 0)));
+    *(GDExtensionInt *)r = rc;
+}
 static void m_set_march(void *ud, GDExtensionClassInstancePtr inst, const GDExtensionConstTypePtr *a, GDExtensionTypePtr r) {
     CloudSkyHIP *self = (CloudSkyHIP *)inst; (void)ud;
-    *(GDExtensionInt *)r = self->ctx ? pass(self, csky_set_march(self->ctx, (int)*(const GDExtensionInt *)a[0], (int)*(const GDExtensionInt *)a[1]))
-                                     : fail(self, CSKY_ERR_STATE, "CloudSkyHIP: create() has not been called");
+    const int ps = (int)*(const GDExtensionInt *)a[0], ls = (int)*(const GDExtensionInt *)a[1];
+    *(GDExtensionInt *)r = !self->ctx ? fail(self, CSKY_ERR_STATE, "CloudSkyHIP: create() has not been called")
+                         : self->multi ? mpass(self, csky_multi_set_march(self->multi, ps, ls)) : pass(self, csky_set_march(self->ctx, ps, ls));
 }
 static void m_render_transmittance(void *ud, GDExtensionClassInstancePtr inst, const GDExtensionConstTypePtr *a, GDExtensionTypePtr r) {
     CloudSkyHIP *self = (CloudSkyHIP *)inst; (void)ud;
     csky_transmittance_params p;
     const float *pc;
+    GDExtensionInt w, h;
     uint8_t *dst;
     if (!self->ctx) { fail(self, CSKY_ERR_STATE, "CloudSkyHIP: create() has not been called"); packed_byte_array_new((csky_packed *)r, 0); return; }
     pc = float_args(self, a[0], 4, "render_transmittance: push constant must be 4 floats (transmittance-lut.glsl:12-15)");
     if (!pc) { packed_byte_array_new((csky_packed *)r, 0); return; }
     memcpy(&p, pc, sizeof p);
-    dst = packed_byte_array_new((csky_packed *)r, (GDExtensionInt)p.texture_size[0] * (GDExtensionInt)p.texture_size[1] * 8);
+    if (!lut_size_ok(p.texture_size, &w, &h)) { fail(self, CSKY_ERR_INVALID, "render_transmittance: texture_size must be finite and in [1, 8192]"); packed_byte_array_new((csky_packed *)r, 0); return; }
+    dst = packed_byte_array_new((csky_packed *)r, w * h * 8);
+    if (!dst) { fail(self, CSKY_ERR_INVALID, "render_transmittance: could not allocate the result array"); G.pba_destroy(r); packed_byte_array_new((csky_packed *)r, 0); return; }
     if (pass(self, csky_render_transmittance(self->ctx, &p, (uint16_t *)dst)) != CSKY_OK) { G.pba_destroy(r); packed_byte_array_new((csky_packed *)r, 0); }
 }
 static void m_render_sky_lut(void *ud, GDExtensionClassInstancePtr inst, const GDExtensionConstTypePtr *a, GDExtensionTypePtr r) {
     CloudSkyHIP *self = (CloudSkyHIP *)inst; (void)ud;
     csky_sky_params p;
     const float *pc;
+    GDExtensionInt w, h;
     uint8_t *dst;
     if (!self->ctx) { fail(self, CSKY_ERR_STATE, "CloudSkyHIP: create() has not been called"); packed_byte_array_new((csky_packed *)r, 0); return; }
     pc = float_args(self, a[0], 8, "render_sky_lut: push constant must be 8 floats (sky-lut.glsl:12-18)");
     if (!pc) { packed_byte_array_new((csky_packed *)r, 0); return; }
     memcpy(&p, pc, sizeof p);
-    dst = packed_byte_array_new((csky_packed *)r, (GDExtensionInt)p.texture_size[0] * (GDExtensionInt)p.texture_size[1] * 8);
-    if (pass(self, csky_render_sky_lut(self->ctx, &p, (uint16_t *)dst)) != CSKY_OK) { G.pba_destroy(r); packed_byte_array_new((csky_packed *)r, 0); }
+    if (!lut_size_ok(p.texture_size, &w, &h)) { fail(self, CSKY_ERR_INVALID, "render_sky_lut: texture_size must be finite and in [1, 8192]"); packed_byte_array_new((csky_packed *)r, 0); return; }
+    dst = packed_byte_array_new((csky_packed *)r, w * h * 8);
+    if (!dst) { fail(self, CSKY_ERR_INVALID, "render_sky_lut: could not allocate the result array"); G.pba_destroy(r); packed_byte_array_new((csky_packed *)r, 0); return; }
+    /* with several devices every one of them needs the LUT for its bands; the bytes come from the first */
+    if (self->multi && mpass(self, csky_multi_render_sky_lut(self->multi, &p)) != CSKY_OK) { G.pba_destroy(r); packed_byte_array_new((csky_packed *)r, 0); return; }
+    if (pass(self, self->multi ? csky_read_sky_lut(self->ctx, (uint16_t *)dst, NULL, NULL) : csky_render_sky_lut(self->ctx, &p, (uint16_t *)dst)) != CSKY_OK) { G.pba_destroy(r); packed_byte_array_new((csky_packed *)r, 0); }
 }
 static void m_render_clouds(void *ud, GDExtensionClassInstancePtr inst, const GDExtensionConstTypePtr *a, GDExtensionTypePtr r) {
     CloudSkyHIP *self = (CloudSkyHIP *)inst; (void)ud;
@@ -179,7 +249,50 @@ static void m_render_clouds(void *ud, GDExtensionClassInstancePtr inst, const GD
     }
     memcpy(&p, pc, sizeof p);
     dst = packed_byte_array_new((csky_packed *)r, w * h * 8);
-    if (pass(self, csky_render_clouds(self->ctx, &p, (int)w, (int)h, (uint16_t *)dst, (size_t)w * 8)) != CSKY_OK) { G.pba_destroy(r); packed_byte_array_new((csky_packed *)r, 0); }
+    if (!dst) { fail(self, CSKY_ERR_INVALID, "render_clouds: could not allocate the result array"); G.pba_destroy(r); packed_byte_array_new((csky_packed *)r, 0); return; }
+    if ((self->multi ? mpass(self, csky_multi_render_clouds(self->multi, &p, (int)w, (int)h, (uint16_t *)dst, (size_t)w * 8))
+                     : pass(self, csky_render_clouds(self->ctx, &p, (int)w, (int)h, (uint16_t *)dst, (size_t)w * 8))) != CSKY_OK) { G.pba_destroy(r); packed_byte_array_new((csky_packed *)r, 0); }
+}
+/* ---- throughput path: frames in flight over the library's pinned ring (csky_submit_clouds / csky_collect) ------------------------------- */
+static void m_set_frames(void *ud, GDExtensionClassInstancePtr inst, const GDExtensionConstTypePtr *a, GDExtensionTypePtr r) {
+    CloudSkyHIP *self = (CloudSkyHIP *)inst; (void)ud;
+    const int n = (int)*(const GDExtensionInt *)a[0];
+    *(GDExtensionInt *)r = !self->ctx ? fail(self, CSKY_ERR_STATE, "CloudSkyHIP: create() has not been called")
+                         : self->multi ? mpass(self, csky_multi_set_host_ring(self->multi, n)) : pass(self, csky_set_host_ring(self->ctx, n));
+}
+static void m_submit_clouds(void *ud, GDExtensionClassInstancePtr inst, const GDExtensionConstTypePtr *a, GDExtensionTypePtr r) {
+    CloudSkyHIP *self = (CloudSkyHIP *)inst; (void)ud;
+    csky_cloud_params p;
+    const float *pc;
+    const GDExtensionInt w = *(const GDExtensionInt *)a[1], h = *(const GDExtensionInt *)a[2];
+    int64_t ticket = -1;
+    int rc;
+    if (!self->ctx) { *(GDExtensionInt *)r = fail(self, CSKY_ERR_STATE, "CloudSkyHIP: create() has not been called"); return; }
+    pc = float_args(self, a[0], 28, "submit_clouds: push constant must be the 28 floats of _fill_push_constant() (clouds.glsl:18-40)");
+    if (!pc) { *(GDExtensionInt *)r = CSKY_ERR_INVALID; return; }
+    if (w < 1 || h < 1 || w > 16384 || h > 16384) { *(GDExtensionInt *)r = fail(self, CSKY_ERR_INVALID, "submit_clouds: tile size out of range"); return; }
+    memcpy(&p, pc, sizeof p);
+    rc = self->multi ? mpass(self, csky_multi_submit_clouds(self->multi, &p, (int)w, (int)h, &ticket)) : pass(self, csky_submit_clouds(self->ctx, &p, (int)w, (int)h, &ticket));
+    *(GDExtensionInt *)r = rc == CSKY_OK ? (GDExtensionInt)ticket : (GDExtensionInt)rc;
+}
+static void m_collect(void *ud, GDExtensionClassInstancePtr inst, const GDExtensionConstTypePtr *a, GDExtensionTypePtr r) {
+    CloudSkyHIP *self = (CloudSkyHIP *)inst; (void)ud;
+    const uint16_t *frame = NULL;
+    size_t bytes = 0;
+    uint8_t *dst;
+    if (!self->ctx) { fail(self, CSKY_ERR_STATE, "CloudSkyHIP: create() has not been called"); packed_byte_array_new((csky_packed *)r, 0); return; }
+    if (pass(self, csky_collect(self->ctx, (int64_t)*(const GDExtensionInt *)a[0], &frame, &bytes)) != CSKY_OK) { packed_byte_array_new((csky_packed *)r, 0); return; }
+    dst = packed_byte_array_new((csky_packed *)r, (GDExtensionInt)bytes);
+    if (!dst) { fail(self, CSKY_ERR_INVALID, "collect: could not allocate the result array"); G.pba_destroy(r); packed_byte_array_new((csky_packed *)r, 0); return; }
+    memcpy(dst, frame, bytes);           /* pinned ring slot -> the array rd.texture_update() takes; the slot is free for the next submit */
+}
+static void m_is_ready(void *ud, GDExtensionClassInstancePtr inst, const GDExtensionConstTypePtr *a, GDExtensionTypePtr r) {
+    CloudSkyHIP *self = (CloudSkyHIP *)inst; (void)ud;
+    int rc;
+    if (!self->ctx) { *(GDExtensionInt *)r = fail(self, CSKY_ERR_STATE, "CloudSkyHIP: create() has not been called"); return; }
+    rc = csky_poll(self->ctx, (int64_t)*(const GDExtensionInt *)a[0]);
+    if (rc < 0) fail(self, rc, csky_last_error(self->ctx)); else { self->status = CSKY_OK; self->err[0] = 0; }
+    *(GDExtensionInt *)r = rc;
 }
 static void m_get_status(void *ud, GDExtensionClassInstancePtr inst, const GDExtensionConstTypePtr *a, GDExtensionTypePtr r) {
     (void)ud; (void)a;
@@ -209,6 +322,14 @@ static const csky_method METHODS[] = {
     {"render_sky_lut", m_render_sky_lut, 1, GDEXTENSION_VARIANT_TYPE_PACKED_BYTE_ARRAY, {GDEXTENSION_VARIANT_TYPE_PACKED_FLOAT32_ARRAY}, {"push_constant"}},
     {"render_clouds", m_render_clouds, 3, GDEXTENSION_VARIANT_TYPE_PACKED_BYTE_ARRAY,
      {GDEXTENSION_VARIANT_TYPE_PACKED_FLOAT32_ARRAY, GDEXTENSION_VARIANT_TYPE_INT, GDEXTENSION_VARIANT_TYPE_INT}, {"push_constant", "tile_w", "tile_h"}},
+    {"create_multi", m_create_multi, 1, GDEXTENSION_VARIANT_TYPE_INT, {GDEXTENSION_VARIANT_TYPE_PACKED_INT32_ARRAY}, {"device_ids"}},
+    {"set_noise_mips", m_set_noise_mips, 3, GDEXTENSION_VARIANT_TYPE_INT,
+     {GDEXTENSION_VARIANT_TYPE_PACKED_BYTE_ARRAY, GDEXTENSION_VARIANT_TYPE_PACKED_BYTE_ARRAY, GDEXTENSION_VARIANT_TYPE_PACKED_BYTE_ARRAY}, {"large_chain_rgba8", "small_chain_rgb8", "weather_rgb8"}},
+    {"set_frames", m_set_frames, 1, GDEXTENSION_VARIANT_TYPE_INT, {GDEXTENSION_VARIANT_TYPE_INT}, {"slots"}},
+    {"submit_clouds", m_submit_clouds, 3, GDEXTENSION_VARIANT_TYPE_INT,
+     {GDEXTENSION_VARIANT_TYPE_PACKED_FLOAT32_ARRAY, GDEXTENSION_VARIANT_TYPE_INT, GDEXTENSION_VARIANT_TYPE_INT}, {"push_constant", "tile_w", "tile_h"}},
+    {"collect", m_collect, 1, GDEXTENSION_VARIANT_TYPE_PACKED_BYTE_ARRAY, {GDEXTENSION_VARIANT_TYPE_INT}, {"ticket"}},
+    {"is_ready", m_is_ready, 1, GDEXTENSION_VARIANT_TYPE_INT, {GDEXTENSION_VARIANT_TYPE_INT}, {"ticket"}},
     {"get_status", m_get_status, 0, GDEXTENSION_VARIANT_TYPE_INT, {GDEXTENSION_VARIANT_TYPE_NIL}, {0}},
     {"get_last_error", m_get_last_error, 0, GDEXTENSION_VARIANT_TYPE_STRING, {GDEXTENSION_VARIANT_TYPE_NIL}, {0}},
 };
@@ -239,6 +360,7 @@ static void call_trampoline(void *method_userdata, GDExtensionClassInstancePtr i
     for (i = 0; i < m->argc; i++) {
         if (m->args[i] == GDEXTENSION_VARIANT_TYPE_PACKED_BYTE_ARRAY) G.pba_destroy(&native[i]);
         else if (m->args[i] == GDEXTENSION_VARIANT_TYPE_PACKED_FLOAT32_ARRAY) G.pfa_destroy(&native[i]);
+        else if (m->args[i] == GDEXTENSION_VARIANT_TYPE_PACKED_INT32_ARRAY) G.pia_destroy(&native[i]);
     }
     if (m->ret == GDEXTENSION_VARIANT_TYPE_PACKED_BYTE_ARRAY) G.pba_destroy(&ret);
     else if (m->ret == GDEXTENSION_VARIANT_TYPE_STRING) { GDExtensionPtrDestructor d = G.get_destructor(GDEXTENSION_VARIANT_TYPE_STRING); if (d) d(&ret); }
@@ -258,7 +380,7 @@ static void free_instance(void *class_userdata, GDExtensionClassInstancePtr inst
     CloudSkyHIP *self = (CloudSkyHIP *)inst;
     (void)class_userdata;
     if (!self) return;
-    if (self->ctx) csky_destroy(self->ctx);
+    release(self);
     G.mem_free(self);
 }
 
@@ -327,6 +449,7 @@ GDExtensionBool csky_gdextension_init(GDExtensionInterfaceGetProcAddress get_pro
     LOAD(pba_index, GDExtensionInterfacePackedByteArrayOperatorIndex, "packed_byte_array_operator_index");
     LOAD(pba_index_const, GDExtensionInterfacePackedByteArrayOperatorIndexConst, "packed_byte_array_operator_index_const");
     LOAD(pfa_index_const, GDExtensionInterfacePackedFloat32ArrayOperatorIndexConst, "packed_float32_array_operator_index_const");
+    LOAD(pia_index_const, GDExtensionInterfacePackedInt32ArrayOperatorIndexConst, "packed_int32_array_operator_index_const");
     LOAD(construct_object, GDExtensionInterfaceClassdbConstructObject, "classdb_construct_object");
     LOAD(object_set_instance, GDExtensionInterfaceObjectSetInstance, "object_set_instance");
     LOAD(register_class, GDExtensionInterfaceClassdbRegisterExtensionClass2, "classdb_register_extension_class2");
@@ -342,11 +465,13 @@ GDExtensionBool csky_gdextension_init(GDExtensionInterfaceGetProcAddress get_pro
     G.string_name_new(&n_resize, "resize", 1);
     G.pba_size = get_builtin(GDEXTENSION_VARIANT_TYPE_PACKED_BYTE_ARRAY, &n_size, CSKY_HASH_PACKED_SIZE);
     G.pfa_size = get_builtin(GDEXTENSION_VARIANT_TYPE_PACKED_FLOAT32_ARRAY, &n_size, CSKY_HASH_PACKED_SIZE);
+    G.pia_size = get_builtin(GDEXTENSION_VARIANT_TYPE_PACKED_INT32_ARRAY, &n_size, CSKY_HASH_PACKED_SIZE);
     G.pba_resize = get_builtin(GDEXTENSION_VARIANT_TYPE_PACKED_BYTE_ARRAY, &n_resize, CSKY_HASH_PACKED_RESIZE);
     G.pba_default_ctor = get_ctor(GDEXTENSION_VARIANT_TYPE_PACKED_BYTE_ARRAY, 0);
     G.pba_destroy = G.get_destructor(GDEXTENSION_VARIANT_TYPE_PACKED_BYTE_ARRAY);
     G.pfa_destroy = G.get_destructor(GDEXTENSION_VARIANT_TYPE_PACKED_FLOAT32_ARRAY);
-    if (!G.pba_size || !G.pfa_size || !G.pba_resize || !G.pba_default_ctor || !G.pba_destroy || !G.pfa_destroy) return 0;
+    G.pia_destroy = G.get_destructor(GDEXTENSION_VARIANT_TYPE_PACKED_INT32_ARRAY);
+    if (!G.pba_size || !G.pfa_size || !G.pia_size || !G.pba_resize || !G.pba_default_ctor || !G.pba_destroy || !G.pfa_destroy || !G.pia_destroy) return 0;
     r_init->minimum_initialization_level = GDEXTENSION_INITIALIZATION_SCENE;
     r_init->userdata = NULL;
     r_init->initialize = initialize_level;

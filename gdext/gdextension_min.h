@@ -36,6 +36,7 @@ typedef enum {
     GDEXTENSION_VARIANT_TYPE_FLOAT = 3,
     GDEXTENSION_VARIANT_TYPE_STRING = 4,
     GDEXTENSION_VARIANT_TYPE_PACKED_BYTE_ARRAY = 29,
+    GDEXTENSION_VARIANT_TYPE_PACKED_INT32_ARRAY = 30,
     GDEXTENSION_VARIANT_TYPE_PACKED_FLOAT32_ARRAY = 32
 } GDExtensionVariantType;
 
@@ -151,6 +152,7 @@ typedef void (*GDExtensionInterfaceStringNewWithUtf8Chars)(GDExtensionStringPtr 
 typedef uint8_t *(*GDExtensionInterfacePackedByteArrayOperatorIndex)(GDExtensionTypePtr p_self, GDExtensionInt p_index);
 typedef const uint8_t *(*GDExtensionInterfacePackedByteArrayOperatorIndexConst)(GDExtensionConstTypePtr p_self, GDExtensionInt p_index);
 typedef const float *(*GDExtensionInterfacePackedFloat32ArrayOperatorIndexConst)(GDExtensionConstTypePtr p_self, GDExtensionInt p_index);
+typedef const int32_t *(*GDExtensionInterfacePackedInt32ArrayOperatorIndexConst)(GDExtensionConstTypePtr p_self, GDExtensionInt p_index);
 typedef GDExtensionObjectPtr (*GDExtensionInterfaceClassdbConstructObject)(GDExtensionConstStringNamePtr p_classname);
 typedef void (*GDExtensionInterfaceObjectSetInstance)(GDExtensionObjectPtr p_o, GDExtensionConstStringNamePtr p_classname, GDExtensionClassInstancePtr p_instance);
 typedef void (*GDExtensionInterfaceClassdbRegisterExtensionClass2)(GDExtensionClassLibraryPtr p_library, GDExtensionConstStringNamePtr p_class_name,

@@ -61,6 +61,10 @@ SYMBOLS = [
     ("csky_render_clouds_device", C.c_int, [C.c_void_p, C.POINTER(CloudParams), C.c_int, C.POINTER(Bands), C.c_void_p, C.c_size_t, C.c_void_p]),
     ("csky_copy_sky_lut_device", C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
     ("csky_sync", C.c_int, [C.c_void_p]),
+    ("csky_set_host_ring", C.c_int, [C.c_void_p, C.c_int]),
+    ("csky_submit_clouds", C.c_int, [C.c_void_p, C.POINTER(CloudParams), C.c_int, C.c_int, C.POINTER(C.c_int64)]),
+    ("csky_collect", C.c_int, [C.c_void_p, C.c_int64, C.POINTER(C.c_void_p), C.POINTER(C.c_size_t)]),
+    ("csky_poll", C.c_int, [C.c_void_p, C.c_int64]),
     ("csky_read_transmittance", C.c_int, [C.c_void_p, C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     ("csky_read_sky_lut", C.c_int, [C.c_void_p, C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     ("csky_composite_sky", C.c_int, [C.c_void_p, C.POINTER(CompositeParams), C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
@@ -90,6 +94,9 @@ SYMBOLS = [
     ("csky_multi_render_clouds_device", C.c_int, [C.c_void_p, C.POINTER(CloudParams), C.c_int, C.c_int, C.c_void_p, C.c_size_t, C.c_void_p]),
     ("csky_multi_render_clouds", C.c_int, [C.c_void_p, C.POINTER(CloudParams), C.c_int, C.c_int, C.c_void_p, C.c_size_t]),
     ("csky_multi_sync", C.c_int, [C.c_void_p]),
+    ("csky_multi_set_host_ring", C.c_int, [C.c_void_p, C.c_int]),
+    ("csky_multi_submit_clouds", C.c_int, [C.c_void_p, C.POINTER(CloudParams), C.c_int, C.c_int, C.POINTER(C.c_int64)]),
+    ("csky_multi_collect", C.c_int, [C.c_void_p, C.c_int64, C.POINTER(C.c_void_p), C.POINTER(C.c_size_t)]),
     ("csky_load_bmp_rgb8", C.c_int, [C.c_char_p, C.POINTER(C.c_int), C.POINTER(C.c_int), C.c_void_p, C.c_size_t]),
     ("csky_load_tga_rgba8", C.c_int, [C.c_char_p, C.POINTER(C.c_int), C.POINTER(C.c_int), C.c_void_p, C.c_size_t]),
     ("csky_strip_to_volume", C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
@@ -279,6 +286,35 @@ class Context:
     def sync(self):
         self._chk(self._L.csky_sync(self._h))
 
+    # ---- asynchronous host form (pinned ring)
+    def set_host_ring(self, slots):
+        self._chk(self._L.csky_set_host_ring(self._h, int(slots)))
+
+    def submit_clouds(self, params, tile_w=None, tile_h=None):
+        """Enqueue march + copy into a pinned ring slot; returns the ticket at once."""
+        p = cloud_params(params)
+        w = int(p.f[0]) if tile_w is None else int(tile_w)
+        h = int(p.f[1]) if tile_h is None else int(tile_h)
+        t = C.c_int64(-1)
+        self._chk(self._L.csky_submit_clouds(self._h, C.byref(p), w, h, C.byref(t)))
+        self._shapes = getattr(self, "_shapes", {})
+        self._shapes[t.value] = (h, w)
+        return t.value
+
+    def collect(self, ticket, copy=True):
+        """Wait for the frame of `ticket`: float16 [h, w, 4].  copy=False returns a VIEW of the pinned ring slot (valid until the slot is reused)."""
+        ptr, n = C.c_void_p(), C.c_size_t()
+        self._chk(self._L.csky_collect(self._h, int(ticket), C.byref(ptr), C.byref(n)))
+        h, w = self._shapes.pop(int(ticket))
+        a = np.ctypeslib.as_array(C.cast(ptr, C.POINTER(C.c_uint16)), shape=(h, w, 4))
+        return (a.copy() if copy else a).view(np.float16)
+
+    def poll(self, ticket):
+        rc = self._L.csky_poll(self._h, int(ticket))
+        if rc < 0:
+            self._chk(rc)
+        return rc == 1
+
     def read_transmittance(self):
         w, h = C.c_int(), C.c_int()
         self._chk(self._L.csky_read_transmittance(self._h, None, C.byref(w), C.byref(h)))
@@ -449,3 +485,23 @@ class MultiContext:
 
     def sync(self):
         self._chk(self._L.csky_multi_sync(self._h))
+
+    def set_host_ring(self, slots):
+        self._chk(self._L.csky_multi_set_host_ring(self._h, int(slots)))
+
+    def submit_clouds(self, params, tile_w=None, tile_h=None):
+        p = cloud_params(params)
+        w = int(p.f[0]) if tile_w is None else int(tile_w)
+        h = int(p.f[1]) if tile_h is None else int(tile_h)
+        t = C.c_int64(-1)
+        self._chk(self._L.csky_multi_submit_clouds(self._h, C.byref(p), w, h, C.byref(t)))
+        self._shapes = getattr(self, "_shapes", {})
+        self._shapes[t.value] = (h, w)
+        return t.value
+
+    def collect(self, ticket, copy=True):
+        ptr, n = C.c_void_p(), C.c_size_t()
+        self._chk(self._L.csky_multi_collect(self._h, int(ticket), C.byref(ptr), C.byref(n)))
+        h, w = self._shapes.pop(int(ticket))
+        a = np.ctypeslib.as_array(C.cast(ptr, C.POINTER(C.c_uint16)), shape=(h, w, 4))
+        return (a.copy() if copy else a).view(np.float16)

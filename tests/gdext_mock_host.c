@@ -17,7 +17,7 @@ typedef void (*ptr_constructor)(GDExtensionTypePtr, const GDExtensionConstTypePt
 static struct {
     char class_name[64], parent[64];
     GDExtensionClassCreationInfo2 ci;
-    struct { char name[64]; GDExtensionClassMethodInfo mi; } methods[16];
+    struct { char name[64]; GDExtensionClassMethodInfo mi; } methods[32];
     int n_methods;
     void *instance;
 } R;
@@ -30,6 +30,7 @@ static void i_string_new(GDExtensionStringPtr dst, const char *s) { *(char **)ds
 static uint8_t *i_pba_index(GDExtensionTypePtr self, GDExtensionInt i) { return ((MockPacked *)self)->data + i; }
 static const uint8_t *i_pba_index_const(GDExtensionConstTypePtr self, GDExtensionInt i) { return ((const MockPacked *)self)->data + i; }
 static const float *i_pfa_index_const(GDExtensionConstTypePtr self, GDExtensionInt i) { return (const float *)((const MockPacked *)self)->data + i; }
+static const int32_t *i_pia_index_const(GDExtensionConstTypePtr self, GDExtensionInt i) { return (const int32_t *)((const MockPacked *)self)->data + i; }
 static GDExtensionObjectPtr i_construct_object(GDExtensionConstStringNamePtr name) { (void)name; return malloc(8); }
 static void i_object_set_instance(GDExtensionObjectPtr o, GDExtensionConstStringNamePtr cls, GDExtensionClassInstancePtr inst) { (void)o; (void)cls; R.instance = inst; }
 static void i_register_class(GDExtensionClassLibraryPtr lib, GDExtensionConstStringNamePtr name, GDExtensionConstStringNamePtr parent, const GDExtensionClassCreationInfo2 *ci) {
@@ -49,7 +50,7 @@ static void i_unregister_class(GDExtensionClassLibraryPtr lib, GDExtensionConstS
 static void v2t_int(GDExtensionTypePtr dst, GDExtensionVariantPtr v) { *(int64_t *)dst = ((MockVariant *)v)->u.i; }
 static void v2t_packed(GDExtensionTypePtr dst, GDExtensionVariantPtr v) {   /* the engine shares the buffer; the mock copies it */
     const MockPacked *s = &((MockVariant *)v)->u.arr; MockPacked *d = (MockPacked *)dst;
-    d->size = s->size; d->data = (uint8_t *)malloc((size_t)(s->size ? s->size : 1) * 4); memcpy(d->data, s->data, (size_t)s->size * (((MockVariant *)v)->type == GDEXTENSION_VARIANT_TYPE_PACKED_FLOAT32_ARRAY ? 4 : 1));
+    d->size = s->size; d->data = (uint8_t *)malloc((size_t)(s->size ? s->size : 1) * 4); memcpy(d->data, s->data, (size_t)s->size * (((MockVariant *)v)->type == GDEXTENSION_VARIANT_TYPE_PACKED_BYTE_ARRAY ? 1 : 4));
 }
 static GDExtensionTypeFromVariantConstructorFunc i_to_type(GDExtensionVariantType t) { return t == GDEXTENSION_VARIANT_TYPE_INT ? v2t_int : v2t_packed; }
 static void t2v_int(GDExtensionVariantPtr v, GDExtensionTypePtr src) { MockVariant *m = (MockVariant *)v; m->type = GDEXTENSION_VARIANT_TYPE_INT; m->u.i = *(int64_t *)src; }
@@ -83,7 +84,7 @@ static GDExtensionInterfaceFunctionPtr get_proc(const char *name) {
     F("mem_alloc", i_mem_alloc); F("mem_free", i_mem_free);
     F("string_name_new_with_latin1_chars", i_string_name_new); F("string_new_with_utf8_chars", i_string_new);
     F("packed_byte_array_operator_index", i_pba_index); F("packed_byte_array_operator_index_const", i_pba_index_const);
-    F("packed_float32_array_operator_index_const", i_pfa_index_const);
+    F("packed_float32_array_operator_index_const", i_pfa_index_const); F("packed_int32_array_operator_index_const", i_pia_index_const);
     F("classdb_construct_object", i_construct_object); F("object_set_instance", i_object_set_instance);
     F("classdb_register_extension_class2", i_register_class); F("classdb_register_extension_class_method", i_register_method);
     F("classdb_unregister_extension_class", i_unregister_class);
@@ -114,8 +115,10 @@ int main(int argc, char **argv) {
     GDExtensionInitialization init;
     GDExtensionInitializationFunction entry;
     void *so;
-    static const char *expect[] = {"create", "set_noise", "set_march", "render_transmittance", "render_sky_lut", "render_clouds", "get_status", "get_last_error"};
-    static const int expect_argc[] = {1, 3, 2, 1, 1, 3, 0, 0};
+    static const char *expect[] = {"create", "set_noise", "set_march", "render_transmittance", "render_sky_lut", "render_clouds", "get_status", "get_last_error",
+                                   "create_multi", "set_noise_mips", "set_frames", "submit_clouds", "collect", "is_ready"};
+    static const int expect_argc[] = {1, 3, 2, 1, 1, 3, 0, 0, 1, 3, 1, 3, 1, 1};
+    enum { N_EXPECT = 14 };
     int i;
     if (argc < 2) return 2;
     so = dlopen(argv[1], RTLD_NOW);
@@ -129,10 +132,10 @@ int main(int argc, char **argv) {
     if (R.class_name[0]) return 7;                                  /* nothing may register before the SCENE level */
     init.initialize(init.userdata, GDEXTENSION_INITIALIZATION_SCENE);
     if (strcmp(R.class_name, "CloudSkyHIP") || strcmp(R.parent, "RefCounted") || !R.ci.create_instance_func || !R.ci.free_instance_func || !R.ci.is_exposed) return 8;
-    if (R.n_methods != 8) return 9;
-    for (i = 0; i < 8; i++) {
+    if (R.n_methods != N_EXPECT) return 9;
+    for (i = 0; i < N_EXPECT; i++) {
         const GDExtensionClassMethodInfo *mi = method(expect[i]);
-        if (!mi || (int)mi->argument_count != expect_argc[i] || !mi->ptrcall_func || !mi->call_func || !mi->has_return_value) return 10 + i;
+        if (!mi || (int)mi->argument_count != expect_argc[i] || !mi->ptrcall_func || !mi->call_func || !mi->has_return_value) return 10;
     }
     free(R.ci.create_instance_func(R.ci.class_userdata));
     if (!R.instance) return 20;
@@ -155,6 +158,8 @@ int main(int argc, char **argv) {
         memset(&vr, 0, sizeof vr);
         method("get_last_error")->call_func(method("get_last_error")->method_userdata, R.instance, NULL, 0, &vr, &ce);
         if (vr.type != GDEXTENSION_VARIANT_TYPE_STRING || !strstr(vr.u.s, "create()")) return 24;
+        if (ptrcall_int("submit_clouds", a) != CSKY_ERR_STATE) return 25;             /* the asynchronous form before create() */
+        { int64_t t = 0; GDExtensionConstTypePtr ta[1] = {&t}; if (ptrcall_bytes("collect", ta).size != 0 || ptrcall_int("is_ready", ta) != CSKY_ERR_STATE) return 26; }
     }
     if (argc >= 4) {   /* the whole chain on the GPU through the shim */
         uint8_t *large, *small, *weather;
@@ -205,6 +210,61 @@ int main(int argc, char **argv) {
             va[1].type = va[2].type = GDEXTENSION_VARIANT_TYPE_INT; va[1].u.i = 64; va[2].u.i = 32;
             method("render_clouds")->call_func(method("render_clouds")->method_userdata, R.instance, vp, 3, &vr, &ce);
             if (ce.error != GDEXTENSION_CALL_OK || vr.u.arr.size != img.size || memcmp(vr.u.arr.data, img.data, (size_t)img.size)) return 39;
+        }
+        {   /* LUT sizes are script-controlled FLOATS: NaN / huge / negative must be refused before any cast or allocation */
+            static const float bad_sizes[][2] = {{0.0f / 0.0f, 64}, {1e30f, 1e30f}, {-5, 64}, {256, 0}, {1.0f / 0.0f, 1}};
+            size_t k;
+            for (k = 0; k < sizeof bad_sizes / sizeof bad_sizes[0]; k++) {
+                float tb[4] = {bad_sizes[k][0], bad_sizes[k][1], 0, 0}, sb[8] = {bad_sizes[k][0], bad_sizes[k][1], 0, 0, 0, 1, 0, 0};
+                MockPacked ptb = {(uint8_t *)tb, 4}, psb = {(uint8_t *)sb, 8};
+                a[0] = &ptb; if (ptrcall_bytes("render_transmittance", a).size != 0 || ptrcall_int("get_status", NULL) != CSKY_ERR_INVALID) return 41;
+                a[0] = &psb; if (ptrcall_bytes("render_sky_lut", a).size != 0 || ptrcall_int("get_status", NULL) != CSKY_ERR_INVALID) return 42;
+            }
+        }
+        {   /* the throughput path: two tickets outstanding over the pinned ring, collected out of order; frames byte-identical to the blocking call */
+            int64_t slots = 2, t0, t1, t2, q;
+            GDExtensionConstTypePtr ta[1];
+            MockPacked f0, f1;
+            ta[0] = &slots; if (ptrcall_int("set_frames", ta) != CSKY_OK) return 43;
+            a[0] = &pc; a[1] = &w; a[2] = &h;
+            t0 = ptrcall_int("submit_clouds", a); t1 = ptrcall_int("submit_clouds", a);
+            if (t0 != 0 || t1 != 1) return 44;
+            t2 = ptrcall_int("submit_clouds", a);                                      /* a third frame while two are outstanding: refused, nothing lost */
+            if (t2 != CSKY_ERR_STATE) return 45;
+            ta[0] = &t1; f1 = ptrcall_bytes("collect", ta);
+            ta[0] = &t0; q = ptrcall_int("is_ready", ta); if (q != 0 && q != 1) return 46;
+            f0 = ptrcall_bytes("collect", ta);
+            if (f0.size != img.size || f1.size != img.size || memcmp(f0.data, img.data, (size_t)img.size) || memcmp(f1.data, img.data, (size_t)img.size)) return 47;
+            if (ptrcall_bytes("collect", ta).size != 0 || ptrcall_int("get_status", NULL) != CSKY_ERR_STATE) return 48;    /* collected already */
+            t2 = ptrcall_int("submit_clouds", a); if (t2 != 2) return 49;             /* tickets keep counting; the ring slot is reused */
+            ta[0] = &t2; f0 = ptrcall_bytes("collect", ta);
+            if (f0.size != img.size || memcmp(f0.data, img.data, (size_t)img.size)) return 50;
+        }
+        {   /* create_multi: two contexts behind the object (both on device 0 here); explicit set_noise_mips; blocking and asynchronous frames */
+            int32_t ids[2] = {0, 0};
+            MockPacked pid = {(uint8_t *)ids, 2}, f;
+            const size_t nl = csky_mip_offset(128, 8, 4), ns = csky_mip_offset(32, 6, 3);
+            uint8_t *lc = (uint8_t *)calloc(nl, 1), *sc = (uint8_t *)calloc(ns, 1);
+            int64_t t;
+            GDExtensionConstTypePtr ta[1];
+            a[0] = &pid; if (ptrcall_int("create_multi", a) != CSKY_OK) return 51;
+            memcpy(lc, large, (size_t)128 * 128 * 128 * 4); memcpy(sc, small, (size_t)32 * 32 * 32 * 3);
+            if (csky_build_mips(lc, 128, 4, 8) != CSKY_OK || csky_build_mips(sc, 32, 3, 6) != CSKY_OK) return 30;
+            pl.data = lc; pl.size = (int64_t)nl; ps.data = sc; ps.size = (int64_t)ns;
+            a[0] = &pl; a[1] = &ps; a[2] = &pw;
+            if (ptrcall_int("set_noise_mips", a) != CSKY_OK) return 52;
+            pl.size -= 4; if (ptrcall_int("set_noise_mips", a) != CSKY_ERR_INVALID) return 53; pl.size += 4;
+            a[0] = &prim; a[1] = &light; if (ptrcall_int("set_march", a) != CSKY_OK) return 54;
+            a[0] = &psc; lut = ptrcall_bytes("render_sky_lut", a); if (lut.size != 200 * 100 * 8) return 55;
+            a[0] = &pc; a[1] = &w; a[2] = &h;
+            f = ptrcall_bytes("render_clouds", a);
+            bad = (f.size == 64 * 32 * 8) ? ctu_bad_pixels((const uint16_t *)f.data, ref, 64 * 32) : -1;
+            if (bad < 0 || bad > 2) return 56;                                        /* (a 64x32 tile over two devices runs as ray segments: equal to rounding) */
+            t = ptrcall_int("submit_clouds", a); if (t < 0) return 57;
+            ta[0] = &t; f = ptrcall_bytes("collect", ta);
+            bad = (f.size == 64 * 32 * 8) ? ctu_bad_pixels((const uint16_t *)f.data, ref, 64 * 32) : -1;
+            if (bad < 0 || bad > 2) return 58;
+            free(lc); free(sc);
         }
     }
     R.ci.free_instance_func(R.ci.class_userdata, R.instance);

@@ -186,3 +186,72 @@ def test_multi_handle_groups_staged_and_four_frames_in_flight(pkg, noise, gpu_ct
                 m.render_clouds(oracle.default_params(W, H, suns[0]), W, 12)         # both forms reject heights that are not whole bands
         finally:
             m.close()
+
+
+# ------------------------------------------------------------------------------------------------ asynchronous host form
+def test_submit_collect_over_the_pinned_ring(pkg, noise, gpu_ctx, oracle):
+    """csky_submit_clouds / csky_collect (include/cloudsky.h): frames in flight over a ring of pinned host buffers.  Every collected frame
+    must be byte-identical to the blocking csky_render_clouds of ITS parameters (different suns in flight at once), tickets count up,
+    collection order is free, a full ring refuses the next submit without losing anything, unknown tickets are errors."""
+    W, H = 512, 256
+    suns = [(1, 1, 0), (0.2, 1, 0.3), (-1, 0.4, 0.5), (0.1, 0.3, -1), (0.7, 0.2, 0.1)]
+    gpu_ctx.set_march(128, 6); gpu_ctx.set_segments(1)
+    refs = []
+    for sun in suns:
+        gpu_ctx.render_sky_lut(norm(sun), 200, 100)
+        refs.append(gpu_ctx.render_clouds(oracle.default_params(W, H, sun)).view(np.uint16).copy())
+    gpu_ctx.set_segments(0)
+    ctx = pkg.Context(0)
+    try:
+        ctx.set_noise(*noise); ctx.set_march(128, 6); ctx.set_segments(1); ctx.render_transmittance(256, 64)
+        for slots in (1, 2, 3, 4):
+            ctx.set_host_ring(slots)
+            pending = []
+            for k in range(3 * slots + 2):
+                sun = suns[k % len(suns)]
+                if len(pending) == slots:
+                    t, ks = pending.pop(0)
+                    got = ctx.collect(t).view(np.uint16)
+                    assert (got == refs[ks % len(suns)]).all(), (slots, k, t)
+                ctx.render_sky_lut_device(norm(sun), 200, 100, None)
+                t = ctx.submit_clouds(oracle.default_params(W, H, sun))
+                pending.append((t, k))
+            assert [t for t, _ in pending] == sorted(t for t, _ in pending)
+            with pytest.raises(pkg.CloudSkyError):                     # ring full
+                ctx.submit_clouds(oracle.default_params(W, H, suns[0]))
+            for t, ks in reversed(pending):                            # any order
+                v = ctx.collect(t, copy=False)
+                assert (v.view(np.uint16) == refs[ks % len(suns)]).all(), (slots, t, "drain")
+            with pytest.raises(pkg.CloudSkyError):
+                ctx.collect(10 ** 9)
+            with pytest.raises(pkg.CloudSkyError):
+                ctx.collect(pending[0][0])                             # collected already
+        # a ragged tile (the host form takes any height) and a frame larger than the ring's current buffers
+        ctx.set_segments(0)
+        ctx.render_sky_lut(norm(suns[0]), 200, 100)
+        t = ctx.submit_clouds(oracle.default_params(200, 72, suns[0]))
+        a = ctx.collect(t)
+        b = ctx.render_clouds(oracle.default_params(200, 72, suns[0]))
+        ok, info = cloud_close(a, b, frac=0.9999, atol=5e-4, rtol=2e-3)
+        assert ok, info
+    finally:
+        ctx.close()
+    # the same through the multi-device handle (two frame groups of two contexts, all on device 0)
+    m = pkg.MultiContext([0] * 4)
+    try:
+        m.set_noise(*noise); m.set_march(128, 6)
+        for i in range(4):
+            m.ctx(i).set_segments(1)
+        m.set_groups(2); m.set_host_ring(4)
+        pending = []
+        for k in range(11):
+            sun = suns[k % len(suns)]
+            if len(pending) == 4:
+                t, ks = pending.pop(0)
+                assert (m.collect(t).view(np.uint16) == refs[ks % len(suns)]).all(), (k, t)
+            m.render_sky_lut(norm(sun))
+            pending.append((m.submit_clouds(oracle.default_params(W, H, sun)), k))
+        for t, ks in pending:
+            assert (m.collect(t).view(np.uint16) == refs[ks % len(suns)]).all(), (t, "drain")
+    finally:
+        m.close()
