@@ -65,6 +65,10 @@ SYMBOLS = [
     ("csky_submit_clouds", C.c_int, [C.c_void_p, C.POINTER(CloudParams), C.c_int, C.c_int, C.POINTER(C.c_int64)]),
     ("csky_collect", C.c_int, [C.c_void_p, C.c_int64, C.POINTER(C.c_void_p), C.POINTER(C.c_size_t)]),
     ("csky_poll", C.c_int, [C.c_void_p, C.c_int64]),
+    ("csky_external_frame_import_fd", C.c_int, [C.c_void_p, C.c_int, C.c_size_t, C.c_size_t, C.c_size_t, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p)]),
+    ("csky_external_frame_import_semaphore_fd", C.c_int, [C.c_void_p, C.c_void_p, C.c_int]),
+    ("csky_external_frame_signal", C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
+    ("csky_external_frame_release", None, [C.c_void_p]),
     ("csky_read_transmittance", C.c_int, [C.c_void_p, C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     ("csky_read_sky_lut", C.c_int, [C.c_void_p, C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     ("csky_composite_sky", C.c_int, [C.c_void_p, C.POINTER(CompositeParams), C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
@@ -107,6 +111,7 @@ SYMBOLS = [
     ("csky_build_mips_device", C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int]),
     ("csky_read_baked_texture", C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_size_t, C.POINTER(C.c_size_t)]),
     ("csky_test_sqrt_shell", C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t]),
+    ("csky_census_clouds", C.c_int, [C.c_void_p, C.POINTER(CloudParams), C.c_int, C.POINTER(Bands), C.c_void_p, C.c_int]),
     ("csky_mip_offset", C.c_size_t, [C.c_int, C.c_int, C.c_int]),
     ("csky_build_mips", C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int]),
     ("csky_decode_bc7", C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
@@ -285,6 +290,14 @@ class Context:
 
     def sync(self):
         self._chk(self._L.csky_sync(self._h))
+
+    def census_clouds(self, params, tile_w, bands, n=256):
+        """Basic-block execution counts of one launch (non-zero only with the census build of the library, tools/isa_profile.py)."""
+        p = cloud_params(params)
+        b = Bands(*[int(x) for x in bands])
+        out = np.zeros(n, np.uint32)
+        self._chk(self._L.csky_census_clouds(self._h, C.byref(p), int(tile_w), C.byref(b), _ptr(out), int(n)))
+        return out
 
     # ---- asynchronous host form (pinned ring)
     def set_host_ring(self, slots):

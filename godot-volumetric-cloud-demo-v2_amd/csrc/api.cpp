@@ -97,7 +97,7 @@ namespace {
 #ifdef CSKY_TIMELINE
 constexpr size_t CSKY_STATS_WORDS = 2 + 4 * 4 * 70000;   // + {t0, t1, where, what} per wavefront of up to 70 000 workgroups (analysis build)
 #else
-constexpr size_t CSKY_STATS_WORDS = 2;
+constexpr size_t CSKY_STATS_WORDS = 2 + 128;             // [0..1] the kernel's own tallies; then 256 32-bit basic-block counters of the census build (tools/isa_profile.py; zero in the product build)
 #endif
 thread_local char g_err[512];
 
@@ -501,6 +501,19 @@ int csky_test_sqrt_shell(csky_ctx* c, const float* in, float* out, size_t n) {
     return CSKY_OK;
 }
 
+int csky_census_clouds(csky_ctx* c, const csky_cloud_params* p, int tile_w, const csky_bands* bands, uint32_t* counts, int n) {
+    if (!c || !counts || n < 1 || n > 256) return fail(c, CSKY_ERR_INVALID, "csky_census_clouds: bad arguments (1 .. 256 counters)");
+    int rc; if ((rc = bind(c))) return rc;
+    if ((rc = check_bands(c, bands, tile_w))) return rc;
+    const size_t rows = (size_t)bands->n_bands * bands->band_rows;
+    if ((rc = ensure_frame(c, (size_t)tile_w * (rows ? rows : 1)))) return rc;
+    HIPCHK(c, hipMemsetAsync(c->d_stats, 0, CSKY_STATS_WORDS * sizeof(unsigned long long), c->stream));
+    if ((rc = clouds_dev(c, p, tile_w, bands, c->d_frame, (size_t)tile_w * 8, c->stream, c->d_stats, true))) return rc;
+    HIPCHK(c, hipMemcpyAsync(counts, reinterpret_cast<const char*>(c->d_stats) + 16, (size_t)n * 4, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return CSKY_OK;
+}
+
 int csky_build_mips_device(csky_ctx* c, uint8_t* vol, int n, int ch, int levels) {
     if (!c) return fail(nullptr, CSKY_ERR_INVALID, "csky_build_mips_device: ctx is NULL");
     if (!vol || n < 1 || n > 1024 || (n & (n - 1)) || ch < 1 || ch > 4 || levels < 1 || (n >> (levels - 1)) < 1) return fail(c, CSKY_ERR_INVALID, "csky_build_mips_device: bad arguments");
@@ -728,6 +741,53 @@ int csky_poll(csky_ctx* c, int64_t ticket) {
             return fail(c, CSKY_ERR_HIP, "csky_poll: %s", hipGetErrorString(e));
         }
     return fail(c, CSKY_ERR_STATE, "csky_poll: ticket %lld is not outstanding", (long long)ticket);
+}
+
+// ---- zero-copy interop: a frame that lives in memory another API allocated (cloudsky.h; gdext/zero_copy_vulkan.c is the Vulkan half) ----
+struct csky_external_frame { int device = 0; hipExternalMemory_t mem = nullptr; void* d_ptr = nullptr; size_t bytes = 0; hipExternalSemaphore_t sem = nullptr; };
+
+int csky_external_frame_import_fd(csky_ctx* c, int opaque_fd, size_t allocation_bytes, size_t offset, size_t frame_bytes, csky_external_frame** out, void** d_ptr) {
+    if (!c || !out || !d_ptr) return fail(c, CSKY_ERR_INVALID, "csky_external_frame_import_fd: NULL argument");
+    *out = nullptr; *d_ptr = nullptr;
+    if (opaque_fd < 0 || frame_bytes == 0 || offset + frame_bytes > allocation_bytes) return fail(c, CSKY_ERR_INVALID, "csky_external_frame_import_fd: bad fd / sizes");
+    int rc; if ((rc = bind(c))) return rc;
+    csky_external_frame* f = new (std::nothrow) csky_external_frame();
+    if (!f) return fail(c, CSKY_ERR_INVALID, "csky_external_frame_import_fd: out of host memory");
+    f->device = c->device; f->bytes = frame_bytes;
+    hipExternalMemoryHandleDesc md; memset(&md, 0, sizeof md);
+    md.type = hipExternalMemoryHandleTypeOpaqueFd; md.handle.fd = opaque_fd; md.size = allocation_bytes;   // the runtime takes ownership of the fd on success
+    hipError_t e = hipImportExternalMemory(&f->mem, &md);
+    if (e == hipSuccess) {
+        hipExternalMemoryBufferDesc bd; memset(&bd, 0, sizeof bd);
+        bd.offset = offset; bd.size = frame_bytes;
+        e = hipExternalMemoryGetMappedBuffer(&f->d_ptr, f->mem, &bd);
+    }
+    if (e != hipSuccess) { csky_external_frame_release(f); return fail(c, CSKY_ERR_HIP, "csky_external_frame_import_fd: %s", hipGetErrorString(e)); }
+    *out = f; *d_ptr = f->d_ptr;
+    return CSKY_OK;
+}
+int csky_external_frame_import_semaphore_fd(csky_ctx* c, csky_external_frame* f, int opaque_fd) {
+    if (!c || !f || opaque_fd < 0) return fail(c, CSKY_ERR_INVALID, "csky_external_frame_import_semaphore_fd: bad argument");
+    int rc; if ((rc = bind(c))) return rc;
+    if (f->sem) { (void)hipDestroyExternalSemaphore(f->sem); f->sem = nullptr; }
+    hipExternalSemaphoreHandleDesc sd; memset(&sd, 0, sizeof sd);
+    sd.type = hipExternalSemaphoreHandleTypeOpaqueFd; sd.handle.fd = opaque_fd;
+    HIPCHK(c, hipImportExternalSemaphore(&f->sem, &sd));
+    return CSKY_OK;
+}
+int csky_external_frame_signal(csky_ctx* c, csky_external_frame* f, void* hip_stream) {
+    if (!c || !f || !f->sem) return fail(c, CSKY_ERR_INVALID, "csky_external_frame_signal: no semaphore imported");
+    int rc; if ((rc = bind(c))) return rc;
+    hipExternalSemaphoreSignalParams sp; memset(&sp, 0, sizeof sp);
+    HIPCHK(c, hipSignalExternalSemaphoresAsync(&f->sem, &sp, 1, hip_stream ? (hipStream_t)hip_stream : c->stream));
+    return CSKY_OK;
+}
+void csky_external_frame_release(csky_external_frame* f) {
+    if (!f) return;
+    (void)hipSetDevice(f->device);
+    if (f->sem) (void)hipDestroyExternalSemaphore(f->sem);
+    if (f->mem) (void)hipDestroyExternalMemory(f->mem);      // unmaps d_ptr
+    delete f;
 }
 
 int csky_read_transmittance(csky_ctx* c, uint16_t* out, int* w, int* h) {

@@ -163,6 +163,22 @@ int csky_submit_clouds(csky_ctx* ctx, const csky_cloud_params* p, int tile_w, in
 int csky_collect(csky_ctx* ctx, int64_t ticket, const uint16_t** frame_rgba16f, size_t* bytes);
 int csky_poll(csky_ctx* ctx, int64_t ticket);
 
+/* ---- zero-copy interop: "returns the same TextureRD" without a host hop ------------------------------------------------------------
+ * The march can store its pixels straight into memory the ENGINE's texture is bound to: the engine side (Vulkan) allocates the image's
+ * memory with VK_EXTERNAL_MEMORY_HANDLE_TYPE_OPAQUE_FD_BIT, exports the fd (vkGetMemoryFdKHR) and hands it over; these entry points import it
+ * (hipImportExternalMemory / hipExternalMemoryGetMappedBuffer) and return a device pointer usable as d_out of csky_render_clouds_device
+ * (row pitch = the image's VkSubresourceLayout.rowPitch for a LINEAR-tiled R16G16B16A16_SFLOAT image).  An exported VkSemaphore, imported with
+ * ..._import_semaphore_fd and signalled on the march's stream by csky_external_frame_signal, orders the engine's sampling behind the march.
+ * gdext/zero_copy_vulkan.c holds the Vulkan half and the Godot glue (RenderingDevice.texture_create_from_extension -> Texture2DRD); neither
+ * Vulkan headers nor an engine exist in this image, so that file is compile-guarded and this half is exercised for its error paths only.
+ * The library takes ownership of the fds on success. */
+typedef struct csky_external_frame csky_external_frame;
+int csky_external_frame_import_fd(csky_ctx* ctx, int opaque_fd, size_t allocation_bytes, size_t offset, size_t frame_bytes,
+                                  csky_external_frame** out, void** d_ptr);
+int csky_external_frame_import_semaphore_fd(csky_ctx* ctx, csky_external_frame* f, int opaque_fd);
+int csky_external_frame_signal(csky_ctx* ctx, csky_external_frame* f, void* hip_stream);
+void csky_external_frame_release(csky_external_frame* f);
+
 /* Read back the context's internal LUT copies (tests, the compositor, Texture2DRD.texture_update). */
 int csky_read_transmittance(csky_ctx* ctx, uint16_t* out_rgba16f, int* w, int* h);
 int csky_read_sky_lut(csky_ctx* ctx, uint16_t* out_rgba16f, int* w, int* h);
@@ -310,6 +326,10 @@ int csky_read_baked_texture(csky_ctx* ctx, int which, void* out, size_t capacity
 /* Test hook: the march's range-restricted exact square root (cloud_core.h::sqrt_shell, |p|^2 of sample positions) over an array, so that
  * a test can check it EXHAUSTIVELY against IEEE sqrtf on the range it is used on (all 30 067 floats in [3.597e13, 3.6097e13]). */
 int csky_test_sqrt_shell(csky_ctx* ctx, const float* in, float* out, size_t n);
+/* Measurement hook of tools/isa_profile.py: one launch of the cloud kernel over `bands` with the statistics buffer bound, then the first n
+ * (<= 256) 32-bit basic-block execution counters behind the kernel's own tallies.  The counters are written only by the CENSUS build of the
+ * library (the product assembly with a counter per basic block, made by that tool); the product build leaves them zero. */
+int csky_census_clouds(csky_ctx* ctx, const csky_cloud_params* p, int tile_w, const csky_bands* bands, uint32_t* counts, int n);
 /* ---- what Godot's importer wrote (godot_import.cpp; host only) ------------------------------------
  * The reference's noise textures are imported with compress/mode=2, compress/high_quality=true (weather.bmp.import:19-20,
  * worlnoise.bmp.import:19-20, perlworlnoise.tga.import:19-20), i.e. as BPTC (BC7) blocks in .godot/imported/<name>-<md5>.bptc.ctex

@@ -255,3 +255,30 @@ def test_submit_collect_over_the_pinned_ring(pkg, noise, gpu_ctx, oracle):
             assert (m.collect(t).view(np.uint16) == refs[ks % len(suns)]).all(), (t, "drain")
     finally:
         m.close()
+
+
+def test_external_frame_import_error_paths(pkg, gpu_ctx):
+    """The HIP half of the zero-copy path (csky_external_frame_*, gdext/zero_copy_vulkan.c holds the Vulkan half): no Vulkan allocation
+    exists here to import, so only the refusals are exercised: bad descriptors never reach the runtime, a non-Vulkan fd is refused BY the
+    runtime with CSKY_ERR_HIP and nothing leaks or crashes."""
+    import ctypes as C
+    L = pkg.lib()
+    f, d = C.c_void_p(), C.c_void_p()
+    assert L.csky_external_frame_import_fd(gpu_ctx._h, -1, 4096, 0, 4096, C.byref(f), C.byref(d)) == pkg._lib.ERR_INVALID
+    assert L.csky_external_frame_import_fd(gpu_ctx._h, 0, 4096, 4000, 4096, C.byref(f), C.byref(d)) == pkg._lib.ERR_INVALID      # offset + size > allocation
+    r, w = os.pipe()
+    try:
+        rc = L.csky_external_frame_import_fd(gpu_ctx._h, r, 1 << 20, 0, 1 << 20, C.byref(f), C.byref(d))
+        assert rc in (pkg._lib.ERR_HIP, pkg._lib.OK)
+        if rc == pkg._lib.OK:      # a runtime that accepts any fd: release must still work
+            L.csky_external_frame_release(f)
+        else:
+            assert not f.value and not d.value and b"csky_external_frame_import_fd" in L.csky_last_error(gpu_ctx._h)
+    finally:
+        os.close(w)
+        try:
+            os.close(r)
+        except OSError:
+            pass
+    L.csky_external_frame_release(None)
+    assert L.csky_external_frame_signal(gpu_ctx._h, None, None) == pkg._lib.ERR_INVALID

@@ -22,6 +22,8 @@ PASSES = {
              "SQ_INSTS_VALU_INT32", "SQ_BUSY_CYCLES"],
     "mem": ["TCP_TOTAL_CACHE_ACCESSES_sum", "TCP_TCC_READ_REQ_sum", "TA_TA_BUSY_sum", "SQ_INSTS_VMEM_RD", "SQ_BUSY_CYCLES", "SQ_WAVE_CYCLES", "SQ_WAIT_INST_ANY",
             "SQ_INSTS_SALU"],
+    # instruction totals by issue unit: the cross-check of the basic-block census (tools/isa_profile.py)
+    "insts": ["SQ_INSTS_VALU", "SQ_INSTS_SALU", "SQ_INSTS_LDS", "SQ_INSTS_SMEM", "SQ_INSTS_VMEM_WR", "SQ_INSTS_VMEM_RD", "SQ_WAVES", "SQ_BUSY_CYCLES"],
     "fetch": ["FETCH_SIZE", "TCC_HIT_sum"],
     "write": ["WRITE_SIZE", "TCC_MISS_sum", "TCC_REQ_sum"],
 }
