@@ -245,6 +245,48 @@ def main_single_process(args):
     m.close()
 
 
+def valu_roofline(census, clocks, pmc, vi, k_solo_ms, ms_per_step):
+    """The VALU-issue roofline from the instruction census and the sampled clocks (see the `roofline.note` of the JSON line)."""
+    out = {"achieved": None, "peak": None, "frac": None, "frac_bounds": None, "headline": None, "valu_issue": None, "clocks": clocks}
+    if not census:
+        return out
+    kp = census["kernels"].get("plain") or {}
+    kq = census["kernels"].get("persistent") or {}
+    mix = census.get("mixed_stream_factor") or {}
+    mix_hi = max(mix.values()) if mix else 1.0
+    ach = kp.get("valu_issue_cycles_per_simd")
+    out["valu_issue"] = {"source": "census", "calibration": census.get("calibration"), "mixed_stream_factor": mix,
+                         "executed": kp.get("executed"), "valu_by_class": kp.get("valu_by_class"), "issue_cycles_per_simd": ach,
+                         "priced_by_measured_kind_fraction": kp.get("valu_priced_by_measured_kind_fraction"),
+                         "frame_identical_to_product": kp.get("frame_identical_to_product"),
+                         "scratch_instructions_per_wavefront": {"plain": kp.get("scratch_instructions_per_wavefront"), "persistent": kq.get("scratch_instructions_per_wavefront")},
+                         "persistent_form_issue_cycles_per_simd": kq.get("valu_issue_cycles_per_simd"), "top_kinds": (kp.get("top_kinds") or [])[:12]}
+    cnt = ((pmc or {}).get("counters_per_launch") or {})
+    ins = cnt.get("insts") or cnt.get("valu") or {}
+    if ins and kp.get("executed"):
+        ex = kp["executed"]
+        pairs = {"valu": "SQ_INSTS_VALU", "salu": "SQ_INSTS_SALU", "smem": "SQ_INSTS_SMEM", "vmem_load": "SQ_INSTS_VMEM_RD", "lds": "SQ_INSTS_LDS"}
+        out["valu_issue"]["census_over_hardware_counters"] = {k: (ex[k] / ins[c] if ins.get(c) else None) for k, c in pairs.items()}
+    ck = (clocks or {}).get("kernel_alone") or {}
+    mhz = (ck.get("sclk") or {}).get("mean_mhz")
+    sq_cycles = vi.get("kernel_cycles")
+    if ach and mhz:
+        k_ms = ck.get("kernel_ms") or k_solo_ms
+        peak = k_ms * 1e-3 * mhz * 1e6
+        out.update({"achieved": ach, "peak": peak, "frac": ach / peak, "frac_bounds": [ach / peak, min(1.0, ach * mix_hi / peak)],
+                    "peak_source": "kernel alone: %.3f ms x %.0f MHz sampled (SQ_BUSY_CYCLES/32 of the counter pass: %s)" % (k_ms, mhz, "%.4g" % sq_cycles if sq_cycles else "n/a")})
+    elif ach and sq_cycles:
+        out.update({"achieved": ach, "peak": sq_cycles, "frac": ach / sq_cycles, "frac_bounds": [ach / sq_cycles, min(1.0, ach * mix_hi / sq_cycles)], "peak_source": "SQ_BUSY_CYCLES/32 (no clock sample)"})
+    ch = (clocks or {}).get("headline") or {}
+    mhz_h = (ch.get("sclk") or {}).get("mean_mhz")
+    achq = kq.get("valu_issue_cycles_per_simd") or ach
+    if achq and mhz_h:
+        peak_h = ms_per_step * 1e-3 * mhz_h * 1e6
+        out["headline"] = {"ms_per_step": ms_per_step, "sclk_mhz": mhz_h, "cycles_per_frame_available": peak_h, "issue_cycles_per_simd": achq, "frac": achq / peak_h,
+                           "frac_bounds": [achq / peak_h, min(1.0, achq * mix_hi / peak_h)], "ms_per_frame_while_sampling": ch.get("ms_per_frame")}
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -524,6 +566,54 @@ def main():
             except Exception as e:   # the bench line is still valid without the fractions
                 pmc, pmc_note = None, "pmc collection failed: %s" % str(e)[:200]
             pmc_s = time.perf_counter() - t_p
+        # ---- the clock of each region + the instruction census (round 3)
+        # SQ_BUSY_CYCLES / 32 is NOT the kernel's duration in cycles when shader engines idle in the launch tail (C3 alone: 2.01 "GHz", C5 alone: 2.31,
+        # profiles/r02), so cycles available = duration x the shader clock SAMPLED during that region (tools/sclk.py: amdgpu hwmon freq1_input).
+        # Every region is re-run for >= 0.4 s with the sampler on; the headline `value` above was timed without it.
+        clocks, census, census_note = None, None, "not collected: N > 1 or --no-pmc"
+        if world == 1 and not args.no_pmc:
+            import sclk
+            import isa_profile
+            pr = torch.cuda.get_device_properties(local_rank)
+            bus = "%04x:%02x:%02x.0" % (getattr(pr, "pci_domain_id", 0), pr.pci_bus_id, getattr(pr, "pci_device_id", 0)) if isinstance(getattr(pr, "pci_bus_id", None), int) else None
+            node = sclk.hwmon_freq_path(bus)
+            clocks = {"source": node}
+
+            def clocked(run_frames, frames_per_call):
+                run_frames()                                     # warm
+                torch.cuda.synchronize()
+                n = 0
+                with sclk.SclkSampler(node) as sm:
+                    t1 = time.perf_counter()
+                    while time.perf_counter() - t1 < 0.4:
+                        run_frames(); n += frames_per_call
+                    torch.cuda.synchronize()
+                    e = time.perf_counter() - t1
+                return {"ms_per_frame": e / n * 1e3, "frames": n, "sclk": sm.stats()}
+
+            ctx.set_frames_in_flight(fif)
+            clocks["headline"] = clocked(lambda: ([step() for _ in range(20)], drain()), 20)
+            ctx.set_frames_in_flight(1)
+            s0c = streams[0]
+
+            def one_by_one():
+                for k in range(10):
+                    fp, fs = (params, sun_n) if sweep is None else sweep[k % len(sweep)]
+                    ctx.render_sky_lut_device(fs, 200, 100, s0c.cuda_stream)
+                    ctx.render_clouds_device(fp, W, bands, local[0].data_ptr(), W * 8, s0c.cuda_stream)
+            clocks["one_frame_at_a_time"] = clocked(one_by_one, 10)
+            solo_ms = []
+            clocks["kernel_alone"] = clocked(lambda: solo_ms.append(ctx.time_clouds(params, W, bands, warmup=0, iters=20)[0]), 20)
+            clocks["kernel_alone"]["kernel_ms"] = sum(solo_ms[1:]) / max(1, len(solo_ms) - 1)
+            ctx.set_frames_in_flight(fif)
+            ok_c, census_note = isa_profile.census_available()
+            if ok_c:
+                try:
+                    cen = isa_profile.report(isa_profile.run_counts(pmc_cfg, quiet=True), quiet=True)
+                    census = cen
+                    census_note = "live in this run (tools/isa_profile.py: the census build of the library, frame byte-identical to the product build)"
+                except BaseException as e:
+                    census, census_note = None, "census failed: %s" % str(e)[:200]
         vi = (pmc or {}).get("valu_issue") or {}
         l1 = (pmc or {}).get("l1_gather") or {}
         hb = (pmc or {}).get("hbm_traffic") or {}
@@ -547,14 +637,14 @@ def main():
                        "variant": gvcd_amd.lib().csky_variant_name(args.variant if args.variant is not None else gvcd_amd._lib.DEFAULT_VARIANT).decode(),
                        "parallelism": "bands%d%s" % (world, "+overlapped-gather" if overlap else ""), "frames_in_flight": fif,
                        "alpha_mean": alpha_mean, "finite": finite},
-            "roofline": {
+            "roofline": dict(valu_roofline(census, clocks, pmc, vi, k_solo, elapsed / args.steps * 1e3), **{
                 # neither "hbm" nor "mfma" binds this path (docstring): the top-level fields are the VALU-issue roof, the one closest to 1
                 "bound": "valu", "kernel": "clouds_kernel<3,1> (compact march), one launch with the GPU to itself; with two frames in flight the timed region runs the same body in its persistent form, clouds_kernel_persistent<3>",
-                "achieved": vi.get("issue_cycles_per_simd"), "peak": vi.get("kernel_cycles"), "unit": "SIMD issue cycles per launch",
-                "frac": vi.get("frac"), "frac_bounds": [vi.get("frac_lower"), vi.get("frac_upper")] if vi else None,
+                "unit": "SIMD issue cycles per launch",
                 "traffic": traffic,
                 "kernel_ms_solo": k_solo, "kernel_ms_in_flight": k_inflight, "kernel_launches_timed": k_launches, "frames_in_flight": fif,
-                "valu_issue": vi or None,
+                "valu_issue_class_counter_model": vi or None,
+                "census_note": census_note,
                 "l1_gather": l1 or None,
                 "hbm": None if traffic is None else {"bytes_per_launch": traffic, "achieved_GBps": traffic / (k_solo * 1e-3) / 1e9, "peak_GBps": HBM_PEAK_GBS,
                                                      "frac": traffic / (k_solo * 1e-3) / 1e9 / HBM_PEAK_GBS, "l2_hit": hb.get("l2_hit"),
@@ -568,11 +658,13 @@ def main():
                                             "for continuity with round 1 only"},
                 "pmc": {"collected": "live in this run (tools/pmc_collect.py)" if pmc else None, "note": pmc_note, "source_hash": (pmc or {}).get("source_hash"),
                         "calibration": (pmc or {}).get("calibration"), "seconds": pmc_s if pmc else None},
-                "note": "fractions are per launch of the cloud kernel ALONE, in cycles of the SQ's own clock (SQ_BUSY_CYCLES / 32 of the same counter pass): "
-                        "valu = wave64 VALU instructions x issue cost measured on gfx950 (full rate 2.29, half rate 4.11, transcendental 8.08 cycles per SIMD) / "
-                        "(1024 SIMDs x kernel cycles), bracketed because the class counters do not see every kind; l1_gather = TA_TA_BUSY / (256 CUs x kernel "
-                        "cycles), ~1.0 in every saturated pattern of tools/ubench/gather_rates.hip.  With two frames in flight (the headline `value`) the next "
-                        "frame fills this launch's tail and the VALU fraction per frame time approaches 1"},
+                "note": "achieved = EXECUTED wave64 VALU instructions by kind (basic-block counts of the census build x the static per-block histogram) x the issue cost "
+                        "of each kind measured on gfx950, per SIMD; peak = the cycles a SIMD had = the region's duration x the shader clock sampled during it.  frac is the "
+                        "additive pricing (a lower bound of the VALU's busy time); frac_bounds[1] applies the measured mixed-stream factor (a 16-instruction stream in the "
+                        "census's proportions costs 1.06-1.09 x the sum of its kinds).  headline = the same for `ms_per_step` (two frames in flight, persistent form).  "
+                        "valu_issue_class_counter_model is round 2's model (hardware class counters, 28 % unclassified) kept for comparison; l1_gather = TA_TA_BUSY / (256 CUs x "
+                        "kernel cycles by SQ_BUSY_CYCLES/32), ~1.0 in every saturated pattern of tools/ubench/gather_rates.hip.  With two frames in flight the next "
+                        "frame fills this launch's tail and the VALU fraction per frame time approaches 1"}),
         }
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(large, small, weather, params, sun_n, W, H, primary, light)

@@ -39,9 +39,21 @@ def test_bench_line_contract_single_gpu():
     assert d["config"]["workload"].startswith("C3: 2048x1024") and d["config"]["finite"] is True
     assert abs(d["value"] - 2048 * 1024 / d["ms_per_step"] / 1e3) < 1e-6 * d["value"]
     assert 100.0 < d["value"] < 1e5 and d["value_one_frame_at_a_time"]["value"] <= d["value"] * 1.05
+    for k in ("value_host_form", "ranks_seen", "per_rank_share_ms"):
+        assert k in d, k
+    assert d["value_host_form"]["2_in_flight"]["Mrays_per_s"] > d["value_host_form"]["1_in_flight"]["Mrays_per_s"] > 100.0
     r = d["roofline"]
     assert r["pmc"]["collected"], r["pmc"]                                     # the counters were collected in THIS run
     assert 0.3 < r["frac"] <= 1.0 and r["frac_bounds"][0] <= r["frac"] <= r["frac_bounds"][1] <= 1.0
+    # round 3: executed instructions come from the basic-block census (no unclassified kinds), cross-checked against the hardware totals, and
+    # the fraction stays <= 1 against the kernel alone AND against the driver-timed ms_per_step at the clock sampled in that region
+    v = r["valu_issue"]
+    assert v["source"] == "census" and v["frame_identical_to_product"] is True and v["priced_by_measured_kind_fraction"] > 0.98
+    for unit, ratio in v["census_over_hardware_counters"].items():
+        assert ratio is None or abs(ratio - 1.0) < 0.03, (unit, ratio)
+    h = r["headline"]
+    assert 0.3 < h["frac"] <= 1.0 and h["frac_bounds"][1] <= 1.0 and 1500 < h["sclk_mhz"] < 2600
+    assert abs(h["ms_per_frame_while_sampling"] - d["ms_per_step"]) < 0.15 * d["ms_per_step"]
     assert 0.2 < r["l1_gather"]["frac"] <= 1.0 and 0.0 < r["hbm"]["frac"] <= 1.0
     assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-9 and r["traffic"] > 1e8
     assert 0.5 < r["kernel_ms_solo"] < 20.0 and r["kernel_ms_in_flight"] >= 0.9 * r["kernel_ms_solo"]

@@ -83,6 +83,31 @@ def block_starts(lines, start, end):
     return starts, endpgm
 
 
+def explicit_arg_offsets(lines, mangled_prefix):
+    """kernarg offsets of the kernel's explicit arguments (by_value / global_buffer; hidden_* arguments follow them) from the amdhsa metadata"""
+    name = next(i for i, l in enumerate(lines) if l.strip().startswith(".name:") and l.split(":", 1)[1].strip().startswith(mangled_prefix))
+    a0 = max(i for i in range(name) if lines[i].strip() == ".args:")
+    offs, cur = [], {}
+    for i in range(a0 + 1, name):
+        t = lines[i].strip()
+        if t.startswith("- "):
+            if cur:
+                offs.append(cur)
+            cur = {}
+            t = t[2:]
+        if not t.startswith("."):
+            if t and not t.startswith("-"):
+                break
+            continue
+        k, _, v = t.partition(":")
+        cur[k.strip()] = v.strip()
+        if k.strip() in (".group_segment_fixed_size", ".kernarg_segment_align"):
+            cur.pop(k.strip()); break
+    if cur:
+        offs.append(cur)
+    return [int(a[".offset"]) for a in offs if a.get(".value_kind") in ("by_value", "global_buffer")]
+
+
 def instrument(lines, mangled_prefix):
     start, end, kd0, kd1 = kernel_span(lines, mangled_prefix)
     kd = {}
@@ -105,7 +130,8 @@ def instrument(lines, mangled_prefix):
     starts, endpgm = block_starts(lines, start, end)
     if len(starts) > 64 * N_CTR_VGPR:
         raise SystemExit("%d basic blocks: more than %d counters" % (len(starts), 64 * N_CTR_VGPR))
-    stats_off = kernarg - 16                # (..., stats, wg_cost): the second-to-last pointer argument
+    stats_off = explicit_arg_offsets(lines, mangled_prefix)[-2]      # (..., stats, wg_cost): the second-to-last explicit argument
+    del kernarg
     ins = collections.defaultdict(list)
     ins[first] += ["\ts_load_dwordx2 s[%d:%d], s[0:1], 0x%x" % (F, F + 1, stats_off)] + ["\tv_mov_b32_e32 v%d, 0" % (C0 + k) for k in range(N_CTR_VGPR)]
     for b, li in enumerate(starts):
@@ -171,13 +197,24 @@ def cmd_build(args):
     print("built %s (%s basic blocks instrumented), static census -> libcloudsky_census.json" % (out, info))
 
 
-def cmd_run(args):
+def census_available():
+    """(ok, why): the census library exists and was built from the kernel sources as they are now"""
+    lib = os.path.join(ROOT, "godot-volumetric-cloud-demo-v2_amd", "libcloudsky_census.so")
+    js = os.path.join(ROOT, "godot-volumetric-cloud-demo-v2_amd", "libcloudsky_census.json")
+    if not (os.path.exists(lib) and os.path.exists(js)):
+        return False, "libcloudsky_census.so not built (python tools/isa_profile.py build)"
+    import pmc_collect
+    if json.load(open(js)).get("source_hash") != pmc_collect.source_hash():
+        return False, "libcloudsky_census.so was built from other kernel sources"
+    return True, ""
+
+
+def run_counts(config, quiet=False):
     """GPU box: counts of one frame of `config` for the plain kernel and (CSKY_PERSISTENT=2) the persistent form."""
-    import hashlib
-    import numpy as np
     lib = os.path.join(ROOT, "godot-volumetric-cloud-demo-v2_amd", "libcloudsky_census.so")
     static = json.load(open(os.path.join(ROOT, "godot-volumetric-cloud-demo-v2_amd", "libcloudsky_census.json")))
-    res = {"config": args.config, "source_hash": static["source_hash"], "kernels": {}}
+    res = {"config": config, "source_hash": static["source_hash"], "kernels": {}}
+    args = argparse.Namespace(config=config)
     for tag in ("plain", "persistent"):
         env = dict(os.environ, CSKY_LIBRARY=lib, CSKY_PERSISTENT="2" if tag == "persistent" else "0")
         code = ("import sys, json, hashlib, numpy as np; sys.path.insert(0, %r); import gvcd_amd\n"
@@ -204,8 +241,14 @@ def cmd_run(args):
         nb = len(static[tag]["blocks"])
         d["counts"] = d["counts"][:nb]
         res["kernels"][tag] = d
-        print("%s: %d blocks, frame identical to the product library: %s, entry block executed %d times" % (tag, nb, d["frame_identical_to_product"], d["counts"][0]))
+        if not quiet:
+            print("%s: %d blocks, frame identical to the product library: %s, entry block executed %d times" % (tag, nb, d["frame_identical_to_product"], d["counts"][0]))
     res["static"] = static
+    return res
+
+
+def cmd_run(args):
+    res = run_counts(args.config)
     os.makedirs(os.path.dirname(os.path.abspath(args.out)), exist_ok=True)
     json.dump(res, open(args.out, "w"))
     print("wrote", args.out)
@@ -222,7 +265,11 @@ def kind_cost(kind, cal):
              "v_bfe_u32": pk["bfe"], "v_bfi_b32": pk["bfi"], "v_lshl_add_u32": pk["lshl_add"], "v_cvt_flr_i32_f32": pk["cvt_flr"], "v_fract_f32": pk["fract"],
              "v_floor_f32": pk["floor"], "v_cvt_f32_i32": pk["cvt_f32_i32"], "v_cvt_f32_u32": pk["cvt_f32_i32"], "v_cvt_f32_f16": pk["cvt_f32_f16"],
              "v_cndmask_b32": pk["cndmask_sgpr"], "v_rcp_f32": pk["rcp"], "v_exp_f32": pk["exp"], "v_log_f32": pk["log"], "v_sqrt_f32": pk["sqrt"], "v_rsq_f32": pk["sqrt"],
-             "v_mul_lo_u32": pk["mul_lo_u32"], "v_mad_u32_u24": pk["mad_u32_u24"], "v_fmaak_f32": pk["fma_sgpr_const"], "v_fmamk_f32": pk["fma_sgpr_const"]}
+             "v_mul_lo_u32": pk["mul_lo_u32"], "v_mad_u32_u24": pk["mad_u32_u24"], "v_fmaak_f32": pk.get("fmamk", pk["fma_sgpr_const"]), "v_fmamk_f32": pk.get("fmamk", pk["fma_sgpr_const"])}
+    for kk, key in (("v_add_lshl_u32", "add_lshl"), ("v_or3_b32", "or3"), ("v_readfirstlane_b32", "readfirstlane"), ("v_mbcnt_lo_u32_b32", "mbcnt"), ("v_mbcnt_hi_u32_b32", "mbcnt"),
+                    ("v_sub_f32", "sub"), ("v_subrev_f32", "sub")):
+        if key in pk:
+            table[kk] = pk[key]
     if kind in table:
         return table[kind], "measured"
     if kind.startswith("v_cmp") or kind.startswith("v_cmpx"):
@@ -231,10 +278,28 @@ def kind_cost(kind, cal):
     return {"full": full, "half": half, "trans": trans, "quarter": 2 * half, "lane": half}.get(c, half), "class:" + c
 
 
-def cmd_report(args):
-    d = json.load(open(args.counts))
-    cal = json.load(open(os.path.join(ROOT, "profiles", "r02", "issue_cost_calibration.json")))
-    out = {"config": d["config"], "source_hash": d["source_hash"], "kernels": {}}
+def calibration_path():
+    for r in ("r03", "r02"):
+        p = os.path.join(ROOT, "profiles", r, "issue_cost_calibration.json")
+        if os.path.exists(p):
+            return p
+    raise SystemExit("no issue-cost calibration under profiles/")
+
+
+def mixed_stream_factor(cal):
+    """measured cost of the 16-instruction stream in the census's proportions / the sum of its kinds' costs (tools/ubench/valu_rates2.hip mix16,
+    mix16_trans): how much a MIXED stream costs more than the additive per-kind pricing.  The kernel runs one transcendental per ~21 VALU
+    instructions, between the two streams (none, 1 in 16): both are returned."""
+    pk = cal["valu"]["per_kind_cycles"]
+    if "mix16" not in pk:
+        return None
+    base = 3 * pk["mul"] + 2 * pk["fma_3src"] + 2 * pk["fmac"] + pk["add"] + pk.get("sub", pk["add"]) + 2 * pk["fma_mix"] + pk["and"] + pk["cvt_flr"] + pk["fract"] + pk["lshl"]
+    return {"no_transcendental": pk["mix16"] / ((base + pk["mov"]) / 16.0), "one_transcendental_in_16": pk["mix16_trans"] / ((base + pk["rcp"]) / 16.0)}
+
+
+def report(d, quiet=False):
+    cal = json.load(open(calibration_path()))
+    out = {"config": d["config"], "source_hash": d["source_hash"], "calibration": os.path.relpath(calibration_path(), ROOT), "mixed_stream_factor": mixed_stream_factor(cal), "kernels": {}}
     for tag, k in d["kernels"].items():
         blocks = d["static"][tag]["blocks"]
         counts = k["counts"]
@@ -263,15 +328,22 @@ def cmd_report(args):
              "scratch_instructions_per_wavefront": classes["scratch"] / max(1, n_waves),
              "top_kinds": per_kind[:40]}
         out["kernels"][tag] = o
+        if quiet:
+            continue
         print("== %s: %d wavefronts, frame identical to product: %s" % (tag, n_waves, k["frame_identical_to_product"]))
         print("   executed wave-instructions: VALU %.4g (full %.4g, half %.4g, trans %.4g)  SALU %.4g  SMEM %.4g  VMEM loads %.4g  LDS %.4g  branches %.4g  waits %.4g  scratch %.4g (%.1f per wavefront)"
               % (n_valu, o["valu_by_class"]["full"], o["valu_by_class"]["half"], o["valu_by_class"]["trans"], classes["salu"], classes["smem"], classes["vmem_load"], classes["lds"],
                  classes["branch"], classes["wait"], classes["scratch"], o["scratch_instructions_per_wavefront"]))
         print("   VALU issue cycles per SIMD: %.4g  (%.1f %% of the VALU instructions priced by a per-kind measurement, the rest by their class)"
               % (cycles / 1024.0, 100 * o["valu_priced_by_measured_kind_fraction"]))
+    return out
+
+
+def cmd_report(args):
+    out = report(json.load(open(args.counts)))
+    print("mixed-stream factor (measured / additive):", out["mixed_stream_factor"])
     if args.out:
         json.dump(out, open(args.out, "w"), indent=1)
-    return out
 
 
 def main():

@@ -8,7 +8,7 @@ import json
 import os
 import sys
 
-d = sys.argv[1] if len(sys.argv) > 1 else "gpurun_out/r02/calib"
+d = sys.argv[1] if len(sys.argv) > 1 else "gpurun_out/r03/calib"
 N_SE, N_SIMD, N_CU = 32, 1024, 256
 
 
@@ -88,4 +88,31 @@ out["tcp"] = {"table": table,
               "note": "one CU's TCP retires one cache access (one 64-byte sector of one line) per cycle when the lanes of a quad fall in distinct lines or the wave is "
                       "coalesced (16 accesses per 1 KiB wave load), up to 1.67 per cycle for fully random lanes; TA_TA_BUSY is 0.93-1.00 of the kernel cycles "
                       "in every saturated pattern, so bench.py reports TA_TA_BUSY / (CUs x kernel cycles) as the L1-gather fraction"}
+# ---- FETCH_SIZE against known byte counts (1 GiB footprint: every line of a wave load misses the L2)
+try:
+    f = dispatches("f", "fetch")
+    big_only = True
+    print("# FETCH_SIZE calibration (1 GiB and 32 MiB footprints): bytes per wave-level load instruction as FETCH_SIZE reports them vs what the pattern must bring in")
+    idx, ftab = 0, []
+    expect = {"coalesced": 1024.0, "same-line": 128.0, "lines-4": 512.0, "lines-16": 2048.0, "random": None}
+    for c in f:
+        if "gather" not in c["_name"]:
+            continue
+        idx += 1
+        if idx % 2:
+            continue
+        k = idx // 2 - 1
+        pat, size = names[k % 5], sizes[2 + k // 5]           # the pass runs `gather_rates big`: 32 MiB and 1 GiB footprints only
+        loads = c["SQ_INSTS_VMEM_RD"]
+        rep = c["FETCH_SIZE"] * 1024.0 / loads
+        miss = c["TCC_MISS_sum"] / loads
+        row = dict(pattern=pat, footprint=size, fetch_size_bytes_per_load=rep, tcc_misses_per_load=miss, fetch_size_bytes_per_miss=c["FETCH_SIZE"] * 1024.0 / max(1.0, c["TCC_MISS_sum"]),
+                   ea_rdreq_per_load=c.get("TCC_EA_RDREQ_sum", 0.0) / loads, ea_rdreq_32b_per_load=c.get("TCC_EA_RDREQ_32B_sum", 0.0) / loads,
+                   known_line_bytes_per_load=expect[pat], reported_over_known=(rep / expect[pat]) if expect[pat] else None)
+        ftab.append(row)
+        print("%-10s %-7s FETCH_SIZE %7.1f B/load  %5.2f TCC misses/load  %5.1f B per miss  EA rdreq %5.2f (32B: %5.2f) per load   known %s B/load  reported/known %s" % (
+            pat, size, rep, miss, row["fetch_size_bytes_per_miss"], row["ea_rdreq_per_load"], row["ea_rdreq_32b_per_load"], expect[pat], "%.2f" % row["reported_over_known"] if expect[pat] else "-"))
+    out["fetch_size"] = {"table": ftab}
+except (OSError, KeyError) as e:
+    print("# no FETCH_SIZE calibration pass:", e)
 json.dump(out, open(os.path.join(os.path.dirname(d.rstrip("/")), "issue_cost_calibration.json"), "w"), indent=1)

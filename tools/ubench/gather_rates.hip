@@ -81,7 +81,8 @@ template <int MODE> int run(const char* name, const uint4* d, size_t bytes, int 
     return 0;
 }
 
-int main() {
+int main(int argc, char** argv) {
+    const bool only_big = argc > 1 && argv[1][0] == 'b';      // "big": the 32 MiB and 1 GiB footprints only (FETCH_SIZE calibration pass), no latency chase
     hipDeviceProp_t prop; CHK(hipGetDeviceProperties(&prop, 0));
     const int cus = prop.multiProcessorCount;
     const size_t maxb = (size_t)1 << 30;
@@ -96,12 +97,14 @@ int main() {
     printf("# %s, %d CUs; 16-byte gathers (global_load_dwordx4), 8 waves/SIMD, 4 independent loads per lane per iteration\n", prop.gcnArchName, cus);
     const size_t sizes[] = {(size_t)16 << 10, (size_t)1 << 20, (size_t)32 << 20, (size_t)1 << 30};
     for (size_t b : sizes) {
+        if (only_big && b < ((size_t)32 << 20)) continue;
         if (run<0>("coalesced", d, b, 0, d_out, d_clk, cus)) return 1;
         if (run<1>("same-line", d, b, 0, d_out, d_clk, cus)) return 1;
         if (run<3>("lines-4", d, b, 4, d_out, d_clk, cus)) return 1;
         if (run<3>("lines-16", d, b, 16, d_out, d_clk, cus)) return 1;
         if (run<2>("random", d, b, 0, d_out, d_clk, cus)) return 1;
     }
+    if (only_big) return 0;
     for (size_t b : sizes) {   // latency: one wave per SIMD, dependent loads
         const unsigned slot_mask = (unsigned)(b / 16 - 1);
         chase<<<cus, 256>>>(d, slot_mask, 50, d_out, d_clk);

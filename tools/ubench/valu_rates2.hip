@@ -95,6 +95,21 @@ KERNEL_PACKED(k_pk_fma_2src, "v_pk_fma_f32 %0, %0, %8, %8\n v_pk_fma_f32 %1, %1,
 KERNEL_PACKED(k_pk_mul, "v_pk_mul_f32 %0, %0, %8\n v_pk_mul_f32 %1, %1, %8\n v_pk_mul_f32 %2, %2, %8\n v_pk_mul_f32 %3, %3, %8\n v_pk_mul_f32 %4, %4, %8\n v_pk_mul_f32 %5, %5, %8\n v_pk_mul_f32 %6, %6, %8\n v_pk_mul_f32 %7, %7, %8")
 KERNEL_PACKED(k_pk_add, "v_pk_add_f32 %0, %0, %8\n v_pk_add_f32 %1, %1, %8\n v_pk_add_f32 %2, %2, %8\n v_pk_add_f32 %3, %3, %8\n v_pk_add_f32 %4, %4, %8\n v_pk_add_f32 %5, %5, %8\n v_pk_add_f32 %6, %6, %8\n v_pk_add_f32 %7, %7, %8")
 
+// round 3: the kinds the basic-block census of the cloud kernel (tools/isa_profile.py) found without a measured cost, and a MIXED stream in
+// the census's own proportions: is the per-kind pricing additive (does a stream of mixed kinds cost the sum of its kinds' costs)?
+KERNEL_SCALAR(k_add_lshl, "v_add_lshl_u32 %0, %0, %12, 2\n v_add_lshl_u32 %1, %1, %12, 2\n v_add_lshl_u32 %2, %2, %12, 2\n v_add_lshl_u32 %3, %3, %12, 2\n v_add_lshl_u32 %4, %4, %12, 2\n v_add_lshl_u32 %5, %5, %12, 2\n v_add_lshl_u32 %6, %6, %12, 2\n v_add_lshl_u32 %7, %7, %12, 2")
+KERNEL_SCALAR(k_or3, "v_or3_b32 %0, %0, %12, %13\n v_or3_b32 %1, %1, %12, %13\n v_or3_b32 %2, %2, %12, %13\n v_or3_b32 %3, %3, %12, %13\n v_or3_b32 %4, %4, %12, %13\n v_or3_b32 %5, %5, %12, %13\n v_or3_b32 %6, %6, %12, %13\n v_or3_b32 %7, %7, %12, %13")
+KERNEL_SCALAR(k_readfirstlane, "v_readfirstlane_b32 s20, %0\n v_readfirstlane_b32 s21, %1\n v_readfirstlane_b32 s20, %2\n v_readfirstlane_b32 s21, %3\n v_readfirstlane_b32 s20, %4\n v_readfirstlane_b32 s21, %5\n v_readfirstlane_b32 s20, %6\n v_readfirstlane_b32 s21, %7")
+KERNEL_SCALAR(k_mbcnt, "v_mbcnt_lo_u32_b32 %0, %12, %0\n v_mbcnt_hi_u32_b32 %1, %12, %1\n v_mbcnt_lo_u32_b32 %2, %12, %2\n v_mbcnt_hi_u32_b32 %3, %12, %3\n v_mbcnt_lo_u32_b32 %4, %12, %4\n v_mbcnt_hi_u32_b32 %5, %12, %5\n v_mbcnt_lo_u32_b32 %6, %12, %6\n v_mbcnt_hi_u32_b32 %7, %12, %7")
+KERNEL_SCALAR(k_sub, "v_sub_f32 %0, %0, %8\n v_sub_f32 %1, %1, %8\n v_sub_f32 %2, %2, %8\n v_sub_f32 %3, %3, %8\n v_sub_f32 %4, %4, %8\n v_sub_f32 %5, %5, %8\n v_sub_f32 %6, %6, %8\n v_sub_f32 %7, %7, %8")
+KERNEL_SCALAR(k_fmamk, "v_fmamk_f32 %0, %0, 0x3f000000, %8\n v_fmamk_f32 %1, %1, 0x3f000000, %8\n v_fmamk_f32 %2, %2, 0x3f000000, %8\n v_fmamk_f32 %3, %3, 0x3f000000, %8\n v_fmamk_f32 %4, %4, 0x3f000000, %8\n v_fmamk_f32 %5, %5, 0x3f000000, %8\n v_fmamk_f32 %6, %6, 0x3f000000, %8\n v_fmamk_f32 %7, %7, 0x3f000000, %8")
+// 16 instructions in the proportions of the cloud kernel's executed mix (census, C3): 3 mul, 2 fma, 2 fmac, add, sub, 2 fma_mix, mov, and, cvt_flr, fract, lshl
+KERNEL_SCALAR(k_mix16, "v_mul_f32 %0, %0, %8\n v_fma_f32 %1, %1, %8, %9\n v_add_f32 %2, %2, %8\n v_fmac_f32 %3, %8, %9\n v_fma_mix_f32 %4, %12, %8, %4 op_sel:[0,0,0] op_sel_hi:[1,0,0]\n v_mov_b32 %5, %8\n v_cvt_flr_i32_f32 %6, %9\n v_fract_f32 %7, %7\n"
+                       " v_mul_f32 %0, %0, %9\n v_fmac_f32 %1, %8, %9\n v_sub_f32 %2, %2, %9\n v_fma_mix_f32 %3, %13, %8, %3 op_sel:[1,0,0] op_sel_hi:[1,0,0]\n v_and_b32 %5, %5, %12\n v_lshlrev_b32 %6, 3, %6\n v_mul_f32 %7, %7, %8\n v_fma_f32 %4, %4, %8, %9")
+// the same 16 with one transcendental in place of the mov (the kernel runs 1 transcendental per ~21 VALU instructions)
+KERNEL_SCALAR(k_mix16_trans, "v_mul_f32 %0, %0, %8\n v_fma_f32 %1, %1, %8, %9\n v_add_f32 %2, %2, %8\n v_fmac_f32 %3, %8, %9\n v_fma_mix_f32 %4, %12, %8, %4 op_sel:[0,0,0] op_sel_hi:[1,0,0]\n v_rcp_f32 %5, %5\n v_cvt_flr_i32_f32 %6, %9\n v_fract_f32 %7, %7\n"
+                             " v_mul_f32 %0, %0, %9\n v_fmac_f32 %1, %8, %9\n v_sub_f32 %2, %2, %9\n v_fma_mix_f32 %3, %13, %8, %3 op_sel:[1,0,0] op_sel_hi:[1,0,0]\n v_and_b32 %5, %5, %12\n v_lshlrev_b32 %6, 3, %6\n v_mul_f32 %7, %7, %8\n v_fma_f32 %4, %4, %8, %9")
+
 typedef void (*kern_t)(float*, Stamp*, int, float);
 struct Test { const char* name; kern_t k; int valu_per_8; };   // VALU instructions among the 8 of one body line
 
@@ -140,6 +155,8 @@ int main() {
         {"v_cvt_f32_i32", k_cvt_f32_i32, 8}, {"v_cvt_f32_f16", k_cvt_f32_f16, 8}, {"v_cmp_gt_f32 -> sgpr", k_cmp_sgpr, 8}, {"v_cndmask_b32 sgpr", k_cndmask_sgpr, 8},
         {"v_rcp_f32", k_rcp, 8}, {"v_exp_f32", k_exp, 8}, {"v_log_f32", k_log, 8}, {"v_sqrt_f32", k_sqrt, 8}, {"1 exp : 3 fma", k_exp_fma_alt, 8},
         {"v_mul_lo_u32", k_mul_lo_u32, 8}, {"v_mad_u32_u24", k_mad_u32_u24, 8}, {"fma + s_nop alternating", k_salu_between, 4},
+        {"v_add_lshl_u32", k_add_lshl, 8}, {"v_or3_b32", k_or3, 8}, {"v_readfirstlane_b32", k_readfirstlane, 8}, {"v_mbcnt_lo/hi", k_mbcnt, 8}, {"v_sub_f32", k_sub, 8},
+        {"v_fmamk_f32", k_fmamk, 8}, {"mix16 (census proportions)", k_mix16, 16}, {"mix16 with 1 rcp", k_mix16_trans, 16},
         {"v_pk_fma_f32 3 src", k_pk_fma, 8}, {"v_pk_fma_f32 2 src", k_pk_fma_2src, 8}, {"v_pk_mul_f32", k_pk_mul, 8}, {"v_pk_add_f32", k_pk_add, 8},
     };
     for (const Test& t : tests) if (run(t, d_out, d_st, h, cus)) return 1;
