@@ -648,8 +648,10 @@ def main():
                 "l1_gather": l1 or None,
                 "hbm": None if traffic is None else {"bytes_per_launch": traffic, "achieved_GBps": traffic / (k_solo * 1e-3) / 1e9, "peak_GBps": HBM_PEAK_GBS,
                                                      "frac": traffic / (k_solo * 1e-3) / 1e9 / HBM_PEAK_GBS, "l2_hit": hb.get("l2_hit"),
-                                                     "note": "memory-side bytes of the L2 (FETCH_SIZE + WRITE_SIZE, KiB -> bytes, Infinity-Cache hits included; the guide's x2 "
-                                                             "FETCH_SIZE correction is for wide streaming reads and is not applied to these 16-byte gathers)"},
+                                                     "fetch_size_correction": hb.get("fetch_size_correction"),
+                                                     "note": "memory-side bytes of the L2: FETCH_SIZE x its calibrated correction + WRITE_SIZE (KiB -> bytes), Infinity-Cache hits "
+                                                             "included.  The correction is measured on gather patterns with known byte counts (profiles/r03/"
+                                                             "issue_cost_calibration_tables.txt): one L2 miss per 128-byte line, FETCH_SIZE tallies 64 bytes per miss => x2.00"},
                 "hbm_algorithmic": {"bytes_per_sample": BYTES_PER_SAMPLE, "rays_per_launch": rays_launch, "bytes_per_launch": floor_bytes,
                                     "bytes_per_launch_incl_light_march": total_bytes, "incloud_fraction": f_incloud,
                                     "achieved_GBps": floor_bytes / (k_solo * 1e-3) / 1e9, "ratio_to_hbm_peak": floor_bytes / (k_solo * 1e-3) / 1e9 / HBM_PEAK_GBS,

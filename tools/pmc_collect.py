@@ -15,7 +15,7 @@ import sys
 import tempfile
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-CALIBRATION = os.path.join(ROOT, "profiles", "r02", "issue_cost_calibration.json")
+CALIBRATION = next(p for p in (os.path.join(ROOT, "profiles", r, "issue_cost_calibration.json") for r in ("r03", "r02")) if os.path.exists(p))
 N_SE, N_SIMD, N_CU = 32, 1024, 256
 PASSES = {
     "valu": ["SQ_INSTS_VALU", "SQ_INSTS_VALU_TRANS_F32", "SQ_INSTS_VALU_FMA_F32", "SQ_INSTS_VALU_ADD_F32", "SQ_INSTS_VALU_MUL_F32", "SQ_INSTS_VALU_CVT",
@@ -69,7 +69,7 @@ def price(c):
     cal = json.load(open(CALIBRATION))
     full, half, trans = cal["valu"]["full_rate_cycles"], cal["valu"]["half_rate_cycles"], cal["valu"]["transcendental_cycles"]
     out = {"calibration": {"full_rate_cycles": full, "half_rate_cycles": half, "transcendental_cycles": trans,
-                           "tcp_cycles_per_access": cal["tcp"]["cycles_per_access_distinct_lines"], "source": "profiles/r02/issue_cost_calibration.json"}}
+                           "tcp_cycles_per_access": cal["tcp"]["cycles_per_access_distinct_lines"], "source": os.path.relpath(CALIBRATION, ROOT)}}
     v = c.get("valu")
     if v:
         cyc = v["SQ_BUSY_CYCLES"] / N_SE
@@ -110,9 +110,16 @@ def price(c):
                             "wave_cycles_waiting_on_issue_frac": m["SQ_WAIT_INST_ANY"] / max(1.0, m["SQ_WAVE_CYCLES"])}
     f, w = c.get("fetch"), c.get("write")
     if f and w:
-        # FETCH_SIZE / WRITE_SIZE are in KiB; the guide's x2 gfx950 correction applies to wide coalesced streaming reads only, these are 16-byte
-        # gathers (uncalibrated width: left as counted); Infinity-Cache hits are included, so true DRAM bytes are lower
-        out["hbm_traffic"] = {"fetch_bytes": f["FETCH_SIZE"] * 1024.0, "write_bytes": w["WRITE_SIZE"] * 1024.0, "bytes": (f["FETCH_SIZE"] + w["WRITE_SIZE"]) * 1024.0,
+        # FETCH_SIZE / WRITE_SIZE are in KiB.  Calibrated in round 3 on patterns with KNOWN byte counts (tools/ubench/calibrate_fetch.sh,
+        # profiles/r03/issue_cost_calibration_tables.txt): the L2 takes ONE miss per 128-byte line (a coalesced 1 KiB wave load = 7.97 misses, a
+        # same-line load = 1.00) and FETCH_SIZE tallies 64 bytes per miss, for 16-byte gathers exactly as for streaming reads: reported / known =
+        # 0.50 in every pattern.  So fetched bytes = 2 x FETCH_SIZE (the guide's gfx950 correction, confirmed).  Infinity-Cache hits are
+        # included, so true DRAM bytes are lower.
+        fs = (cal.get("fetch_size") or {}).get("table") or []
+        known = [r["reported_over_known"] for r in fs if r.get("reported_over_known") and r["footprint"] == "1 GiB"]
+        corr = (1.0 / (sum(known) / len(known))) if known else 2.0
+        out["hbm_traffic"] = {"fetch_bytes": f["FETCH_SIZE"] * 1024.0 * corr, "fetch_size_counter_bytes": f["FETCH_SIZE"] * 1024.0, "fetch_size_correction": corr,
+                              "write_bytes": w["WRITE_SIZE"] * 1024.0, "bytes": (f["FETCH_SIZE"] * corr + w["WRITE_SIZE"]) * 1024.0,
                               "l2_hit": f["TCC_HIT_sum"] / max(1.0, f["TCC_HIT_sum"] + w["TCC_MISS_sum"]) if "TCC_MISS_sum" in w else None}
     return out
 
