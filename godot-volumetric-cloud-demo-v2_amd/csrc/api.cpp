@@ -104,6 +104,7 @@ thread_local char g_err[512];
 int fail(csky_ctx* c, int code, const char* fmt, ...) {
     char* dst = c ? c->err : g_err;
     va_list ap; va_start(ap, fmt); vsnprintf(dst, 512, fmt, ap); va_end(ap);
+    if (code == CSKY_ERR_HIP) (void)hipGetLastError();       // the runtime's last-error slot is sticky: a failed call must not resurface as the "launch error" of a later kernel
     return code;
 }
 #define HIPCHK(c, call) do { hipError_t e_ = (call); if (e_ != hipSuccess) return fail((c), CSKY_ERR_HIP, "%s failed: %s", #call, hipGetErrorString(e_)); } while (0)

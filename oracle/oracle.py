@@ -89,6 +89,18 @@ class OracleTextures:
         self.weather = np.ascontiguousarray(weather_rgb8, np.uint8).reshape(512, 512, 3)
         self.c = Textures(_ptr(self.large), 8, _ptr(self.small), 6, _ptr(self.weather))
 
+    @classmethod
+    def from_chains(cls, large_chain_rgba8, small_chain_rgb8, weather_rgb8):
+        """Caller-supplied mip chains (all levels back to back, level 0 first) instead of the 2x2x2 box chains: what a host binds with
+        csky_set_noise_mips when it has the importer's own chains (perlworlnoise.tga.import:24, worlnoise.bmp.import:24)."""
+        o = cls.__new__(cls)
+        o.large = np.ascontiguousarray(large_chain_rgba8, np.uint8).reshape(-1).copy()
+        o.small = np.ascontiguousarray(small_chain_rgb8, np.uint8).reshape(-1).copy()
+        assert o.large.size == lib().csko_mip_total(128, 8, 4) and o.small.size == lib().csko_mip_total(32, 6, 3)
+        o.weather = np.ascontiguousarray(weather_rgb8, np.uint8).reshape(512, 512, 3)
+        o.c = Textures(_ptr(o.large), 8, _ptr(o.small), 6, _ptr(o.weather))
+        return o
+
 
 def transmittance_lut(w=256, h=64):
     out = np.zeros((h, w, 4), np.uint16)

@@ -282,3 +282,72 @@ def test_external_frame_import_error_paths(pkg, gpu_ctx):
             pass
     L.csky_external_frame_release(None)
     assert L.csky_external_frame_signal(gpu_ctx._h, None, None) == pkg._lib.ERR_INVALID
+
+
+# ------------------------------------------------------------------------------------------------ untested corners of round 2
+@pytest.mark.parametrize("theta", [2.0, 178.0])
+def test_c5_sweep_end_points_full_size_vs_oracle(gpu_ctx, oracle, otex, o_trans, theta):
+    """BASELINE configs[4]: the grazing end points of the 64-frame sun sweep (theta = 2 and 178 degrees: hg_g2 = 0.4 - 1.4 ldir.y and the
+    sky-LUT taps of clouds.glsl:160-167 at their extremes) as WHOLE 4096x2048 @ 128x6 frames against the oracle at the tight gate
+    (the sweep itself was only checked at 128x64)."""
+    from bench import usable_cores
+    W, H = 4096, 2048
+    sun = (np.cos(np.radians(theta)), np.sin(np.radians(theta)), 0.0)
+    gpu_ctx.set_variant(-1); gpu_ctx.set_schedule(-1); gpu_ctx.set_segments(0); gpu_ctx.set_early_out(0.0); gpu_ctx.set_march(128, 6)
+    sk = gpu_ctx.render_sky_lut(norm(sun), 200, 100)
+    sk_o = oracle.sky_lut(norm(sun), o_trans, 200, 100)
+    assert int(np.abs(sk.view(np.int16).astype(np.int32) - sk_o.view(np.int16).astype(np.int32)).max()) <= 1
+    p = oracle.default_params(W, H, sun)
+    img = gpu_ctx.render_clouds(p)
+    st = gpu_ctx.cloud_stats()
+    ref, st_o = oracle.clouds(otex, p, sk_o, nthreads=max(1, min(oracle.max_threads(), usable_cores())), return_stats=True)
+    ok, info = cloud_tight(img, ref)
+    assert ok and info["within1"] >= 0.9998 and info["beyond2_pixels"] <= 1e-4 * W * H, (theta, info)
+    assert st["primary_samples"] == st_o["primary_samples"]
+    assert abs(int(st["incloud_samples"]) - int(st_o["incloud_samples"])) <= 2e-6 * st_o["incloud_samples"] + 1
+    print("C5 sweep end point theta = %g: %s" % (theta, info))
+
+
+def test_importer_style_mip_chains_vs_oracle(pkg, noise, oracle, o_trans):
+    """csky_set_noise_mips with chains that are deliberately NOT the 2x2x2 box filter (here: every level decimated from level 0 by the texel at
+    the cell's corner, plus a per-level offset, so that a wrong level, a wrong level offset or a silently re-derived box chain all show):
+    the HIP path must sample exactly the texels it was given -- rendered against the oracle fed the SAME chains, tight gate; and the frame
+    must differ from the box-chain frame (the light march samples LODs 1-5, clouds.glsl:117,132).  The first HIP-vs-oracle test of the
+    importer path ((f)-4)."""
+    large, small, weather = noise
+    def chain(vol, n, ch, levels):
+        v = np.ascontiguousarray(vol, np.uint8).reshape(n, n, n, ch)
+        out = [v.reshape(-1)]
+        for l in range(1, levels):
+            s = 1 << l
+            lv = v[::s, ::s, ::s, :].astype(np.int32) + 3 * l          # corner decimation + a level-dependent offset
+            out.append(np.clip(lv, 0, 255).astype(np.uint8).reshape(-1))
+        return np.concatenate(out)
+    lc, sc = chain(large, 128, 4, 8), chain(small, 32, 3, 6)
+    assert lc.size == pkg.lib().csky_mip_offset(128, 8, 4) and sc.size == pkg.lib().csky_mip_offset(32, 6, 3)
+    sun = (1, 1, 0)
+    sk_o = oracle.sky_lut(norm(sun), o_trans, 200, 100)
+    otex_chain = oracle.OracleTextures.from_chains(lc, sc, weather)
+    p = oracle.default_params(256, 128, sun)
+    ref, st_o = oracle.clouds(otex_chain, p, sk_o, nthreads=oracle.max_threads(), return_stats=True)
+    ref_box, _ = oracle.clouds(oracle.OracleTextures(large, small, weather), p, sk_o, nthreads=oracle.max_threads(), return_stats=True)
+    ctx = pkg.Context(0)
+    try:
+        import warnings
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore", RuntimeWarning)      # decimated chains may have finite differences beyond fp16's exact range
+            ctx.set_noise_mips(lc, sc, weather)
+        ctx.set_march(128, 6); ctx.render_transmittance(256, 64); ctx.render_sky_lut(norm(sun), 200, 100)
+        img = ctx.render_clouds(p)
+        st = ctx.cloud_stats()
+        if ctx.noise_inexact_coeffs() == 0:
+            ok, info = cloud_tight(img, ref)
+        else:
+            ok, info = cloud_close(img, ref, frac=0.999, atol=2e-3, rtol=1e-2)
+        assert ok, (info, ctx.noise_inexact_coeffs())
+        assert abs(int(st["incloud_samples"]) - int(st_o["incloud_samples"])) <= 1e-3 * st_o["incloud_samples"]
+        d = np.abs(img.astype(np.float32) - ref_box.astype(np.float32))
+        assert d.max() > 5e-3 and (d > 2e-3).mean() > 1e-3, "the custom chains were not used: the frame equals the box-chain frame"
+        print("importer-style chains: %s; differs from the box-chain frame by up to %.3g" % (info, float(d.max())))
+    finally:
+        ctx.close()
