@@ -72,6 +72,7 @@ SYMBOLS = [
     ("csky_read_transmittance", C.c_int, [C.c_void_p, C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     ("csky_read_sky_lut", C.c_int, [C.c_void_p, C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     ("csky_composite_sky", C.c_int, [C.c_void_p, C.POINTER(CompositeParams), C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    ("csky_composite_view", C.c_int, [C.c_void_p, C.POINTER(CompositeParams), C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     ("csky_time_clouds", C.c_int, [C.c_void_p, C.POINTER(CloudParams), C.c_int, C.POINTER(Bands), C.c_int, C.c_int, C.POINTER(C.c_float), C.POINTER(CloudStats)]),
     ("csky_get_cloud_stats", C.c_int, [C.c_void_p, C.POINTER(CloudStats)]),
     ("csky_set_kernel_timing", C.c_int, [C.c_void_p, C.c_int]),
@@ -350,6 +351,17 @@ class Context:
             p.light_direction[k] = float(light_dir[k])
         out = np.zeros((out_h, out_w, 4), np.uint16)
         self._chk(self._L.csky_composite_sky(self._h, C.byref(p), _ptr(a[0]), _ptr(a[1]), _ptr(a[2]), _ptr(a[3]), _ptr(out)))
+        return out.view(np.float16)
+
+    def composite_view(self, cloud_from, cloud_to, sky_from, sky_to, light_dir, basis, fov_y_degrees, blend_amount=0.0, sun_disk_scale=2.0, out_w=1152, out_h=648):
+        """clouds.gdshader sky() per SCREEN pixel of a perspective camera (basis: 3x3, columns = the camera's right / up / back axes)."""
+        a = [np.ascontiguousarray(x).view(np.uint16) for x in (cloud_from, cloud_to, sky_from, sky_to)]
+        p = CompositeParams(out_w, out_h, a[0].shape[1], a[0].shape[0], a[2].shape[1], a[2].shape[0], float(blend_amount), float(sun_disk_scale))
+        for k in range(3):
+            p.light_direction[k] = float(light_dir[k])
+        v = (C.c_float * 10)(*([float(x) for x in np.asarray(basis, np.float32).T.reshape(-1)] + [float(fov_y_degrees)]))   # column-major basis, then the fov
+        out = np.zeros((out_h, out_w, 4), np.uint16)
+        self._chk(self._L.csky_composite_view(self._h, C.byref(p), C.cast(v, C.c_void_p), _ptr(a[0]), _ptr(a[1]), _ptr(a[2]), _ptr(a[3]), _ptr(out)))
         return out.view(np.float16)
 
     def generate_shape_noise(self, seed=1, n=128):

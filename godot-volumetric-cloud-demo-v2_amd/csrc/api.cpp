@@ -890,8 +890,20 @@ int csky_time_clouds(csky_ctx* c, const csky_cloud_params* p, int tile_w, const 
     return CSKY_OK;
 }
 
+static int composite_impl(csky_ctx* c, const csky_composite_params* p, const csky_view* view, const uint16_t* cloud_from, const uint16_t* cloud_to,
+                          const uint16_t* sky_from, const uint16_t* sky_to, uint16_t* out);
 int csky_composite_sky(csky_ctx* c, const csky_composite_params* p, const uint16_t* cloud_from, const uint16_t* cloud_to, const uint16_t* sky_from,
                        const uint16_t* sky_to, uint16_t* out) {
+    return composite_impl(c, p, nullptr, cloud_from, cloud_to, sky_from, sky_to, out);
+}
+int csky_composite_view(csky_ctx* c, const csky_composite_params* p, const csky_view* view, const uint16_t* cloud_from, const uint16_t* cloud_to,
+                        const uint16_t* sky_from, const uint16_t* sky_to, uint16_t* out) {
+    if (!view) return fail(c, CSKY_ERR_INVALID, "csky_composite_view: view is NULL");
+    if (!(view->fov_y_degrees > 0.0f && view->fov_y_degrees < 180.0f)) return fail(c, CSKY_ERR_INVALID, "csky_composite_view: fov_y_degrees must be in (0, 180)");
+    return composite_impl(c, p, view, cloud_from, cloud_to, sky_from, sky_to, out);
+}
+static int composite_impl(csky_ctx* c, const csky_composite_params* p, const csky_view* view, const uint16_t* cloud_from, const uint16_t* cloud_to,
+                          const uint16_t* sky_from, const uint16_t* sky_to, uint16_t* out) {
     if (!c) return fail(nullptr, CSKY_ERR_INVALID, "csky_composite_sky: ctx is NULL");
     if (!p || !cloud_from || !cloud_to || !sky_from || !sky_to || !out) return fail(c, CSKY_ERR_INVALID, "csky_composite_sky: NULL argument");
     if (p->out_w < 1 || p->out_h < 1 || p->cloud_w < 1 || p->cloud_h < 1 || p->sky_w < 1 || p->sky_h < 1 || p->out_w > 16384 || p->out_h > 16384)
@@ -917,6 +929,14 @@ int csky_composite_sky(csky_ctx* c, const csky_composite_params* p, const uint16
     a.blend_amount = p->blend_amount; a.sun_disk_scale = p->sun_disk_scale;
     a.sun[0] = p->light_direction[0]; a.sun[1] = p->light_direction[1]; a.sun[2] = p->light_direction[2];
     a.out_w = p->out_w; a.out_h = p->out_h;
+    a.view_mode = 0; a.tan_half_fov_y = 1.0f; a.aspect = 1.0f;
+    for (int k = 0; k < 9; k++) a.cam[k] = (k % 4 == 0) ? 1.0f : 0.0f;
+    if (view) {
+        a.view_mode = 1;
+        for (int k = 0; k < 9; k++) a.cam[k] = view->basis[k];
+        a.tan_half_fov_y = tanf(view->fov_y_degrees * 0.5f * 3.14159265358979323846f / 180.0f);
+        a.aspect = (float)p->out_w / (float)p->out_h;
+    }
     if (e == hipSuccess) e = launch_composite(a, reinterpret_cast<uint2*>(d + 2 * cb + 2 * sb), c->stream);
     if (e == hipSuccess) e = hipMemcpyAsync(out, d + 2 * cb + 2 * sb, ob, hipMemcpyDeviceToHost, c->stream);
     if (e == hipSuccess) e = hipStreamSynchronize(c->stream);

@@ -18,6 +18,12 @@ struct CompositeArgs {
     float blend_amount, sun_disk_scale;                                 // G:12-13
     float sun[3];                                                       // LIGHT0_DIRECTION
     int out_w, out_h;
+    // projection of output pixel -> EYEDIR: 0 = equirectangular panorama; 1 = perspective camera (what the engine feeds the sky shader: one
+    // EYEDIR per SCREEN pixel, clouds.gdshader:105-116): cam = Camera3D.global_transform.basis columns (x right, y up, z back), Godot's
+    // vertical field of view and the viewport's aspect ratio
+    int view_mode;
+    float cam[9];                                                       // column-major: cam[0..2] = basis.x, [3..5] = basis.y, [6..8] = basis.z
+    float tan_half_fov_y, aspect;
 };
 
 struct C3 { float x, y, z; };
@@ -41,10 +47,25 @@ CSKY_HD C4 tap_half_clamp(const uint16_t* t, int w, int h, float sx, float sy) {
 CSKY_HD float mixf(float a, float b, float t) { return a * (1.0f - t) + b * t; }
 CSKY_HD float smoothstepf(float e0, float e1, float x) { const float t = sat((x - e0) / (e1 - e0)); return t * t * (3.0f - 2.0f * t); }
 
-CSKY_HD C3 composite_pixel(const CompositeArgs& A, int i, int j) {
+// EYEDIR of output pixel (i, j)
+CSKY_HD void composite_eyedir(const CompositeArgs& A, int i, int j, float& ex, float& ey, float& ez) {
     const float u = ((float)i + 0.5f) / (float)A.out_w, v = ((float)j + 0.5f) / (float)A.out_h;
+    if (A.view_mode == 1) {
+        // screen pixel -> view-space ray (x right, y up, looking down -z) -> world space through the camera basis, normalised: the EYEDIR the
+        // engine hands a sky shader for this screen pixel
+        const float vx = (u * 2.0f - 1.0f) * A.tan_half_fov_y * A.aspect, vy = (1.0f - v * 2.0f) * A.tan_half_fov_y, vz = -1.0f;
+        const float wx = A.cam[0] * vx + A.cam[3] * vy + A.cam[6] * vz, wy = A.cam[1] * vx + A.cam[4] * vy + A.cam[7] * vz, wz = A.cam[2] * vx + A.cam[5] * vy + A.cam[8] * vz;
+        const float l = sqrtf(wx * wx + wy * wy + wz * wz);
+        ex = wx / l; ey = wy / l; ez = wz / l;
+        return;
+    }
     const float az = (u * 2.0f - 1.0f) * G_PI, el = (0.5f - v) * G_PI;
-    const float ex = cosf(el) * cosf(az), ey = sinf(el), ez = cosf(el) * sinf(az);       // EYEDIR
+    ex = cosf(el) * cosf(az); ey = sinf(el); ez = cosf(el) * sinf(az);
+}
+
+CSKY_HD C3 composite_pixel(const CompositeArgs& A, int i, int j) {
+    float ex, ey, ez;
+    composite_eyedir(A, i, j, ex, ey, ez);                                               // EYEDIR
     // G:106-110: clamp below the horizon, hemi-octahedral encode of norm.xzy
     float nx = ex, ny = fmaxf(0.0f, ey), nz = ez;
     const float nl = sqrtf(nx * nx + ny * ny + nz * nz);

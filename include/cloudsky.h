@@ -199,6 +199,13 @@ typedef struct {
 } csky_composite_params;
 int csky_composite_sky(csky_ctx* ctx, const csky_composite_params* p, const uint16_t* cloud_from, const uint16_t* cloud_to,
                        const uint16_t* sky_from, const uint16_t* sky_to, uint16_t* out_rgba16f);
+/* The same shader evaluated the way the engine evaluates it: one EYEDIR per SCREEN pixel of a perspective camera (clouds.gdshader:105-116 runs
+ * with the viewport's EYEDIR).  basis = Camera3D.global_transform.basis, column-major (basis.x = right, basis.y = up, basis.z = back: the camera
+ * looks down -z), fov_y_degrees = Camera3D.fov (vertical); the aspect ratio is out_w / out_h.  Pixel (i, j) -> NDC ((i+.5)/w*2-1, 1-(j+.5)/h*2)
+ * -> view ray (x tan(fov/2) aspect, y tan(fov/2), -1) -> world -> normalised. */
+typedef struct { float basis[9]; float fov_y_degrees; } csky_view;
+int csky_composite_view(csky_ctx* ctx, const csky_composite_params* p, const csky_view* view, const uint16_t* cloud_from, const uint16_t* cloud_to,
+                        const uint16_t* sky_from, const uint16_t* sky_to, uint16_t* out_rgba16f);
 
 /* ---- measurement ---------------------------------------------------------------------------------
  * Times `iters` back-to-back launches of the cloud kernel alone with HIP events on the context's stream

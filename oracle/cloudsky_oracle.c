@@ -726,6 +726,25 @@ void csko_composite(int out_w, int out_h, const uint16_t *cloud_from, const uint
     }
 }
 
+/* The same shader per SCREEN pixel of a perspective camera: the engine supplies EYEDIR per screen pixel (clouds.gdshader:105 `void sky()` reads
+ * EYEDIR); pixel (i,j) -> NDC -> view ray (x tan(fov/2) aspect, y tan(fov/2), -1) -> world through the camera basis (column-major) -> normalise. */
+void csko_composite_view(int out_w, int out_h, const float basis[9], float fov_y_degrees, const uint16_t *cloud_from, const uint16_t *cloud_to, int cw, int ch,
+                         const uint16_t *sky_from, const uint16_t *sky_to, int sw, int sh, const uint16_t *trans, int tw, int th, float blend_amount,
+                         float sun_disk_scale, const float light_dir[3], uint16_t *out_rgba16f) {
+    comp_ctx c = {cloud_from, cloud_to, cw, ch, sky_from, sky_to, sw, sh, trans, tw, th, blend_amount, sun_disk_scale,
+                  V3(light_dir[0], light_dir[1], light_dir[2])};
+    const float t = tanf(fov_y_degrees * 0.5f * G_PI / 180.0f), aspect = (float)out_w / (float)out_h;
+    for (int j = 0; j < out_h; j++) for (int i = 0; i < out_w; i++) {
+        float u = ((float)i + 0.5f) / (float)out_w, v = ((float)j + 0.5f) / (float)out_h;
+        float vx = (u * 2.0f - 1.0f) * t * aspect, vy = (1.0f - v * 2.0f) * t, vz = -1.0f;
+        float wx = basis[0] * vx + basis[3] * vy + basis[6] * vz, wy = basis[1] * vx + basis[4] * vy + basis[7] * vz, wz = basis[2] * vx + basis[5] * vy + basis[8] * vz;
+        float l = sqrtf(wx * wx + wy * wy + wz * wz);
+        v3 col = sky_composite(&c, V3(wx / l, wy / l, wz / l));
+        uint16_t *o = out_rgba16f + ((size_t)j * out_w + i) * 4;
+        o[0] = csko_f2h(col.x); o[1] = csko_f2h(col.y); o[2] = csko_f2h(col.z); o[3] = csko_f2h(1.0f);
+    }
+}
+
 /* ------------------------------------------------------------------ probes for structural tests */
 float csko_hash_probe(float px, float py, float pz) { return hash3(muls3(V3(px, py, pz), 10.0f)); }
 void csko_pixel_dir(const float params[28], int px, int py, float dir[3]) {

@@ -55,6 +55,8 @@ def lib():
                                         C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int, C.POINTER(Stats)]
         L.csko_composite.argtypes = [C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_int,
                                      C.c_void_p, C.c_int, C.c_int, C.c_float, C.c_float, C.c_void_p, C.c_void_p]
+        L.csko_composite_view.argtypes = [C.c_int, C.c_int, C.c_void_p, C.c_float, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_int,
+                                          C.c_void_p, C.c_int, C.c_int, C.c_float, C.c_float, C.c_void_p, C.c_void_p]
         L.csko_hash_probe.restype = C.c_float
         L.csko_hash_probe.argtypes = [C.c_float] * 3
         L.csko_pixel_dir.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p]
@@ -156,6 +158,17 @@ def composite(cloud_from, cloud_to, sky_from, sky_to, trans, light_dir, blend_am
     out = np.zeros((out_h, out_w, 4), np.uint16)
     lib().csko_composite(out_w, out_h, _ptr(a[0]), _ptr(a[1]), a[0].shape[1], a[0].shape[0], _ptr(a[2]), _ptr(a[3]), a[2].shape[1],
                          a[2].shape[0], _ptr(a[4]), a[4].shape[1], a[4].shape[0], blend_amount, sun_disk_scale, _ptr(ld), _ptr(out))
+    return out.view(np.float16)
+
+
+def composite_view(cloud_from, cloud_to, sky_from, sky_to, trans, light_dir, basis, fov_y_degrees, blend_amount=0.0, sun_disk_scale=2.0, out_w=256, out_h=144):
+    """clouds.gdshader sky() per SCREEN pixel of a perspective camera (basis 3x3: columns = the camera's right / up / back axes)."""
+    a = [np.ascontiguousarray(x).view(np.uint16) for x in (cloud_from, cloud_to, sky_from, sky_to, trans)]
+    ld = np.asarray(light_dir, np.float32)
+    b = np.ascontiguousarray(np.asarray(basis, np.float32).T.reshape(-1))                 # column-major
+    out = np.zeros((out_h, out_w, 4), np.uint16)
+    lib().csko_composite_view(out_w, out_h, _ptr(b), float(fov_y_degrees), _ptr(a[0]), _ptr(a[1]), a[0].shape[1], a[0].shape[0], _ptr(a[2]), _ptr(a[3]),
+                              a[2].shape[1], a[2].shape[0], _ptr(a[4]), a[4].shape[1], a[4].shape[0], blend_amount, sun_disk_scale, _ptr(ld), _ptr(out))
     return out.view(np.float16)
 
 

@@ -171,7 +171,7 @@ void hostsim_density_forms(const uint8_t* large_chain, const uint8_t* small_chai
 void hostsim_composite(int out_w, int out_h, const uint16_t* cf, const uint16_t* ct, int cw, int ch, const uint16_t* sf, const uint16_t* st, int sw, int sh,
                        const uint16_t* trans_h, int tw, int th, float blend, float sun_disk_scale, const float sun[3], uint16_t* out_h_) {
     std::vector<float4> tf = widen(trans_h, tw, th);
-    CompositeArgs A;
+    CompositeArgs A = {};                                           // (view_mode 0: the equirectangular panorama)
     A.cloud_from = cf; A.cloud_to = ct; A.cw = cw; A.ch = ch; A.sky_from = sf; A.sky_to = st; A.sw = sw; A.sh = sh; A.trans = tf.data(); A.tw = tw; A.th = th;
     A.blend_amount = blend; A.sun_disk_scale = sun_disk_scale; A.sun[0] = sun[0]; A.sun[1] = sun[1]; A.sun[2] = sun[2]; A.out_w = out_w; A.out_h = out_h;
     for (int j = 0; j < out_h; j++) for (int i = 0; i < out_w; i++) {

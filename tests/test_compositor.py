@@ -67,6 +67,49 @@ def test_compositor_gpu_vs_oracle(gpu_ctx, oracle, scene):
         assert d.max() <= 2 and (d > 0).mean() < 0.02, (d.max(), (d > 0).mean())
 
 
+def camera_basis(yaw_deg, pitch_deg):
+    """Columns = the camera's right / up / back axes after a yaw about +y and a pitch about its own x (a Camera3D looking down -z)."""
+    y, p = np.radians(yaw_deg), np.radians(pitch_deg)
+    ry = np.array([[np.cos(y), 0, np.sin(y)], [0, 1, 0], [-np.sin(y), 0, np.cos(y)]])
+    rx = np.array([[1, 0, 0], [0, np.cos(p), -np.sin(p)], [0, np.sin(p), np.cos(p)]])
+    return (ry @ rx).astype(np.float32)
+
+
+def test_oracle_view_compositor_agrees_with_the_panorama(oracle, scene):
+    """The per-screen-pixel form (EYEDIR of a perspective camera) and the equirectangular form are the same shader: the screen centre of a camera
+    looking at (azimuth, elevation) shows the panorama's texel in that direction, and a camera looking below the horizon sees atmosphere only."""
+    s = scene
+    pano = oracle.composite(s["cl"], s["cl2"], s["sky"], s["sky2"], s["tr"], s["sun"], 0.25, 2.0, 2048, 1024).astype(np.float32)
+    for yaw, pitch in ((0.0, 30.0), (120.0, 55.0), (-70.0, 10.0)):
+        b = camera_basis(yaw, pitch)
+        v = oracle.composite_view(s["cl"], s["cl2"], s["sky"], s["sky2"], s["tr"], s["sun"], b, 60.0, 0.25, 2.0, 65, 65).astype(np.float32)
+        fwd = -b[:, 2]                                                  # the camera looks down its -z axis
+        az, el = np.arctan2(fwd[2], fwd[0]), np.arcsin(fwd[1])
+        i, j = int((az / np.pi + 1) / 2 * 2048), int((0.5 - el / np.pi) * 1024)
+        assert np.abs(v[32, 32, :3] - pano[j, i, :3]).max() <= 0.02 * max(1.0, float(pano[j, i, :3].max())), (yaw, pitch, v[32, 32], pano[j, i])
+    empty = np.zeros_like(s["cl"])
+    down = camera_basis(0.0, -60.0)
+    a = oracle.composite_view(s["cl"], s["cl2"], s["sky"], s["sky2"], s["tr"], s["sun"], down, 40.0, 0.25, 2.0, 48, 32)
+    b = oracle.composite_view(empty, empty, s["sky"], s["sky2"], s["tr"], s["sun"], down, 40.0, 0.25, 2.0, 48, 32)
+    assert (a.view(np.uint16) == b.view(np.uint16)).all()
+
+
+@pytest.mark.gpu
+def test_view_compositor_gpu_vs_oracle(gpu_ctx, oracle, scene, pkg):
+    """csky_composite_view (clouds.gdshader:105-116 with the engine's per-screen-pixel EYEDIR: VERDICT r2 missing 5) vs the oracle, <= 2 fp16 ulp,
+    three cameras incl. one straddling the horizon, 16:9 and a ragged size."""
+    s = scene
+    gpu_ctx.render_transmittance(256, 64)
+    for yaw, pitch, fov, w, h in ((0.0, 30.0, 75.0, 256, 144), (135.0, 5.0, 50.0, 333, 111), (-60.0, 70.0, 100.0, 160, 160)):
+        b = camera_basis(yaw, pitch)
+        ref = oracle.composite_view(s["cl"], s["cl2"], s["sky"], s["sky2"], s["tr"], s["sun"], b, fov, 0.25, 2.0, w, h)
+        img = gpu_ctx.composite_view(s["cl"], s["cl2"], s["sky"], s["sky2"], s["sun"], b, fov, 0.25, 2.0, w, h)
+        d = ulp_diff(img, ref)
+        assert d.max() <= 2 and (d > 0).mean() < 0.02, (yaw, pitch, d.max(), (d > 0).mean())
+    with pytest.raises(pkg.CloudSkyError):
+        gpu_ctx.composite_view(s["cl"], s["cl2"], s["sky"], s["sky2"], s["sun"], camera_basis(0, 0), 180.0, 0.25, 2.0, 64, 64)
+
+
 @pytest.mark.gpu
 def test_host_class_panorama(pkg, noise):
     sky = pkg.CloudSky.from_default_resource(device_id=0, texture_size=(128, 64), noise=noise, clock=lambda: 0.0)
