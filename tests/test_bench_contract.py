@@ -44,6 +44,7 @@ def test_bench_line_contract_single_gpu():
     assert d["value_host_form"]["2_in_flight"]["Mrays_per_s"] > d["value_host_form"]["1_in_flight"]["Mrays_per_s"] > 100.0
     r = d["roofline"]
     assert r["pmc"]["collected"], r["pmc"]                                     # the counters were collected in THIS run
+    assert r["frac"] is not None and r["headline"] is not None, r["census_note"]   # the census ran in THIS run (libcloudsky_census.so is built with the library)
     assert 0.3 < r["frac"] <= 1.0 and r["frac_bounds"][0] <= r["frac"] <= r["frac_bounds"][1] <= 1.0
     # round 3: executed instructions come from the basic-block census (no unclassified kinds), cross-checked against the hardware totals, and
     # the fraction stays <= 1 against the kernel alone AND against the driver-timed ms_per_step at the clock sampled in that region
