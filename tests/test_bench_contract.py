@@ -54,7 +54,7 @@ def test_bench_line_contract_single_gpu():
         assert ratio is None or abs(ratio - 1.0) < 0.03, (unit, ratio)
     h = r["headline"]
     assert 0.3 < h["frac"] <= 1.0 and h["frac_bounds"][1] <= 1.0 and 1500 < h["sclk_mhz"] < 2600
-    assert abs(h["ms_per_frame_while_sampling"] - d["ms_per_step"]) < 0.15 * d["ms_per_step"]
+    assert 0.5 * d["ms_per_step"] < h["ms_per_frame_while_sampling"] <= 1.05 * d["ms_per_step"]   # (6 timed steps pay the pipeline's fill and drain; the sampled loop runs >= 0.4 s)
     assert 0.2 < r["l1_gather"]["frac"] <= 1.0 and 0.0 < r["hbm"]["frac"] <= 1.0
     assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-9 and r["traffic"] > 1e8
     assert 0.5 < r["kernel_ms_solo"] < 20.0 and r["kernel_ms_in_flight"] >= 0.9 * r["kernel_ms_solo"]
