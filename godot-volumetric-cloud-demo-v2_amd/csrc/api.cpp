@@ -283,7 +283,10 @@ int clouds_dev(csky_ctx* c, const csky_cloud_params* p, int tile_w, const csky_b
     const int static_grid = c->order_grid_ring[slot];
     if (!feedback) {
         if (kt) HIPCHK(c, hipEventRecord(kt[0], s));
-        HIPCHK(c, launch_clouds(variant, seg, texset(c), c->d_fc, g, d_static, static_grid, d_out, d_stats, nullptr, s, heads, resident));
+        {   // a failed persistent launch may leave the slot's pop counters armed: re-zero them so that the next launch on this slot starts clean
+            const hipError_t le = launch_clouds(variant, seg, texset(c), c->d_fc, g, d_static, static_grid, d_out, d_stats, nullptr, s, heads, resident);
+            if (le != hipSuccess) { if (heads) (void)hipMemsetAsync(heads, 0, 16 * sizeof(uint32_t), s); return fail(c, CSKY_ERR_HIP, "cloud kernel launch failed: %s", hipGetErrorString(le)); }
+        }
         if (kt) HIPCHK(c, hipEventRecord(kt[1], s));
         HIPCHK(c, hipEventRecord(c->ev_clouds[c->fc_cur], s)); c->clouds_pending[c->fc_cur] = true;
         return CSKY_OK;
@@ -315,7 +318,10 @@ int clouds_dev(csky_ctx* c, const csky_cloud_params* p, int tile_w, const csky_b
     const uint32_t* const use_order = c->lpt_valid[slot] ? lorder : d_static;
     const int use_grid = c->lpt_valid[slot] ? nblocks : static_grid;
     if (kt) HIPCHK(c, hipEventRecord(kt[0], s));
-    HIPCHK(c, launch_clouds(variant, seg, texset(c), c->d_fc, g, use_order, use_grid, d_out, d_stats, cost, s, heads, resident));
+    {
+        const hipError_t le = launch_clouds(variant, seg, texset(c), c->d_fc, g, use_order, use_grid, d_out, d_stats, cost, s, heads, resident);
+        if (le != hipSuccess) { if (heads) (void)hipMemsetAsync(heads, 0, 16 * sizeof(uint32_t), s); return fail(c, CSKY_ERR_HIP, "cloud kernel launch failed: %s", hipGetErrorString(le)); }
+    }
     if (kt) HIPCHK(c, hipEventRecord(kt[1], s));
     int shift = 0;
     while ((((long long)256 * (c->primary_steps + 16)) >> shift) >= 1024) shift++;     // largest cost: 4 wavefronts x 64 rays x (steps + 16)

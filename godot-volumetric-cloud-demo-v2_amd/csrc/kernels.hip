@@ -1041,7 +1041,7 @@ __global__ __launch_bounds__(256, VARIANT == 3 ? CSKY_COMPACT_WAVES : 7) void cl
         uint32_t* __restrict__ wg_cost) {
     unsigned xcc;
     asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
-    xcc &= 7u;
+    xcc &= 7u;                                                 // eight sequences: MI355X has 8 XCDs; a part with fewer just leaves sequences to be stolen, one with more folds two XCDs onto one sequence (both still correct: every entry is popped exactly once)
     const uint32_t per_xcd = (n_items + 7u) >> 3;
     __shared__ uint32_t ticket, slot_ready[2], slot_reads[2], slot_entry[2], slot_rec[2];
     if (threadIdx.x == 0) { ticket = 0; slot_ready[0] = slot_ready[1] = 0; slot_reads[0] = slot_reads[1] = 0; }
