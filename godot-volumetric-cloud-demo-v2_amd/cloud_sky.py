@@ -74,7 +74,7 @@ class CloudSky:
     FRAMES_TO_UPDATE_CHOICES = (1, 4, 16, 64, 256)   # cloud_sky.gd:36 plus 1 = full hemisphere per call
 
     def __init__(self, device_id=0, texture_size=768, frames_to_update=1, noise=None, clock=None, device_buffers=False,
-                 rank=0, world_size=1, dist=None, ctx=None):
+                 rank=0, world_size=1, dist=None, ctx=None, async_host=False):
         # exported properties, cloud_sky.gd:5-50 with the defaults of the script (clouds_sky.tres overrides some)
         self.wind_direction = 0.0
         self.wind_speed = 1.0
@@ -101,6 +101,12 @@ class CloudSky:
             clock = lambda: _time.monotonic() - t0  # noqa: E731
         self.clock = clock
         self.device_buffers = bool(device_buffers)
+        # async_host: the host-buffer path through csky_submit_clouds / csky_collect (what the GDExtension's submit_clouds() / collect() wrap,
+        # INTEGRATION.md): _render_process() collects the tile submitted by the PREVIOUS call into its texture and submits this call's tile, so
+        # march + copy of one tile overlap the host's work on the next; the textures trail by one call, flush() collects the last tile.  The
+        # reference's loop tolerates that by construction: it draws with the textures finished in earlier passes (cloud_sky.gd:137-148).
+        self.async_host = bool(async_host) and not self.device_buffers
+        self._pending = None
         self.rank, self.world_size, self.dist = int(rank), int(world_size), dist
         self.last_frame = None
         self._side_stream = None
@@ -216,7 +222,22 @@ class CloudSky:
         self.sky_lut.update_lut(fd.LIGHT_DIRECTION, stream)
         done()
 
+    def flush(self):
+        """async_host: wait for the tile in flight (if any) and write it into its texture."""
+        if self._pending is not None:
+            ticket, texidx, (x0, y0, rw, rh) = self._pending
+            self._pending = None
+            tile = self.ctx.collect(ticket, copy=False)
+            if self.textures[texidx] is not None:
+                self.textures[texidx][y0:y0 + rh, x0:x0 + rw] = tile
+
     def cleanup(self):  # cloud_sky.gd:197-212
+        if getattr(self, "_pending", None) is not None:                     # a tile of the old geometry is in flight: drop it
+            try:
+                self.ctx.collect(self._pending[0], copy=False)
+            except Exception:
+                pass
+            self._pending = None
         self.can_run = False
         self.frame = 0
         self.texture_to_update, self.texture_to_blend_from, self.texture_to_blend_to = 0, 1, 2
@@ -232,9 +253,20 @@ class CloudSky:
         atmosphere with the sun disk, evaluated on an equirectangular panorama (csky_composite_sky).  float16 [h, w, 4]."""
         def host(t):
             return t.cpu().numpy() if hasattr(t, "cpu") else t
+        self.flush()
         bf, bt = host(self.textures[self.texture_to_blend_from]), host(self.textures[self.texture_to_blend_to])
         sf, st = (host(t) for t in self.sky_lut.back_texture)   # sky_blend_from/to_texture = the two OLDER ring copies (cloud_sky.gd:147-148)
         return self.ctx.composite_sky(bf, bt, sf, st, self.frame_data.LIGHT_DIRECTION, self.blend_amount, self.sun_disk_scale, out_w, out_h)
+
+    def sky_view(self, basis, fov_y_degrees=75.0, out_w=1152, out_h=648):
+        """The same through a perspective camera: one EYEDIR per SCREEN pixel, the way the engine evaluates clouds.gdshader
+        (csky_composite_view).  basis: 3x3, columns = the camera's right / up / back axes (Camera3D.global_transform.basis)."""
+        def host(t):
+            return t.cpu().numpy() if hasattr(t, "cpu") else t
+        self.flush()
+        bf, bt = host(self.textures[self.texture_to_blend_from]), host(self.textures[self.texture_to_blend_to])
+        sf, st = (host(t) for t in self.sky_lut.back_texture)
+        return self.ctx.composite_view(bf, bt, sf, st, self.frame_data.LIGHT_DIRECTION, basis, fov_y_degrees, self.blend_amount, self.sun_disk_scale, out_w, out_h)
 
     # ---- render thread ------------------------------------------------------------------------------------
     def _march_stream(self):
@@ -290,6 +322,11 @@ class CloudSky:
         W, H = self._texture_size
         rw, rh = self.update_region_size
         x0, y0 = self.update_position
+        if self.async_host:
+            self.flush()                                                    # the previous call's tile -> its texture (rd.texture_update there)
+            self._pending = (self.ctx.submit_clouds(pc, rw, rh), p_texture_to_update, (x0, y0, rw, rh))
+            self.last_frame = tex
+            return tex
         if not self.device_buffers:
             tile = self.ctx.render_clouds(pc, rw, rh)                       # dispatch(num_workgroups, num_workgroups, 1)
             tex[y0:y0 + rh, x0:x0 + rw] = tile

@@ -351,3 +351,31 @@ def test_importer_style_mip_chains_vs_oracle(pkg, noise, oracle, o_trans):
         print("importer-style chains: %s; differs from the box-chain frame by up to %.3g" % (info, float(d.max())))
     finally:
         ctx.close()
+
+
+@pytest.mark.parametrize("ftu", [1, 16])
+def test_host_class_async_host_path_matches_the_blocking_one(pkg, noise, ftu):
+    """CloudSky(async_host=True): the GDScript-side change of INTEGRATION.md (collect the previous call's tile, submit this one) in the
+    host mirror, whole-frame mode and the reference's 16-tile temporal split (cloud_sky.gd:129-163): after flush() the three ring
+    textures equal the blocking host path's byte for byte, and the perspective-camera view renders from them."""
+    t = [0.0]
+    def mk(async_host):
+        t[0] = 0.0
+        sky = pkg.CloudSky.from_default_resource(device_id=0, texture_size=(256, 128), frames_to_update=ftu, noise=noise, clock=lambda: t[0], async_host=async_host)
+        sky.sun = pkg.cloud_sky.DirectionalLight(direction=(-0.6, 0.35, 0.3))
+        return sky
+    a, b = mk(False), mk(True)
+    try:
+        for k in range(2 * ftu + 3):
+            for s in (a, b):
+                t[0] = 0.25 * k
+                s.update_sky()
+        b.flush()
+        for i in range(3):
+            assert (np.asarray(a.textures[i]).view(np.uint16) == np.asarray(b.textures[i]).view(np.uint16)).all(), (ftu, i)
+        assert a.blend_amount == b.blend_amount and a.texture_to_update == b.texture_to_update
+        basis = np.array([[1, 0, 0], [0, np.cos(0.5), -np.sin(0.5)], [0, np.sin(0.5), np.cos(0.5)]], np.float32)
+        va, vb = a.sky_view(basis, 70.0, 160, 90), b.sky_view(basis, 70.0, 160, 90)
+        assert (va.view(np.uint16) == vb.view(np.uint16)).all() and np.isfinite(va.astype(np.float32)).all() and float(va[..., :3].astype(np.float32).max()) > 0.05
+    finally:
+        a.close(); b.close()
