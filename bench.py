@@ -369,28 +369,45 @@ def main():
     # (tools/share_matrix.py).  Buffer set b = frame number mod frames in flight: band buffer, stream, gather target.
     # The rings are four deep; more than two frames in flight only pay for small rank shares (a 1/8 share of C3: 0.32 -> 0.28 ms per
     # frame as whole rays), so the default is 4 for 3072..6143 tiles per rank at N > 1 and 2 everywhere else.
-    bands = tiling.bands_for_rank(H, rank, world)
+    # Frame groups (--groups G, throughput workloads such as C5's 64-frame sweep): the ranks are split into G groups of world / G; consecutive
+    # frames go to the groups in turn and the ranks of a group split THEIR frame's bands (world / G)-way.  A rank's share is G times larger
+    # (fewer, fuller launches), every frame is still gathered on rank 0: group g's collective runs on a communicator of {0} + its ranks, to
+    # which rank 0 contributes an unused dummy when it is not a member.  G = 1 (default): every rank works on every frame (the C4 split).
+    G = max(1, args.groups)
+    if world % G:
+        raise SystemExit("bench.py: --groups must divide --gpus")
+    per = world // G
+    my_group, kidx = rank // per, rank % per
+    bands = tiling.bands_for_rank(H, kidx, per)
     tiles_per_rank = ((W + 7) // 8) * bands[3]
-    fif_default = 4 if (world > 1 and 3072 <= tiles_per_rank < 6144) else 2    # measured per frame, x2 / x4: 1/4 share 0.485 / 0.512, 1/8 share 0.316 / 0.283, 1/16 share 0.191 / 0.250
+    fif_default = 4 if (per > 1 and 3072 <= tiles_per_rank < 6144) else 2    # measured per frame, x2 / x4: 1/4 share 0.485 / 0.512, 1/8 share 0.316 / 0.283, 1/16 share 0.191 / 0.250
     fif = max(1, min(4, args.frames_in_flight if args.frames_in_flight is not None else fif_default))
     if os.environ.get("CSKY_BENCH_SYNC_GATHER") == "1":
         fif = 1                                      # debugging aid: gather-then-render, one frame at a time
     ctx.set_frames_in_flight(fif)
-    streams = [torch.cuda.Stream(device=dev) for _ in range(fif)]   # always real streams: handle 0 (torch's default stream) would select the
+    members = [sorted(set(([0] if G > 1 else []) + list(range(g * per, (g + 1) * per)))) for g in range(G)]
+    pgs = [None] * G                                 # None = the world communicator
+    if world > 1 and G > 1:
+        for g in range(G):                           # every rank creates every group, in the same order (a collective)
+            pgs[g] = dist.new_group(members[g])
+    # rank 0 takes part in every frame's gather (G x fif in flight), the others in their group's frames only
+    nbuf = fif * G if (rank == 0 and G > 1) else fif
+    streams = [torch.cuda.Stream(device=dev) for _ in range(nbuf)]   # always real streams: handle 0 (torch's default stream) would select the
     stream = streams[0].cuda_stream                                  # library's own non-blocking stream, unordered against the gather
-    mb = tiling.max_bands(H, world)
+    mb = tiling.max_bands(H, per)
     # N > 1: the gather of frame k (RCCL, its own stream, ordered behind the stream of frame k at the call) overlaps the march of
     # the following frames on the other streams; wait() orders frame k's stream behind its collective before that buffer set is reused.
-    overlap = world > 1 and fif > 1
-    nbuf = fif
+    overlap = world > 1 and nbuf > 1
     local = [torch.zeros((mb * tiling.BAND_ROWS, W, 4), dtype=torch.int16, device=dev) for _ in range(nbuf)]
     local_b = [t.view(torch.uint8) for t in local]   # collectives move raw bytes (RCCL has no int16 type)
     gdev = "cpu" if debug_one_gpu else dev
-    gathered = [torch.empty((world,) + tuple(local[0].shape), dtype=torch.int16, device=gdev) for _ in range(nbuf)] if (world > 1 and rank == 0) else None
-    parts = [[g[i].view(torch.uint8) for i in range(world)] for g in gathered] if gathered is not None else [None] * nbuf
+    n_max = max(len(m) for m in members)
+    gathered = [torch.empty((n_max,) + tuple(local[0].shape), dtype=torch.int16, device=gdev) for _ in range(nbuf)] if (world > 1 and rank == 0) else None
     pending = [None] * nbuf
+    pend_group = [0] * nbuf
     frame = [None]
     counter = [0]
+    taken = [0]                                      # frames this rank took part in: its buffer-set rotation
 
     def finish(o):
         """Frame in buffer set o has been gathered: order ITS stream behind the collective and assemble the frame on rank 0."""
@@ -398,22 +415,34 @@ def main():
             pending[o].wait()
             pending[o] = None
             if rank == 0:
-                frame[0] = tiling.interleave(gathered[o].to(dev) if debug_one_gpu else gathered[o], H, world)
+                m = members[pend_group[o]]
+                got = gathered[o][: len(m)]
+                if 0 not in range(pend_group[o] * per, (pend_group[o] + 1) * per):
+                    got = got[1:]                    # rank 0's dummy contribution to another group's gather
+                frame[0] = tiling.interleave(got.to(dev) if debug_one_gpu else got, H, per)
 
     def step():
         k = counter[0]
         counter[0] += 1
-        bset = k % nbuf
+        grp = k % G
+        mine = grp == my_group
+        if not mine and rank != 0:
+            return
+        bset = taken[0] % nbuf
+        taken[0] += 1
         fp, fs = (params, sun_n) if sweep is None else sweep[k % len(sweep)]
         st_k = streams[bset].cuda_stream
-        ctx.render_sky_lut_device(fs, 200, 100, st_k)                                          # sky_lut.gd:122-148
-        ctx.render_clouds_device(fp, W, bands, local[bset].data_ptr(), W * 8, st_k)           # cloud_sky.gd:234-248
+        if mine:
+            ctx.render_sky_lut_device(fs, 200, 100, st_k)                                          # sky_lut.gd:122-148
+            ctx.render_clouds_device(fp, W, bands, local[bset].data_ptr(), W * 8, st_k)           # cloud_sky.gd:234-248
         if world == 1:
             frame[0] = local[bset]
             return
         with torch.cuda.stream(streams[bset]):       # the collective is ordered behind the CURRENT stream: make it this frame's
             src = local_b[bset].cpu() if debug_one_gpu else local_b[bset]
-            pending[bset] = dist.gather(src, gather_list=parts[bset], dst=0, async_op=True)
+            glist = [gathered[bset][i].view(torch.uint8) for i in range(len(members[grp]))] if rank == 0 else None
+            pending[bset] = dist.gather(src, gather_list=glist, dst=0, group=pgs[grp], async_op=True)
+            pend_group[bset] = grp
         if overlap:
             o = (bset + 1) % nbuf          # the oldest frame in flight (its buffer set is the next one to be reused):
             if pending[o] is not None:     # its gather ran while the younger frames were marching
@@ -423,7 +452,7 @@ def main():
 
     def drain():
         for i in range(1, nbuf + 1):       # oldest first
-            o = (counter[0] - 1 + i) % nbuf
+            o = (taken[0] - 1 + i) % nbuf
             if pending[o] is not None:
                 finish(o)
 
@@ -544,7 +573,9 @@ def main():
         if debug_one_gpu and world > 1:   # the gathered frame must equal a single-context full-frame render
             full = torch.zeros((H, W, 4), dtype=torch.int16, device=dev)
             ctx.set_segments(1)
-            ctx.render_clouds_device(params, W, (H, 0, 1, 1), full.data_ptr(), W * 8, stream)
+            fp_l, fs_l = (params, sun_n) if sweep is None else sweep[(counter[0] - 1) % len(sweep)]   # the LAST frame of the run (rank 0 holds it whatever group rendered it)
+            ctx.render_sky_lut_device(fs_l, 200, 100, stream)
+            ctx.render_clouds_device(fp_l, W, (H, 0, 1, 1), full.data_ptr(), W * 8, stream)
             torch.cuda.synchronize()
             a, b = full.view(torch.float16).float(), frame[0].view(torch.float16).float()
             err = (a - b).abs()
@@ -635,7 +666,7 @@ def main():
                                    % (args.config, W, H, primary, light, sun_n[0], sun_n[1], sun_n[2]),
                        "texture_size": [W, H], "primary_steps": primary, "light_steps": light, "early_out_eps": args.early_out, "with_early_out": early,
                        "variant": gvcd_amd.lib().csky_variant_name(args.variant if args.variant is not None else gvcd_amd._lib.DEFAULT_VARIANT).decode(),
-                       "parallelism": "bands%d%s" % (world, "+overlapped-gather" if overlap else ""), "frames_in_flight": fif,
+                       "parallelism": "bands%d%s%s" % (per, "+overlapped-gather" if overlap else "", " x %d frame groups" % G if G > 1 else ""), "frames_in_flight": fif, "frame_groups": G,
                        "alpha_mean": alpha_mean, "finite": finite},
             "roofline": dict(valu_roofline(census, clocks, pmc, vi, k_solo, elapsed / args.steps * 1e3), **{
                 # neither "hbm" nor "mfma" binds this path (docstring): the top-level fields are the VALU-issue roof, the one closest to 1

@@ -107,3 +107,20 @@ def test_bench_single_process_form(mode):
     assert d["n_gpus"] == int(n) and d["ranks_seen"] == int(n) and len(d["per_rank_share_ms"]) == int(n)
     assert d["config"]["frame_groups"] == int(g) and d["config"]["finite"] is True and d["config"]["alpha_mean"] > 0.05
     assert "-device frame vs single-context frame" in out.stderr
+
+
+@pytest.mark.parametrize("cfg", [("4", "2", "C3"), ("3", "3", "C5"), ("4", "1", "C2")])
+def test_bench_frame_groups_process_form(cfg):
+    """`--groups G` in the one-process-per-GPU form: consecutive frames go to G groups of ranks in turn, each group splits its frame and gathers it
+    on rank 0 over its own communicator ({0} + the group).  Self-launched, all ranks on GPU 0 through gloo; G = world is pure frame parallelism
+    (BASELINE config 5's sweep: every rank renders whole frames of the 64-frame sun sweep); bench.py checks the LAST frame against a
+    single-context render of ITS parameters."""
+    n, g, config = cfg
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env["CSKY_BENCH_ONE_GPU_DEBUG"] = "1"
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", n, "--groups", g, "--config", config, "--steps", "7", "--warmup", "2", "--no-cpu-baseline"],
+                         capture_output=True, text=True, cwd=ROOT, env=env, timeout=900)
+    assert out.returncode == 0, (out.stdout[-1500:], out.stderr[-2500:])
+    d = _last_json(out.stdout)
+    assert d["n_gpus"] == int(n) and d["ranks_seen"] == int(n) and d["config"]["frame_groups"] == int(g) and d["config"]["finite"] is True
+    assert "gathered %s-rank frame vs single-rank frame" % n in out.stderr
