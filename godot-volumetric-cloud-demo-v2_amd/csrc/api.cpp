@@ -48,6 +48,7 @@ struct csky_ctx {
     // noise set (cloud_sky.gd:298-341)
     uint8_t* d_raw_large = nullptr; uint8_t* d_raw_small = nullptr; uint8_t* d_raw_weather = nullptr; uint8_t* d_bake_meta = nullptr;   // 8-bit mip chains (inputs of the device bake)
     ShapeTexel* d_shape = nullptr; unsigned long long inexact_coeffs = 0; uint4* d_detail = nullptr; uint4* d_weather = nullptr; uint16_t* d_detail_h = nullptr; bool have_noise = false;
+    float* d_brick = nullptr;                                               // CSKY_BRICK_BOUND experiment build only
     uint32_t shape_off[SHAPE_LEVELS] = {}, detail_off[DETAIL_LEVELS] = {};
     float detail_lod5 = 0.0f;
     double w_rmin = 0.0, w_rmax = 1.0, w_bmax = 1.0;   // range of the weather map's cloud-type / coverage channels
@@ -147,6 +148,9 @@ int render_trans_dev(csky_ctx* c, int w, int h, hipStream_t s) {
 
 TexSet texset(const csky_ctx* c) {
     TexSet t;
+#ifdef CSKY_BRICK_BOUND
+    t.brick = c->d_brick;
+#endif
     t.shape = c->d_shape; t.detail = c->d_detail; t.weather = c->d_weather; t.sky = c->d_sky_f; t.sky_w = c->sw; t.sky_h = c->sh; t.detail_lod5 = c->detail_lod5; t.detail_h = c->d_detail_h; t.detail_lds = nullptr;
     return t;
 }
@@ -450,6 +454,22 @@ static int set_noise_impl(csky_ctx* c, const uint8_t* large_rgba8, const uint8_t
     }
     HIPCHK(c, launch_bake(c->d_raw_large, c->d_raw_small, c->d_raw_weather, c->d_shape, c->d_detail, c->d_detail_h, c->d_weather,
                           reinterpret_cast<unsigned long long*>(c->d_bake_meta), reinterpret_cast<int*>(c->d_bake_meta + 8), s));
+#ifdef CSKY_BRICK_BOUND
+    {   // per 8^3 brick (+1 apron on the high side, REPEAT): bmax = (rmax + 1 - fmin) / (2 - fmin), a hair above (the kernel's rcp is approximate)
+        std::vector<float> tab(16 * 16 * 16);
+        for (int bz = 0; bz < 16; bz++) for (int by = 0; by < 16; by++) for (int bx = 0; bx < 16; bx++) {
+            int rm = 0, fm = 1 << 30;
+            for (int z = bz * 8; z <= bz * 8 + 8; z++) for (int y = by * 8; y <= by * 8 + 8; y++) for (int x = bx * 8; x <= bx * 8 + 8; x++) {
+                const uint8_t* tx = large_rgba8 + ((((size_t)(z & 127) * 128 + (y & 127)) * 128 + (x & 127)) * 4);
+                rm = std::max(rm, (int)tx[0]); fm = std::min(fm, 5 * tx[1] + 2 * tx[2] + tx[3]);
+            }
+            const float r = rm * (1.0f / 255.0f), f = fm * (1.0f / (8.0f * 255.0f));
+            tab[((size_t)bz * 16 + by) * 16 + bx] = (r + (1.0f - f)) / (2.0f - f) * 1.000004f;
+        }
+        if (!c->d_brick) HIPCHK(c, hipMalloc(reinterpret_cast<void**>(&c->d_brick), tab.size() * sizeof(float)));
+        HIPCHK(c, hipMemcpy(c->d_brick, tab.data(), tab.size() * sizeof(float), hipMemcpyHostToDevice));
+    }
+#endif
     uint8_t t5[3] = {0, 0, 0};                                // detail LOD 5 is one texel: every tap at that level returns it (cloud_core.h::detail_tap)
     HIPCHK(c, hipMemcpyAsync(&meta, c->d_bake_meta, sizeof meta, hipMemcpyDeviceToHost, s));
     HIPCHK(c, hipMemcpyAsync(t5, c->d_raw_small + chain_offset(DETAIL_N, 5, 3), 3, hipMemcpyDeviceToHost, s));

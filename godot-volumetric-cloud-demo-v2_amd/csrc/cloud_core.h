@@ -398,6 +398,18 @@ CSKY_HD float density(const TexSet& T, const FrameConsts& fc, float px, float py
     if (!(g > omw)) return 0.0f;                                             // exact reject (1)
     float qx, qy, qz, sx, sy, sz;
     shape_coord(fc, px, py, pz, qx, qy, qz, sx, sy, sz);
+#ifdef CSKY_BRICK_BOUND
+    // EXPERIMENT BUILD ONLY (make brick; profiles/r03/brick_bound_reject_analysis.txt): base_cloud = (r + 1 - fbm) / (2 - fbm) is increasing in r and
+    // decreasing in fbm and a trilinear tap lies between its corners, so bmax = that expression at (max r, min fbm) over the brick the cell's base
+    // index lies in (+1 texel apron) bounds it; bmax * g <= 1 - wc proves the remap at :124 <= 0, i.e. density() == 0, without the 32-byte gather.
+    if (lod_shape == 0) {
+        int bx, by, bz; float fx_, fy_, fz_;
+        split_coord(sx * 128.0f - 0.5f, bx, fx_); split_coord(sy * 128.0f - 0.5f, by, fy_); split_coord(sz * 128.0f - 0.5f, bz, fz_);
+        const uint32_t bi = ((((uint32_t)bz & 127u) >> 3) << 8) | ((((uint32_t)by & 127u) >> 3) << 4) | (((uint32_t)bx & 127u) >> 3);
+        const float bm = T.brick[bi];
+        if (!(bm * g > omw)) return 0.0f;
+    }
+#endif
     float nr, fbm;
     shape_tap(T, lod_shape, sx, sy, sz, nr, fbm);                           // :117-118
     CSKY_STAGE(2);

@@ -77,6 +77,9 @@ struct TexSet {
     const uint16_t* detail_h;     // global: unpacked fp16 numerators of the detail chain (source of the LDS copy), 37 449 texels
     const uint16_t* detail_lds;   // LDS copy of detail_h inside the "lds" kernel variant, else nullptr
     float detail_lod5;      // the single texel of detail LOD 5 (1x1x1) as hfbm = (5r+2g+b)/(8*255): the filtered value of EVERY tap at that level
+#ifdef CSKY_BRICK_BOUND
+    const float* brick;     // experiment build only (round 3): per 8^3-texel brick of shape level 0 (+1 apron) an upper bound of base_cloud
+#endif
 };
 
 // Ray-invariant per-frame constants, computed once per frame by frame_setup() (clouds.glsl:143-170).
