@@ -268,7 +268,8 @@ def valu_roofline(census, clocks, pmc, vi, k_solo_ms, ms_per_step):
         pairs = {"valu": "SQ_INSTS_VALU", "salu": "SQ_INSTS_SALU", "smem": "SQ_INSTS_SMEM", "vmem_load": "SQ_INSTS_VMEM_RD", "lds": "SQ_INSTS_LDS"}
         out["valu_issue"]["census_over_hardware_counters"] = {k: (ex[k] / ins[c] if ins.get(c) else None) for k, c in pairs.items()}
     ck = (clocks or {}).get("kernel_alone") or {}
-    mhz = (ck.get("sclk") or {}).get("mean_mhz")
+    nominal = (clocks or {}).get("nominal_mhz")          # no hwmon node readable: the device's maximum clock (fractions come out LOW, never above 1 by that)
+    mhz = (ck.get("sclk") or {}).get("mean_mhz") or nominal
     sq_cycles = vi.get("kernel_cycles")
     if ach and mhz:
         k_ms = ck.get("kernel_ms") or k_solo_ms
@@ -278,7 +279,7 @@ def valu_roofline(census, clocks, pmc, vi, k_solo_ms, ms_per_step):
     elif ach and sq_cycles:
         out.update({"achieved": ach, "peak": sq_cycles, "frac": ach / sq_cycles, "frac_bounds": [ach / sq_cycles, min(1.0, ach * mix_hi / sq_cycles)], "peak_source": "SQ_BUSY_CYCLES/32 (no clock sample)"})
     ch = (clocks or {}).get("headline") or {}
-    mhz_h = (ch.get("sclk") or {}).get("mean_mhz")
+    mhz_h = (ch.get("sclk") or {}).get("mean_mhz") or nominal
     achq = kq.get("valu_issue_cycles_per_simd") or ach
     if achq and mhz_h:
         peak_h = ms_per_step * 1e-3 * mhz_h * 1e6
@@ -608,7 +609,7 @@ def main():
             pr = torch.cuda.get_device_properties(local_rank)
             bus = "%04x:%02x:%02x.0" % (getattr(pr, "pci_domain_id", 0), pr.pci_bus_id, getattr(pr, "pci_device_id", 0)) if isinstance(getattr(pr, "pci_bus_id", None), int) else None
             node = sclk.hwmon_freq_path(bus)
-            clocks = {"source": node}
+            clocks = {"source": node, "nominal_mhz": (getattr(pr, "clock_rate", 0) or 2400000) / 1e3}
 
             def clocked(run_frames, frames_per_call):
                 run_frames()                                     # warm
