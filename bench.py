@@ -271,13 +271,15 @@ def valu_roofline(census, clocks, pmc, vi, k_solo_ms, ms_per_step):
     nominal = (clocks or {}).get("nominal_mhz")          # no hwmon node readable: the device's maximum clock (fractions come out LOW, never above 1 by that)
     mhz = (ck.get("sclk") or {}).get("mean_mhz") or nominal
     sq_cycles = vi.get("kernel_cycles")
+    alone = None
     if ach and mhz:
         k_ms = ck.get("kernel_ms") or k_solo_ms
         peak = k_ms * 1e-3 * mhz * 1e6
-        out.update({"achieved": ach, "peak": peak, "frac": ach / peak, "frac_bounds": [ach / peak, min(1.0, ach * mix_hi / peak)],
-                    "peak_source": "kernel alone: %.3f ms x %.0f MHz sampled (SQ_BUSY_CYCLES/32 of the counter pass: %s)" % (k_ms, mhz, "%.4g" % sq_cycles if sq_cycles else "n/a")})
+        alone = {"achieved": ach, "peak": peak, "frac": ach / peak, "frac_bounds": [ach / peak, min(1.0, ach * mix_hi / peak)], "kernel_ms": k_ms, "sclk_mhz": mhz,
+                 "peak_source": "kernel alone: %.3f ms x %.0f MHz sampled (SQ_BUSY_CYCLES/32 of the counter pass: %s)" % (k_ms, mhz, "%.4g" % sq_cycles if sq_cycles else "n/a")}
     elif ach and sq_cycles:
-        out.update({"achieved": ach, "peak": sq_cycles, "frac": ach / sq_cycles, "frac_bounds": [ach / sq_cycles, min(1.0, ach * mix_hi / sq_cycles)], "peak_source": "SQ_BUSY_CYCLES/32 (no clock sample)"})
+        alone = {"achieved": ach, "peak": sq_cycles, "frac": ach / sq_cycles, "frac_bounds": [ach / sq_cycles, min(1.0, ach * mix_hi / sq_cycles)], "peak_source": "SQ_BUSY_CYCLES/32 (no clock sample)"}
+    out["kernel_alone"] = alone
     ch = (clocks or {}).get("headline") or {}
     mhz_h = (ch.get("sclk") or {}).get("mean_mhz") or nominal
     achq = kq.get("valu_issue_cycles_per_simd") or ach
@@ -285,6 +287,12 @@ def valu_roofline(census, clocks, pmc, vi, k_solo_ms, ms_per_step):
         peak_h = ms_per_step * 1e-3 * mhz_h * 1e6
         out["headline"] = {"ms_per_step": ms_per_step, "sclk_mhz": mhz_h, "cycles_per_frame_available": peak_h, "issue_cycles_per_simd": achq, "frac": achq / peak_h,
                            "frac_bounds": [achq / peak_h, min(1.0, achq * mix_hi / peak_h)], "ms_per_frame_while_sampling": ch.get("ms_per_frame")}
+        # top level = the TIMED REGION: every launch's VALU issue cycles over the cycles the region had (launches overlap there, two frames in flight, so
+        # a per-launch duration means nothing; elapsed / launches = ms_per_step is the effective one).  `kernel_alone` is one launch with the GPU to itself.
+        out.update({"achieved": achq, "peak": peak_h, "frac": achq / peak_h, "frac_bounds": out["headline"]["frac_bounds"],
+                    "peak_source": "timed region: ms_per_step %.4f ms x %.0f MHz sampled while the same loop ran" % (ms_per_step, mhz_h)})
+    elif alone:
+        out.update({k: alone[k] for k in ("achieved", "peak", "frac", "frac_bounds", "peak_source")})
     return out
 
 
@@ -671,7 +679,7 @@ def main():
                        "alpha_mean": alpha_mean, "finite": finite},
             "roofline": dict(valu_roofline(census, clocks, pmc, vi, k_solo, elapsed / args.steps * 1e3), **{
                 # neither "hbm" nor "mfma" binds this path (docstring): the top-level fields are the VALU-issue roof, the one closest to 1
-                "bound": "valu", "kernel": "clouds_kernel<3,1> (compact march), one launch with the GPU to itself; with two frames in flight the timed region runs the same body in its persistent form, clouds_kernel_persistent<3>",
+                "bound": "valu", "kernel": "the cloud march: clouds_kernel_persistent<3> over the timed region (two frames in flight; top level and `headline`), clouds_kernel<3,1> = the same body as a plain launch with the GPU to itself (`kernel_alone`)",
                 "unit": "SIMD issue cycles per launch",
                 "traffic": traffic,
                 "kernel_ms_solo": k_solo, "kernel_ms_in_flight": k_inflight, "kernel_launches_timed": k_launches, "frames_in_flight": fif,
@@ -693,9 +701,10 @@ def main():
                 "pmc": {"collected": "live in this run (tools/pmc_collect.py)" if pmc else None, "note": pmc_note, "source_hash": (pmc or {}).get("source_hash"),
                         "calibration": (pmc or {}).get("calibration"), "seconds": pmc_s if pmc else None},
                 "note": "achieved = EXECUTED wave64 VALU instructions by kind (basic-block counts of the census build x the static per-block histogram) x the issue cost "
-                        "of each kind measured on gfx950, per SIMD; peak = the cycles a SIMD had = the region's duration x the shader clock sampled during it.  frac is the "
-                        "additive pricing (a lower bound of the VALU's busy time); frac_bounds[1] applies the measured mixed-stream factor (a 16-instruction stream in the "
-                        "census's proportions costs 1.06-1.09 x the sum of its kinds).  headline = the same for `ms_per_step` (two frames in flight, persistent form).  "
+                        "of each kind measured on gfx950, per SIMD and per launch; peak = the cycles a SIMD had per launch = duration x the shader clock sampled during it.  "
+                        "Top level (= `headline`) is the TIMED REGION: per-frame time ms_per_step (launches overlap there: two frames in flight, persistent form); "
+                        "`kernel_alone` is one launch with the GPU to itself.  frac is the additive pricing (a lower bound of the VALU's busy time); frac_bounds[1] applies "
+                        "the measured mixed-stream factor (a 16-instruction stream in the census's proportions costs 1.06-1.09 x the sum of its kinds).  "
                         "valu_issue_class_counter_model is round 2's model (hardware class counters, 28 % unclassified) kept for comparison; l1_gather = TA_TA_BUSY / (256 CUs x "
                         "kernel cycles by SQ_BUSY_CYCLES/32), ~1.0 in every saturated pattern of tools/ubench/gather_rates.hip.  With two frames in flight the next "
                         "frame fills this launch's tail and the VALU fraction per frame time approaches 1"}),

@@ -52,8 +52,9 @@ def test_bench_line_contract_single_gpu():
     assert v["source"] == "census" and v["frame_identical_to_product"] is True and v["priced_by_measured_kind_fraction"] > 0.98
     for unit, ratio in v["census_over_hardware_counters"].items():
         assert ratio is None or abs(ratio - 1.0) < 0.03, (unit, ratio)
-    h = r["headline"]
+    h, ka = r["headline"], r["kernel_alone"]
     assert 0.3 < h["frac"] <= 1.0 and h["frac_bounds"][1] <= 1.0 and 1500 < h["sclk_mhz"] < 2600
+    assert r["frac"] == h["frac"] and 0.3 < ka["frac"] <= h["frac"] * 1.1 and ka["frac_bounds"][1] <= 1.0      # top level = the timed region; one launch alone has its tail exposed
     assert 0.5 * d["ms_per_step"] < h["ms_per_frame_while_sampling"] <= 1.05 * d["ms_per_step"]   # (6 timed steps pay the pipeline's fill and drain; the sampled loop runs >= 0.4 s)
     assert 0.2 < r["l1_gather"]["frac"] <= 1.0 and 0.0 < r["hbm"]["frac"] <= 1.0
     assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-9 and r["traffic"] > 1e8
