@@ -385,35 +385,29 @@ def main():
     G = max(1, args.groups)
     if world % G:
         raise SystemExit("bench.py: --groups must divide --gpus")
-    per = world // G
-    my_group, kidx = rank // per, rank % per
-    bands = tiling.bands_for_rank(H, kidx, per)
+    fg = tiling.FrameGroups(rank, world, G, dist)     # (creates the per-group communicators: a collective)
+    per = fg.per
+    bands = fg.bands(H)
     tiles_per_rank = ((W + 7) // 8) * bands[3]
     fif_default = 4 if (per > 1 and 3072 <= tiles_per_rank < 6144) else 2    # measured per frame, x2 / x4: 1/4 share 0.485 / 0.512, 1/8 share 0.316 / 0.283, 1/16 share 0.191 / 0.250
     fif = max(1, min(4, args.frames_in_flight if args.frames_in_flight is not None else fif_default))
     if os.environ.get("CSKY_BENCH_SYNC_GATHER") == "1":
         fif = 1                                      # debugging aid: gather-then-render, one frame at a time
     ctx.set_frames_in_flight(fif)
-    members = [sorted(set(([0] if G > 1 else []) + list(range(g * per, (g + 1) * per)))) for g in range(G)]
-    pgs = [None] * G                                 # None = the world communicator
-    if world > 1 and G > 1:
-        for g in range(G):                           # every rank creates every group, in the same order (a collective)
-            pgs[g] = dist.new_group(members[g])
     # rank 0 takes part in every frame's gather (G x fif in flight), the others in their group's frames only
     nbuf = fif * G if (rank == 0 and G > 1) else fif
     streams = [torch.cuda.Stream(device=dev) for _ in range(nbuf)]   # always real streams: handle 0 (torch's default stream) would select the
     stream = streams[0].cuda_stream                                  # library's own non-blocking stream, unordered against the gather
-    mb = tiling.max_bands(H, per)
+    mb = fg.max_bands(H)
     # N > 1: the gather of frame k (RCCL, its own stream, ordered behind the stream of frame k at the call) overlaps the march of
     # the following frames on the other streams; wait() orders frame k's stream behind its collective before that buffer set is reused.
     overlap = world > 1 and nbuf > 1
     local = [torch.zeros((mb * tiling.BAND_ROWS, W, 4), dtype=torch.int16, device=dev) for _ in range(nbuf)]
     local_b = [t.view(torch.uint8) for t in local]   # collectives move raw bytes (RCCL has no int16 type)
     gdev = "cpu" if debug_one_gpu else dev
-    n_max = max(len(m) for m in members)
-    gathered = [torch.empty((n_max,) + tuple(local[0].shape), dtype=torch.int16, device=gdev) for _ in range(nbuf)] if (world > 1 and rank == 0) else None
+    gathered = [torch.empty((fg.max_members,) + tuple(local[0].shape), dtype=torch.int16, device=gdev) for _ in range(nbuf)] if (world > 1 and rank == 0) else [None] * nbuf
     pending = [None] * nbuf
-    pend_group = [0] * nbuf
+    pend_frame = [0] * nbuf
     frame = [None]
     counter = [0]
     taken = [0]                                      # frames this rank took part in: its buffer-set rotation
@@ -424,24 +418,18 @@ def main():
             pending[o].wait()
             pending[o] = None
             if rank == 0:
-                m = members[pend_group[o]]
-                got = gathered[o][: len(m)]
-                if 0 not in range(pend_group[o] * per, (pend_group[o] + 1) * per):
-                    got = got[1:]                    # rank 0's dummy contribution to another group's gather
-                frame[0] = tiling.interleave(got.to(dev) if debug_one_gpu else got, H, per)
+                frame[0] = fg.assemble(pend_frame[o], gathered[o].to(dev) if debug_one_gpu else gathered[o], H)
 
     def step():
         k = counter[0]
         counter[0] += 1
-        grp = k % G
-        mine = grp == my_group
-        if not mine and rank != 0:
+        if not fg.takes_part(k):
             return
         bset = taken[0] % nbuf
         taken[0] += 1
         fp, fs = (params, sun_n) if sweep is None else sweep[k % len(sweep)]
         st_k = streams[bset].cuda_stream
-        if mine:
+        if fg.renders(k):
             ctx.render_sky_lut_device(fs, 200, 100, st_k)                                          # sky_lut.gd:122-148
             ctx.render_clouds_device(fp, W, bands, local[bset].data_ptr(), W * 8, st_k)           # cloud_sky.gd:234-248
         if world == 1:
@@ -449,9 +437,8 @@ def main():
             return
         with torch.cuda.stream(streams[bset]):       # the collective is ordered behind the CURRENT stream: make it this frame's
             src = local_b[bset].cpu() if debug_one_gpu else local_b[bset]
-            glist = [gathered[bset][i].view(torch.uint8) for i in range(len(members[grp]))] if rank == 0 else None
-            pending[bset] = dist.gather(src, gather_list=glist, dst=0, group=pgs[grp], async_op=True)
-            pend_group[bset] = grp
+            pending[bset] = fg.gather(k, src, gathered[bset], async_op=True)
+            pend_frame[bset] = k
         if overlap:
             o = (bset + 1) % nbuf          # the oldest frame in flight (its buffer set is the next one to be reused):
             if pending[o] is not None:     # its gather ran while the younger frames were marching

@@ -59,3 +59,60 @@ def render_sharded(render_bands, height, width, rank, world, dist=None, device=N
         return interleave(gathered, height, world, band_rows)
     dist.gather(lb, gather_list=None, dst=0)
     return None
+
+
+class FrameGroups:
+    """Frame groups for throughput workloads (BASELINE config 5's 64-frame sweep): the `world` ranks are split into `groups` groups of
+    world / groups; frame f belongs to group f % groups, whose ranks split ITS bands (world / groups)-way; every frame is gathered on rank 0.
+    Group g's collective runs on a communicator of {0} + its ranks: rank 0 takes part in every frame's gather and contributes an unused
+    dummy when it is not a member.  groups = 1 is the plain split (every rank works on every frame, the world communicator).
+    The same dealing as csky_multi_set_groups behind the C ABI."""
+
+    def __init__(self, rank, world, groups=1, dist=None):
+        if groups < 1 or world % groups:
+            raise ValueError("the group count %d must divide the world size %d" % (groups, world))
+        self.rank, self.world, self.groups, self.dist = int(rank), int(world), int(groups), dist
+        self.per = world // groups
+        self.my_group, self.index = rank // self.per, rank % self.per
+        self.members = [sorted(set(([0] if groups > 1 else []) + list(range(g * self.per, (g + 1) * self.per)))) for g in range(groups)]
+        self.pgs = [None] * groups                       # None = the world communicator
+        if dist is not None and world > 1 and groups > 1:
+            for g in range(groups):                      # every rank creates every group, in the same order (a collective)
+                self.pgs[g] = dist.new_group(self.members[g])
+
+    @property
+    def max_members(self):
+        return max(len(m) for m in self.members)
+
+    def bands(self, height, band_rows=BAND_ROWS):
+        return bands_for_rank(height, self.index, self.per, band_rows)
+
+    def max_bands(self, height, band_rows=BAND_ROWS):
+        return max_bands(height, self.per, band_rows)
+
+    def group_of(self, frame_no):
+        return frame_no % self.groups
+
+    def renders(self, frame_no):
+        return self.group_of(frame_no) == self.my_group
+
+    def takes_part(self, frame_no):
+        return self.renders(frame_no) or self.rank == 0
+
+    def gather(self, frame_no, src_bytes, gathered=None, async_op=False):
+        """src_bytes: this rank's compact bands as a uint8 view (any content when rank 0 is not a member); gathered (rank 0): a tensor of at
+        least len(members) band buffers.  Returns the collective's work handle (async_op) or None."""
+        g = self.group_of(frame_no)
+        glist = None
+        if self.rank == 0:
+            import torch
+            glist = [gathered[i].view(torch.uint8) for i in range(len(self.members[g]))]
+        return self.dist.gather(src_bytes, gather_list=glist, dst=0, group=self.pgs[g], async_op=async_op)
+
+    def assemble(self, frame_no, gathered, height, band_rows=BAND_ROWS):
+        """Rank 0, after the gather of frame_no completed: [height, W, C]."""
+        g = self.group_of(frame_no)
+        got = gathered[: len(self.members[g])]
+        if self.groups > 1 and g != 0:
+            got = got[1:]                                # rank 0's dummy contribution to another group's gather
+        return interleave(got, height, self.per, band_rows)

@@ -80,3 +80,90 @@ def test_band_partition_is_exact():
             assert sorted(seen) == list(range(H // 8))      # every band exactly once
     with pytest.raises(ValueError):
         T.bands_for_rank(30, 0, 2)
+
+
+def _group_worker(rank, world, groups, port, H, W, frames, q):
+    """tiling.FrameGroups (the dealing bench.py --groups uses): frame f goes to group f % groups, the group's ranks split its bands, rank 0
+    receives every frame over that group's communicator.  Synthetic bands (value = a function of frame and pixel row), two gathers in flight."""
+    sys.path.insert(0, ROOT)
+    import torch
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import gvcd_amd
+    T = gvcd_amd.tiling
+    fg = T.FrameGroups(rank, world, groups, dist)
+    br, first, stride, n = fg.bands(H)
+    mb = fg.max_bands(H)
+    nbuf = 2 * (groups if rank == 0 else 1)
+    local = [torch.zeros((mb * br, W, 4), dtype=torch.int16) for _ in range(nbuf)]
+    gathered = [torch.empty((fg.max_members,) + tuple(local[0].shape), dtype=torch.int16) for _ in range(nbuf)] if rank == 0 else [None] * nbuf
+    pending, ok, taken = [], True, 0
+
+    def check(f, b):
+        frame = fg.assemble(f, gathered[b], H)
+        rows = torch.arange(H, dtype=torch.int32).view(H, 1, 1)
+        want = ((f * 37 + rows * 3) % 30000).to(torch.int16).expand(H, W, 4)
+        return bool((frame == want).all()) and tuple(frame.shape) == (H, W, 4)
+
+    for f in range(frames):
+        if not fg.takes_part(f):
+            continue
+        b = taken % nbuf
+        taken += 1
+        if fg.renders(f):
+            for k in range(n):
+                y0 = (first + k * stride) * br
+                rows = torch.arange(y0, y0 + br, dtype=torch.int32).view(br, 1, 1)
+                local[b][k * br:(k + 1) * br] = ((f * 37 + rows * 3) % 30000).to(torch.int16).expand(br, W, 4)
+        else:
+            local[b].fill_(-1)                        # rank 0's dummy for another group's frame: must never show up
+        pending.append((fg.gather(f, local[b].view(torch.uint8), gathered[b], async_op=True), f, b))
+        if len(pending) == nbuf:                      # the oldest gather ran while the younger frames were produced
+            w, f0, b0 = pending.pop(0)
+            w.wait()
+            if rank == 0:
+                ok = ok and check(f0, b0)
+    for w, f0, b0 in pending:
+        w.wait()
+        if rank == 0:
+            ok = ok and check(f0, b0)
+    if rank == 0:
+        q.put(ok)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,groups,H", [(4, 2, 64), (3, 3, 40), (2, 1, 32), (4, 4, 16)])
+def test_frame_groups_deliver_every_frame_to_rank_0(world, groups, H):
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_group_worker, args=(r, world, groups, port, H, 24, 11, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(300)
+        assert p.exitcode == 0
+    assert q.get(timeout=10) is True
+
+
+def test_frame_groups_partition():
+    sys.path.insert(0, ROOT)
+    import gvcd_amd
+    T = gvcd_amd.tiling
+    for world, G in ((8, 1), (8, 2), (8, 4), (8, 8), (6, 3)):
+        seen = {}
+        for r in range(world):
+            fg = T.FrameGroups(r, world, G)
+            assert fg.per == world // G and fg.max_members == (fg.per + 1 if G > 1 else fg.per)
+            for f in range(2 * G):
+                if fg.renders(f):
+                    br, first, stride, n = fg.bands(64)
+                    seen.setdefault(f, []).extend(first + k * stride for k in range(n))
+                assert fg.takes_part(f) == (fg.renders(f) or r == 0)
+        assert all(sorted(v) == list(range(8)) for v in seen.values()) and len(seen) == 2 * G     # every band of every frame exactly once
+    with pytest.raises(ValueError):
+        T.FrameGroups(0, 8, 3)
