@@ -308,6 +308,7 @@ def main():
     ap.add_argument("--also-early-out", action="store_true", help="add a secondary measurement with the wave early-out (eps = 1e-3) to the JSON line")
     ap.add_argument("--kernel-iters", type=int, default=1, help="solo (one launch in flight) cloud-kernel launches timed after the timed region")
     ap.add_argument("--no-pmc", action="store_true", help="skip the live rocprofv3 counter passes (roofline fractions become null)")
+    ap.add_argument("--no-host-form", action="store_true", help="skip the value_host_form leg (frames delivered to pinned host memory): for profiling the timed region alone")
     ap.add_argument("--frames-in-flight", type=int, default=None,
                     help="consecutive frames rotate over this many streams per rank, 1..4 (default 2: the tail of frame k overlaps the head of "
                          "frame k+1 and, at N > 1, its gather; 4 for rank shares of 3072..6143 tiles; 1 = strictly one frame at a time)")
@@ -518,7 +519,7 @@ def main():
     # The host form (N = 1): frames delivered into PINNED HOST memory per second through csky_submit_clouds / csky_collect (what the GDExtension's
     # submit_clouds() / collect() wrap), with 1 and 2 frames in flight.  PCIe-inclusive: never the headline `value` (frames resident in HBM).
     host_form = None
-    if world == 1:
+    if world == 1 and not args.no_host_form:
         host_form = {}
         nh = max(10, min(args.steps, 100))
         for slots in (1, 2):

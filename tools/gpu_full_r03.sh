@@ -6,8 +6,8 @@ timeout -s KILL 200 python __graft_entry__.py smoke 2>&1 | tail -1 | tee $O/smok
 timeout -s KILL 400 python bench.py > $O/bench_C3_n1.json 2> $O/bench_C3_n1.err
 cp gpurun_out/bench_pmc_C3.json $O/clouds_C3_pmc_live_from_bench.json 2>/dev/null
 timeout -s KILL 300 python bench.py --frames-in-flight 1 --no-cpu-baseline --no-pmc > $O/bench_C3_n1_one_frame_at_a_time.json 2>/dev/null
-(cd /tmp && export TMPDIR=/tmp && timeout -s KILL 300 rocprofv3 --kernel-trace --stats -f csv -d $O/bench_trace -o b -- python $R/bench.py --no-cpu-baseline --no-pmc > $O/bench_trace.log 2>&1)
-(cd /tmp && export TMPDIR=/tmp && timeout -s KILL 300 rocprofv3 --kernel-trace --stats -f csv -d $O/bench_trace_fif1 -o b -- python $R/bench.py --no-cpu-baseline --no-pmc --frames-in-flight 1 > $O/bench_trace_fif1.log 2>&1)
+(cd /tmp && export TMPDIR=/tmp && timeout -s KILL 300 rocprofv3 --kernel-trace --stats -f csv -d $O/bench_trace -o b -- python $R/bench.py --no-cpu-baseline --no-pmc --no-host-form > $O/bench_trace.log 2>&1)
+(cd /tmp && export TMPDIR=/tmp && timeout -s KILL 300 rocprofv3 --kernel-trace --stats -f csv -d $O/bench_trace_fif1 -o b -- python $R/bench.py --no-cpu-baseline --no-pmc --no-host-form --frames-in-flight 1 > $O/bench_trace_fif1.log 2>&1)
 cp $O/bench_trace/b_kernel_stats.csv $O/bench_py_C3_n1_kernel_stats.csv 2>/dev/null
 cp $O/bench_trace_fif1/b_kernel_stats.csv $O/bench_py_C3_n1_one_frame_at_a_time_kernel_stats.csv 2>/dev/null
 {
