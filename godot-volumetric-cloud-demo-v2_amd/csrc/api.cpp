@@ -81,7 +81,6 @@ struct csky_ctx {
     long long order_key_ring[RING][4];     // csky_create fills them with -1
     // cost-feedback schedule (mode 7): per-workgroup costs of the last launch -> heaviest-first order of the next one
     uint32_t* d_wg_cost = nullptr; uint32_t* d_lpt_order = nullptr; uint32_t* d_lpt_hist = nullptr; size_t lpt_cap = 0;
-    long long ilp_max_waves = 0, ilp_min_waves = 0;     // launch-size range of the "compact-ilp" kernel under the automatic policy (0 = never)
     uint32_t* d_heads = nullptr; int persistent = 1; int resident_wgs = 0;   // persistent launches: 2 ring slots x (8 per-XCD pop counters + exit counter)
     bool lpt_valid[RING] = {}; long long lpt_key[RING][11];   // csky_create fills the keys with -1
     // optional per-launch timing of the cloud kernel (csky_set_kernel_timing): HIP event pairs recorded around the launch on ITS stream
@@ -229,17 +228,11 @@ int clouds_dev(csky_ctx* c, const csky_cloud_params* p, int tile_w, const csky_b
     // A lone wavefront is bound by its chain of dependent gathers, so small launches want more, shorter wavefronts; large
     // launches want the fewest instructions.  (The "queue" variant keeps its own, earlier crossovers: 6144 / 1536 wavefronts.)
     const long long waves = ((long long)(tile_w + 7) / 8) * (((long long)b->n_bands * b->band_rows + 7) / 8);
-    // Launches of at most ilp_max_waves whole-ray wavefronts (one GPU's share of a split frame: <= ~4 wavefronts per SIMD) run the "compact-ilp"
-    // variant: two primary steps / two light samples in flight per wavefront, 128 VGPRs (kernels.hip::march_compact_ilp).  Only when the segment
-    // count is automatic: an explicit csky_set_segments keeps the plain compact kernel.
-    int variant = c->variant;
-    if (variant == 3 && c->segments == 0 && c->ilp_max_waves > 0 && waves <= c->ilp_max_waves && waves >= c->ilp_min_waves) variant = 4;
+    const int variant = c->variant;
     const bool queued = variant == 1 || variant == 3;
     int seg = queued ? c->segments : 1;
     int auto_mode;
-    if (variant == 4) {
-        auto_mode = waves >= 12288 ? 5 : (waves >= 768 ? 7 : 2);
-    } else if (c->variant == 3 && c->frames_in_flight >= 2) {
+    if (c->variant == 3 && c->frames_in_flight >= 2) {
         // the caller keeps two frames in flight on two streams (csky_set_frames_in_flight): the next frame's workgroups fill this
         // launch's tail, so fewer, longer wavefronts win (tools/share_matrix.py, ms per frame at 1/2, 1/4, 1/8, 1/16 of the frame):
         //   seg 1: 0.96 (s5) 0.52 (s7) 0.42 0.35    seg 2: 1.18 0.61 0.34 (s7) 0.29    seg 4: 1.27 0.75 0.39 0.22 (s7)
@@ -259,7 +252,7 @@ int clouds_dev(csky_ctx* c, const csky_cloud_params* p, int tile_w, const csky_b
     int mode = c->sched_mode >= 0 ? c->sched_mode : auto_mode;
     const int bw = seg == 5 ? 8 : (seg == 16 ? 128 : 32 / seg);   // workgroup footprint = bw x 8 pixels (seg 5: one tile; seg 16: the 16-wavefront "lds" strip)
     const int tiles_x = (g.tile_w + bw - 1) / bw, slabs = (g.n_bands * g.band_rows + 7) >> 3, nblocks = tiles_x * slabs;
-    bool feedback = mode == 7 && (queued || variant == 4) && seg != 5;   // kernels that record per-workgroup costs
+    bool feedback = mode == 7 && queued && seg != 5;             // kernels that record per-workgroup costs
     if (mode == 7 && !feedback) mode = waves >= 12288 ? 5 : 2;
     const int static_mode = mode == 7 ? (waves >= 12288 ? 5 : 2) : mode;   // order of the first launch of a geometry under feedback
     const int slot = c->fc_cur;
@@ -384,8 +377,6 @@ int csky_create(csky_ctx** out, int device_id) {
     { int cus = 0; (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device_id); c->resident_wgs = (cus > 0 ? cus : 256) * cloud_resident_workgroups_per_cu(); }
     // A/B switch of tools/persistent_ab.sh: 0 = never, 1 = the policy of clouds_dev (default), 2 = every whole-ray launch
     if (const char* pe = getenv("CSKY_PERSISTENT")) c->persistent = atoi(pe);
-    if (const char* pe = getenv("CSKY_ILP_MAX_WAVES")) c->ilp_max_waves = atoll(pe);   // A/B switch of tools/share_matrix.py
-    if (const char* pe = getenv("CSKY_ILP_MIN_WAVES")) c->ilp_min_waves = atoll(pe);
     if (const char* pe = getenv("CSKY_PERSISTENT_WGS")) { const int n = atoi(pe); if (n > 0) c->resident_wgs = n; }
     *out = c;
     return CSKY_OK;

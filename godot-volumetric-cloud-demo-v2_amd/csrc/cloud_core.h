@@ -343,28 +343,6 @@ CSKY_HD float smoothstep_fast(float e0, float e1, float x) {
 // clouds.glsl:82-95.  mixGradients() is piecewise linear in the cloud type ct: below 0.5 only stratus (1-2ct) and
 // stratocumulus (2ct) are non-zero, above 0.5 only stratocumulus (2-2ct) and cumulus (2ct-1), so each of the four
 // gradient corners is A + ct*B with (A,B) picked by the branch (8 selects + 4 FMA instead of 3 weights x 4 x 2 FMA).
-template <int CT_MODE>
-CSKY_HD float density_height_gradient_t(float hf, float ct) {
-    const float c = ct;                                       // ct is a filtered UNORM8 texel ON THE TEXEL SCALE 0..255 (weather_filter): slopes carry the 1/255
-    constexpr float K = 1.0f / 255.0f;
-    // ct < 0.5 : STRATUS + ct*2*(STRATOCUMULUS - STRATUS)   ; ct >= 0.5 : (2*STRATOCUMULUS - CUMULUS) + ct*2*(CUMULUS - STRATOCUMULUS)
-    float gx, gy, gz, gw;
-    if (CT_MODE == 1) {
-        // every texel of the bound weather map is >= 128/255, and bilinear filtering stays inside the texel range: the branch of
-        // the piecewise form is known for the whole frame (a scalar test) and its 8 selects + compare disappear.  Same arithmetic.
-        gx = 0.03f + c * (-0.02f * K); gy = 0.3375f + c * (-0.275f * K); gz = 0.18f + c * (0.6f * K); gw = 0.25f + c * (0.75f * K);
-    } else if (CT_MODE == 2) {
-        gx = 0.02f + c * 0.0f; gy = 0.05f + c * (0.3f * K); gz = 0.09f + c * (0.78f * K); gw = 0.11f + c * (1.03f * K);
-    } else {
-        const bool hi = ct >= 127.5f;
-        gx = (hi ? 0.03f : 0.02f) + c * (hi ? -0.02f * K : 0.0f);
-        gy = (hi ? 0.3375f : 0.05f) + c * (hi ? -0.275f * K : 0.3f * K);
-        gz = (hi ? 0.18f : 0.09f) + c * (hi ? 0.6f * K : 0.78f * K);
-        gw = (hi ? 0.25f : 0.11f) + c * (hi ? 0.75f * K : 1.03f * K);
-    }
-    return smoothstep_fast(gx, gy, hf) - smoothstep_fast(gz, gw, hf);
-}
-// (the original run-time form: kept textually separate so that the kernels built on it compile exactly as before)
 CSKY_HD float density_height_gradient(const FrameConsts& fc, float hf, float ct) {
     const float c = ct;
     constexpr float K = 1.0f / 255.0f;
@@ -522,71 +500,6 @@ CSKY_HD float sample_density_eager(const TexSet& T, const FrameConsts& fc, float
     return sample_density(T, fc, px, py, pz, hf, wx, wy, lod_shape, lod_detail);
 }
 #endif
-
-// ---- staged form of one density sample ("ilp" variant, round 3) -----------------------------------------------------------------
-// The same arithmetic as sample_density_eager, cut at the points where a texture fetch is consumed, so that a caller can keep the fetches of
-// SEVERAL samples in flight and evaluate them afterwards (kernels.hip::march_compact_ilp: two primary steps / two light samples at a time).
-// A lone wavefront is bound by its chain of dependent gathers and dependent VALU results (5.1 cycles between its own instructions, 2.2 when
-// four or more wavefronts share the SIMD); one GPU's 1/8 share of a frame is 4 wavefronts per SIMD, so independent work inside the wavefront
-// is what shortens it.  Costs registers (24 per sample in flight), not instructions.
-struct SampleWS { uint4 wq, tr, tf; float wax, way, sax, say, saz; };    // weather cell + the two shape cells of one sample, with its fractions
-struct SampleDC { uint4 dq; float dax, day, daz; };                      // detail cell
-#if CSKY_SHAPE_POLY == 3
-CSKY_HD void fetch_ws(const TexSet& T, const FrameConsts& fc, float px, float py, float pz, float wx, float wy, int lod_shape, SampleWS& F) {
-    float wsx, wsy;
-    weather_coord(px, pz, wx, wy, wsx, wsy);
-    int wix, wiy;
-    split_coord(wsx * 512.0f - 0.5f, wix, F.wax); split_coord(wsy * 512.0f - 0.5f, wiy, F.way);
-    F.wq = *reinterpret_cast<const uint4*>(reinterpret_cast<const char*>(T.weather) + (((((uint32_t)(wiy & 511)) << 9) | (uint32_t)(wix & 511)) << 4));
-    float qx, qy, qz, sx, sy, sz;
-    shape_coord(fc, px, py, pz, qx, qy, qz, sx, sy, sz);
-    const int sm = (SHAPE_N >> lod_shape) - 1;
-    const float sfn = pow2f(7 - lod_shape);
-    int six, siy, siz;
-    split_coord(sx * sfn - 0.5f, six, F.sax); split_coord(sy * sfn - 0.5f, siy, F.say); split_coord(sz * sfn - 0.5f, siz, F.saz);
-    const uint32_t sidx = shape_level_offset(lod_shape) + shape_cell_offset((uint32_t)(six & sm), (uint32_t)(siy & sm), (uint32_t)(siz & sm), (uint32_t)(7 - lod_shape));
-    const uint4* __restrict__ sp = reinterpret_cast<const uint4*>(reinterpret_cast<const char*>(T.shape) + (sidx << 5));
-    F.tr = sp[0]; F.tf = sp[1];
-}
-CSKY_HD void fetch_dc(const TexSet& T, const FrameConsts& fc, float px, float py, float pz, int lod_detail, SampleDC& D) {
-    if (lod_detail == 5) return;                               // wave-uniform; LOD 5 is one texel (detail_tap)
-    float qx, qy, qz, sx, sy, sz, dsx, dsy, dsz;
-    shape_coord(fc, px, py, pz, qx, qy, qz, sx, sy, sz);
-    detail_coord(fc, qx, qy, qz, dsx, dsy, dsz);
-    const int dm = (DETAIL_N >> lod_detail) - 1;
-    const float dfn = pow2f(5 - lod_detail);
-    int dix, diy, diz;
-    split_coord(dsx * dfn - 0.5f, dix, D.dax); split_coord(dsy * dfn - 0.5f, diy, D.day); split_coord(dsz * dfn - 0.5f, diz, D.daz);
-    const uint32_t dsh = (uint32_t)(5 - lod_detail);
-    const uint32_t didx = detail_level_offset(lod_detail) + ((((((uint32_t)(diz & dm)) << dsh) | (uint32_t)(diy & dm)) << dsh) | (uint32_t)(dix & dm));
-    D.dq = *reinterpret_cast<const uint4*>(reinterpret_cast<const char*>(T.detail) + (didx << 4));
-}
-#endif
-// clouds.glsl:117-125 on fetched cells: the value of base_cloud after :125, or 0 when exact reject (1) fires (<= 0 means density() == 0)
-template <int CT_MODE>
-CSKY_HD float eval_base(const FrameConsts& fc, const SampleWS& F, float hf) {
-    const float wr = fmaf(F.way, lerp_h(F.wq.y, F.wax), lerp_h(F.wq.x, F.wax));
-    const float wb = fmaf(F.way, lerp_h(F.wq.w, F.wax), lerp_h(F.wq.z, F.wax));
-    const float wc = fc.cov255 * wb;                                         // :123
-    const float g = density_height_gradient_t<CT_MODE>(hf, wr);             // :121 (the caller branches on fc.ct_mode ONCE for a group of samples)
-    const float omw = 1.0f - wc;
-    const float nr = fmaf(F.saz, fmaf(F.say, lerp_h(F.tr.w, F.sax), lerp_h(F.tr.z, F.sax)), fmaf(F.say, lerp_h(F.tr.y, F.sax), lerp_h(F.tr.x, F.sax))) * (1.0f / 255.0f);
-    const float fbm = fmaf(F.saz, fmaf(F.say, lerp_h(F.tf.w, F.sax), lerp_h(F.tf.z, F.sax)), fmaf(F.say, lerp_h(F.tf.y, F.sax), lerp_h(F.tf.x, F.sax))) * (1.0f / (8.0f * 255.0f));
-    const float omf = 1.0f - fbm;
-    float base = (nr + omf) * fast_rcp(1.0f + omf);                         // :122
-    base = base * g - omw;                                                   // :124-125 (see density())
-    return (g > omw) ? base : 0.0f;                                          // exact reject (1) as a select: no branch between two samples' arithmetic
-}
-// clouds.glsl:132-136 on a fetched detail cell; base > 0 (exact reject (2) is the caller's select)
-CSKY_HD float eval_finish(const TexSet& T, const SampleDC& D, float base, float hf, int lod_detail) {
-    float hfbm = lod_detail == 5 ? T.detail_lod5
-                                 : fmaf(D.daz, fmaf(D.day, lerp_h(D.dq.w, D.dax), lerp_h(D.dq.z, D.dax)), fmaf(D.day, lerp_h(D.dq.y, D.dax), lerp_h(D.dq.x, D.dax))) * (1.0f / (8.0f * 255.0f));
-    const float k = sat(hf * 4.0f);
-    hfbm = hfbm + k * (1.0f - 2.0f * hfbm);                                 // :134
-    const float hm = hfbm * 0.4f * hf;
-    base = (base - hm) * fast_rcp(1.0f - hm);                               // :135
-    return fast_pow(sat(base), (1.0f - hf) * 0.8f + 0.5f);                  // :136
-}
 
 CSKY_HD float henyey_greenstein(float c, float g) {                         // clouds.glsl:72-75, once per ray
     const float x = 1.0f + g * g - 2.0f * g * c;                            // >= (1 - |g|)^2 >= 0

@@ -509,203 +509,13 @@ __device__ __forceinline__ MarchOut march_compact(const TexSet& T, const FrameCo
     return o;
 }
 
-// ---- compacted march with instruction-level parallelism (variant "compact-ilp", round 3) ------------------------------------------
-// Same queue, same flush, same compositing order as march_compact; what changes is how much INDEPENDENT work a wavefront has in flight:
-//   * the primary march takes TWO steps per round: both positions are known up front (p + s, p + s + s: the same fp32 additions), so the
-//     weather + shape gathers of both samples are issued together, then both base-cloud values are evaluated, then both detail gathers, then
-//     both densities (cloud_core.h: fetch_ws / eval_base / fetch_dc / eval_finish);
-//   * the light march of a queued sample evaluates its cone samples in PAIRS (j, j+1): the position of j+1 is one addition away from j's, all
-//     six gathers of the pair are in flight together and the two evaluations are branch-free (exact rejects as selects), so the scheduler
-//     interleaves their dependent chains.
-// Why: a wavefront on an otherwise idle SIMD issues one of its own VALU instructions every ~5 cycles and waits a full L2 round trip per
-// dependent gather; one GPU's 1/8 share of a C3 frame is 4 096 wavefronts = 4 per SIMD, and its march time is set by that chain
-// (duration ~ 0.16 ms + 6 us per flush, profiles/r02/share_matrix.txt), not by throughput.  The price is registers (128 VGPRs -> 4 waves
-// per SIMD, which is all such a launch has anyway), not instructions; large launches keep march_compact (72 VGPRs, 7 waves per SIMD).
-// Per-ray arithmetic and its order are those of march_compact (same helper expressions; the exact rejects become selects).
-#ifndef CSKY_ILP_WAVES
-#define CSKY_ILP_WAVES 4
-#endif
-// base-cloud values of two fetched samples with ONE wave-uniform branch on the frame's cloud-type mode around both (a branch inside each
-// evaluation would end the basic block between them and keep the scheduler from interleaving the two dependent chains)
-__device__ __forceinline__ void eval_base_pair(const FrameConsts& fc, const SampleWS& FA, float hfa, const SampleWS& FB, float hfb, float& ea, float& eb) {
-    if (fc.ct_mode == 1) { ea = eval_base<1>(fc, FA, hfa); eb = eval_base<1>(fc, FB, hfb); }
-    else if (fc.ct_mode == 2) { ea = eval_base<2>(fc, FA, hfa); eb = eval_base<2>(fc, FB, hfb); }
-    else { ea = eval_base<0>(fc, FA, hfa); eb = eval_base<0>(fc, FB, hfb); }
-}
-__device__ __forceinline__ MarchOut march_compact_ilp(const TexSet& T, const FrameConsts& fc, Ray ray, float* __restrict__ q) {
-    float* __restrict__ ev_px = q;
-    float* __restrict__ ev_py = q + CQ_CAP;
-    float* __restrict__ ev_pz = q + 2 * CQ_CAP;
-    float* __restrict__ ev_t = q + 3 * CQ_CAP;
-    float* __restrict__ ev_hf = q + 4 * CQ_CAP;
-    float* __restrict__ ev_cd = q + 5 * CQ_CAP;                                  // [64]
-    unsigned* __restrict__ st_lo = reinterpret_cast<unsigned*>(q + 5 * CQ_CAP + 64);   // [CQ_STEPS]
-    unsigned* __restrict__ st_hi = st_lo + CQ_STEPS;
-    unsigned* __restrict__ st_base = st_hi + CQ_STEPS;
-
-    MarchOut o; o.r = o.g = o.b = o.a = 0.0f; o.t = 1.0f; o.incloud = 0;
-    const int lane = threadIdx.x & 63;
-    const int ls = fc.light_steps;
-    float phase = 0.0f;
-    if (ray.above) {
-        const float ct = fc.ldir[0] * ray.dx + fc.ldir[1] * ray.dy + fc.ldir[2] * ray.dz;                       // clouds.glsl:158
-        phase = fmaxf(fmaxf(henyey_greenstein(ct, 0.6f), henyey_greenstein(ct, fc.hg_g2)), henyey_greenstein(ct, -0.2f));  // :160
-    }
-    float Tr = 1.0f, alpha = 0.0f, Lr = 0.0f, Lg = 0.0f, Lb = 0.0f;
-    float px = ray.px, py = ray.py, pz = ray.pz;
-    const float nd = -fc.density;
-    bool live = ray.above;
-    int count = 0, cs = 0;                                    // queued samples / steps owning them (uniform)
-    if (!__any(live)) return o;
-    int end = fc.primary_steps;                               // shrinks when the whole wavefront has left the height window (march_compact)
-    bool done = false;
-    for (int i = 0; !done;) {
-        // ---- A: two primary samples per lane, their fetches in flight together
-        float tA = 0.0f, hfA = 0.0f, tB = 0.0f, hfB = 0.0f, ax = 0.0f, ay = 0.0f, az = 0.0f, bx = 0.0f, by = 0.0f, bz = 0.0f;
-        const int nst = i < end ? (i + 1 < end ? 2 : 1) : 0;  // uniform
-        if (nst) {
-            if (live) {
-                advance(px, py, pz, ray.sx, ray.sy, ray.sz);                                                   // :173
-                ax = px; ay = py; az = pz;
-                hfA = height_fraction(length3_shell(ax, ay, az));                                              // :175
-                bool inB = false;
-                if (nst == 2) {
-                    advance(px, py, pz, ray.sx, ray.sy, ray.sz);
-                    bx = px; by = py; bz = pz;
-                    hfB = height_fraction(length3_shell(bx, by, bz));
-                    inB = hfB > fc.hf_lo && hfB < fc.hf_hi;
-                }
-                const bool inA = hfA > fc.hf_lo && hfA < fc.hf_hi;                                             // exact height-window reject (sample_density)
-                if (inA || inB) {
-                    SampleWS FA = {}, FB = {};
-                    if (inA) fetch_ws(T, fc, ax, ay, az, fc.wpos_x, fc.wpos_y, 0, FA);                         // :174, :117
-                    if (inB) fetch_ws(T, fc, bx, by, bz, fc.wpos_x, fc.wpos_y, 0, FB);
-                    float ea, eb;
-                    eval_base_pair(fc, FA, hfA, FB, hfB, ea, eb);
-                    const float baseA = inA ? ea : 0.0f, baseB = inB ? eb : 0.0f;
-                    const bool dA = baseA > 0.0f, dB = baseB > 0.0f;                                           // exact reject (2)
-                    if (dA || dB) {
-                        SampleDC DA = {}, DB = {};
-                        if (dA) fetch_dc(T, fc, ax, ay, az, 0, DA);                                            // :132
-                        if (dB) fetch_dc(T, fc, bx, by, bz, 0, DB);
-                        const float fa = eval_finish(T, DA, baseA, hfA, 0), fb = eval_finish(T, DB, baseB, hfB, 0);
-                        tA = dA ? fa : 0.0f; tB = dB ? fb : 0.0f;
-                    }
-                }
-            }
-            const float hfl = nst == 2 ? hfB : hfA;
-            i += nst;
-            if (!__any(live && !(hfl >= fc.hf_hi))) end = i;   // exact early end of the march (march_compact): checked once per round
-        }
-        // ---- append the round's samples step by step (the queue's invariants are those of march_compact: one step at a time), flushing in between
-#pragma unroll 1
-        for (int h = 0; h < (nst ? nst : 1); h++) {
-            if (nst) {
-                const float t = h ? tB : tA, hf = h ? hfB : hfA, sx = h ? bx : ax, sy = h ? by : ay, sz = h ? bz : az;
-                const bool have = t > 0.0f;                                                                    // :184
-                const unsigned long long m = __ballot(have);
-                if (m != 0ull) {
-                    const int slot = count + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));
-                    if (have) { ev_px[slot] = sx; ev_py[slot] = sy; ev_pz[slot] = sz; ev_t[slot] = t; ev_hf[slot] = hf; }
-                    if (lane == 0) { st_lo[cs] = (unsigned)m; st_hi[cs] = (unsigned)(m >> 32); st_base[cs] = (unsigned)count; }
-                    count += __popcll(m);
-                    cs++;
-                }
-            }
-            const bool last = i >= end && h + 1 >= nst;
-            while (count >= 64 || (last && count > 0)) {
-                // ---- B: the light march of the first n = min(count, 64) queued samples, one per lane, cone samples in pairs
-                wave_lds_fence();
-                const int n = count < 64 ? count : 64;
-                if (lane < n) {
-                    const float ex = ev_px[lane], ey = ev_py[lane], ez = ev_pz[lane];
-                    float lx = ex, ly = ey, lz = ez, cd = 0.0f;
-                    int j = 0;
-#pragma unroll 1
-                    for (; j + 1 < ls; j += 2) {                                                               // :186, samples j and j + 1
-                        advance(lx, ly, lz, fc.linc[j][0], fc.linc[j][1], fc.linc[j][2]);                      // :187
-                        const float cx = lx, cy = ly, cz = lz;
-                        advance(lx, ly, lz, fc.linc[j + 1][0], fc.linc[j + 1][1], fc.linc[j + 1][2]);
-                        const float hfa = height_fraction(length3_shell(cx, cy, cz)), hfb = height_fraction(length3_shell(lx, ly, lz));   // :188
-                        const bool inA = hfa > fc.hf_lo && hfa < fc.hf_hi, inB = hfb > fc.hf_lo && hfb < fc.hf_hi;
-                        SampleWS FA = {}, FB = {}; SampleDC DA = {}, DB = {};
-                        if (inA) { fetch_ws(T, fc, cx, cy, cz, fc.wpos_x, fc.wpos_y, j > 2 ? j - 2 : 0, FA); fetch_dc(T, fc, cx, cy, cz, j, DA); }           // :189-190
-                        if (inB) { fetch_ws(T, fc, lx, ly, lz, fc.wpos_x, fc.wpos_y, j > 1 ? j - 1 : 0, FB); fetch_dc(T, fc, lx, ly, lz, j + 1, DB); }
-                        float ba, bb;
-                        eval_base_pair(fc, FA, hfa, FB, hfb, ba, bb);
-                        const float fa = eval_finish(T, DA, ba, hfa, j), fb = eval_finish(T, DB, bb, hfb, j + 1);
-                        cd += (inA && ba > 0.0f) ? fa : 0.0f;                                                  // :191, in the reference's order
-                        cd += (inB && bb > 0.0f) ? fb : 0.0f;
-                    }
-                    {   // the odd cone sample (if any) together with the distant sample, :195-199
-                        float cx = lx, cy = ly, cz = lz, hfa = 0.0f;
-                        const bool odd = j < ls;                                                               // uniform
-                        bool inA = false;
-                        if (odd) {
-                            advance(cx, cy, cz, fc.linc[j][0], fc.linc[j][1], fc.linc[j][2]);
-                            hfa = height_fraction(length3_shell(cx, cy, cz));
-                            inA = hfa > fc.hf_lo && hfa < fc.hf_hi;
-                        }
-                        float dx = ex, dy = ey, dz = ez;
-                        advance(dx, dy, dz, fc.ldist[0], fc.ldist[1], fc.ldist[2]);
-                        const float hfb = height_fraction(length3_shell(dx, dy, dz));
-                        const bool inB = hfb > fc.hf_lo && hfb < fc.hf_hi;
-                        SampleWS FA = {}, FB = {}; SampleDC DA = {}, DB = {};
-                        if (inA) { fetch_ws(T, fc, cx, cy, cz, fc.wpos_x, fc.wpos_y, j > 2 ? j - 2 : 0, FA); fetch_dc(T, fc, cx, cy, cz, j, DA); }
-                        if (inB) { fetch_ws(T, fc, dx, dy, dz, 0.0f, 0.0f, 3, FB); fetch_dc(T, fc, dx, dy, dz, 5, DB); }               // :197 has no weather_pos
-                        float ba, bb;
-                        eval_base_pair(fc, FA, hfa, FB, hfb, ba, bb);            // (FA is all zeros when there is no odd sample: its value is not used)
-                        if (odd) {
-                            const float fa = eval_finish(T, DA, ba, hfa, j);
-                            cd += (inA && ba > 0.0f) ? fa : 0.0f;
-                        }
-                        const float fb = eval_finish(T, DB, bb, hfb, 5);
-                        const float ld = (inB && bb > 0.0f) ? fb : 0.0f;
-                        cd += fast_pow(ld, (1.0f - hfb) * 0.8f + 0.5f);                                        // :198 (second pow)
-                    }
-                    ev_cd[lane] = cd;
-                }
-                wave_lds_fence();
-                // ---- C: replay the steps in order; owners of evaluated samples (slot < n) composite (:202-210)
-                unsigned long long carry = 0ull;                 // lanes of the last step whose sample is still queued
-                for (int s = 0; s < cs; s++) {
-                    const unsigned lo = st_lo[s], hi = st_hi[s];
-                    const bool mine = lane < 32 ? ((lo >> lane) & 1u) : ((hi >> (lane - 32)) & 1u);
-                    const int slot = (int)st_base[s] + (int)__builtin_amdgcn_mbcnt_hi(hi, __builtin_amdgcn_mbcnt_lo(lo, 0u));
-                    if (mine && slot < n) {
-                        const float cd = ev_cd[slot];
-                        const float et = ev_t[slot], ehf = ev_hf[slot];
-                        const float dt = fast_exp(nd * et * ray.ss);                                           // :178
-                        shade_sample(fc, phase, et, ehf, dt, cd, Tr, alpha, Lr, Lg, Lb);
-                        o.incloud++;
-                    }
-                    if (s == cs - 1) carry = __ballot(mine && slot >= n);
-                }
-                wave_lds_fence();
-                const int rem = count - n;
-                if (rem > 0) {
-                    float a0 = 0.0f, a1 = 0.0f, a2 = 0.0f, a3 = 0.0f, a4 = 0.0f;
-                    if (lane < rem) { a0 = ev_px[n + lane]; a1 = ev_py[n + lane]; a2 = ev_pz[n + lane]; a3 = ev_t[n + lane]; a4 = ev_hf[n + lane]; }
-                    wave_lds_fence();
-                    if (lane < rem) { ev_px[lane] = a0; ev_py[lane] = a1; ev_pz[lane] = a2; ev_t[lane] = a3; ev_hf[lane] = a4; }
-                    if (lane == 0) { st_lo[0] = (unsigned)carry; st_hi[0] = (unsigned)(carry >> 32); st_base[0] = 0u; }
-                    wave_lds_fence();
-                    count = rem; cs = 1;
-                } else {
-                    count = 0; cs = 0;
-                }
-                if (fc.early_eps > 0.0f) {                                 // build-side early-out (off by default, bounded error)
-                    if (Tr < fc.early_eps) live = false;
-                    if (!__any(live)) { done = true; count = 0; }
-                }
-            }
-            if (done) break;
-            if (last) done = true;
-        }
-    }
-    o.r = Lr; o.g = Lg; o.b = Lb; o.a = sat(alpha); o.t = Tr;                                                  // :213-214
-    return o;
-}
+// ---- instruction-level parallelism for small launches (round 3: built as kernel variant "compact-ilp", measured, removed) ------------
+// Two primary steps and two light samples in flight per wavefront (their gathers issued together, the exact rejects as selects so that the
+// scheduler interleaves the two dependent chains), 116 VGPRs -> 4 waves per SIMD, which is all one GPU's 1/8 share of a frame has anyway.
+// Parity green (tight gate, sample counts equal to march_compact for seven march shapes), but ms per frame at 1/8 share x1 / x2 / x4 frames in
+// flight: 0.508 / 0.300 / 0.332 against 0.436 / 0.327 / 0.281 for the policy below, whole frame 2.42 vs 2.08: a lone wavefront issues ONE of
+// its own VALU instructions per ~5 cycles whether or not they depend on each other, so independent work inside a wavefront buys only the
+// overlapped gathers.  profiles/r03/share_matrix_compact_ilp_ab.txt; the code is in the history (commit "compact-ilp kernel variant").
 
 // ---- interleaved ray segments (small launches) ------------------------------------------------------------------
 // One workgroup = ONE 8x8 tile; wavefront w marches the primary samples i = 4m + w of every ray of the tile.  In-cloud
@@ -966,10 +776,9 @@ __device__ __forceinline__ void render_block(TexSet T, const FrameConsts* __rest
         static_assert(SEG == 1, "the lock-step reference variant marches whole rays");
         o = march(T, fc, ray);
     } else {
-        __shared__ float lds[4][VARIANT >= 3 ? CQ_FLOATS : Q_FLOATS];
+        __shared__ float lds[4][VARIANT == 3 ? CQ_FLOATS : Q_FLOATS];
         const int s0 = (fc.primary_steps * seg) / SEG, s1 = (fc.primary_steps * (seg + 1)) / SEG;
-        if constexpr (VARIANT == 4) { static_assert(SEG == 1, "the ilp variant marches whole rays"); o = march_compact_ilp(T, fc, ray, &lds[wave][0]); }
-        else if constexpr (VARIANT == 3) o = march_compact(T, fc, ray, &lds[wave][0], s0, s1);
+        if constexpr (VARIANT == 3) o = march_compact(T, fc, ray, &lds[wave][0], s0, s1);
         else o = march_queue(T, fc, ray, &lds[wave][0], s0, s1);
         if constexpr (SEG > 1) {
             __shared__ float comb[4][5][64];
@@ -1011,7 +820,7 @@ __device__ __forceinline__ void render_block(TexSet T, const FrameConsts* __rest
 }
 
 template <int VARIANT, int SEG>
-__global__ __launch_bounds__(256, VARIANT == 3 ? CSKY_COMPACT_WAVES : (VARIANT == 4 ? CSKY_ILP_WAVES : 7)) void clouds_kernel(TexSet T, const FrameConsts* __restrict__ fcp, RenderGeom G, const uint32_t* __restrict__ order,
+__global__ __launch_bounds__(256, VARIANT == 3 ? CSKY_COMPACT_WAVES : 7) void clouds_kernel(TexSet T, const FrameConsts* __restrict__ fcp, RenderGeom G, const uint32_t* __restrict__ order,
                                                      uint2* __restrict__ out, unsigned long long* __restrict__ stats, uint32_t* __restrict__ wg_cost) {
     const uint32_t logical = order[blockIdx.x];
     if (logical == 0xffffffffu) return;                        // workgroup-uniform
@@ -1175,7 +984,7 @@ hipError_t launch_static_order(int mode, int tiles_x, int slabs, int grid, uint3
     return hipGetLastError();
 }
 
-static const char* const kVariantNames[] = {"lockstep", "queue", "queue-lds", "compact", "compact-ilp"};
+static const char* const kVariantNames[] = {"lockstep", "queue", "queue-lds", "compact"};
 int cloud_resident_workgroups_per_cu() { return CSKY_COMPACT_WAVES; }
 int cloud_variant_count() { return (int)(sizeof(kVariantNames) / sizeof(kVariantNames[0])); }
 const char* cloud_variant_name(int v) { return (v >= 0 && v < cloud_variant_count()) ? kVariantNames[v] : nullptr; }
@@ -1194,7 +1003,6 @@ hipError_t launch_clouds(int variant, int seg, const TexSet& t, const FrameConst
     else if (variant == 3 && seg == 1) clouds_kernel<3, 1><<<grid, 256, 0, s>>>(t, d_fc, g, d_order, d_out, d_stats, d_wg_cost);
     else if (variant == 3 && seg == 2) clouds_kernel<3, 2><<<grid, 256, 0, s>>>(t, d_fc, g, d_order, d_out, d_stats, d_wg_cost);
     else if (variant == 3 && seg == 4) clouds_kernel<3, 4><<<grid, 256, 0, s>>>(t, d_fc, g, d_order, d_out, d_stats, d_wg_cost);
-    else if (variant == 4 && seg == 1) clouds_kernel<4, 1><<<grid, 256, 0, s>>>(t, d_fc, g, d_order, d_out, d_stats, d_wg_cost);
     else if ((variant == 1 || variant == 3) && seg == 5) {                      // 5 = 4 interleaved segments, one tile per workgroup, 76 KB of LDS
         // > 64 KB of dynamic LDS needs the opt-in attribute; it is per device, so set it on every launch (cheap, idempotent)
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&clouds_kernel_interleaved<0>), hipFuncAttributeMaxDynamicSharedMemorySize,

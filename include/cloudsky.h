@@ -35,7 +35,7 @@ extern "C" {
 #define CSKY_ERR_IO (-4)         /* asset file problem                                       */
 #define CSKY_ERR_STATE (-5)      /* e.g. clouds requested before noise / LUTs exist          */
 
-#define CSKY_ABI_VERSION 4  /* 4: csky_submit_* / csky_collect, csky_multi_set_groups / _set_staged, "compact-ilp" kernel; 3: csky_set_noise_mips, csky_decode_bc7, csky_load_ctex[3d]; 2: csky_multi_*, device asset builders */
+#define CSKY_ABI_VERSION 4  /* 4: csky_submit_* / csky_collect, csky_multi_set_groups / _set_staged, csky_composite_view, csky_external_frame_*; 3: csky_set_noise_mips, csky_decode_bc7, csky_load_ctex[3d]; 2: csky_multi_*, device asset builders */
 
 typedef struct csky_ctx csky_ctx; /* opaque: owns every device allocation, the HIP stream and events */
 
