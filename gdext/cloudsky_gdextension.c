@@ -99,12 +99,14 @@ static GDExtensionInt packed_size(csky_builtin_method size_fn, GDExtensionConstT
     size_fn((GDExtensionTypePtr)arr, NULL, &n, 0);
     return n;
 }
-/* r_out = PackedByteArray(); r_out.resize(bytes); returns its writable data pointer, NULL if bytes == 0 OR the resize failed (the caller
- * must tell the two apart).  The ptrcall return slot is UNINITIALISED memory by the GDExtension convention (the engine placement-constructs
- * nothing there for builtin return types; godot-cpp's PtrToArg::encode does the same), so it is constructed, not assigned. */
+/* *r_out = PackedByteArray(); r_out.resize(bytes); returns its writable data pointer, NULL if bytes == 0 OR the resize failed (the caller
+ * must tell the two apart).  A ptrcall return slot holds an INITIALISED value of the return type (the engine's own PtrToArg<Packed*Array>::encode
+ * ASSIGNS into it, core/variant/method_ptrcall.h; GDScript and godot-cpp pass a default-constructed value), so this is an assignment: the old
+ * value is destroyed first, otherwise a caller that passes a non-empty array would leak it. */
 static uint8_t *packed_byte_array_new(csky_packed *r_out, GDExtensionInt bytes) {
     GDExtensionInt arg = bytes, ret = 0;
     GDExtensionConstTypePtr args[1];
+    G.pba_destroy(r_out);
     G.pba_default_ctor(r_out, NULL);
     if (bytes <= 0) return NULL;
     args[0] = &arg;
@@ -214,8 +216,8 @@ static void m_render_transmittance(void *ud, GDExtensionClassInstancePtr inst, c
     memcpy(&p, pc, sizeof p);
     if (!lut_size_ok(p.texture_size, &w, &h)) { fail(self, CSKY_ERR_INVALID, "render_transmittance: texture_size must be finite and in [1, 8192]"); packed_byte_array_new((csky_packed *)r, 0); return; }
     dst = packed_byte_array_new((csky_packed *)r, w * h * 8);
-    if (!dst) { fail(self, CSKY_ERR_INVALID, "render_transmittance: could not allocate the result array"); G.pba_destroy(r); packed_byte_array_new((csky_packed *)r, 0); return; }
-    if (pass(self, csky_render_transmittance(self->ctx, &p, (uint16_t *)dst)) != CSKY_OK) { G.pba_destroy(r); packed_byte_array_new((csky_packed *)r, 0); }
+    if (!dst) { fail(self, CSKY_ERR_INVALID, "render_transmittance: could not allocate the result array"); packed_byte_array_new((csky_packed *)r, 0); return; }
+    if (pass(self, csky_render_transmittance(self->ctx, &p, (uint16_t *)dst)) != CSKY_OK) { packed_byte_array_new((csky_packed *)r, 0); }
 }
 static void m_render_sky_lut(void *ud, GDExtensionClassInstancePtr inst, const GDExtensionConstTypePtr *a, GDExtensionTypePtr r) {
     CloudSkyHIP *self = (CloudSkyHIP *)inst; (void)ud;
@@ -229,10 +231,10 @@ static void m_render_sky_lut(void *ud, GDExtensionClassInstancePtr inst, const G
     memcpy(&p, pc, sizeof p);
     if (!lut_size_ok(p.texture_size, &w, &h)) { fail(self, CSKY_ERR_INVALID, "render_sky_lut: texture_size must be finite and in [1, 8192]"); packed_byte_array_new((csky_packed *)r, 0); return; }
     dst = packed_byte_array_new((csky_packed *)r, w * h * 8);
-    if (!dst) { fail(self, CSKY_ERR_INVALID, "render_sky_lut: could not allocate the result array"); G.pba_destroy(r); packed_byte_array_new((csky_packed *)r, 0); return; }
+    if (!dst) { fail(self, CSKY_ERR_INVALID, "render_sky_lut: could not allocate the result array"); packed_byte_array_new((csky_packed *)r, 0); return; }
     /* with several devices every one of them needs the LUT for its bands; the bytes come from the first */
-    if (self->multi && mpass(self, csky_multi_render_sky_lut(self->multi, &p)) != CSKY_OK) { G.pba_destroy(r); packed_byte_array_new((csky_packed *)r, 0); return; }
-    if (pass(self, self->multi ? csky_read_sky_lut(self->ctx, (uint16_t *)dst, NULL, NULL) : csky_render_sky_lut(self->ctx, &p, (uint16_t *)dst)) != CSKY_OK) { G.pba_destroy(r); packed_byte_array_new((csky_packed *)r, 0); }
+    if (self->multi && mpass(self, csky_multi_render_sky_lut(self->multi, &p)) != CSKY_OK) { packed_byte_array_new((csky_packed *)r, 0); return; }
+    if (pass(self, self->multi ? csky_read_sky_lut(self->ctx, (uint16_t *)dst, NULL, NULL) : csky_render_sky_lut(self->ctx, &p, (uint16_t *)dst)) != CSKY_OK) { packed_byte_array_new((csky_packed *)r, 0); }
 }
 static void m_render_clouds(void *ud, GDExtensionClassInstancePtr inst, const GDExtensionConstTypePtr *a, GDExtensionTypePtr r) {
     CloudSkyHIP *self = (CloudSkyHIP *)inst; (void)ud;
@@ -249,9 +251,9 @@ static void m_render_clouds(void *ud, GDExtensionClassInstancePtr inst, const GD
     }
     memcpy(&p, pc, sizeof p);
     dst = packed_byte_array_new((csky_packed *)r, w * h * 8);
-    if (!dst) { fail(self, CSKY_ERR_INVALID, "render_clouds: could not allocate the result array"); G.pba_destroy(r); packed_byte_array_new((csky_packed *)r, 0); return; }
+    if (!dst) { fail(self, CSKY_ERR_INVALID, "render_clouds: could not allocate the result array"); packed_byte_array_new((csky_packed *)r, 0); return; }
     if ((self->multi ? mpass(self, csky_multi_render_clouds(self->multi, &p, (int)w, (int)h, (uint16_t *)dst, (size_t)w * 8))
-                     : pass(self, csky_render_clouds(self->ctx, &p, (int)w, (int)h, (uint16_t *)dst, (size_t)w * 8))) != CSKY_OK) { G.pba_destroy(r); packed_byte_array_new((csky_packed *)r, 0); }
+                     : pass(self, csky_render_clouds(self->ctx, &p, (int)w, (int)h, (uint16_t *)dst, (size_t)w * 8))) != CSKY_OK) { packed_byte_array_new((csky_packed *)r, 0); }
 }
 /* ---- throughput path: frames in flight over the library's pinned ring (csky_submit_clouds / csky_collect) ------------------------------- */
 static void m_set_frames(void *ud, GDExtensionClassInstancePtr inst, const GDExtensionConstTypePtr *a, GDExtensionTypePtr r) {
@@ -283,7 +285,7 @@ static void m_collect(void *ud, GDExtensionClassInstancePtr inst, const GDExtens
     if (!self->ctx) { fail(self, CSKY_ERR_STATE, "CloudSkyHIP: create() has not been called"); packed_byte_array_new((csky_packed *)r, 0); return; }
     if (pass(self, csky_collect(self->ctx, (int64_t)*(const GDExtensionInt *)a[0], &frame, &bytes)) != CSKY_OK) { packed_byte_array_new((csky_packed *)r, 0); return; }
     dst = packed_byte_array_new((csky_packed *)r, (GDExtensionInt)bytes);
-    if (!dst) { fail(self, CSKY_ERR_INVALID, "collect: could not allocate the result array"); G.pba_destroy(r); packed_byte_array_new((csky_packed *)r, 0); return; }
+    if (!dst) { fail(self, CSKY_ERR_INVALID, "collect: could not allocate the result array"); packed_byte_array_new((csky_packed *)r, 0); return; }
     memcpy(dst, frame, bytes);           /* pinned ring slot -> the array rd.texture_update() takes; the slot is free for the next submit */
 }
 static void m_is_ready(void *ud, GDExtensionClassInstancePtr inst, const GDExtensionConstTypePtr *a, GDExtensionTypePtr r) {

@@ -106,7 +106,8 @@ static int64_t ptrcall_int(const char *name, const GDExtensionConstTypePtr *args
     return r;
 }
 static MockPacked ptrcall_bytes(const char *name, const GDExtensionConstTypePtr *args) {
-    MockPacked r = {NULL, -1};
+    MockPacked r = {NULL, 0};                      /* the return slot holds an initialised (empty) PackedByteArray, like the engine's */
+    r.data = (uint8_t *)malloc(16); r.size = 16;   /* ... here even a NON-empty one: the shim must assign (destroy the old value), not construct over it */
     method(name)->ptrcall_func(method(name)->method_userdata, R.instance, args, &r);
     return r;
 }
