@@ -17,13 +17,21 @@ frame k's launch overlaps the head of frame k+1's and, at N > 1, frame k's gathe
 at a time).  `value` is the pipelined whole-job rate; the same K frames strictly one at a time are timed right after it and
 reported next to it (`value_one_frame_at_a_time`): quote both.
 
-`roofline` (round 2): the path is not HBM-bound (82 MB of baked inputs live in L2 / Infinity Cache) and has no contraction, so
-neither "hbm" nor "mfma" bounds it; the binding units are VALU issue and the vector-L1 gather path.  Their fractions are computed
-from hardware counters collected LIVE by this run (tools/pmc_collect.py: rocprofv3 --pmc passes over the same workload in child
-processes, after the timed region) and priced with issue costs MEASURED on gfx950 (profiles/r02/issue_cost_calibration.json);
-all durations are of the kernel with the GPU to itself (HIP event pairs on the launch's stream).  Nothing is read from a committed
-counter file: without rocprofv3 the fractions are null.  The contract's algorithmic-bytes figure is kept as `hbm_algorithmic`
-with its ratio to the HBM peak (> 1: the taps are served by L1/L2, it stopped discriminating in round 1).
+`roofline` (round 3): the path is not HBM-bound (82 MB of baked inputs live in L2 / Infinity Cache) and has no contraction, so
+neither "hbm" nor "mfma" bounds it; the binding unit is VALU issue, with the vector-L1 gather path close behind.  Everything is measured in
+this run, after the timed region: executed instructions = basic-block execution counts of the CENSUS build of the library (the product's own
+assembly with a counter per block, tools/isa_profile.py; its frame is byte-identical) x the static per-block histogram, priced per KIND with issue
+costs measured on gfx950 (profiles/r03/issue_cost_calibration.json) and cross-checked against the hardware totals (rocprofv3 --pmc passes in child
+processes, tools/pmc_collect.py); cycles available = duration x the shader clock SAMPLED while the same loop re-runs (tools/sclk.py).  Top level =
+the timed region (`ms_per_step`); `kernel_alone` = one launch with the GPU to itself.  Nothing is read from a committed counter file: without
+rocprofv3 / the census library the corresponding fields are null.  The contract's algorithmic-bytes figure is kept as `hbm_algorithmic` with
+its ratio to the HBM peak (> 1: the taps are served by L1/L2, it stopped discriminating in round 1).
+
+`value_host_form`: the same frames delivered into PINNED HOST memory through csky_submit_clouds / csky_collect (what the GDExtension's
+submit_clouds() / collect() wrap), with one and two frames in flight: PCIe-inclusive, never the headline `value`.
+
+N > 1 without a launcher around it (`python bench.py --gpus 8`): bench.py starts its own ranks.  `--single-process`: the N devices behind ONE
+csky_multi handle (no torch.distributed).  `--groups G`: consecutive frames go to G groups of devices / ranks in turn (throughput workloads).
 
 Prints ONE JSON line on rank 0.
 """
