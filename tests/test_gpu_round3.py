@@ -306,3 +306,46 @@ def test_host_class_async_host_path_matches_the_blocking_one(pkg, noise, ftu):
         assert (va.view(np.uint16) == vb.view(np.uint16)).all() and np.isfinite(va.astype(np.float32)).all() and float(va[..., :3].astype(np.float32).max()) > 0.05
     finally:
         a.close(); b.close()
+
+
+# ------------------------------------------------------------------------------------------------ the push-constant block at the headline size
+SWEEP = [("nearly clear", (1, 1, 0), dict(coverage=0.05), True),
+         ("overcast", (0.3, 1, 0.2), dict(coverage=0.8), False),
+         ("thin", (1, 1, 0), dict(density=0.01), False),
+         ("wind 3 h, diagonal", (-0.5, 0.4, 0.7), dict(coverage=0.3, cloud_pos=(7636.75, 7636.75), detailed_pos=(7636.75, 7636.75), weather_pos=(7.63675, 7.63675), t=10800.0), False),
+         ("sun below the horizon, bright warm light, green ground", (0.0, -0.0872, 0.9962), dict(coverage=0.3, energy=3.0, colour=(1.0, 0.7, 0.4), ground=(0.1, 0.5, 0.1)), False)]
+
+
+@pytest.mark.parametrize("name,sun,kw,sparse", SWEEP, ids=[s[0].split(",")[0].replace(" ", "_") for s in SWEEP])
+def test_whole_c3_frames_over_the_push_constant_block(gpu_ctx, oracle, otex, o_trans, name, sun, kw, sparse):
+    """The fuzz of test_gpu_parity.py at the HEADLINE size: whole 2048x1024 @ 128x6 frames with non-default coverage / density
+    (cloud_sky.gd:22-26), wind-integrated positions and time (cloud_sky.gd:176-187), light energy / colour (cloud_sky.gd:76-79) and ground
+    colour against the oracle at the tight gate.  The nearly clear sky is mostly values below 1e-3, where fp16 resolves finer than the
+    march's fp32 `1 - dt` can deliver: its beyond-2-ulp count is taken above the 2^-18 absolute floor (parity_metrics.ABS_FLOOR; measured:
+    809 pixels beyond 2 ulp-equivalents, every one of them on a value below 0.01, 99 % of them off by < 1e-5)."""
+    from bench import usable_cores
+    W, H = 2048, 1024
+    kw = dict(kw)
+    p = oracle.default_params(W, H, sun, coverage=kw.pop("coverage", 0.2), density=kw.pop("density", 0.05))
+    p[4:6], p[6:8], p[8:10] = kw.pop("cloud_pos", (0, 0)), kw.pop("detailed_pos", (0, 0)), kw.pop("weather_pos", (0, 0))
+    p[19], p[20:23], p[23] = kw.pop("energy", 1.0), kw.pop("colour", (1, 1, 1)), kw.pop("t", 0.0)
+    if "ground" in kw:
+        p[12:15] = kw.pop("ground")
+    assert not kw
+    s = p[16:19].copy()
+    gpu_ctx.set_variant(-1); gpu_ctx.set_schedule(-1); gpu_ctx.set_segments(0); gpu_ctx.set_early_out(0.0); gpu_ctx.set_march(128, 6)
+    gpu_ctx.render_sky_lut(s, 200, 100)
+    sk_o = oracle.sky_lut(s, o_trans, 200, 100)
+    img = gpu_ctx.render_clouds(p)
+    st = gpu_ctx.cloud_stats()
+    ref, st_o = oracle.clouds(otex, p, sk_o, nthreads=max(1, min(oracle.max_threads(), usable_cores())), return_stats=True)
+    ok, info = cloud_tight(img, ref, sparse=sparse)
+    assert ok, (name, info)
+    if sparse:                                       # what the floor rests on: the disagreements sit on tiny values only
+        a, b = img.astype(np.float64), ref.astype(np.float64)
+        from parity_metrics import ulp16
+        bad = np.abs(a - b) / ulp16(b) > 2.0
+        assert bad.any() and np.abs(b[bad]).max() < 0.01 and np.abs(a - b)[bad].max() < 1e-4, (name, info)
+    assert st["primary_samples"] == st_o["primary_samples"]
+    assert abs(int(st["incloud_samples"]) - int(st_o["incloud_samples"])) <= 1e-5 * st_o["incloud_samples"] + 2
+    print("C3 sweep %s: %s" % (name, info))
