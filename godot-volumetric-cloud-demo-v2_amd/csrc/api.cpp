@@ -723,7 +723,7 @@ int csky_submit_clouds(csky_ctx* c, const csky_cloud_params* p, int tile_w, int 
     if (tile_w < 1 || tile_h < 1 || tile_w > 16384 || tile_h > 16384) return fail(c, CSKY_ERR_INVALID, "csky_submit_clouds: tile size out of range");
     int rc; if ((rc = bind(c))) return rc;
     csky_ctx::HostSlot& hs = c->hring[c->next_ticket % c->hslots];
-    if (hs.busy) return fail(c, CSKY_ERR_STATE, "csky_submit_clouds: %d frames are already in flight (csky_set_host_ring); collect ticket %lld first", c->hslots, hs.ticket);
+    if (hs.busy) return fail(c, CSKY_ERR_STATE, "csky_submit_clouds: %d frames are already in flight (csky_set_host_ring); collect ticket %lld first", c->hslots, (long long)hs.ticket);
     const size_t px = (size_t)tile_w * tile_h;
     if ((rc = host_slot_prepare(c, hs, px, true))) return rc;
     const csky_bands b = {tile_h, 0, 1, 1};
