@@ -89,6 +89,7 @@ def test_bench_gpus_2_starts_its_own_ranks():
     assert out.returncode == 0, (out.stdout[-1500:], out.stderr[-2500:])
     d = _last_json(out.stdout)
     assert d["n_gpus"] == 2 and d["ranks_seen"] == 2 and len(d["per_rank_share_ms"]) == 2 and all(0.05 < x < 50 for x in d["per_rank_share_ms"])
+    assert d["gathered_frame_check"]["within_1_fp16_ulp_frac"] >= 0.9999 and d["gathered_frame_check"]["max_abs_diff"] <= 2e-3, d["gathered_frame_check"]
     assert "gathered 2-rank frame vs single-rank frame" in out.stderr
 
 
@@ -106,6 +107,7 @@ def test_bench_single_process_form(mode):
     assert out.returncode == 0, (out.stdout[-1500:], out.stderr[-2500:])
     d = _last_json(out.stdout)
     assert d["n_gpus"] == int(n) and d["ranks_seen"] == int(n) and len(d["per_rank_share_ms"]) == int(n)
+    assert d["gathered_frame_check"]["within_1_fp16_ulp_frac"] >= 0.9999 and d["gathered_frame_check"]["max_abs_diff"] <= 2e-3, d["gathered_frame_check"]
     assert d["config"]["frame_groups"] == int(g) and d["config"]["finite"] is True and d["config"]["alpha_mean"] > 0.05
     assert "-device frame vs single-context frame" in out.stderr
 
@@ -124,4 +126,5 @@ def test_bench_frame_groups_process_form(cfg):
     assert out.returncode == 0, (out.stdout[-1500:], out.stderr[-2500:])
     d = _last_json(out.stdout)
     assert d["n_gpus"] == int(n) and d["ranks_seen"] == int(n) and d["config"]["frame_groups"] == int(g) and d["config"]["finite"] is True
+    assert d["gathered_frame_check"]["within_1_fp16_ulp_frac"] >= 0.9999 and d["gathered_frame_check"]["max_abs_diff"] <= 2e-3, d["gathered_frame_check"]
     assert "gathered %s-rank frame vs single-rank frame" % n in out.stderr
