@@ -3,7 +3,8 @@
  *
  * COMPILE-GUARDED: neither <vulkan/vulkan.h> nor an engine exist in this image, so nothing here is built or run by this repository
  * (gdext/Makefile builds it only with CSKY_HAVE_VULKAN=1).  The HIP half it calls IS built and lives in libcloudsky.so:
- * csky_external_frame_import_fd / _import_semaphore_fd / _signal / _release (include/cloudsky.h, csrc/api.cpp).
+ * csky_external_frame_import_fd / _import_semaphore_fd / _signal / _fence / _ready / _wait / _release (include/cloudsky.h, csrc/api.cpp);
+ * its memory half is exercised on the GPU against a foreign allocator (tools/ext_frame_roundtrip.py).
  *
  * Design.  cloud_sky.gd keeps three RGBA16F textures created with rd.texture_create() (cloud_sky.gd:368-378) and hands one of them to the
  * sky material as Texture2DRD.texture_rd_rid (:137-148).  The copy path (CloudSkyHIP.collect() + rd.texture_update()) fills those textures
@@ -14,14 +15,20 @@
  *      HIP kernel can address: VkSubresourceLayout.rowPitch is the row pitch handed to csky_render_clouds_device), usage SAMPLED |
  *      TRANSFER_DST, VkExternalMemoryImageCreateInfo{OPAQUE_FD}; dedicated allocation with VkExportMemoryAllocateInfo{OPAQUE_FD};
  *      vkGetMemoryFdKHR -> fd; csky_external_frame_import_fd(ctx, fd, ...) -> device pointer of the image's texels in HIP's address space.
- *   3. An exportable VkSemaphore (VkExportSemaphoreCreateInfo{OPAQUE_FD}) -> vkGetSemaphoreFdKHR -> csky_external_frame_import_semaphore_fd.
+ *   3. Ordering.  Preferred: an exportable VkSemaphore (VkExportSemaphoreCreateInfo{OPAQUE_FD}) -> vkGetSemaphoreFdKHR ->
+ *      csky_external_frame_import_semaphore_fd.  MEASURED on the MI355X box: ROCm 7.2's Linux runtime answers hipErrorNotSupported to
+ *      hipImportExternalSemaphore (a drm_syncobj fd, which is what an amdgpu opaque-fd semaphore is; tools/ext_semaphore_probe.py), so on this
+ *      runtime the image is created WITHOUT a semaphore and ordered by the host: csky_external_frame_fence() behind the march,
+ *      csky_external_frame_ready() polled at the start of the next update pass (csky_zc_ready below).
  *   4. GDScript wraps the VkImage: rid = rd.texture_create_from_extension(TEXTURE_TYPE_2D, DATA_FORMAT_R16G16B16A16_SFLOAT, TEXTURE_SAMPLES_1,
  *      TEXTURE_USAGE_SAMPLING_BIT, image_handle, w, h, 1, 1) and texture.texture_rd_rid = rid -- the SAME Texture2DRD the material already
  *      samples (cloud_sky.gd:137-148), now backed by memory the march writes.
- *   5. Per update pass: csky_render_clouds_device(ctx, pc, w, bands, zc->d_ptr, zc->row_pitch, stream); csky_external_frame_signal(...).
- *      The engine's next submission that samples the texture waits on the semaphore (csky_zc_wait_semaphore() returns it for
- *      RenderingDevice's external-semaphore hook of the build in use, or the host simply calls csky_sync() before frame_pre_draw returns: the
- *      reference's three-texture ring already leaves a whole update pass between "written" and "sampled", cloud_sky.gd:137-148).
+ *   5. Per update pass: csky_render_clouds_device(ctx, pc, w, bands, zc->d_ptr, zc->row_pitch, stream), then
+ *      csky_external_frame_signal(...) when a semaphore was imported (the engine's next submission that samples the texture waits on it:
+ *      csky_zc_wait_semaphore() returns it for RenderingDevice's external-semaphore hook of the build in use) or csky_external_frame_fence(...)
+ *      when not: the reference's three-texture ring already leaves a whole update pass between "written" and "sampled"
+ *      (cloud_sky.gd:137-148), so the host rotates the ring only once csky_zc_ready() says the frame is complete -- normally true at the
+ *      first poll of the next pass (a C3 frame takes 1.7 ms).
  *      The image stays in VK_IMAGE_LAYOUT_GENERAL / SHADER_READ_ONLY_OPTIMAL as the engine set it; LINEAR tiling makes the layout a no-op
  *      for the texel addresses.
  *
@@ -113,7 +120,11 @@ int csky_zc_create_image(csky_ctx *ctx, VkPhysicalDevice phys, VkDevice device, 
     get_sem_fd.semaphore = z->semaphore;
     if (p_get_semaphore_fd(device, &get_sem_fd, &fd) != VK_SUCCESS) { csky_zc_destroy_image(z); return CSKY_ERR_HIP; }
     rc = csky_external_frame_import_semaphore_fd(ctx, z->frame, fd);
-    if (rc != CSKY_OK) { close(fd); csky_zc_destroy_image(z); return rc; }
+    if (rc != CSKY_OK) {                       /* the runtime cannot import semaphores (ROCm 7.2 / Linux): host-side fence instead, step 3 */
+        close(fd);
+        vkDestroySemaphore(device, z->semaphore, NULL);
+        z->semaphore = VK_NULL_HANDLE;
+    }
     *out = z;
     return CSKY_OK;
 }
@@ -123,8 +134,11 @@ int csky_zc_render(csky_ctx *ctx, csky_zc_image *z, const csky_cloud_params *pc,
     const csky_bands whole = {z->height, 0, 1, 1};
     int rc = csky_render_clouds_device(ctx, pc, z->width, &whole, z->d_ptr, (size_t)z->row_pitch, hip_stream);
     if (rc != CSKY_OK) return rc;
-    return csky_external_frame_signal(ctx, z->frame, hip_stream);      /* the engine's sampling waits on z->semaphore */
+    if (z->semaphore) return csky_external_frame_signal(ctx, z->frame, hip_stream);      /* the engine's sampling waits on z->semaphore */
+    return csky_external_frame_fence(ctx, z->frame, hip_stream);                             /* ... or the host polls csky_zc_ready() */
 }
+/* 1 = the last csky_zc_render() into this image is complete (safe to sample), 0 = still marching, negative = error. */
+int csky_zc_ready(csky_ctx *ctx, csky_zc_image *z) { return z->semaphore ? 1 : csky_external_frame_ready(ctx, z->frame); }
 uint64_t csky_zc_image_handle(const csky_zc_image *z) { return (uint64_t)z->image; }       /* -> rd.texture_create_from_extension(..., image, w, h, 1, 1) */
 VkSemaphore csky_zc_wait_semaphore(const csky_zc_image *z) { return z->semaphore; }
 #endif /* CSKY_HAVE_VULKAN */

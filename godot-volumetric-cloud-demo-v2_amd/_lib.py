@@ -68,6 +68,9 @@ SYMBOLS = [
     ("csky_external_frame_import_fd", C.c_int, [C.c_void_p, C.c_int, C.c_size_t, C.c_size_t, C.c_size_t, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p)]),
     ("csky_external_frame_import_semaphore_fd", C.c_int, [C.c_void_p, C.c_void_p, C.c_int]),
     ("csky_external_frame_signal", C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
+    ("csky_external_frame_fence", C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
+    ("csky_external_frame_ready", C.c_int, [C.c_void_p, C.c_void_p]),
+    ("csky_external_frame_wait", C.c_int, [C.c_void_p, C.c_void_p]),
     ("csky_external_frame_release", None, [C.c_void_p]),
     ("csky_read_transmittance", C.c_int, [C.c_void_p, C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     ("csky_read_sky_lut", C.c_int, [C.c_void_p, C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_int)]),

@@ -762,7 +762,7 @@ int csky_poll(csky_ctx* c, int64_t ticket) {
 }
 
 // ---- zero-copy interop: a frame that lives in memory another API allocated (cloudsky.h; gdext/zero_copy_vulkan.c is the Vulkan half) ----
-struct csky_external_frame { int device = 0; hipExternalMemory_t mem = nullptr; void* d_ptr = nullptr; size_t bytes = 0; hipExternalSemaphore_t sem = nullptr; };
+struct csky_external_frame { int device = 0; hipExternalMemory_t mem = nullptr; void* d_ptr = nullptr; size_t bytes = 0; hipExternalSemaphore_t sem = nullptr; hipEvent_t fence = nullptr; bool fenced = false; };
 
 int csky_external_frame_import_fd(csky_ctx* c, int opaque_fd, size_t allocation_bytes, size_t offset, size_t frame_bytes, csky_external_frame** out, void** d_ptr) {
     if (!c || !out || !d_ptr) return fail(c, CSKY_ERR_INVALID, "csky_external_frame_import_fd: NULL argument");
@@ -800,9 +800,35 @@ int csky_external_frame_signal(csky_ctx* c, csky_external_frame* f, void* hip_st
     HIPCHK(c, hipSignalExternalSemaphoresAsync(&f->sem, &sp, 1, hip_stream ? (hipStream_t)hip_stream : c->stream));
     return CSKY_OK;
 }
+// Host-side ordering for runtimes that cannot import a semaphore (ROCm 7.2 on Linux answers hipErrorNotSupported for every handle type,
+// tools/ext_semaphore_probe.py): an event behind the march that the host polls before it lets the engine sample the image.
+int csky_external_frame_fence(csky_ctx* c, csky_external_frame* f, void* hip_stream) {
+    if (!c || !f) return fail(c, CSKY_ERR_INVALID, "csky_external_frame_fence: NULL argument");
+    int rc; if ((rc = bind(c))) return rc;
+    if (!f->fence) HIPCHK(c, hipEventCreateWithFlags(&f->fence, hipEventDisableTiming));
+    HIPCHK(c, hipEventRecord(f->fence, hip_stream ? (hipStream_t)hip_stream : c->stream));
+    f->fenced = true;
+    return CSKY_OK;
+}
+int csky_external_frame_ready(csky_ctx* c, csky_external_frame* f) {
+    if (!c || !f) return fail(c, CSKY_ERR_INVALID, "csky_external_frame_ready: NULL argument");
+    if (!f->fenced) return fail(c, CSKY_ERR_STATE, "csky_external_frame_ready: no fence recorded (csky_external_frame_fence)");
+    const hipError_t e = hipEventQuery(f->fence);
+    if (e == hipSuccess) return 1;
+    if (e == hipErrorNotReady) { (void)hipGetLastError(); return 0; }
+    return fail(c, CSKY_ERR_HIP, "csky_external_frame_ready: %s", hipGetErrorString(e));
+}
+int csky_external_frame_wait(csky_ctx* c, csky_external_frame* f) {
+    if (!c || !f) return fail(c, CSKY_ERR_INVALID, "csky_external_frame_wait: NULL argument");
+    if (!f->fenced) return fail(c, CSKY_ERR_STATE, "csky_external_frame_wait: no fence recorded (csky_external_frame_fence)");
+    int rc; if ((rc = bind(c))) return rc;
+    HIPCHK(c, hipEventSynchronize(f->fence));
+    return CSKY_OK;
+}
 void csky_external_frame_release(csky_external_frame* f) {
     if (!f) return;
     (void)hipSetDevice(f->device);
+    if (f->fence) { (void)hipEventSynchronize(f->fence); (void)hipEventDestroy(f->fence); }   // never unmap memory a march may still be writing
     if (f->sem) (void)hipDestroyExternalSemaphore(f->sem);
     if (f->mem) (void)hipDestroyExternalMemory(f->mem);      // unmaps d_ptr
     delete f;

@@ -35,7 +35,7 @@ extern "C" {
 #define CSKY_ERR_IO (-4)         /* asset file problem                                       */
 #define CSKY_ERR_STATE (-5)      /* e.g. clouds requested before noise / LUTs exist          */
 
-#define CSKY_ABI_VERSION 4  /* 4: csky_submit_* / csky_collect, csky_multi_set_groups / _set_staged, csky_composite_view, csky_external_frame_*; 3: csky_set_noise_mips, csky_decode_bc7, csky_load_ctex[3d]; 2: csky_multi_*, device asset builders */
+#define CSKY_ABI_VERSION 4  /* 4: csky_submit_* / csky_collect, csky_multi_set_groups / _set_staged, csky_composite_view, csky_external_frame_* (incl. _fence / _ready / _wait); 3: csky_set_noise_mips, csky_decode_bc7, csky_load_ctex[3d]; 2: csky_multi_*, device asset builders */
 
 typedef struct csky_ctx csky_ctx; /* opaque: owns every device allocation, the HIP stream and events */
 
@@ -170,13 +170,22 @@ int csky_poll(csky_ctx* ctx, int64_t ticket);
  * (row pitch = the image's VkSubresourceLayout.rowPitch for a LINEAR-tiled R16G16B16A16_SFLOAT image).  An exported VkSemaphore, imported with
  * ..._import_semaphore_fd and signalled on the march's stream by csky_external_frame_signal, orders the engine's sampling behind the march.
  * gdext/zero_copy_vulkan.c holds the Vulkan half and the Godot glue (RenderingDevice.texture_create_from_extension -> Texture2DRD); neither
- * Vulkan headers nor an engine exist in this image, so that file is compile-guarded and this half is exercised for its error paths only.
- * The library takes ownership of the fds on success. */
+ * Vulkan headers nor an engine exist in this image, so that file is compile-guarded; this half is exercised against a foreign allocator
+ * (a hipMemCreate allocation exported as a dma-buf fd: tools/ext_frame_roundtrip.py, tests/test_gpu_round3.py).
+ * The library takes ownership of the fds on success.
+ * Ordering without a semaphore: ROCm 7.2 on Linux refuses hipImportExternalSemaphore for every handle type (hipErrorNotSupported,
+ * tools/ext_semaphore_probe.py; ..._import_semaphore_fd then returns CSKY_ERR_HIP and the frame stays usable).  ..._fence records an event
+ * behind the march on its stream; the host polls ..._ready (1 = the frame is complete, 0 = still marching) or blocks in ..._wait before it
+ * lets the engine sample the image -- the reference draws with textures finished in EARLIER passes (cloud_sky.gd:137-148), so the poll
+ * at the start of the next pass normally finds the frame done. */
 typedef struct csky_external_frame csky_external_frame;
 int csky_external_frame_import_fd(csky_ctx* ctx, int opaque_fd, size_t allocation_bytes, size_t offset, size_t frame_bytes,
                                   csky_external_frame** out, void** d_ptr);
 int csky_external_frame_import_semaphore_fd(csky_ctx* ctx, csky_external_frame* f, int opaque_fd);
 int csky_external_frame_signal(csky_ctx* ctx, csky_external_frame* f, void* hip_stream);
+int csky_external_frame_fence(csky_ctx* ctx, csky_external_frame* f, void* hip_stream);
+int csky_external_frame_ready(csky_ctx* ctx, csky_external_frame* f);   /* 1 / 0, negative = error */
+int csky_external_frame_wait(csky_ctx* ctx, csky_external_frame* f);
 void csky_external_frame_release(csky_external_frame* f);
 
 /* Read back the context's internal LUT copies (tests, the compositor, Texture2DRD.texture_update). */

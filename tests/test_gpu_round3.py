@@ -383,6 +383,31 @@ def test_external_frame_round_trip_through_a_foreign_allocation(pkg, noise, gpu_
         got = ex.read(W * H * 8, OFFSET).view(np.uint16).reshape(H, W, 4)
         assert (got == ref.view(np.uint16)).all()
         assert (ex.read(OFFSET, 0) == 0x5C).all() and (ex.read(4096, OFFSET + W * H * 8) == 0x5C).all()
+        # ordering without a semaphore (what ROCm 7.2 on Linux needs: it refuses hipImportExternalSemaphore): fence behind the marches, polled
+        assert L.csky_external_frame_ready(gpu_ctx._h, ef) == pkg._lib.ERR_STATE                       # no fence recorded yet
+        import torch
+        st = torch.cuda.Stream()
+        big = X.ExportedAllocation(hip, 0, 2048 * 1024 * 8)
+        try:
+            ef2, d2 = C.c_void_p(), C.c_void_p()
+            assert L.csky_external_frame_import_fd(gpu_ctx._h, os.dup(big.fd), C.c_size_t(big.size), C.c_size_t(0), C.c_size_t(2048 * 1024 * 8), C.byref(ef2), C.byref(d2)) == 0
+            p3, _ = default_params(2048, 1024, (1, 1, 0))
+            gpu_ctx.set_march(128, 6)
+            for _ in range(10):                                                                          # ~20 ms of marching in front of the fence
+                gpu_ctx.render_clouds_device(p3, 2048, (1024, 0, 1, 1), d2.value, 2048 * 8, st.cuda_stream)
+            assert L.csky_external_frame_fence(gpu_ctx._h, ef2, C.c_void_p(st.cuda_stream)) == 0
+            assert L.csky_external_frame_ready(gpu_ctx._h, ef2) == 0                                     # still marching
+            assert L.csky_external_frame_wait(gpu_ctx._h, ef2) == 0
+            assert L.csky_external_frame_ready(gpu_ctx._h, ef2) == 1
+            # a semaphore fd the runtime cannot import (or a bad one) is an error that leaves the frame usable
+            r, w = os.pipe()
+            assert L.csky_external_frame_import_semaphore_fd(gpu_ctx._h, ef2, w) == pkg._lib.ERR_HIP
+            os.close(r); os.close(w)
+            gpu_ctx.render_clouds_device(p3, 2048, (1024, 0, 1, 1), d2.value, 2048 * 8, st.cuda_stream)
+            assert L.csky_external_frame_fence(gpu_ctx._h, ef2, C.c_void_p(st.cuda_stream)) == 0 and L.csky_external_frame_wait(gpu_ctx._h, ef2) == 0
+            L.csky_external_frame_release(ef2)                                                           # (waits for the fence before unmapping)
+        finally:
+            big.close()
         L.csky_external_frame_release(ef)
         # after the release the exporter's memory is still valid and unchanged
         assert (ex.read(W * H * 8, OFFSET).view(np.uint16).reshape(H, W, 4) == got).all()
