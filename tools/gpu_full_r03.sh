@@ -19,5 +19,8 @@ echo "== variants"; timeout -s KILL 120 python tools/prof_kernel.py --time --fra
 } > $O/secondary_numbers.log
 NS=1,2,4 timeout -s KILL 400 python tools/share_matrix.py 1 2 4 8 2>/dev/null > $O/share_matrix.txt
 python tools/isa_profile.py run --config C3 --out $O/census_counts_C3.json 2>&1 | tail -3 > $O/census_run.log
+timeout -s KILL 300 python tools/parity_sweep.py 2>&1 | grep '^{' > $O/parity_sweep.txt
+timeout -s KILL 200 python tools/ext_frame_roundtrip.py --time 2>&1 | grep -v amdgpu.ids > $O/external_frame_round_trip.txt
+timeout -s KILL 200 python tools/ext_semaphore_probe.py 2>&1 | grep -v amdgpu.ids > $O/external_semaphore_probe.txt
 rm -rf $O/bench_trace $O/bench_trace_fif1
 ls -la $O
