@@ -26,8 +26,15 @@
  *   is_ready(ticket: int) -> int                                    1 ready, 0 in flight, < 0 error
  * cloud_sky.gd's loop already draws with the texture finished in an EARLIER pass (:137-148), so collect(ticket of the previous update) right
  * before submit_clouds(this update) drops in without changing what is on screen when.
- * A zero-copy design (the march writes into memory the engine's VkImage is bound to: no host hop at all) is in gdext/zero_copy_vulkan.c,
- * compile-only here (no Vulkan headers / no engine in this image).
+ * Zero-copy path (round 3): the march writes into memory ANOTHER API allocated -- the engine's VkImage, exported as a POSIX fd with
+ * VK_KHR_external_memory_fd (gdext/zero_copy_vulkan.c holds that half, compile-guarded: no Vulkan headers / no engine in this image) -- so
+ * "returns the same TextureRD" needs no host hop at all:
+ *   import_frame_fd(fd: int, layout: PackedInt32Array) -> int       layout = [allocation_bytes, offset_bytes, row_pitch_bytes, width, height]; returns a slot (0..3)
+ *                                                                   or < 0; the library owns the fd on success (csky_external_frame_import_fd)
+ *   render_clouds_into(slot: int, pc: PackedFloat32Array) -> int    enqueue the march of the whole width x height tile into that memory + a fence; returns at once
+ *   frame_ready(slot: int) -> int                                   1 = the last march into that slot is complete (safe to sample), 0 = in flight, < 0 error
+ *   release_frame(slot: int) -> int                                 waits for the slot's fence and drops the library's mapping (the exporter's memory is untouched)
+ * Exercised in tests/gdext_mock_host.c with an allocation from HIP's virtual-memory API exported as a dma-buf fd standing in for the VkImage.
  *
  * The render methods return the image as tightly packed RGBA16F bytes (what texture_update takes); on error they
  * return an empty array and get_status() / get_last_error() say why.  Nothing here computes anything: every method is
@@ -86,9 +93,11 @@ static struct {
     csky_name class_name, parent_name;
 } G;
 
+#define CSKY_EXT_SLOTS 4   /* the reference keeps three cloud textures (cloud_sky.gd:368-378) */
 typedef struct {
     csky_ctx *ctx;        /* the context every method talks to: the object's own, or the first device's context of `multi` */
     csky_multi *multi;    /* create_multi(): the devices of the node behind this object (owns ctx then) */
+    struct { csky_external_frame *frame; void *d_ptr; int w, h; size_t pitch; } ext[CSKY_EXT_SLOTS];   /* import_frame_fd() */
     int status;
     char err[512];
 } CloudSkyHIP;
@@ -138,6 +147,9 @@ static const float *float_args(CloudSkyHIP *self, GDExtensionConstTypePtr arr, G
 }
 
 static void release(CloudSkyHIP *self) {
+    int i;
+    for (i = 0; i < CSKY_EXT_SLOTS; i++)
+        if (self->ext[i].frame) { csky_external_frame_release(self->ext[i].frame); self->ext[i].frame = NULL; }    /* waits for its fence */
     if (self->multi) { csky_multi_destroy(self->multi); self->multi = NULL; self->ctx = NULL; }
     if (self->ctx) { csky_destroy(self->ctx); self->ctx = NULL; }
 }
@@ -296,6 +308,67 @@ static void m_is_ready(void *ud, GDExtensionClassInstancePtr inst, const GDExten
     if (rc < 0) fail(self, rc, csky_last_error(self->ctx)); else { self->status = CSKY_OK; self->err[0] = 0; }
     *(GDExtensionInt *)r = rc;
 }
+/* ---- zero-copy path: frames that live in memory another API allocated ------------------------------------------------------- */
+static void m_import_frame_fd(void *ud, GDExtensionClassInstancePtr inst, const GDExtensionConstTypePtr *a, GDExtensionTypePtr r) {
+    CloudSkyHIP *self = (CloudSkyHIP *)inst; (void)ud;
+    const GDExtensionInt fd = *(const GDExtensionInt *)a[0];
+    const int32_t *l;
+    int slot, rc;
+    if (!self->ctx) { *(GDExtensionInt *)r = fail(self, CSKY_ERR_STATE, "CloudSkyHIP: create() has not been called"); return; }
+    if (packed_size(G.pia_size, a[1]) != 5) { *(GDExtensionInt *)r = fail(self, CSKY_ERR_INVALID, "import_frame_fd: layout = [allocation_bytes, offset_bytes, row_pitch_bytes, width, height]"); return; }
+    l = G.pia_index_const(a[1], 0);
+    if (fd < 0 || fd > 0x7fffffff || l[0] < 1 || l[1] < 0 || l[3] < 1 || l[4] < 1 || l[3] > 16384 || l[4] > 16384 || (int64_t)l[2] < (int64_t)l[3] * 8 ||
+        (int64_t)l[1] + (int64_t)l[2] * l[4] > (int64_t)l[0]) { *(GDExtensionInt *)r = fail(self, CSKY_ERR_INVALID, "import_frame_fd: the frame does not fit the allocation"); return; }
+    for (slot = 0; slot < CSKY_EXT_SLOTS && self->ext[slot].frame; slot++) {}
+    if (slot == CSKY_EXT_SLOTS) { *(GDExtensionInt *)r = fail(self, CSKY_ERR_STATE, "import_frame_fd: all 4 slots are in use (release_frame)"); return; }
+    rc = pass(self, csky_external_frame_import_fd(self->ctx, (int)fd, (size_t)l[0], (size_t)l[1], (size_t)l[2] * (size_t)l[4], &self->ext[slot].frame, &self->ext[slot].d_ptr));
+    if (rc != CSKY_OK) { self->ext[slot].frame = NULL; *(GDExtensionInt *)r = rc; return; }
+    self->ext[slot].pitch = (size_t)l[2]; self->ext[slot].w = l[3]; self->ext[slot].h = l[4];
+    *(GDExtensionInt *)r = slot;
+}
+static int ext_slot(CloudSkyHIP *self, GDExtensionInt slot) {
+    if (!self->ctx) return fail(self, CSKY_ERR_STATE, "CloudSkyHIP: create() has not been called");
+    if (slot < 0 || slot >= CSKY_EXT_SLOTS || !self->ext[slot].frame) return fail(self, CSKY_ERR_INVALID, "no imported frame in that slot (import_frame_fd)");
+    return CSKY_OK;
+}
+static void m_render_clouds_into(void *ud, GDExtensionClassInstancePtr inst, const GDExtensionConstTypePtr *a, GDExtensionTypePtr r) {
+    CloudSkyHIP *self = (CloudSkyHIP *)inst; (void)ud;
+    const GDExtensionInt slot = *(const GDExtensionInt *)a[0];
+    csky_cloud_params p;
+    const float *pc;
+    int rc;
+    if ((rc = ext_slot(self, slot)) != CSKY_OK) { *(GDExtensionInt *)r = rc; return; }
+    pc = float_args(self, a[1], 28, "render_clouds_into: push constant must be the 28 floats of _fill_push_constant() (clouds.glsl:18-40)");
+    if (!pc) { *(GDExtensionInt *)r = CSKY_ERR_INVALID; return; }
+    memcpy(&p, pc, sizeof p);
+    if (self->multi) {
+        rc = mpass(self, csky_multi_render_clouds_device(self->multi, &p, self->ext[slot].w, self->ext[slot].h, self->ext[slot].d_ptr, self->ext[slot].pitch, NULL));
+    } else {
+        const csky_bands whole = {self->ext[slot].h, 0, 1, 1};
+        rc = pass(self, csky_render_clouds_device(self->ctx, &p, self->ext[slot].w, &whole, self->ext[slot].d_ptr, self->ext[slot].pitch, NULL));
+    }
+    if (rc == CSKY_OK) rc = pass(self, csky_external_frame_fence(self->ctx, self->ext[slot].frame, NULL));   /* NULL = the same stream the march was ordered on */
+    *(GDExtensionInt *)r = rc;
+}
+static void m_frame_ready(void *ud, GDExtensionClassInstancePtr inst, const GDExtensionConstTypePtr *a, GDExtensionTypePtr r) {
+    CloudSkyHIP *self = (CloudSkyHIP *)inst; (void)ud;
+    const GDExtensionInt slot = *(const GDExtensionInt *)a[0];
+    int rc;
+    if ((rc = ext_slot(self, slot)) != CSKY_OK) { *(GDExtensionInt *)r = rc; return; }
+    rc = csky_external_frame_ready(self->ctx, self->ext[slot].frame);
+    if (rc < 0) fail(self, rc, csky_last_error(self->ctx)); else { self->status = CSKY_OK; self->err[0] = 0; }
+    *(GDExtensionInt *)r = rc;
+}
+static void m_release_frame(void *ud, GDExtensionClassInstancePtr inst, const GDExtensionConstTypePtr *a, GDExtensionTypePtr r) {
+    CloudSkyHIP *self = (CloudSkyHIP *)inst; (void)ud;
+    const GDExtensionInt slot = *(const GDExtensionInt *)a[0];
+    int rc;
+    if ((rc = ext_slot(self, slot)) != CSKY_OK) { *(GDExtensionInt *)r = rc; return; }
+    csky_external_frame_release(self->ext[slot].frame);
+    self->ext[slot].frame = NULL; self->ext[slot].d_ptr = NULL;
+    self->status = CSKY_OK; self->err[0] = 0;
+    *(GDExtensionInt *)r = CSKY_OK;
+}
 static void m_get_status(void *ud, GDExtensionClassInstancePtr inst, const GDExtensionConstTypePtr *a, GDExtensionTypePtr r) {
     (void)ud; (void)a;
     *(GDExtensionInt *)r = ((CloudSkyHIP *)inst)->status;
@@ -332,6 +405,10 @@ static const csky_method METHODS[] = {
      {GDEXTENSION_VARIANT_TYPE_PACKED_FLOAT32_ARRAY, GDEXTENSION_VARIANT_TYPE_INT, GDEXTENSION_VARIANT_TYPE_INT}, {"push_constant", "tile_w", "tile_h"}},
     {"collect", m_collect, 1, GDEXTENSION_VARIANT_TYPE_PACKED_BYTE_ARRAY, {GDEXTENSION_VARIANT_TYPE_INT}, {"ticket"}},
     {"is_ready", m_is_ready, 1, GDEXTENSION_VARIANT_TYPE_INT, {GDEXTENSION_VARIANT_TYPE_INT}, {"ticket"}},
+    {"import_frame_fd", m_import_frame_fd, 2, GDEXTENSION_VARIANT_TYPE_INT, {GDEXTENSION_VARIANT_TYPE_INT, GDEXTENSION_VARIANT_TYPE_PACKED_INT32_ARRAY}, {"fd", "layout"}},
+    {"render_clouds_into", m_render_clouds_into, 2, GDEXTENSION_VARIANT_TYPE_INT, {GDEXTENSION_VARIANT_TYPE_INT, GDEXTENSION_VARIANT_TYPE_PACKED_FLOAT32_ARRAY}, {"slot", "push_constant"}},
+    {"frame_ready", m_frame_ready, 1, GDEXTENSION_VARIANT_TYPE_INT, {GDEXTENSION_VARIANT_TYPE_INT}, {"slot"}},
+    {"release_frame", m_release_frame, 1, GDEXTENSION_VARIANT_TYPE_INT, {GDEXTENSION_VARIANT_TYPE_INT}, {"slot"}},
     {"get_status", m_get_status, 0, GDEXTENSION_VARIANT_TYPE_INT, {GDEXTENSION_VARIANT_TYPE_NIL}, {0}},
     {"get_last_error", m_get_last_error, 0, GDEXTENSION_VARIANT_TYPE_STRING, {GDEXTENSION_VARIANT_TYPE_NIL}, {0}},
 };

@@ -5,6 +5,7 @@
  *   gdext_mock_host <libcloudsky_gdext.so> <asset_dir> <fixture>    + create / set_noise / LUTs / a 64x32 cloud frame vs the fixture
  * Mock object model: StringName = const char*, String = char*, Packed*Array = {data, size}, Variant = {type, payload}. */
 #include <dlfcn.h>
+#include <unistd.h>
 #include "../gdext/gdextension_min.h"
 #include "c_test_util.h"
 
@@ -112,14 +113,48 @@ static MockPacked ptrcall_bytes(const char *name, const GDExtensionConstTypePtr 
     return r;
 }
 
+/* ---- a foreign allocator for the zero-copy path: HIP's virtual-memory API standing in for the engine's VkDeviceMemory ------------------
+ * (hipMemCreate + hipMemExportToShareableHandle: a dma-buf fd, the kind of object VK_KHR_external_memory_fd hands out on amdgpu; the
+ * declarations below are the handful of hip_runtime_api.h entries used, looked up at run time so that this C99 file needs no HIP headers) */
+typedef struct { int type; int id; } MockMemLocation;
+typedef struct { int type; int requestedHandleType; MockMemLocation location; void *win32HandleMetaData; struct { unsigned char c, g; unsigned short u; } allocFlags; } MockMemAllocationProp;
+typedef struct { MockMemLocation location; int flags; } MockMemAccessDesc;
+typedef struct { void *hip; void *handle; void *ptr; size_t size; int fd;
+                 int (*memcpy_)(void *, const void *, size_t, int); int (*unmap)(void *, size_t); int (*addr_free)(void *, size_t); int (*release)(void *); } ForeignAlloc;
+static int foreign_alloc(ForeignAlloc *f, size_t bytes) {
+    MockMemAllocationProp prop; MockMemAccessDesc acc; size_t gran = 0;
+    int (*granularity)(size_t *, const void *, int), (*create)(void **, size_t, const void *, unsigned long long), (*export_)(void *, void *, int, unsigned long long);
+    int (*reserve)(void **, size_t, size_t, void *, unsigned long long), (*map)(void *, size_t, size_t, void *, unsigned long long), (*set_access)(void *, size_t, const void *, size_t);
+    memset(f, 0, sizeof *f); f->fd = -1;
+    f->hip = dlopen("libamdhip64.so", RTLD_NOW);
+    if (!f->hip) return -1;
+    *(void **)&granularity = dlsym(f->hip, "hipMemGetAllocationGranularity"); *(void **)&create = dlsym(f->hip, "hipMemCreate");
+    *(void **)&export_ = dlsym(f->hip, "hipMemExportToShareableHandle"); *(void **)&reserve = dlsym(f->hip, "hipMemAddressReserve");
+    *(void **)&map = dlsym(f->hip, "hipMemMap"); *(void **)&set_access = dlsym(f->hip, "hipMemSetAccess");
+    *(void **)&f->memcpy_ = dlsym(f->hip, "hipMemcpy"); *(void **)&f->unmap = dlsym(f->hip, "hipMemUnmap");
+    *(void **)&f->addr_free = dlsym(f->hip, "hipMemAddressFree"); *(void **)&f->release = dlsym(f->hip, "hipMemRelease");
+    if (!granularity || !create || !export_ || !reserve || !map || !set_access || !f->memcpy_ || !f->unmap || !f->addr_free || !f->release) return -2;
+    memset(&prop, 0, sizeof prop); prop.type = 1; prop.requestedHandleType = 1; prop.location.type = 1; prop.location.id = 0;   /* pinned, POSIX fd, device 0 */
+    if (granularity(&gran, &prop, 0) != 0 || gran == 0) return -3;
+    f->size = (bytes + gran - 1) / gran * gran;
+    if (create(&f->handle, f->size, &prop, 0) != 0) return -4;
+    if (export_(&f->fd, f->handle, 1, 0) != 0) return -5;
+    if (reserve(&f->ptr, f->size, 0, NULL, 0) != 0 || map(f->ptr, f->size, 0, f->handle, 0) != 0) return -6;
+    memset(&acc, 0, sizeof acc); acc.location.type = 1; acc.location.id = 0; acc.flags = 3;
+    if (set_access(f->ptr, f->size, &acc, 1) != 0) return -7;
+    return 0;
+}
+static void foreign_free(ForeignAlloc *f) { if (f->ptr) { f->unmap(f->ptr, f->size); f->addr_free(f->ptr, f->size); } if (f->handle) f->release(f->handle); }
+
 int main(int argc, char **argv) {
     GDExtensionInitialization init;
     GDExtensionInitializationFunction entry;
     void *so;
     static const char *expect[] = {"create", "set_noise", "set_march", "render_transmittance", "render_sky_lut", "render_clouds", "get_status", "get_last_error",
-                                   "create_multi", "set_noise_mips", "set_frames", "submit_clouds", "collect", "is_ready"};
-    static const int expect_argc[] = {1, 3, 2, 1, 1, 3, 0, 0, 1, 3, 1, 3, 1, 1};
-    enum { N_EXPECT = 14 };
+                                   "create_multi", "set_noise_mips", "set_frames", "submit_clouds", "collect", "is_ready",
+                                   "import_frame_fd", "render_clouds_into", "frame_ready", "release_frame"};
+    static const int expect_argc[] = {1, 3, 2, 1, 1, 3, 0, 0, 1, 3, 1, 3, 1, 1, 2, 2, 1, 1};
+    enum { N_EXPECT = 18 };
     int i;
     if (argc < 2) return 2;
     so = dlopen(argv[1], RTLD_NOW);
@@ -240,6 +275,50 @@ int main(int argc, char **argv) {
             t2 = ptrcall_int("submit_clouds", a); if (t2 != 2) return 49;             /* tickets keep counting; the ring slot is reused */
             ta[0] = &t2; f0 = ptrcall_bytes("collect", ta);
             if (f0.size != img.size || memcmp(f0.data, img.data, (size_t)img.size)) return 50;
+        }
+        {   /* the zero-copy path: the march writes into memory a FOREIGN allocator owns (exported as a dma-buf fd, imported at an offset with a
+             * padded row pitch); read back through the exporter's own mapping: byte-identical to the blocking call, padding untouched */
+            ForeignAlloc fa;
+            const int32_t pitch = 64 * 8 + 128, offset = 4096;
+            int32_t layout[5];
+            MockPacked pl5 = {(uint8_t *)layout, 5};
+            int64_t fdv, slot, q;
+            GDExtensionConstTypePtr za[2];
+            const int frc = foreign_alloc(&fa, (size_t)offset + (size_t)pitch * 32);
+            if (frc == 0) {
+                uint8_t *back = (uint8_t *)malloc((size_t)pitch * 32);
+                int y, same = 1, pad_ok = 1;
+                layout[0] = (int32_t)fa.size; layout[1] = offset; layout[2] = pitch; layout[3] = 64; layout[4] = 32;
+                fdv = dup(fa.fd); za[0] = &fdv; za[1] = &pl5;
+                slot = ptrcall_int("import_frame_fd", za);
+                if (slot != 0) { fprintf(stderr, "import_frame_fd: %lld\n", (long long)slot); return 60; }
+                layout[0] = 1000; fdv = 0;                                           /* a frame that does not fit its allocation is refused before the fd is touched */
+                if (ptrcall_int("import_frame_fd", za) != CSKY_ERR_INVALID) return 61;
+                q = 3; za[0] = &q; if (ptrcall_int("frame_ready", za) != CSKY_ERR_INVALID) return 62;            /* empty slot */
+                za[0] = &slot; if (ptrcall_int("frame_ready", za) != CSKY_ERR_STATE) return 63;                 /* nothing marched into it yet */
+                {   /* fill the window with a pattern through the exporter's mapping, then march */
+                    uint8_t *pat = (uint8_t *)malloc((size_t)pitch * 32); memset(pat, 0xA7, (size_t)pitch * 32);
+                    if (fa.memcpy_((uint8_t *)fa.ptr + offset, pat, (size_t)pitch * 32, 1) != 0) return 64;      /* hipMemcpyHostToDevice */
+                    free(pat);
+                }
+                za[0] = &slot; za[1] = &pc;
+                if (ptrcall_int("render_clouds_into", za) != CSKY_OK) return 65;
+                do { q = ptrcall_int("frame_ready", za); } while (q == 0);
+                if (q != 1) return 66;
+                if (fa.memcpy_(back, (uint8_t *)fa.ptr + offset, (size_t)pitch * 32, 2) != 0) return 67;         /* hipMemcpyDeviceToHost, the EXPORTER's address */
+                for (y = 0; y < 32; y++) {
+                    int x;
+                    if (memcmp(back + (size_t)y * pitch, img.data + (size_t)y * 64 * 8, 64 * 8)) same = 0;
+                    for (x = 64 * 8; x < pitch; x++) if (back[(size_t)y * pitch + x] != 0xA7) pad_ok = 0;
+                }
+                printf("zero-copy frame in the foreign allocation vs the blocking call: %s, row padding untouched: %s\n", same ? "identical" : "DIFFERENT", pad_ok ? "yes" : "NO");
+                if (!same || !pad_ok) return 68;
+                if (ptrcall_int("release_frame", za) != CSKY_OK || ptrcall_int("release_frame", za) != CSKY_ERR_INVALID) return 69;
+                free(back);
+                foreign_free(&fa);
+            } else {
+                printf("zero-copy scenario skipped: no exportable allocation from this runtime (%d)\n", frc);
+            }
         }
         {   /* create_multi: two contexts behind the object (both on device 0 here); explicit set_noise_mips; blocking and asynchronous frames */
             int32_t ids[2] = {0, 0};

@@ -33,11 +33,14 @@ def c_abi_exe(pkg, tmp_path_factory):
 
 
 def test_shim_registers_class_and_methods(mock_host):
-    """No GPU needed: entry symbol, SCENE-level registration of CloudSkyHIP(RefCounted) with its 8 methods, instance create/free,
+    """No GPU needed: entry symbol, SCENE-level registration of CloudSkyHIP(RefCounted) with its 18 methods, instance create/free,
     ERR_STATE + empty image before create() through ptrcall AND through the Variant-call trampoline."""
     exe, so = mock_host
     out = subprocess.run([exe, so], capture_output=True, text=True)
     assert out.returncode == 0 and "gdext mock host ok" in out.stdout, (out.returncode, out.stdout, out.stderr)
+    # the zero-copy methods (import_frame_fd / render_clouds_into / frame_ready / release_frame) against a foreign allocation's dma-buf fd
+    assert "zero-copy frame in the foreign allocation vs the blocking call: identical, row padding untouched: yes" in out.stdout, out.stdout
+    print(out.stdout)
 
 
 def test_shim_exports_only_the_entry_symbol(mock_host):
