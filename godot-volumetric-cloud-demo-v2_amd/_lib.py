@@ -295,6 +295,14 @@ class Context:
     def sync(self):
         self._chk(self._L.csky_sync(self._h))
 
+    def import_external_frame(self, fd, allocation_bytes, offset_bytes, frame_bytes):
+        """Zero-copy interop (csky_external_frame_import_fd): memory another API allocated, handed over as a POSIX fd (the library owns the fd on
+        success).  Returns an ExternalFrame whose `.ptr` is usable as d_out of render_clouds_device."""
+        ef, dptr = C.c_void_p(), C.c_void_p()
+        self._chk(self._L.csky_external_frame_import_fd(self._h, int(fd), C.c_size_t(int(allocation_bytes)), C.c_size_t(int(offset_bytes)), C.c_size_t(int(frame_bytes)),
+                                                        C.byref(ef), C.byref(dptr)))
+        return ExternalFrame(self, ef, dptr.value)
+
     def census_clouds(self, params, tile_w, bands, n=256):
         """Basic-block execution counts of one launch (non-zero only with the census build of the library, tools/isa_profile.py)."""
         p = cloud_params(params)
@@ -428,6 +436,30 @@ class Context:
         st = CloudStats()
         self._chk(self._L.csky_get_cloud_stats(self._h, C.byref(st)))
         return dict(rays=st.rays, primary_samples=st.primary_samples, incloud_samples=st.incloud_samples)
+
+
+class ExternalFrame:
+    """A frame that lives in imported memory.  Ordering is the host-side fence (ROCm 7.2 on Linux refuses external semaphores)."""
+
+    def __init__(self, ctx, handle, ptr):
+        self._ctx, self._h, self.ptr = ctx, handle, ptr
+
+    def fence(self, stream=None):
+        self._ctx._chk(self._ctx._L.csky_external_frame_fence(self._ctx._h, self._h, C.c_void_p(stream or 0)))
+
+    def ready(self):
+        rc = self._ctx._L.csky_external_frame_ready(self._ctx._h, self._h)
+        if rc < 0:
+            self._ctx._chk(rc)
+        return bool(rc)
+
+    def wait(self):
+        self._ctx._chk(self._ctx._L.csky_external_frame_wait(self._ctx._h, self._h))
+
+    def release(self):
+        if self._h is not None:
+            self._ctx._L.csky_external_frame_release(self._h)
+            self._h, self.ptr = None, 0
 
 
 class MultiContext:

@@ -142,13 +142,8 @@ def time_c3(ctx, hip, L, frames=200):
     streams = [torch.cuda.Stream() for _ in range(2)]
     own = [torch.zeros((H, W, 4), dtype=torch.int16, device="cuda:0") for _ in range(2)]
     exs = [ExportedAllocation(hip, 0, W * H * 8) for _ in range(2)]
-    efs, ptrs = [], []
-    for ex in exs:
-        ef, dptr = C.c_void_p(), C.c_void_p()
-        if L.csky_external_frame_import_fd(ctx._h, os.dup(ex.fd), C.c_size_t(ex.size), C.c_size_t(0), C.c_size_t(W * H * 8), C.byref(ef), C.byref(dptr)) != 0:
-            print("import refused:", L.csky_last_error(ctx._h).decode())
-            return 2
-        efs.append(ef), ptrs.append(dptr.value)
+    efs = [ctx.import_external_frame(os.dup(ex.fd), ex.size, 0, W * H * 8) for ex in exs]      # (the Python wrapper of the same entry point)
+    ptrs = [ef.ptr for ef in efs]
 
     def loop(targets, n):
         for k in range(n):
@@ -167,8 +162,11 @@ def time_c3(ctx, hip, L, frames=200):
     a = np.frombuffer(exs[1].read(W * H * 8), np.uint16)
     same = bool((a == own[1].cpu().numpy().view(np.uint16).reshape(-1)).all())
     print("last frame in the imported allocation == last frame in the hipMalloc one: %s" % same)
+    efs[0].fence(streams[0].cuda_stream)
+    efs[0].wait()
+    assert efs[0].ready()
     for ef in efs:
-        L.csky_external_frame_release(ef)
+        ef.release()
     for ex in exs:
         ex.close()
     return 0 if same else 1
