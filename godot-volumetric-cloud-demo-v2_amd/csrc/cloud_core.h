@@ -506,10 +506,12 @@ CSKY_HD float henyey_greenstein(float c, float g) {                         // c
     return 0.0795774715459f * (1.0f - g * g) / (x * sqrtf(x));             // pow(x, 1.5) = x sqrt(x): ~15 instructions instead of powf's ~80, within 2 fp32 ulp of it
 }
 
-// clouds.glsl:202-210: shade one in-cloud sample (density t, height fraction hf, step transmittance dt, summed light-march
-// density cd) and composite it front to back into (L, alpha, T).
-CSKY_HD void shade_sample(const FrameConsts& fc, float phase, float t, float hf, float dt, float cd, float& Tr, float& alpha, float& Lr,
-                          float& Lg, float& Lb) {
+// clouds.glsl:202-210 in two halves.  shade_terms: everything about one in-cloud sample that does not depend on the ray's running state
+// (density t, height fraction hf, step transmittance dt, summed light-march density cd, the ray's phase value): D = r - r dt per channel
+// and q = 1 / max(1e-7, t).  composite_sample: the front-to-back recurrences on (L, alpha, T).  The compact march evaluates the first
+// half in the light march's lane layout (one SAMPLE per lane, all 64 lanes busy) and only the second while replaying the steps in order
+// (one owner RAY per lane, ~1/6 of the lanes busy per step); the expressions and their order are those of the one-piece form.
+CSKY_HD void shade_terms(const FrameConsts& fc, float phase, float t, float hf, float dt, float cd, float& Dr, float& Dg, float& Db, float& q) {
     const float lss = (SKY_T_RADIUS - SKY_B_RADIUS) / 64.0f;
     const float nd = -fc.density;
     const float beers = fast_exp(nd * cd * lss * 3.0f);                                  // :202
@@ -519,12 +521,22 @@ CSKY_HD void shade_sample(const FrameConsts& fc, float phase, float t, float hf,
     const float ar = fc.gnd_c[0] * (1.0f - sm) + fc.amb_c[0] * sm;                       // :206
     const float ag = fc.gnd_c[1] * (1.0f - sm) + fc.amb_c[1] * sm;
     const float ab = fc.gnd_c[2] * (1.0f - sm) + fc.amb_c[2] * sm;
-    alpha += (1.0f - dt) * (1.0f - alpha);                                               // :207
     const float k = bt * phase;
     const float rr = (ar + k * fc.sun_c[0]) * t, rg = (ag + k * fc.sun_c[1]) * t, rb = (ab + k * fc.sun_c[2]) * t;  // :208
-    const float w = Tr * fast_rcp(fmaxf(0.0000001f, t));                                 // :209
-    Lr += (rr - rr * dt) * w; Lg += (rg - rg * dt) * w; Lb += (rb - rb * dt) * w;
+    q = fast_rcp(fmaxf(0.0000001f, t));                                                  // :209
+    Dr = rr - rr * dt; Dg = rg - rg * dt; Db = rb - rb * dt;
+}
+CSKY_HD void composite_sample(float dt, float q, float Dr, float Dg, float Db, float& Tr, float& alpha, float& Lr, float& Lg, float& Lb) {
+    alpha += (1.0f - dt) * (1.0f - alpha);                                               // :207
+    const float w = Tr * q;                                                              // :209
+    Lr += Dr * w; Lg += Dg * w; Lb += Db * w;
     Tr *= dt;                                                                            // :210
+}
+CSKY_HD void shade_sample(const FrameConsts& fc, float phase, float t, float hf, float dt, float cd, float& Tr, float& alpha, float& Lr,
+                          float& Lg, float& Lb) {
+    float Dr, Dg, Db, q;
+    shade_terms(fc, phase, t, hf, dt, cd, Dr, Dg, Db, q);
+    composite_sample(dt, q, Dr, Dg, Db, Tr, alpha, Lr, Lg, Lb);
 }
 
 struct MarchOut { float r, g, b, a, t; uint32_t incloud; };   // L.rgb, alpha, transmittance T, #in-cloud samples

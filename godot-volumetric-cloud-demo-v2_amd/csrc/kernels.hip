@@ -370,7 +370,7 @@ __device__ __forceinline__ MarchOut march_queue(const TexSet& T, const FrameCons
 // the final flush of a ray segment runs with idle lanes.
 constexpr int CQ_CAP = 128;                                  // a flush is taken as soon as 64 samples are queued: count <= 63 + 64
 constexpr int CQ_STEPS = 66;                                 // steps-with-events between flushes: <= 1 carried + 64 (>= 1 event each)
-constexpr int CQ_FLOATS = 5 * CQ_CAP + 64 + 3 * CQ_STEPS;    // pos(3) t hf | cd | per-step mask lo/hi + base = 3.6 KB per wavefront
+constexpr int CQ_FLOATS = 7 * CQ_CAP + 3 * CQ_STEPS;         // pos(3) t hf ss phase (after the light march: D(3) q dt) | per-step mask lo/hi + base = 4.4 KB per wavefront
 
 #ifndef CSKY_EAGER_LIGHT
 #define CSKY_EAGER_LIGHT 1
@@ -397,8 +397,9 @@ __device__ __forceinline__ MarchOut march_compact(const TexSet& T, const FrameCo
     float* __restrict__ ev_pz = q + 2 * CQ_CAP;
     float* __restrict__ ev_t = q + 3 * CQ_CAP;
     float* __restrict__ ev_hf = q + 4 * CQ_CAP;
-    float* __restrict__ ev_cd = q + 5 * CQ_CAP;                                  // [64]
-    unsigned* __restrict__ st_lo = reinterpret_cast<unsigned*>(q + 5 * CQ_CAP + 64);   // [CQ_STEPS]
+    float* __restrict__ ev_ss = q + 5 * CQ_CAP;                                  // the owner ray's step length and phase value (per-ray constants
+    float* __restrict__ ev_ph = q + 6 * CQ_CAP;                                  // the sample's lane needs for the shading terms)
+    unsigned* __restrict__ st_lo = reinterpret_cast<unsigned*>(q + 7 * CQ_CAP);  // [CQ_STEPS]
     unsigned* __restrict__ st_hi = st_lo + CQ_STEPS;
     unsigned* __restrict__ st_base = st_hi + CQ_STEPS;
 
@@ -437,7 +438,7 @@ __device__ __forceinline__ MarchOut march_compact(const TexSet& T, const FrameCo
             const unsigned long long m = __ballot(have);
             if (m != 0ull) {
                 const int slot = count + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));
-                if (have) { ev_px[slot] = px; ev_py[slot] = py; ev_pz[slot] = pz; ev_t[slot] = t; ev_hf[slot] = hf; }
+                if (have) { ev_px[slot] = px; ev_py[slot] = py; ev_pz[slot] = pz; ev_t[slot] = t; ev_hf[slot] = hf; ev_ss[slot] = ray.ss; ev_ph[slot] = phase; }
                 if (lane == 0) { st_lo[cs] = (unsigned)m; st_hi[cs] = (unsigned)(m >> 32); st_base[cs] = (unsigned)count; }
                 count += __popcll(m);
                 cs++;
@@ -447,7 +448,9 @@ __device__ __forceinline__ MarchOut march_compact(const TexSet& T, const FrameCo
         const bool last = i >= end;
         if (count == 0) { if (last) break; continue; }
         if (count < 64 && !last) continue;
-        // ---- B: the light march of the first n = min(count, 64) queued samples, one per lane
+        // ---- B: the light march of the first n = min(count, 64) queued samples, one per lane, and the state-independent half of their
+        //         shading (clouds.glsl:178, :202-209) while all lanes are busy: the replay below runs with ~1/6 of them (round 3: the census
+        //         put 15 % of the kernel's issue time in the replay loop, 43 VALU instructions per step incl. 4 transcendentals)
         wave_lds_fence();
         const int n = count < 64 ? count : 64;
         if (lane < n) {
@@ -467,20 +470,21 @@ __device__ __forceinline__ MarchOut march_compact(const TexSet& T, const FrameCo
                 const float ld = CSKY_LIGHT_SAMPLE(T, fc, lx, ly, lz, lhf, 0.0f, 0.0f, 3, 5);                  // :197 has no weather_pos
                 cd += fast_pow(ld, (1.0f - lhf) * 0.8f + 0.5f);                                                // :198 (second pow)
             }
-            ev_cd[lane] = cd;
+            const float et = ev_t[lane], ehf = ev_hf[lane];
+            const float dt = fast_exp(nd * et * ev_ss[lane]);                                                  // :178
+            float Dr, Dg, Db, rq;
+            shade_terms(fc, ev_ph[lane], et, ehf, dt, cd, Dr, Dg, Db, rq);                                     // :202-209
+            ev_px[lane] = Dr; ev_py[lane] = Dg; ev_pz[lane] = Db; ev_t[lane] = rq; ev_hf[lane] = dt;           // the sample's slot now holds its terms
         }
         wave_lds_fence();
-        // ---- C: replay the steps in order; owners of evaluated samples (slot < n) composite (:202-210)
+        // ---- C: replay the steps in order; owners of evaluated samples (slot < n) composite (:207-210)
         unsigned long long carry = 0ull;                     // lanes of the last step whose sample is still queued
         for (int s = 0; s < cs; s++) {
             const unsigned lo = st_lo[s], hi = st_hi[s];
             const bool mine = lane < 32 ? ((lo >> lane) & 1u) : ((hi >> (lane - 32)) & 1u);
             const int slot = (int)st_base[s] + (int)__builtin_amdgcn_mbcnt_hi(hi, __builtin_amdgcn_mbcnt_lo(lo, 0u));
             if (mine && slot < n) {
-                const float cd = ev_cd[slot];
-                const float et = ev_t[slot], ehf = ev_hf[slot];
-                const float dt = fast_exp(nd * et * ray.ss);                                                   // :178
-                shade_sample(fc, phase, et, ehf, dt, cd, Tr, alpha, Lr, Lg, Lb);
+                composite_sample(ev_hf[slot], ev_t[slot], ev_px[slot], ev_py[slot], ev_pz[slot], Tr, alpha, Lr, Lg, Lb);
                 o.incloud++;
             }
             if (s == cs - 1) carry = __ballot(mine && slot >= n);
@@ -489,10 +493,10 @@ __device__ __forceinline__ MarchOut march_compact(const TexSet& T, const FrameCo
         // ---- keep what was not evaluated: samples n..count-1 move to the front, the last step keeps its unevaluated lanes
         const int rem = count - n;
         if (rem > 0) {
-            float a0 = 0.0f, a1 = 0.0f, a2 = 0.0f, a3 = 0.0f, a4 = 0.0f;
-            if (lane < rem) { a0 = ev_px[n + lane]; a1 = ev_py[n + lane]; a2 = ev_pz[n + lane]; a3 = ev_t[n + lane]; a4 = ev_hf[n + lane]; }
+            float a0 = 0.0f, a1 = 0.0f, a2 = 0.0f, a3 = 0.0f, a4 = 0.0f, a5 = 0.0f, a6 = 0.0f;
+            if (lane < rem) { a0 = ev_px[n + lane]; a1 = ev_py[n + lane]; a2 = ev_pz[n + lane]; a3 = ev_t[n + lane]; a4 = ev_hf[n + lane]; a5 = ev_ss[n + lane]; a6 = ev_ph[n + lane]; }
             wave_lds_fence();
-            if (lane < rem) { ev_px[lane] = a0; ev_py[lane] = a1; ev_pz[lane] = a2; ev_t[lane] = a3; ev_hf[lane] = a4; }
+            if (lane < rem) { ev_px[lane] = a0; ev_py[lane] = a1; ev_pz[lane] = a2; ev_t[lane] = a3; ev_hf[lane] = a4; ev_ss[lane] = a5; ev_ph[lane] = a6; }
             if (lane == 0) { st_lo[0] = (unsigned)carry; st_hi[0] = (unsigned)(carry >> 32); st_base[0] = 0u; }
             wave_lds_fence();
             count = rem; cs = 1;
