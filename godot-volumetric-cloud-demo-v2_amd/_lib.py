@@ -86,8 +86,6 @@ SYMBOLS = [
     ("csky_set_schedule", C.c_int, [C.c_void_p, C.c_int]),
     ("csky_set_height_window", C.c_int, [C.c_void_p, C.c_int]),
     ("csky_set_segments", C.c_int, [C.c_void_p, C.c_int]),
-    ("csky_set_exchange", C.c_int, [C.c_void_p, C.c_int]),
-    ("csky_exchange_counters", C.c_int, [C.c_void_p, C.POINTER(C.c_uint32), C.c_int]),
     ("csky_variant_name", C.c_char_p, [C.c_int]),
     ("csky_multi_create", C.c_int, [C.POINTER(C.c_void_p), C.POINTER(C.c_int), C.c_int]),
     ("csky_multi_destroy", None, [C.c_void_p]),
@@ -128,7 +126,7 @@ SYMBOLS = [
 
 
 DEFAULT_VARIANT = 3   # include/cloudsky.h CSKY_DEFAULT_VARIANT ("compact"); set_variant(-1) selects it
-ABI_VERSION = 5       # include/cloudsky.h CSKY_ABI_VERSION
+ABI_VERSION = 4       # include/cloudsky.h CSKY_ABI_VERSION
 
 
 def library_path():
@@ -252,17 +250,6 @@ class Context:
 
     def set_variant(self, v):
         self._chk(self._L.csky_set_variant(self._h, int(v)))
-
-    def set_exchange(self, mode):
-        """Light-march packet exchange between wavefronts of a persistent launch: 0 never, 1 policy, 2 every whole-ray launch."""
-        self._chk(self._L.csky_set_exchange(self._h, int(mode)))
-
-    def exchange_counters(self, reset=1):
-        """(packets published, packets run by helpers, waited sweeps, helpers that found no packet after one, timed-out spins) since the last reset.
-        reset: 0 read, 1 read + zero + switch counting ON, 2 read + switch it OFF, 3 zero + off (counting is off by default)."""
-        a = (C.c_uint32 * 16)()
-        self._chk(self._L.csky_exchange_counters(self._h, a, int(reset)))
-        return tuple(int(v) for v in a)
 
     # ---- kernels, host-buffer forms
     def render_transmittance(self, w=256, h=64):

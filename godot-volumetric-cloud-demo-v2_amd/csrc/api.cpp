@@ -83,11 +83,6 @@ struct csky_ctx {
     uint32_t* d_wg_cost = nullptr; uint32_t* d_lpt_order = nullptr; uint32_t* d_lpt_hist = nullptr; size_t lpt_cap = 0;
     uint32_t* d_heads = nullptr; int persistent = 1; int resident_wgs = 0;   // persistent launches: 2 ring slots x (8 per-XCD pop counters + exit counter)
     bool lpt_valid[RING] = {}; long long lpt_key[RING][11];   // csky_create fills the keys with -1
-    // light-march packet exchange (kernels.hip::clouds_kernel_exchange, exchange.h): per ring slot the queue control words, the eight queues,
-    // the wavefronts' packet slots and the launch epoch that salts every tag; allocated at a slot's first exchange launch
-    int exchange = 1;                                  // 0 = never, 1 = the policy of clouds_dev, 2 = every whole-ray launch of the compact kernel (CSKY_EXCHANGE / csky_set_exchange)
-    uint32_t* d_xctl[RING] = {}; unsigned long long* d_xring[RING] = {}; unsigned long long* d_xslots[RING] = {}; uint32_t xepoch[RING] = {};
-    uint32_t* d_xdiag = nullptr; bool xdiag_on = false; // csky_exchange_counters (counting costs one atomic per packet on ONE word: off unless asked for)
     // optional per-launch timing of the cloud kernel (csky_set_kernel_timing): HIP event pairs recorded around the launch on ITS stream
     bool kt_on = false; std::vector<hipEvent_t> kt_ev; int kt_count = 0;   // the event pool grows on demand (clouds_dev)
     uint8_t* d_composite = nullptr; size_t composite_cap = 0;              // grow-only scratch of csky_composite_sky
@@ -191,39 +186,6 @@ int ensure_order(csky_ctx* c, int slot, int mode, int tile_w, int tiles_x, int s
     return CSKY_OK;
 }
 
-// When the exchange pays (mode 1).  Filled in from measurements (tools/exchange_ab.py, profiles/r04/exchange_ab.txt).
-bool exchange_policy(const csky_ctx* c, long long waves) {
-    (void)c; (void)waves;
-    return false;
-}
-
-// Exchange state of ring slot `slot` for one launch on stream s (exchange.h).  Tags carry a 10-bit launch epoch, so nothing is zeroed between
-// launches; the pool is zeroed when it is created and when the epoch wraps (every 1023 launches of the slot).
-int ensure_exchange(csky_ctx* c, int slot, hipStream_t s, XchArgs* x) {
-    const size_t waves = (size_t)c->resident_wgs * 4;
-    if (waves > (size_t)XCH_MAX_WAVES) return fail(c, CSKY_ERR_INVALID, "exchange: %zu resident wavefronts exceed the %d the queue entries can name", waves, XCH_MAX_WAVES);
-    const size_t slot_bytes = waves * XK * XS_U64 * sizeof(unsigned long long), ring_bytes = (size_t)8 * XQ_N * sizeof(unsigned long long);
-    bool zero = false;
-    if (!c->d_xslots[slot]) {
-        HIPCHK(c, hipMalloc(reinterpret_cast<void**>(&c->d_xctl[slot]), XCTL_WORDS * sizeof(uint32_t)));
-        HIPCHK(c, hipMalloc(reinterpret_cast<void**>(&c->d_xring[slot]), ring_bytes));
-        HIPCHK(c, hipMalloc(reinterpret_cast<void**>(&c->d_xslots[slot]), slot_bytes));
-        HIPCHK(c, hipMemsetAsync(c->d_xctl[slot], 0, XCTL_WORDS * sizeof(uint32_t), s));      // the kernel's last wavefront leaves it zero
-        c->xepoch[slot] = 0; zero = true;
-    }
-    if (!c->d_xdiag) {
-        HIPCHK(c, hipMalloc(reinterpret_cast<void**>(&c->d_xdiag), XDIAG_N * XDIAG_STRIDE * sizeof(uint32_t)));
-        HIPCHK(c, hipMemsetAsync(c->d_xdiag, 0, XDIAG_N * XDIAG_STRIDE * sizeof(uint32_t), s));
-    }
-    if (++c->xepoch[slot] > 1023u) { c->xepoch[slot] = 1; zero = true; }
-    if (zero) {
-        HIPCHK(c, hipMemsetAsync(c->d_xring[slot], 0, ring_bytes, s));
-        HIPCHK(c, hipMemsetAsync(c->d_xslots[slot], 0, slot_bytes, s));
-    }
-    x->ctl = c->d_xctl[slot]; x->ring = c->d_xring[slot]; x->slots = c->d_xslots[slot]; x->diag = c->xdiag_on ? c->d_xdiag : nullptr; x->epoch = c->xepoch[slot]; x->total_tiles = 0;
-    return CSKY_OK;
-}
-
 // frame_setup + clouds on stream s into d_out (compact rows).  stats: optional device counters.
 int clouds_dev(csky_ctx* c, const csky_cloud_params* p, int tile_w, const csky_bands* b, uint2* d_out, size_t pitch_bytes, hipStream_t s,
                unsigned long long* d_stats, bool setup, bool out_full = false) {
@@ -287,12 +249,6 @@ int clouds_dev(csky_ctx* c, const csky_cloud_params* p, int tile_w, const csky_b
         auto_mode = waves >= 6144 ? 5 : 2;
     }
     if (variant == 2) seg = 16;
-    // Light-march packet exchange (clouds_kernel_exchange): whole rays in the persistent form, idle wavefronts serve the light marches of the
-    // tiles still being marched.  CSKY_EXCHANGE / csky_set_exchange: 0 never, 1 the measured policy, 2 every launch of the compact kernel
-    // that may march whole rays.
-    const bool xch_wanted = variant == 3 && !(c->early_eps > 0.0f) && (c->segments == 0 || c->segments == 1) &&
-                            (c->exchange == 2 || (c->exchange == 1 && exchange_policy(c, waves)));
-    if (xch_wanted) { seg = 1; auto_mode = waves >= 12288 ? 5 : 2; }
     int mode = c->sched_mode >= 0 ? c->sched_mode : auto_mode;
     const int bw = seg == 5 ? 8 : (seg == 16 ? 128 : 32 / seg);   // workgroup footprint = bw x 8 pixels (seg 5: one tile; seg 16: the 16-wavefront "lds" strip)
     const int tiles_x = (g.tile_w + bw - 1) / bw, slabs = (g.n_bands * g.band_rows + 7) >> 3, nblocks = tiles_x * slabs;
@@ -307,12 +263,9 @@ int clouds_dev(csky_ctx* c, const csky_cloud_params* p, int tile_w, const csky_b
     // launches refill freed slots at least as well when nothing else is in flight), 1/4 frame 0.477 -> 0.539 (barely deeper than
     // the resident grid), 4096x2048 6.13 -> 6.19 (no tail to fill), cost-feedback order 1.90 -> 2.09.  So: whole-ray launches of
     // 12 Ki to 64 Ki wavefronts (they run in the static XCD-row order) while the caller keeps two frames in flight.
-    const bool xch = xch_wanted && seg == 1;
-    const bool persist = seg == 1 && variant == 3 && (xch || c->persistent == 2 || (c->persistent == 1 && !feedback && c->frames_in_flight >= 2 && waves >= 12288 && waves <= 65536));
+    const bool persist = seg == 1 && variant == 3 && (c->persistent == 2 || (c->persistent == 1 && !feedback && c->frames_in_flight >= 2 && waves >= 12288 && waves <= 65536));
     uint32_t* const heads = persist ? c->d_heads + slot * 16 : nullptr;
-    XchArgs xargs; const XchArgs* xp = nullptr;
-    if (xch) { if ((rc = ensure_exchange(c, slot, s, &xargs))) return rc; xp = &xargs; }
-    const int resident = xch ? c->resident_wgs / cloud_resident_workgroups_per_cu() * cloud_exchange_workgroups_per_cu() : c->resident_wgs;
+    const int resident = c->resident_wgs;
     hipEvent_t* kt = nullptr;                                    // timing pair of this launch (csky_set_kernel_timing)
     if (c->kt_on) {
         if ((size_t)c->kt_count * 2 + 2 > c->kt_ev.size()) {    // the pool grows on demand: no launch is ever dropped from the sum
@@ -328,7 +281,7 @@ int clouds_dev(csky_ctx* c, const csky_cloud_params* p, int tile_w, const csky_b
     if (!feedback) {
         if (kt) HIPCHK(c, hipEventRecord(kt[0], s));
         {   // a failed persistent launch may leave the slot's pop counters armed: re-zero them so that the next launch on this slot starts clean
-            const hipError_t le = launch_clouds(variant, seg, texset(c), c->d_fc, g, d_static, static_grid, d_out, d_stats, nullptr, s, heads, resident, xp);
+            const hipError_t le = launch_clouds(variant, seg, texset(c), c->d_fc, g, d_static, static_grid, d_out, d_stats, nullptr, s, heads, resident);
             if (le != hipSuccess) { if (heads) (void)hipMemsetAsync(heads, 0, 16 * sizeof(uint32_t), s); return fail(c, CSKY_ERR_HIP, "cloud kernel launch failed: %s", hipGetErrorString(le)); }
         }
         if (kt) HIPCHK(c, hipEventRecord(kt[1], s));
@@ -363,7 +316,7 @@ int clouds_dev(csky_ctx* c, const csky_cloud_params* p, int tile_w, const csky_b
     const int use_grid = c->lpt_valid[slot] ? nblocks : static_grid;
     if (kt) HIPCHK(c, hipEventRecord(kt[0], s));
     {
-        const hipError_t le = launch_clouds(variant, seg, texset(c), c->d_fc, g, use_order, use_grid, d_out, d_stats, cost, s, heads, resident, xp);
+        const hipError_t le = launch_clouds(variant, seg, texset(c), c->d_fc, g, use_order, use_grid, d_out, d_stats, cost, s, heads, resident);
         if (le != hipSuccess) { if (heads) (void)hipMemsetAsync(heads, 0, 16 * sizeof(uint32_t), s); return fail(c, CSKY_ERR_HIP, "cloud kernel launch failed: %s", hipGetErrorString(le)); }
     }
     if (kt) HIPCHK(c, hipEventRecord(kt[1], s));
@@ -425,8 +378,6 @@ int csky_create(csky_ctx** out, int device_id) {
     // A/B switch of tools/persistent_ab.sh: 0 = never, 1 = the policy of clouds_dev (default), 2 = every whole-ray launch
     if (const char* pe = getenv("CSKY_PERSISTENT")) c->persistent = atoi(pe);
     if (const char* pe = getenv("CSKY_PERSISTENT_WGS")) { const int n = atoi(pe); if (n > 0) c->resident_wgs = n; }
-    if (const char* pe = getenv("CSKY_EXCHANGE")) c->exchange = atoi(pe);
-    if (const char* pe = getenv("CSKY_EXCHANGE_DIAG")) c->xdiag_on = atoi(pe) != 0;
     *out = c;
     return CSKY_OK;
 }
@@ -438,11 +389,7 @@ void csky_destroy(csky_ctx* c) {
     void* ptrs[] = {c->d_shape, c->d_detail, c->d_weather, c->d_trans_h, c->d_trans_f, c->sky_h_ring[0], c->sky_h_ring[1], c->sky_f_ring[0], c->sky_f_ring[1],
                     c->d_stats, c->d_frame, c->d_composite, c->d_raw_large, c->d_raw_small, c->d_raw_weather, c->d_bake_meta, c->d_detail_h, c->d_wg_cost, c->d_lpt_order, c->d_lpt_hist, c->d_heads};
     for (void* p : ptrs) if (p) (void)hipFree(p);
-    if (c->d_xdiag) (void)hipFree(c->d_xdiag);
     for (int k = 0; k < RING; k++) {
-        if (c->d_xctl[k]) (void)hipFree(c->d_xctl[k]);
-        if (c->d_xring[k]) (void)hipFree(c->d_xring[k]);
-        if (c->d_xslots[k]) (void)hipFree(c->d_xslots[k]);
         if (c->fc_ring[k]) (void)hipFree(c->fc_ring[k]);
         if (c->d_order_ring[k]) (void)hipFree(c->d_order_ring[k]);
         if (c->ev_setup[k]) (void)hipEventDestroy(c->ev_setup[k]);
@@ -664,26 +611,6 @@ int csky_set_segments(csky_ctx* c, int segments) {
     if (!c) return fail(nullptr, CSKY_ERR_INVALID, "csky_set_segments: ctx is NULL");
     if (segments != 0 && segments != 1 && segments != 2 && segments != 4 && segments != 5) return fail(c, CSKY_ERR_INVALID, "csky_set_segments: 0 (auto), 1, 2, 4 (step ranges) or 5 (4 interleaved)");
     c->segments = segments; return CSKY_OK;
-}
-int csky_set_exchange(csky_ctx* c, int mode) {
-    if (!c) return fail(nullptr, CSKY_ERR_INVALID, "csky_set_exchange: ctx is NULL");
-    if (mode < 0 || mode > 2) return fail(c, CSKY_ERR_INVALID, "csky_set_exchange: 0 (never), 1 (policy) or 2 (every whole-ray launch of the compact kernel)");
-    c->exchange = mode; return CSKY_OK;
-}
-int csky_exchange_counters(csky_ctx* c, uint32_t counters[16], int reset) {
-    if (!c) return fail(nullptr, CSKY_ERR_INVALID, "csky_exchange_counters: ctx is NULL");
-    if (!counters) return fail(c, CSKY_ERR_INVALID, "csky_exchange_counters: counters is NULL");
-    int rc; if ((rc = bind(c))) return rc;
-    for (int k = 0; k < XDIAG_N; k++) counters[k] = 0;
-    if (reset & 1) c->xdiag_on = true;
-    if (reset & 2) c->xdiag_on = false;
-    if (!c->d_xdiag) return CSKY_OK;
-    HIPCHK(c, hipDeviceSynchronize());                       // a diagnostic: launches may sit on caller streams
-    uint32_t raw[XDIAG_N * XDIAG_STRIDE];
-    HIPCHK(c, hipMemcpy(raw, c->d_xdiag, sizeof raw, hipMemcpyDeviceToHost));
-    for (int k = 0; k < XDIAG_N; k++) counters[k] = raw[k * XDIAG_STRIDE];
-    if (reset & 1) HIPCHK(c, hipMemset(c->d_xdiag, 0, sizeof raw));
-    return CSKY_OK;
 }
 int csky_set_height_window(csky_ctx* c, int enabled) {
     if (!c) return fail(nullptr, CSKY_ERR_INVALID, "csky_set_height_window: ctx is NULL");

@@ -3,7 +3,6 @@
 #include <hip/hip_runtime_api.h>
 #include "csky_common.h"
 #include "composite_core.h"
-#include "exchange_args.h"
 
 namespace csky {
 
@@ -21,11 +20,9 @@ hipError_t launch_frame_setup(const CloudParams& p, const float4* d_sky, int sw,
 // seg = ray segments per ray (1, 2 or 4; variant 1 only): a workgroup covers 4/seg tiles of 8x8 pixels.
 // d_order[grid]: physical workgroup -> workgroup-footprint id (0xffffffff = idle), see api.cpp::build_schedule.
 hipError_t launch_clouds(int variant, int seg, const TexSet& t, const FrameConsts* d_fc, const RenderGeom& g, const uint32_t* d_order, int grid,
-                         uint2* d_out, unsigned long long* d_stats, uint32_t* d_wg_cost, hipStream_t s, uint32_t* d_heads = nullptr, int resident = 0,
-                         const XchArgs* xch = nullptr);   // xch: the persistent form with the light-march packet exchange (exchange.h; total_tiles is filled in here)
+                         uint2* d_out, unsigned long long* d_stats, uint32_t* d_wg_cost, hipStream_t s, uint32_t* d_heads = nullptr, int resident = 0);
 // resident 256-thread workgroups per CU of the "compact" kernel (its launch bound): the size of a persistent launch
 int cloud_resident_workgroups_per_cu();
-int cloud_exchange_workgroups_per_cu();   // the same for clouds_kernel_exchange
 // next launch's workgroup order from this launch's per-workgroup costs, heaviest first.  d_cost[n] and d_scratch[2048] must be zero
 // before their first use and are left zeroed (the cloud kernel accumulates the next costs into d_cost).
 hipError_t launch_lpt_order(uint32_t* d_cost, int n, int shift, uint32_t* d_scratch, uint32_t* d_order, hipStream_t s);

@@ -13,7 +13,6 @@
 #include "composite_core.h"
 #include "noise_core.h"
 #include "bake_core.h"
-#include "exchange.h"
 
 namespace csky {
 
@@ -394,8 +393,8 @@ constexpr int CQ_FLOATS = 7 * CQ_CAP + 3 * CQ_STEPS;         // pos(3) t hf ss p
 #endif
 // Step B of the compact march for ONE queued in-cloud sample: the reference's light march (clouds.glsl:186-199) from its position and the
 // state-independent half of its shading (:178, :202-209).  In: position, density t, height fraction, the owner ray's step length and phase
-// value.  Out: D.rgb, 1 / max(1e-7, t), dt (shade_terms).  Called by the sample's owner wavefront and, in clouds_kernel_exchange, by helper
-// wavefronts on other CUs (exchange.h): the same code on the same seven floats, so a frame does not depend on who ran it.
+// value.  Out: D.rgb, 1 / max(1e-7, t), dt (shade_terms).  A function of those seven floats alone (round 4's packet exchange ran it on other
+// CUs' wavefronts and got byte-identical frames: see the record further down).
 // `late(et, ehf, ess, eph)` delivers the four inputs the light march itself does not need AFTER it (the owner reads them from its LDS queue
 // then: four registers fewer across the march).
 template <class Late>
@@ -422,9 +421,7 @@ __device__ __forceinline__ void light_march_terms(const TexSet& T, const FrameCo
     shade_terms(fc, eph, et, ehf, dt, cd, Dr, Dg, Db, rq);                                             // :202-209
 }
 
-// XCH (clouds_kernel_exchange only): a flush may be PUBLISHED for a helper wavefront instead of executed, and is replayed later (exchange.h)
-template <bool XCH = false>
-__device__ __forceinline__ MarchOut march_compact(const TexSet& T, const FrameConsts& fc, Ray ray, float* __restrict__ q, int step_begin, int step_end, XchWave* xw = nullptr) {
+__device__ __forceinline__ MarchOut march_compact(const TexSet& T, const FrameConsts& fc, Ray ray, float* __restrict__ q, int step_begin, int step_end) {
     float* __restrict__ ev_px = q;
     float* __restrict__ ev_py = q + CQ_CAP;
     float* __restrict__ ev_pz = q + 2 * CQ_CAP;
@@ -452,60 +449,6 @@ __device__ __forceinline__ MarchOut march_compact(const TexSet& T, const FrameCo
     if (!__any(live)) return o;
     for (int i = 0; i < step_begin; i++) advance(px, py, pz, ray.sx, ray.sy, ray.sz);   // segment start: replay the fp32 additions (:173)
     int end = step_end;                                       // shrinks when the whole wavefront has left the height window
-    // exchange.h: composite the steps of this wavefront's OLDEST outstanding packet from the helper's results (clouds.glsl:207-210).  The five
-    // results of sample k sit in lane k, the step records in lane s: readlane / bpermute instead of an LDS round trip (the LDS queue is
-    // already collecting the next samples).
-    unsigned long long pg[5] = {0ull, 0ull, 0ull, 0ull, 0ull};   // XCH: result granules of the oldest outstanding packet, requested ahead of their use
-    uint32_t pseq = 0u; bool pvalid = false;
-    auto prefetch_oldest = [&]() {
-        if constexpr (XCH) {
-            const uint32_t seq = xw->rep;
-            const unsigned long long* sl = xw->slot0 + (size_t)(seq % (uint32_t)XK) * XS_U64;
-#pragma unroll
-            for (int p = 0; p < 5; p++) pg[p] = xld64(sl + (7 + p) * 64 + lane);
-            pseq = seq; pvalid = true;
-        }
-    };
-    auto replay_oldest = [&]() {
-        if constexpr (XCH) {
-            const uint32_t seq = xw->rep, tag = (xw->epoch << 19) | seq;
-            const unsigned long long* sl = xw->slot0 + (size_t)(seq % (uint32_t)XK) * XS_U64;
-            float r[5];
-            const unsigned long long t5 = XT_NOW();
-            bool ready = false;
-            if (pvalid && pseq == seq) {                      // the results were requested one flush ago (prefetch_oldest): usually all there
-                bool ok = true;
-#pragma unroll
-                for (int p = 0; p < 5; p++) { r[p] = __uint_as_float((uint32_t)pg[p]); ok = ok && (uint32_t)(pg[p] >> 32) == tag; }
-                ready = __all(ok);
-            }
-            pvalid = false;
-            if (!ready) xch_sweep<5>(sl + 7 * 64, lane, tag, r, xw->diag);
-            XT_ADD(xw->diag, 5, t5);
-#ifdef CSKY_XCH_TIMING
-            if (xw->diag && lane == 0) (void)xadd32(xw->diag + 13 * XDIAG_STRIDE, ((uint32_t)wall_clock64() - xw->tnote[seq % (uint32_t)XK]) >> 3);
-#endif
-            const uint4 rec = *reinterpret_cast<const uint4*>(sl + 12 * 64 + 2 * lane);
-            const uint32_t meta = xrfl(rec.w);
-            const int rn = (int)(meta & 0xffu), rcs = (int)(meta >> 8);
-            for (int s = 0; s < rcs; s++) {
-                const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)rec.x, s), hi = (unsigned)__builtin_amdgcn_readlane((int)rec.y, s);
-                const int base = __builtin_amdgcn_readlane((int)rec.z, s);
-                const bool mine = lane < 32 ? ((lo >> lane) & 1u) : ((hi >> (lane - 32)) & 1u);
-                const int slot = base + (int)__builtin_amdgcn_mbcnt_hi(hi, __builtin_amdgcn_mbcnt_lo(lo, 0u));
-                const int a = (slot & 63) << 2;
-                const float d0 = __int_as_float(__builtin_amdgcn_ds_bpermute(a, __float_as_int(r[0]))), d1 = __int_as_float(__builtin_amdgcn_ds_bpermute(a, __float_as_int(r[1])));
-                const float d2 = __int_as_float(__builtin_amdgcn_ds_bpermute(a, __float_as_int(r[2]))), d3 = __int_as_float(__builtin_amdgcn_ds_bpermute(a, __float_as_int(r[3])));
-                const float d4 = __int_as_float(__builtin_amdgcn_ds_bpermute(a, __float_as_int(r[4])));
-                if (mine && slot < rn) {
-                    composite_sample(d4, d3, d0, d1, d2, Tr, alpha, Lr, Lg, Lb);
-                    o.incloud++;
-                }
-            }
-            xw->rep = seq + 1u;
-        }
-    };
-    if constexpr (XCH) xch_ask(*xw, lane == 0, true);
     for (int i = step_begin;;) {
         // ---- A: one primary sample per lane (none once the segment is exhausted and only carried samples remain)
         if (i < end) {
@@ -531,7 +474,6 @@ __device__ __forceinline__ MarchOut march_compact(const TexSet& T, const FrameCo
                 cs++;
             }
             i++;
-            if constexpr (XCH) xch_flush_entry(*xw, lane == 0);      // the ticket of a packet published before this step is back by now
         }
         const bool last = i >= end;
         if (count == 0) { if (last) break; continue; }
@@ -542,69 +484,23 @@ __device__ __forceinline__ MarchOut march_compact(const TexSet& T, const FrameCo
         wave_lds_fence();
         const int n = count < 64 ? count : 64;
         unsigned long long carry = 0ull;                     // lanes of the last step whose sample is still queued
-        bool published = false;
-        if constexpr (XCH) {
-            // exchange.h: hand the flush to a helper wavefront when this XCD has some and their queue is shallow; the steps are replayed
-            // later, in order, from the helper's results.  (The bounded-error early-out needs T after every flush: no exchange then.)
-            if (cs <= 64 && !(fc.early_eps > 0.0f) && xch_should_publish(*xw)) {
-                const unsigned long long t6 = XT_NOW();
-                xch_flush_entry(*xw, lane == 0);           // (two flushes without a primary step in between: the end of a march)
-                if (xw->pub - xw->rep == (uint32_t)XK) replay_oldest();
-                const uint32_t seq = xw->pub, tag = (xw->epoch << 19) | seq;
-                unsigned long long* sl = xw->slot0 + (size_t)(seq % (uint32_t)XK) * XS_U64;
-                const bool act = lane < n;                   // unused lanes carry t = 0
-                xst64(sl + 0 * 64 + lane, xgranule(tag, act ? ev_px[lane] : 0.0f)); xst64(sl + 1 * 64 + lane, xgranule(tag, act ? ev_py[lane] : 0.0f));
-                xst64(sl + 2 * 64 + lane, xgranule(tag, act ? ev_pz[lane] : 0.0f)); xst64(sl + 3 * 64 + lane, xgranule(tag, act ? ev_t[lane] : 0.0f));
-                xst64(sl + 4 * 64 + lane, xgranule(tag, act ? ev_hf[lane] : 0.0f)); xst64(sl + 5 * 64 + lane, xgranule(tag, act ? ev_ss[lane] : 0.0f));
-                xst64(sl + 6 * 64 + lane, xgranule(tag, act ? ev_ph[lane] : 0.0f));
-                uint4 rec;                                   // this wavefront's own step records, read back by the same lanes at replay time
-                rec.x = lane < cs ? st_lo[lane] : 0u; rec.y = lane < cs ? st_hi[lane] : 0u; rec.z = lane < cs ? st_base[lane] : 0u; rec.w = ((uint32_t)cs << 8) | (uint32_t)n;
-                *reinterpret_cast<uint4*>(sl + 12 * 64 + 2 * lane) = rec;
-                if (lane == 0) { xw->tkv = xadd32(xw->ctl + XCTL_TAIL + 32 * xw->xcc, 1u); if (xw->diag) (void)xadd32(xw->diag + 0 * XDIAG_STRIDE, 1u); }
-                xw->pend = 1u; xw->pub = seq + 1u;
-                const unsigned lo = st_lo[cs - 1], hi = st_hi[cs - 1];
-                const bool mine = lane < 32 ? ((lo >> lane) & 1u) : ((hi >> (lane - 32)) & 1u);
-                const int slot = (int)st_base[cs - 1] + (int)__builtin_amdgcn_mbcnt_hi(hi, __builtin_amdgcn_mbcnt_lo(lo, 0u));
-                carry = __ballot(mine && slot >= n);
-                published = true;
-                if (xw->pub - xw->rep == (uint32_t)XK) prefetch_oldest();   // the next publication replays the oldest packet first: ask for its results now
-#ifdef CSKY_XCH_TIMING
-                if (lane == 0) xw->tnote[seq % (uint32_t)XK] = (uint32_t)wall_clock64();
-#endif
-                XT_ADD(xw->diag, 6, t6);
-            } else if (xw->pub != xw->rep) {                 // a local flush composites now: everything older first
-                xch_flush_entry(*xw, lane == 0);
-                while (xw->pub != xw->rep) replay_oldest();
-            }
-            xch_ask(*xw, lane == 0, false);                  // (answer consumed at the next flush: its latency hides behind the primary steps in between)
+        if (lane < n) {
+            float Dr, Dg, Db, rq, dt;
+            light_march_terms(T, fc, ls, nd, ev_px[lane], ev_py[lane], ev_pz[lane],
+                              [&](float& et, float& ehf, float& ess, float& eph) { et = ev_t[lane]; ehf = ev_hf[lane]; ess = ev_ss[lane]; eph = ev_ph[lane]; }, Dr, Dg, Db, rq, dt);
+            ev_px[lane] = Dr; ev_py[lane] = Dg; ev_pz[lane] = Db; ev_t[lane] = rq; ev_hf[lane] = dt;           // the sample's slot now holds its terms
         }
-        if (!published) {
-            if constexpr (XCH) {                                     // nothing is outstanding here: tell the register allocator that the prefetch registers are dead across the light march
-                pvalid = false;
-#pragma unroll
-                for (int p = 0; p < 5; p++) pg[p] = 0ull;
+        wave_lds_fence();
+        // ---- C: replay the steps in order; owners of evaluated samples (slot < n) composite (:207-210)
+        for (int s = 0; s < cs; s++) {
+            const unsigned lo = st_lo[s], hi = st_hi[s];
+            const bool mine = lane < 32 ? ((lo >> lane) & 1u) : ((hi >> (lane - 32)) & 1u);
+            const int slot = (int)st_base[s] + (int)__builtin_amdgcn_mbcnt_hi(hi, __builtin_amdgcn_mbcnt_lo(lo, 0u));
+            if (mine && slot < n) {
+                composite_sample(ev_hf[slot], ev_t[slot], ev_px[slot], ev_py[slot], ev_pz[slot], Tr, alpha, Lr, Lg, Lb);
+                o.incloud++;
             }
-#ifdef CSKY_XCH_TIMING
-            if constexpr (XCH) { if (xw->diag && lane == 0) (void)xadd32(xw->diag + 14 * XDIAG_STRIDE, 1u); }
-#endif
-            if (lane < n) {
-                float Dr, Dg, Db, rq, dt;
-                light_march_terms(T, fc, ls, nd, ev_px[lane], ev_py[lane], ev_pz[lane],
-                                  [&](float& et, float& ehf, float& ess, float& eph) { et = ev_t[lane]; ehf = ev_hf[lane]; ess = ev_ss[lane]; eph = ev_ph[lane]; }, Dr, Dg, Db, rq, dt);
-                ev_px[lane] = Dr; ev_py[lane] = Dg; ev_pz[lane] = Db; ev_t[lane] = rq; ev_hf[lane] = dt;           // the sample's slot now holds its terms
-            }
-            wave_lds_fence();
-            // ---- C: replay the steps in order; owners of evaluated samples (slot < n) composite (:207-210)
-            for (int s = 0; s < cs; s++) {
-                const unsigned lo = st_lo[s], hi = st_hi[s];
-                const bool mine = lane < 32 ? ((lo >> lane) & 1u) : ((hi >> (lane - 32)) & 1u);
-                const int slot = (int)st_base[s] + (int)__builtin_amdgcn_mbcnt_hi(hi, __builtin_amdgcn_mbcnt_lo(lo, 0u));
-                if (mine && slot < n) {
-                    composite_sample(ev_hf[slot], ev_t[slot], ev_px[slot], ev_py[slot], ev_pz[slot], Tr, alpha, Lr, Lg, Lb);
-                    o.incloud++;
-                }
-                if (s == cs - 1) carry = __ballot(mine && slot >= n);
-            }
+            if (s == cs - 1) carry = __ballot(mine && slot >= n);
         }
         wave_lds_fence();
         // ---- keep what was not evaluated: samples n..count-1 move to the front, the last step keeps its unevaluated lanes
@@ -625,10 +521,6 @@ __device__ __forceinline__ MarchOut march_compact(const TexSet& T, const FrameCo
             if (!__any(live)) break;
         }
         if (last && count == 0) break;                               // carried samples get one more (partial) flush
-    }
-    if constexpr (XCH) {                                             // the ray is complete when every published flush has been composited
-        xch_flush_entry(*xw, lane == 0);
-        while (xw->pub != xw->rep) replay_oldest();
     }
     o.r = Lr; o.g = Lg; o.b = Lb; o.a = sat(alpha); o.t = Tr;                                                  // :213-214
     return o;
@@ -873,10 +765,9 @@ __global__ __launch_bounds__(1024) void clouds_kernel_lds(TexSet T, const FrameC
                                // together) 7 waves x 72 VGPRs beat 8 waves x 64 VGPRs + spills: whole frame 1.83 -> 1.80 ms, 1/4 frame 0.49 -> 0.48
 #endif
 // One workgroup's footprint (4 tiles / SEG): `logical` = slab * tiles_x + bx, `rec` = its position in the launch order (timeline build).
-template <int VARIANT, int SEG, bool XCH = false>
+template <int VARIANT, int SEG>
 __device__ __forceinline__ void render_block(TexSet T, const FrameConsts* __restrict__ fcp, const RenderGeom& G, const uint32_t logical, const uint32_t rec,
-                                             uint2* __restrict__ out, unsigned long long* __restrict__ stats, uint32_t* __restrict__ wg_cost, const int tile_of_wave = -1,
-                                             XchWave* xw = nullptr) {
+                                             uint2* __restrict__ out, unsigned long long* __restrict__ stats, uint32_t* __restrict__ wg_cost, const int tile_of_wave = -1) {
     constexpr int BW = 32 / SEG;                               // workgroup footprint width in pixels
     const int tiles_x = (G.tile_w + BW - 1) / BW;
     const int local_rows = G.n_bands * G.band_rows;
@@ -904,7 +795,7 @@ __device__ __forceinline__ void render_block(TexSet T, const FrameConsts* __rest
     } else {
         __shared__ float lds[4][VARIANT == 3 ? CQ_FLOATS : Q_FLOATS];
         const int s0 = (fc.primary_steps * seg) / SEG, s1 = (fc.primary_steps * (seg + 1)) / SEG;
-        if constexpr (VARIANT == 3) o = march_compact<XCH>(T, fc, ray, &lds[wave][0], s0, s1, xw);
+        if constexpr (VARIANT == 3) o = march_compact(T, fc, ray, &lds[wave][0], s0, s1);
         else o = march_queue(T, fc, ray, &lds[wave][0], s0, s1);
         if constexpr (SEG > 1) {
             __shared__ float comb[4][5][64];
@@ -1027,153 +918,21 @@ __global__ __launch_bounds__(256, VARIANT == 3 ? CSKY_COMPACT_WAVES : 7) void cl
     }
 }
 
-// ---- light-march packet exchange (round 4; protocol in exchange.h) ---------------------------------------------------------------
-// A helper wavefront of XCD xcc: take the queue's next ticket, wait at its ring entry, run step B for the packet published there, write the
-// five results back; on an EXIT entry pass it on (exchange.h) and leave.
-__device__ __forceinline__ void xch_help(const TexSet& T, const FrameConsts& fc, const XchArgs& X, const uint32_t xcc, const int lane) {
-    const bool lane0 = lane == 0;
-    const int ls = fc.light_steps;
-    const float nd = -fc.density;
-    unsigned long long* const ring = X.ring + (size_t)xcc * XQ_N;
-    const unsigned long long t15 = XT_NOW();
-    for (;;) {
-        uint32_t tv = 0;
-        if (lane0) tv = xadd32(X.ctl + XCTL_HEAD + 32 * xcc, 1u);
-        const uint32_t h = xrfl(tv);
-        // the queue entry: {epoch << 22 | ticket + 1, wavefront << 19 | packet number}
-        const unsigned long long* ent = ring + (h & (uint32_t)(XQ_N - 1));
-        const uint32_t qtag = (X.epoch << 22) | ((h + 1u) & 0x3fffffu);
-        const unsigned long long t9 = XT_NOW();
-        uint32_t elo;
-        for (uint32_t spins = 0;; spins++) {
-            unsigned long long e = 0ull;
-            if (lane0) e = xld64(ent);
-            elo = xrfl((uint32_t)e);
-            if (xrfl((uint32_t)(e >> 32)) == qtag) break;
-            if (spins < 8u) __builtin_amdgcn_s_sleep(2); else if (spins < 64u) __builtin_amdgcn_s_sleep(16); else __builtin_amdgcn_s_sleep(64);   // 0.05, 0.4, 1.7 us
-        }
-        XT_ADD(X.diag, 9, t9);
-        if (elo == XCH_EXIT) {                                // the launch is complete: tell the holders of tickets tail + 64 (i + 1) + lane, leave
-            uint32_t tl = 0;
-            if (lane0) tl = xld32(X.ctl + XCTL_TAIL + 32 * xcc);
-            tl = xrfl(tl);
-            const uint32_t k = tl + 64u * (h - tl + 1u) + (uint32_t)lane;
-            if (h - tl < (uint32_t)XQ_N / 64u - 1u) xst64(ring + (k & (uint32_t)(XQ_N - 1)), ((unsigned long long)((X.epoch << 22) | ((k + 1u) & 0x3fffffu)) << 32) | XCH_EXIT);
-            XT_ADD(X.diag, 15, t15);
-            return;
-        }
-        const uint32_t w = elo >> 19, seq = elo & 0x7ffffu, tag = (X.epoch << 19) | seq;
-        unsigned long long* sl = X.slots + ((size_t)w * XK + (seq % (uint32_t)XK)) * XS_U64;
-        float in[7];
-        const unsigned long long t10 = XT_NOW();
-        xch_sweep<7>(sl, lane, tag, in, X.diag);
-        XT_ADD(X.diag, 10, t10);
-        const unsigned long long t11 = XT_NOW();
-        float Dr = 0.0f, Dg = 0.0f, Db = 0.0f, rq = 0.0f, dt = 0.0f;
-        if (in[3] > 0.0f) {                                   // t > 0 for every real sample (clouds.glsl:184); unused lanes carry 0
-            light_march_terms(T, fc, ls, nd, in[0], in[1], in[2],
-                              [&](float& et, float& ehf, float& ess, float& eph) { et = in[3]; ehf = in[4]; ess = in[5]; eph = in[6]; }, Dr, Dg, Db, rq, dt);
-        }
-        XT_ADD(X.diag, 11, t11);
-        xst64(sl + 7 * 64 + lane, xgranule(tag, Dr)); xst64(sl + 8 * 64 + lane, xgranule(tag, Dg)); xst64(sl + 9 * 64 + lane, xgranule(tag, Db));
-        xst64(sl + 10 * 64 + lane, xgranule(tag, rq)); xst64(sl + 11 * 64 + lane, xgranule(tag, dt));
-        if (lane0 && X.diag) (void)xadd32(X.diag + 1 * XDIAG_STRIDE, 1u);
-    }
-}
-
-// clouds_kernel_persistent whose wavefronts stay after the tile sequences are empty and serve the light marches of the tiles still being
-// marched (exchange.h).  Launched with as many workgroups as the chip holds WHATEVER the number of tiles: in a rank's 1/8 share 43 % of the
-// wavefront slots have no tile at all and help from the first microsecond.
-#ifndef CSKY_XCH_WAVES
-#define CSKY_XCH_WAVES 6       // waves/SIMD of the exchange kernel: the results of the oldest packet are held in ten registers across the primary steps
-#endif
-template <int VARIANT>
-__global__ __launch_bounds__(256, CSKY_XCH_WAVES) void clouds_kernel_exchange(TexSet T, const FrameConsts* __restrict__ fcp, RenderGeom G,
-        const uint32_t* __restrict__ order, const uint32_t n_items, uint32_t* __restrict__ heads, XchArgs X, uint2* __restrict__ out, unsigned long long* __restrict__ stats,
-        uint32_t* __restrict__ wg_cost) {
-    unsigned xcc;
-    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
-    xcc &= 7u;
-    const uint32_t per_xcd = (n_items + 7u) >> 3;
-    __shared__ uint32_t ticket, slot_ready[2], slot_reads[2], slot_entry[2], slot_rec[2];
-    if (threadIdx.x == 0) { ticket = 0; slot_ready[0] = slot_ready[1] = 0; slot_reads[0] = slot_reads[1] = 0; }
-    __syncthreads();
-    const int lane = threadIdx.x & 63;
-    const bool lane0 = lane == 0;
-    XchWave xw;
-    xw.wave_id = blockIdx.x * 4u + (threadIdx.x >> 6);
-    xw.slot0 = X.slots + (size_t)xw.wave_id * XK * XS_U64;
-    xw.ctl = X.ctl; xw.xcc = xcc;
-    xw.ring = X.ring + (size_t)xcc * XQ_N;
-    xw.diag = X.diag;
-#ifdef CSKY_XCH_TIMING
-    __shared__ uint32_t xtnote[4][XK];
-    xw.tnote = &xtnote[threadIdx.x >> 6][0];
-#else
-    xw.tnote = nullptr;
-#endif
-    xw.epoch = X.epoch; xw.pub = 0u; xw.rep = 0u; xw.pend = 0u; xw.tkv = 0u; xw.have = 0u; xw.asked = 0u; xw.nfl = 0u; xw.anyv = 0u;
-    for (;;) {
-        uint32_t tv = 0;
-        if (lane0) tv = __hip_atomic_fetch_add(&ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-        const uint32_t t = (uint32_t)__builtin_amdgcn_readfirstlane((int)tv);
-        const uint32_t f = t >> 2, sl = f & 1u;
-        const int tile = (int)(t & 3u);
-        uint32_t logical = 0xfffffffeu, rec = 0;               // 0xfffffffe: every sequence is empty
-        if (tile == 0) {
-            for (unsigned k = 0; k < 8u; k++) {
-                const unsigned y = (xcc + k) & 7u;
-                uint32_t jv = 0;
-                if (lane0) jv = atomicAdd(&heads[y], 1u);
-                const uint32_t j = (uint32_t)__builtin_amdgcn_readfirstlane((int)jv);
-                const uint32_t i = 8u * j + y;
-                if (j < per_xcd && i < n_items) { logical = order[i]; rec = i; break; }
-            }
-            for (;;) {                                         // the slot's previous footprint (f - 2) had three readers
-                const uint32_t r = (uint32_t)__builtin_amdgcn_readfirstlane((int)__hip_atomic_load(&slot_reads[sl], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP));
-                if (r == 3u * (f >> 1)) break;
-                __builtin_amdgcn_s_sleep(1);
-            }
-            if (lane0) {
-                slot_entry[sl] = logical; slot_rec[sl] = rec;
-                __hip_atomic_store(&slot_ready[sl], f + 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
-            }
-        } else {
-            for (;;) {
-                const uint32_t r = (uint32_t)__builtin_amdgcn_readfirstlane((int)__hip_atomic_load(&slot_ready[sl], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP));
-                if (r == f + 1u) break;
-                __builtin_amdgcn_s_sleep(1);
-            }
-            logical = (uint32_t)__builtin_amdgcn_readfirstlane((int)slot_entry[sl]);
-            rec = (uint32_t)__builtin_amdgcn_readfirstlane((int)slot_rec[sl]);
-            if (lane0) __hip_atomic_fetch_add(&slot_reads[sl], 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
-        }
-        if (logical == 0xfffffffeu) break;
-        const unsigned long long t7 = XT_NOW();
-        if (logical != 0xffffffffu) render_block<VARIANT, 1, true>(T, fcp, G, logical, rec, out, stats, wg_cost, tile, &xw);
-        XT_ADD(X.diag, 7, t7);
-        // one more tile finished (idle padding entries count: total = 4 x entries).  Whoever finishes the LAST one releases the helpers: EXIT
-        // into the first 64 unserved tickets of every queue (no publication can follow: every owner is through); the helpers pass it on.
-        uint32_t dv = 0;
-        if (lane0) dv = xadd32(X.ctl + XCTL_DONE, 1u);
-        if (xrfl(dv) + 1u == X.total_tiles) {
-            uint32_t tlv = 0;
-            if (lane < 8) tlv = xld32(X.ctl + XCTL_TAIL + 32 * lane);
-            for (int y = 0; y < 8; y++) {
-                const uint32_t k = (uint32_t)__builtin_amdgcn_readlane((int)tlv, y) + (uint32_t)lane;
-                xst64(X.ring + (size_t)y * XQ_N + (k & (uint32_t)(XQ_N - 1)), ((unsigned long long)((X.epoch << 22) | ((k + 1u) & 0x3fffffu)) << 32) | XCH_EXIT);
-            }
-        }
-    }
-    // no tile left for this wavefront: serve the light marches of the ones still marching on this XCD until the launch is complete
-    if (lane0 && xld32(X.ctl + XCTL_ANY + xcc) == 0u) __hip_atomic_store((xg32*)(X.ctl + XCTL_ANY + xcc), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    xch_help(T, *fcp, X, xcc, lane);
-    if (lane0 && atomicAdd(&heads[8], 1u) == gridDim.x * 4u - 1u) {   // the last wavefront out re-arms every counter for the slot's next launch
-        for (unsigned k = 0; k < 9u; k++) atomicExch(&heads[k], 0u);
-        for (unsigned k = 0; k < 8u; k++) { atomicExch(&X.ctl[XCTL_TAIL + 32 * k], 0u); atomicExch(&X.ctl[XCTL_HEAD + 32 * k], 0u); atomicExch(&X.ctl[XCTL_ANY + k], 0u); }
-        atomicExch(&X.ctl[XCTL_DONE], 0u);
-    }
-}
+// ---- light-march packet exchange (round 4: built, measured, removed; evidence profiles/r04/exchange_ab.txt; code: commit "exchange: ...") ----
+// the persistent form above whose wavefronts, once every sequence is empty, stay and serve the light marches of the tiles
+// still being marched.  An owner published a flush (the 7 floats x 64 samples march_compact parks in LDS) to a per-XCD ticket queue in global
+// memory instead of running step B, kept marching, and composited the helper's five results per sample IN ORDER later (readlane / ds_bpermute
+// replay, 4-8 packets outstanding per wavefront); helpers ran the same light_march_terms().  Transport per cdna_hip_programming.md G16: 8-byte
+// {tag, value} granules, relaxed agent-scope (sc1) stores and loads, a per-launch epoch in the tags: no fence, no L1 invalidate.
+//   * Frames BYTE-IDENTICAL to clouds_kernel<3,1> in every build (512x256, C3, a rank's 1/8 share), no spin ever hit its bound.
+//   * Slower everywhere.  ms per C3 frame alone / two in flight / 1/8 share x1: product 2.03 / 1.69 / 0.41; four protocols 144.8 -> 65.5
+//     -> 5.94 -> 2.88 / 2.78 / 0.96 (idle helpers scanning shared words; compare-exchange pops: one winner per round trip with hundreds in
+//     flight; owners reading a policy word per flush; finally static per-XCD queues where no shared word is polled at all).  The kernel's own
+//     cost with publication compiled out: 2.23 / 2.22 / 0.86 (helpers hold their slots to the end, so the next frame cannot fill the tail).
+//   * Why: publication -> results read takes ~43 us (six memory hops at 2-5 us each on a loaded chip) against 6.8 us of work per packet;
+//     with four packets outstanding an owner waits ~11 us per flush where running it costs 6.  Hiding it needs ~20 packets in flight per
+//     wavefront plus prefetched results in a kernel at its 72-VGPR budget (the prefetch build: 51 spilled registers, 4.0 ms).  The unit of
+//     work the compact march can hand over is an order of magnitude too small for a cross-CU hand-off on this chip.
 
 // ---- launch-tail / share experiments of round 2 (measured, removed; evidence under profiles/r02/) -----------------------------
 // A whole-frame launch drains for the last ~27 % of its span with the chip 3/4 empty (time-integral of occupancy 72-76 %).  Three
@@ -1260,19 +1019,12 @@ hipError_t launch_static_order(int mode, int tiles_x, int slabs, int grid, uint3
 
 static const char* const kVariantNames[] = {"lockstep", "queue", "queue-lds", "compact"};
 int cloud_resident_workgroups_per_cu() { return CSKY_COMPACT_WAVES; }
-int cloud_exchange_workgroups_per_cu() { return CSKY_XCH_WAVES; }
 int cloud_variant_count() { return (int)(sizeof(kVariantNames) / sizeof(kVariantNames[0])); }
 const char* cloud_variant_name(int v) { return (v >= 0 && v < cloud_variant_count()) ? kVariantNames[v] : nullptr; }
 
 hipError_t launch_clouds(int variant, int seg, const TexSet& t, const FrameConsts* d_fc, const RenderGeom& g, const uint32_t* d_order, int grid,
-                         uint2* d_out, unsigned long long* d_stats, uint32_t* d_wg_cost, hipStream_t s, uint32_t* d_heads, int resident, const XchArgs* xch) {
+                         uint2* d_out, unsigned long long* d_stats, uint32_t* d_wg_cost, hipStream_t s, uint32_t* d_heads, int resident) {
     if (grid <= 0) return hipSuccess;
-    if (xch && d_heads && variant == 3 && seg == 1) {          // persistent form with the light-march packet exchange: always a chip-filling launch
-        XchArgs x = *xch;
-        x.total_tiles = 4u * (uint32_t)grid;
-        clouds_kernel_exchange<3><<<resident, 256, 0, s>>>(t, d_fc, g, d_order, (uint32_t)grid, d_heads, x, d_out, d_stats, d_wg_cost);
-        return hipGetLastError();
-    }
     if (d_heads && variant == 3 && seg == 1) {                 // persistent form, see clouds_kernel_persistent
         clouds_kernel_persistent<3><<<grid < resident ? grid : resident, 256, 0, s>>>(t, d_fc, g, d_order, (uint32_t)grid, d_heads, d_out, d_stats, d_wg_cost);
         return hipGetLastError();

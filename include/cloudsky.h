@@ -15,7 +15,7 @@
  * Process environment: when libcloudsky.so is LOADED it sets GPU_MAX_HW_QUEUES=8 for the process unless the variable is already set (the HIP
  * runtime reads it at its first call; with the default of 4 the streams of two frames in flight share hardware queues and do not overlap).
  * CSKY_NO_ENV=1 in the environment disables that; csky_set_frames_in_flight(>= 2) then leaves a warning in csky_last_error when the
- * variable is not in effect.  Other variables read (all optional, A/B switches): CSKY_PERSISTENT, CSKY_PERSISTENT_WGS, CSKY_EXCHANGE, CSKY_MULTI_STAGED.
+ * variable is not in effect.  Other variables read (all optional, A/B switches): CSKY_PERSISTENT, CSKY_PERSISTENT_WGS, CSKY_MULTI_STAGED.
  *
  * Images are tightly packed little-endian RGBA half floats (DATA_FORMAT_R16G16B16A16_SFLOAT,
  * cloud_sky.gd:369; sky_lut.gd:84; transmittance_lut.gd:37), row-major, row 0 = pixel y == 0.
@@ -35,7 +35,7 @@ extern "C" {
 #define CSKY_ERR_IO (-4)         /* asset file problem                                       */
 #define CSKY_ERR_STATE (-5)      /* e.g. clouds requested before noise / LUTs exist          */
 
-#define CSKY_ABI_VERSION 5  /* 5: csky_set_exchange, csky_exchange_counters; 4: csky_submit_* / csky_collect, csky_multi_set_groups / _set_staged, csky_composite_view, csky_external_frame_* (incl. _fence / _ready / _wait); 3: csky_set_noise_mips, csky_decode_bc7, csky_load_ctex[3d]; 2: csky_multi_*, device asset builders */
+#define CSKY_ABI_VERSION 4  /* 4: csky_submit_* / csky_collect, csky_multi_set_groups / _set_staged, csky_composite_view, csky_external_frame_* (incl. _fence / _ready / _wait); 3: csky_set_noise_mips, csky_decode_bc7, csky_load_ctex[3d]; 2: csky_multi_*, device asset builders */
 
 typedef struct csky_ctx csky_ctx; /* opaque: owns every device allocation, the HIP stream and events */
 
@@ -250,18 +250,6 @@ int csky_set_schedule(csky_ctx* ctx, int mode);
  * step ranges for one GPU's share of a split frame, 4 interleaved step sets for tile-sized launches such as the
  * reference's 96x96 temporal tiles), 1, 2, 4 (step ranges) or 5 (4 interleaved). */
 int csky_set_segments(csky_ctx* ctx, int segments);
-/* Light-march packet exchange (tuning knob, results are identical): whole-ray launches of the compact kernel run in a persistent form
- * whose wavefronts, once the tile sequences are empty, serve the light marches (clouds.glsl:186-199) of the tiles still being marched:
- * an owner wavefront publishes a flush of 64 in-cloud samples to a per-XCD queue, keeps marching, and composites the results in order
- * later (csrc/exchange.h).  0 = never, 1 = where it was measured to pay (api.cpp::exchange_policy; default), 2 = every launch that may
- * march whole rays.  Environment variable CSKY_EXCHANGE, read by csky_create, sets the initial mode.  Not used with csky_set_early_out > 0. */
-int csky_set_exchange(csky_ctx* ctx, int mode);
-/* Diagnostics of the exchange since the last reset: [0] packets published, [1] packets run by helper wavefronts, [2] result sweeps that had
- * to wait, [3] helpers that found no packet right after finishing one, [4] spins that ran into their bound (a protocol fault: must be 0).
- * Counting costs an atomic per packet on one word, so it is OFF until asked for: reset = 1 reads, zeroes and switches it ON for the following
- * launches, reset = 2 reads and switches it OFF, reset = 3 zeroes and switches it off, 0 only reads (environment CSKY_EXCHANGE_DIAG=1: on from
- * csky_create).  Waits for the device. */
-int csky_exchange_counters(csky_ctx* ctx, uint32_t counters[16], int reset);   /* [5..15]: phase times of the diagnostic build (csrc -DCSKY_XCH_TIMING), else 0 */
 /* Policy hint for the automatic segment / schedule choice: n = 2..4: the caller keeps n frames in flight by rotating n streams
  * between consecutive csky_render_*_device calls (always safe: per-frame state lives in four-deep rings ordered by events); the
  * next frame then fills the tail of this one and fewer, longer wavefronts are the better choice for partial frames.  Default 1;
