@@ -336,29 +336,33 @@ CSKY_HD float detail_tap(const TexSet& T, int lvl, float sx, float sy, float sz)
 
 CSKY_HD float height_fraction(float r) { return sat((r - SKY_B_RADIUS) * (1.0f / (SKY_T_RADIUS - SKY_B_RADIUS))); }  // clouds.glsl:77-80
 
-CSKY_HD float smoothstep_fast(float e0, float e1, float x) {
-    const float t = sat((x - e0) * fast_rcp(e1 - e0));
-    return t * t * (3.0f - 2.0f * t);
-}
-// clouds.glsl:82-95.  mixGradients() is piecewise linear in the cloud type ct: below 0.5 only stratus (1-2ct) and
-// stratocumulus (2ct) are non-zero, above 0.5 only stratocumulus (2-2ct) and cumulus (2ct-1), so each of the four
-// gradient corners is A + ct*B with (A,B) picked by the branch (8 selects + 4 FMA instead of 3 weights x 4 x 2 FMA).
+// clouds.glsl:82-95: g = smoothstep(gx, gy, hf) - smoothstep(gz, gw, hf), the four corners mixed by cloud type.
+//  * mixGradients() is piecewise linear in the cloud type ct: below 0.5 only stratus (1-2ct) and stratocumulus (2ct) are non-zero, above 0.5
+//    only stratocumulus (2-2ct) and cumulus (2ct-1), so each corner is A + ct*B with (A,B) picked by the branch.
+//  * Round 4: the two ramps never overlap -- gy < gz for every cloud type (0.05..0.2 < 0.09..0.48 below 0.5, 0.0625..0.2 < 0.48..0.78 above) --
+//    so of t1 = sat((hf-gx)/(gy-gx)) and t2 = sat((hf-gz)/(gw-gz)) at most one lies strictly inside (0,1): t1 < 1 implies t2 == 0, t2 > 0
+//    implies t1 == 1.  With S(t) = t^2 (3 - 2t) and S(1 - t) = 1 - S(t):   S(t1) - S(t2) = S(t1 - t2),   ONE polynomial instead of two; and
+//    both reciprocals come from ONE v_rcp_f32: r = 1 / (d1 d2), 1/d1 = r d2, 1/d2 = r d1, with the widths d1 = gy-gx, d2 = gw-gz linear in ct
+//    like the corners.  55 -> 42 issue cycles per evaluation (7.5 M wave-level evaluations per C3 frame, profiles/r04/line_profile_*.txt);
+//    the value moves by ~1e-7 (section B tolerance; the height window keeps 0.03 of slack in g, bake.h).
 CSKY_HD float density_height_gradient(const FrameConsts& fc, float hf, float ct) {
     const float c = ct;
     constexpr float K = 1.0f / 255.0f;
-    float gx, gy, gz, gw;
+    float gx, d1, gz, d2;
     if (fc.ct_mode == 1) {
-        gx = 0.03f + c * (-0.02f * K); gy = 0.3375f + c * (-0.275f * K); gz = 0.18f + c * (0.6f * K); gw = 0.25f + c * (0.75f * K);
+        gx = 0.03f + c * (-0.02f * K); d1 = (0.3375f - 0.03f) + c * ((-0.275f + 0.02f) * K); gz = 0.18f + c * (0.6f * K); d2 = (0.25f - 0.18f) + c * ((0.75f - 0.6f) * K);
     } else if (fc.ct_mode == 2) {
-        gx = 0.02f + c * 0.0f; gy = 0.05f + c * (0.3f * K); gz = 0.09f + c * (0.78f * K); gw = 0.11f + c * (1.03f * K);
+        gx = 0.02f + c * 0.0f; d1 = (0.05f - 0.02f) + c * (0.3f * K); gz = 0.09f + c * (0.78f * K); d2 = (0.11f - 0.09f) + c * ((1.03f - 0.78f) * K);
     } else {
         const bool hi = ct >= 127.5f;
         gx = (hi ? 0.03f : 0.02f) + c * (hi ? -0.02f * K : 0.0f);
-        gy = (hi ? 0.3375f : 0.05f) + c * (hi ? -0.275f * K : 0.3f * K);
+        d1 = (hi ? 0.3375f - 0.03f : 0.05f - 0.02f) + c * (hi ? (-0.275f + 0.02f) * K : 0.3f * K);
         gz = (hi ? 0.18f : 0.09f) + c * (hi ? 0.6f * K : 0.78f * K);
-        gw = (hi ? 0.25f : 0.11f) + c * (hi ? 0.75f * K : 1.03f * K);
+        d2 = (hi ? 0.25f - 0.18f : 0.11f - 0.09f) + c * (hi ? (0.75f - 0.6f) * K : (1.03f - 0.78f) * K);
     }
-    return smoothstep_fast(gx, gy, hf) - smoothstep_fast(gz, gw, hf);
+    const float r = fast_rcp(d1 * d2);
+    const float t = sat((hf - gx) * (r * d2)) - sat((hf - gz) * (r * d1));
+    return t * t * (3.0f - 2.0f * t);
 }
 
 // clouds.glsl:109-137 density().  (px,py,pz) sample point, hf its height fraction, (wr,wb) the weather
@@ -391,19 +395,20 @@ CSKY_HD float density(const TexSet& T, const FrameConsts& fc, float px, float py
     float nr, fbm;
     shape_tap(T, lod_shape, sx, sy, sz, nr, fbm);                           // :117-118
     CSKY_STAGE(2);
-    const float omf = 1.0f - fbm;
-    float base = (nr + omf) * fast_rcp(1.0f + omf);                         // :122 remap(n.r, -(1-fbm), 1, 0, 1)
-    // :124-125: remap(base*g, 1-wc, 1, 0, 1) * wc = (base*g - omw) / (1 - omw) * wc.  In fp32 1 - omw = 1 - (1 - wc) equals wc up to
-    // one rounding of 1 - wc, i.e. the factor wc / (1 - omw) is 1 + O(6e-8 / wc): dropped (same sign, relative change < 1e-6)
-    base = base * g - omw;
-    if (!(base > 0.0f)) return 0.0f;                                        // exact reject (2)
+    const float omf = 1.0f - fbm, den1 = 1.0f + omf;                        // den1 in [1, 2]
+    // :122 base = remap(n.r, -(1-fbm), 1, 0, 1) = (nr + omf) / den1;  :124-125 remap(base*g, 1-wc, 1, 0, 1) * wc = (base*g - omw) * [wc / (1 - omw)]:
+    // the bracket is 1 + O(6e-8 / wc) in fp32 (1 - (1 - wc) equals wc up to one rounding of 1 - wc) and is left out (section B; the
+    // coverage-0.05 sweep frame of tools/parity_sweep.py has the largest 1/wc).  Round 4: the quotient is kept as numerator / den1 through
+    // reject (2), whose sign test needs no division, and divided ONCE together with :135's denominator: one v_rcp_f32 less per sample.
+    const float num = (nr + omf) * g - omw * den1;                          // = (base*g - omw) * den1
+    if (!(num > 0.0f)) return 0.0f;                                         // reject (2): base*g - omw <= 0
     detail_coord(fc, qx, qy, qz, sx, sy, sz);                               // :128-129
     float hfbm = detail_tap(T, lod_detail, sx, sy, sz);                     // :132-133
     CSKY_STAGE(3);
     const float k = sat(hf * 4.0f);
     hfbm = hfbm + k * (1.0f - 2.0f * hfbm);                                 // :134 mix(hfbm, 1-hfbm, k)
-    const float hm = hfbm * 0.4f * hf;
-    base = (base - hm) * fast_rcp(1.0f - hm);                               // :135
+    const float hm = hfbm * 0.4f * hf, den2 = 1.0f - hm;                    // den2 >= 0.6
+    const float base = (num - hm * den1) * fast_rcp(den1 * den2);           // :135 (num/den1 - hm) / den2
     return fast_pow(sat(base), (1.0f - hf) * 0.8f + 0.5f);                  // :136
 }
 
@@ -476,10 +481,9 @@ CSKY_HD float sample_density_eager(const TexSet& T, const FrameConsts& fc, float
     if (!(g > omw)) return 0.0f;                                             // exact reject (1)
     const float nr = fmaf(saz, fmaf(say, lerp_h(tr.w, sax), lerp_h(tr.z, sax)), fmaf(say, lerp_h(tr.y, sax), lerp_h(tr.x, sax))) * (1.0f / 255.0f);
     const float fbm = fmaf(saz, fmaf(say, lerp_h(tf.w, sax), lerp_h(tf.z, sax)), fmaf(say, lerp_h(tf.y, sax), lerp_h(tf.x, sax))) * (1.0f / (8.0f * 255.0f));
-    const float omf = 1.0f - fbm;
-    float base = (nr + omf) * fast_rcp(1.0f + omf);                         // :122
-    base = base * g - omw;                                                   // :124-125 (see density())
-    if (!(base > 0.0f)) return 0.0f;                                        // exact reject (2)
+    const float omf = 1.0f - fbm, den1 = 1.0f + omf;
+    const float num = (nr + omf) * g - omw * den1;                          // :122, :124-125 as numerator / den1 (see density())
+    if (!(num > 0.0f)) return 0.0f;                                         // reject (2)
     float hfbm;
     if (EAGER_DETAIL) {
         hfbm = lod_detail == 5 ? T.detail_lod5
@@ -489,8 +493,8 @@ CSKY_HD float sample_density_eager(const TexSet& T, const FrameConsts& fc, float
     }
     const float k = sat(hf * 4.0f);
     hfbm = hfbm + k * (1.0f - 2.0f * hfbm);                                 // :134
-    const float hm = hfbm * 0.4f * hf;
-    base = (base - hm) * fast_rcp(1.0f - hm);                               // :135
+    const float hm = hfbm * 0.4f * hf, den2 = 1.0f - hm;
+    const float base = (num - hm * den1) * fast_rcp(den1 * den2);           // :135
     return fast_pow(sat(base), (1.0f - hf) * 0.8f + 0.5f);                  // :136
 }
 #else
@@ -515,7 +519,7 @@ CSKY_HD void shade_terms(const FrameConsts& fc, float phase, float t, float hf, 
     const float lss = (SKY_T_RADIUS - SKY_B_RADIUS) / 64.0f;
     const float nd = -fc.density;
     const float beers = fast_exp(nd * cd * lss * 3.0f);                                  // :202
-    const float powder = 1.0f - fast_exp(nd * cd * lss * 3.0f * 2.0f);                   // :203
+    const float powder = 1.0f - beers * beers;                                           // :203 exp(2x) = exp(x)^2: one v_exp_f32 less (round 4)
     const float bt = 2.0f * beers * powder;                                              // :204
     const float sm = hf * hf * (3.0f - 2.0f * hf);                                       // smoothstep(0,1,hf), hf already in [0,1]
     const float ar = fc.gnd_c[0] * (1.0f - sm) + fc.amb_c[0] * sm;                       // :206
