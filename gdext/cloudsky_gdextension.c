@@ -27,7 +27,7 @@
  * cloud_sky.gd's loop already draws with the texture finished in an EARLIER pass (:137-148), so collect(ticket of the previous update) right
  * before submit_clouds(this update) drops in without changing what is on screen when.
  * Zero-copy path (round 3): the march writes into memory ANOTHER API allocated -- the engine's VkImage, exported as a POSIX fd with
- * VK_KHR_external_memory_fd (gdext/zero_copy_vulkan.c holds that half, compile-guarded: no Vulkan headers / no engine in this image) -- so
+ * VK_KHR_external_memory_fd (gdext/unverified/zero_copy_vulkan.c holds that half, compile-guarded: no Vulkan headers / no engine in this image) -- so
  * "returns the same TextureRD" needs no host hop at all:
  *   import_frame_fd(fd: int, layout: PackedInt32Array) -> int       layout = [allocation_bytes, offset_bytes, row_pitch_bytes, width, height]; returns a slot (0..3)
  *                                                                   or < 0; the library owns the fd on success (csky_external_frame_import_fd)

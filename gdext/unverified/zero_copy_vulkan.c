@@ -40,7 +40,7 @@
 #include <stdlib.h>
 #include <string.h>
 #include <unistd.h>
-#include "../include/cloudsky.h"
+#include "../../include/cloudsky.h"
 
 typedef struct csky_zc_image {
     VkDevice device;

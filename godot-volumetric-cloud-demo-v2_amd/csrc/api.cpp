@@ -761,7 +761,7 @@ int csky_poll(csky_ctx* c, int64_t ticket) {
     return fail(c, CSKY_ERR_STATE, "csky_poll: ticket %lld is not outstanding", (long long)ticket);
 }
 
-// ---- zero-copy interop: a frame that lives in memory another API allocated (cloudsky.h; gdext/zero_copy_vulkan.c is the Vulkan half) ----
+// ---- zero-copy interop: a frame that lives in memory another API allocated (cloudsky.h; gdext/unverified/zero_copy_vulkan.c is the Vulkan half) ----
 struct csky_external_frame { int device = 0; hipExternalMemory_t mem = nullptr; void* d_ptr = nullptr; size_t bytes = 0; hipExternalSemaphore_t sem = nullptr; hipEvent_t fence = nullptr; bool fenced = false; };
 
 int csky_external_frame_import_fd(csky_ctx* c, int opaque_fd, size_t allocation_bytes, size_t offset, size_t frame_bytes, csky_external_frame** out, void** d_ptr) {

@@ -169,7 +169,7 @@ int csky_poll(csky_ctx* ctx, int64_t ticket);
  * (hipImportExternalMemory / hipExternalMemoryGetMappedBuffer) and return a device pointer usable as d_out of csky_render_clouds_device
  * (row pitch = the image's VkSubresourceLayout.rowPitch for a LINEAR-tiled R16G16B16A16_SFLOAT image).  An exported VkSemaphore, imported with
  * ..._import_semaphore_fd and signalled on the march's stream by csky_external_frame_signal, orders the engine's sampling behind the march.
- * gdext/zero_copy_vulkan.c holds the Vulkan half and the Godot glue (RenderingDevice.texture_create_from_extension -> Texture2DRD); neither
+ * gdext/unverified/zero_copy_vulkan.c holds the Vulkan half and the Godot glue (RenderingDevice.texture_create_from_extension -> Texture2DRD); neither
  * Vulkan headers nor an engine exist in this image, so that file is compile-guarded; this half is exercised against a foreign allocator
  * (a hipMemCreate allocation exported as a dma-buf fd: tools/ext_frame_roundtrip.py, tests/test_gpu_round3.py).
  * The library takes ownership of the fds on success.

@@ -186,7 +186,7 @@ def test_submit_collect_over_the_pinned_ring(pkg, noise, gpu_ctx, oracle):
 
 
 def test_external_frame_import_error_paths(pkg, gpu_ctx):
-    """The HIP half of the zero-copy path (csky_external_frame_*, gdext/zero_copy_vulkan.c holds the Vulkan half): no Vulkan allocation
+    """The HIP half of the zero-copy path (csky_external_frame_*, gdext/unverified/zero_copy_vulkan.c holds the Vulkan half): no Vulkan allocation
     exists here to import, so only the refusals are exercised: bad descriptors never reach the runtime, a non-Vulkan fd is refused BY the
     runtime with CSKY_ERR_HIP and nothing leaks or crashes."""
     import ctypes as C

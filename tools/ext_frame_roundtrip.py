@@ -2,7 +2,7 @@
 """Positive round trip of the zero-copy HIP half (csky_external_frame_*) without Vulkan: memory that THIS library did not allocate, handed
 over as a POSIX file descriptor, is imported, marched into, and read back through the allocator's own mapping.
 
-The exporter stands in for the engine's VkDeviceMemory (VK_KHR_external_memory_fd, gdext/zero_copy_vulkan.c): a physical allocation made
+The exporter stands in for the engine's VkDeviceMemory (VK_KHR_external_memory_fd, gdext/unverified/zero_copy_vulkan.c): a physical allocation made
 with HIP's virtual-memory API (hipMemCreate, requestedHandleType = POSIX fd), exported with hipMemExportToShareableHandle -- on Linux that
 is a dma-buf fd, the same kind of object the amdgpu Vulkan drivers hand out -- and mapped by the exporter at its own address
 (hipMemAddressReserve / hipMemMap / hipMemSetAccess).  The library never sees that address: it gets the fd."""
