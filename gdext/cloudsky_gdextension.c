@@ -342,7 +342,11 @@ static void m_render_clouds_into(void *ud, GDExtensionClassInstancePtr inst, con
     if (!pc) { *(GDExtensionInt *)r = CSKY_ERR_INVALID; return; }
     memcpy(&p, pc, sizeof p);
     if (self->multi) {
-        rc = mpass(self, csky_multi_render_clouds_device(self->multi, &p, self->ext[slot].w, self->ext[slot].h, self->ext[slot].d_ptr, self->ext[slot].pitch, NULL));
+        /* An imported allocation is mapped on the first device only (hipExternalMemoryGetMappedBuffer); peer stores of the other devices into
+         * it are not guaranteed and have never run on a multi-GPU box, and the fence below is recorded on the first context's stream while a
+         * multi handle rotates streams: refused until it has been exercised.  create() + render_clouds_into is the tested form. */
+        *(GDExtensionInt *)r = fail(self, CSKY_ERR_STATE, "render_clouds_into: not available on a create_multi() object (imported memory is mapped on one device only)");
+        return;
     } else {
         const csky_bands whole = {self->ext[slot].h, 0, 1, 1};
         rc = pass(self, csky_render_clouds_device(self->ctx, &p, self->ext[slot].w, &whole, self->ext[slot].d_ptr, self->ext[slot].pitch, NULL));

@@ -86,6 +86,8 @@ SYMBOLS = [
     ("csky_set_schedule", C.c_int, [C.c_void_p, C.c_int]),
     ("csky_set_height_window", C.c_int, [C.c_void_p, C.c_int]),
     ("csky_set_segments", C.c_int, [C.c_void_p, C.c_int]),
+    ("csky_set_exact_cells", C.c_int, [C.c_void_p, C.c_int]),
+    ("csky_last_warning", C.c_char_p, [C.c_void_p]),
     ("csky_variant_name", C.c_char_p, [C.c_int]),
     ("csky_multi_create", C.c_int, [C.POINTER(C.c_void_p), C.POINTER(C.c_int), C.c_int]),
     ("csky_multi_destroy", None, [C.c_void_p]),
@@ -126,7 +128,7 @@ SYMBOLS = [
 
 
 DEFAULT_VARIANT = 3   # include/cloudsky.h CSKY_DEFAULT_VARIANT ("compact"); set_variant(-1) selects it
-ABI_VERSION = 4       # include/cloudsky.h CSKY_ABI_VERSION
+ABI_VERSION = 5       # include/cloudsky.h CSKY_ABI_VERSION
 
 
 def library_path():
@@ -207,11 +209,7 @@ class Context:
         c = np.ascontiguousarray(weather_rgb8, np.uint8)
         if a.size != 128 ** 3 * 4 or b.size != 32 ** 3 * 3 or c.size != 512 * 512 * 3:
             raise ValueError("set_noise: expected 128^3 RGBA8, 32^3 RGB8, 512^2 RGB8")
-        self._chk(self._L.csky_set_noise(self._h, _ptr(a), _ptr(b), _ptr(c)))
-        n = self.noise_inexact_coeffs()
-        if n:   # never silent.  The taps stay within the parity tolerance (test_white_noise_textures) but are no longer exact
-            import warnings
-            warnings.warn((self._L.csky_last_error(self._h) or b"").decode() or "csky_set_noise: %d inexact fp16 coefficients" % n, RuntimeWarning)
+        self._chk(self._L.csky_set_noise(self._h, _ptr(a), _ptr(b), _ptr(c)))   # (textures that do not fit the fp16 cells are marched on exact fp32 cells: last_warning() says so)
 
     def set_noise_mips(self, large_chain_rgba8, small_chain_rgb8, weather_rgb8):
         """csky_set_noise_mips: full mip chains supplied by the caller (all levels back to back), e.g. the importer's own from
@@ -222,10 +220,6 @@ class Context:
         if a.size != self._L.csky_mip_offset(128, 8, 4) or b.size != self._L.csky_mip_offset(32, 6, 3) or c.size != 512 * 512 * 3:
             raise ValueError("set_noise_mips: expected the 8-level 128^3 RGBA8 chain, the 6-level 32^3 RGB8 chain, 512^2 RGB8")
         self._chk(self._L.csky_set_noise_mips(self._h, _ptr(a), _ptr(b), _ptr(c)))
-        n = self.noise_inexact_coeffs()
-        if n:
-            import warnings
-            warnings.warn((self._L.csky_last_error(self._h) or b"").decode() or "csky_set_noise_mips: %d inexact fp16 coefficients" % n, RuntimeWarning)
 
     def noise_inexact_coeffs(self):
         """Finite-difference coefficients of the bound textures that fp16 could not hold exactly (0 for natural noise)."""
@@ -250,6 +244,13 @@ class Context:
 
     def set_variant(self, v):
         self._chk(self._L.csky_set_variant(self._h, int(v)))
+
+    def set_exact_cells(self, mode):
+        """1: build and march the exact fp32-coefficient cells at the next set_noise whatever the textures need; 0: only when a coefficient does not fit fp16."""
+        self._chk(self._L.csky_set_exact_cells(self._h, int(mode)))
+
+    def last_warning(self):
+        return (self._L.csky_last_warning(self._h) or b"").decode()
 
     # ---- kernels, host-buffer forms
     def render_transmittance(self, w=256, h=64):

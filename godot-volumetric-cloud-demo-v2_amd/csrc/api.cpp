@@ -12,6 +12,7 @@
 #include <cmath>
 #include <string>
 #include <vector>
+#include <unistd.h>
 #include "../../include/cloudsky.h"
 #include "kernels.h"
 #include "bake.h"
@@ -26,12 +27,11 @@ using namespace csky;
 // the first HIP call; this runs when libcloudsky.so is loaded, so a host that cannot set environment variables (a GDExtension inside Godot)
 // still gets the overlap as long as it has not used HIP before loading the library.  An existing value is never overwritten.
 // Opt-out: CSKY_NO_ENV=1 in the environment leaves the process's environment alone (a host that loads other HIP users and wants the runtime's
-// defaults); csky_set_frames_in_flight then warns through csky_last_error when the variable is not in effect.
-static bool g_env_set_by_us = false;
+// defaults); csky_set_frames_in_flight then warns through csky_last_warning when the variable is not in effect.
 __attribute__((constructor)) static void csky_runtime_defaults() {
     const char* no = getenv("CSKY_NO_ENV");
     if (no && no[0] && no[0] != '0') return;
-    if (!getenv("GPU_MAX_HW_QUEUES")) { setenv("GPU_MAX_HW_QUEUES", "8", /*overwrite=*/0); g_env_set_by_us = true; }
+    if (!getenv("GPU_MAX_HW_QUEUES")) setenv("GPU_MAX_HW_QUEUES", "8", /*overwrite=*/0);
 }
 
 static_assert(sizeof(csky_cloud_params) == sizeof(CloudParams), "ABI struct mismatch");
@@ -49,6 +49,8 @@ struct csky_ctx {
     uint8_t* d_raw_large = nullptr; uint8_t* d_raw_small = nullptr; uint8_t* d_raw_weather = nullptr; uint8_t* d_bake_meta = nullptr;   // 8-bit mip chains (inputs of the device bake)
     ShapeTexel* d_shape = nullptr; unsigned long long inexact_coeffs = 0; uint4* d_detail = nullptr; uint4* d_weather = nullptr; uint16_t* d_detail_h = nullptr; bool have_noise = false;
     float* d_brick = nullptr;                                               // CSKY_BRICK_BOUND experiment build only
+    // exact cells (bake_core.h): fp32-coefficient layouts, built when a coefficient of the bound textures does not fit fp16 (or exact_cells == 1)
+    float4* d_shape32 = nullptr; float4* d_detail32 = nullptr; float4* d_weather32 = nullptr; bool cell32 = false; int exact_cells = 0;
     uint32_t shape_off[SHAPE_LEVELS] = {}, detail_off[DETAIL_LEVELS] = {};
     float detail_lod5 = 0.0f;
     double w_rmin = 0.0, w_rmax = 1.0, w_bmax = 1.0;   // range of the weather map's cloud-type / coverage channels
@@ -91,6 +93,7 @@ struct csky_ctx {
     struct HostSlot { hipStream_t s = nullptr; hipEvent_t done = nullptr; uint2* d = nullptr; void* h = nullptr; size_t px = 0; long long ticket = -1; int w = 0, hh = 0; bool busy = false; };
     HostSlot hring[HOST_RING]; int hslots = 2; long long next_ticket = 0;
     char err[512] = {0};
+    char warn[512] = {0};                              // csky_last_warning: text of the last call that succeeded with a caveat (never mixed into err)
 };
 
 namespace {
@@ -151,6 +154,13 @@ TexSet texset(const csky_ctx* c) {
     t.brick = c->d_brick;
 #endif
     t.shape = c->d_shape; t.detail = c->d_detail; t.weather = c->d_weather; t.sky = c->d_sky_f; t.sky_w = c->sw; t.sky_h = c->sh; t.detail_lod5 = c->detail_lod5; t.detail_h = c->d_detail_h; t.detail_lds = nullptr;
+    return t;
+}
+
+TexSet32 texset32(const csky_ctx* c) {
+    TexSet32 t;
+    static_cast<TexSet&>(t) = texset(c);
+    t.shape32 = c->d_shape32; t.detail32 = c->d_detail32; t.weather32 = c->d_weather32;
     return t;
 }
 
@@ -228,9 +238,9 @@ int clouds_dev(csky_ctx* c, const csky_cloud_params* p, int tile_w, const csky_b
     // A lone wavefront is bound by its chain of dependent gathers, so small launches want more, shorter wavefronts; large
     // launches want the fewest instructions.  (The "queue" variant keeps its own, earlier crossovers: 6144 / 1536 wavefronts.)
     const long long waves = ((long long)(tile_w + 7) / 8) * (((long long)b->n_bands * b->band_rows + 7) / 8);
-    const int variant = c->variant;
+    const int variant = c->cell32 ? 3 : c->variant;              // exact cells exist for the compact whole-ray kernel only
     const bool queued = variant == 1 || variant == 3;
-    int seg = queued ? c->segments : 1;
+    int seg = c->cell32 ? 1 : (queued ? c->segments : 1);
     int auto_mode;
     if (c->variant == 3 && c->frames_in_flight >= 2) {
         // the caller keeps two frames in flight on two streams (csky_set_frames_in_flight): the next frame's workgroups fill this
@@ -263,9 +273,11 @@ int clouds_dev(csky_ctx* c, const csky_cloud_params* p, int tile_w, const csky_b
     // launches refill freed slots at least as well when nothing else is in flight), 1/4 frame 0.477 -> 0.539 (barely deeper than
     // the resident grid), 4096x2048 6.13 -> 6.19 (no tail to fill), cost-feedback order 1.90 -> 2.09.  So: whole-ray launches of
     // 12 Ki to 64 Ki wavefronts (they run in the static XCD-row order) while the caller keeps two frames in flight.
-    const bool persist = seg == 1 && variant == 3 && (c->persistent == 2 || (c->persistent == 1 && !feedback && c->frames_in_flight >= 2 && waves >= 12288 && waves <= 65536));
+    const bool persist = !c->cell32 && seg == 1 && variant == 3 && (c->persistent == 2 || (c->persistent == 1 && !feedback && c->frames_in_flight >= 2 && waves >= 12288 && waves <= 65536));
     uint32_t* const heads = persist ? c->d_heads + slot * 16 : nullptr;
     const int resident = c->resident_wgs;
+    TexSet32 t32; const TexSet32* t32p = nullptr;
+    if (c->cell32) { t32 = texset32(c); t32p = &t32; }
     hipEvent_t* kt = nullptr;                                    // timing pair of this launch (csky_set_kernel_timing)
     if (c->kt_on) {
         if ((size_t)c->kt_count * 2 + 2 > c->kt_ev.size()) {    // the pool grows on demand: no launch is ever dropped from the sum
@@ -281,7 +293,7 @@ int clouds_dev(csky_ctx* c, const csky_cloud_params* p, int tile_w, const csky_b
     if (!feedback) {
         if (kt) HIPCHK(c, hipEventRecord(kt[0], s));
         {   // a failed persistent launch may leave the slot's pop counters armed: re-zero them so that the next launch on this slot starts clean
-            const hipError_t le = launch_clouds(variant, seg, texset(c), c->d_fc, g, d_static, static_grid, d_out, d_stats, nullptr, s, heads, resident);
+            const hipError_t le = launch_clouds(variant, seg, texset(c), c->d_fc, g, d_static, static_grid, d_out, d_stats, nullptr, s, heads, resident, t32p);
             if (le != hipSuccess) { if (heads) (void)hipMemsetAsync(heads, 0, 16 * sizeof(uint32_t), s); return fail(c, CSKY_ERR_HIP, "cloud kernel launch failed: %s", hipGetErrorString(le)); }
         }
         if (kt) HIPCHK(c, hipEventRecord(kt[1], s));
@@ -316,7 +328,7 @@ int clouds_dev(csky_ctx* c, const csky_cloud_params* p, int tile_w, const csky_b
     const int use_grid = c->lpt_valid[slot] ? nblocks : static_grid;
     if (kt) HIPCHK(c, hipEventRecord(kt[0], s));
     {
-        const hipError_t le = launch_clouds(variant, seg, texset(c), c->d_fc, g, use_order, use_grid, d_out, d_stats, cost, s, heads, resident);
+        const hipError_t le = launch_clouds(variant, seg, texset(c), c->d_fc, g, use_order, use_grid, d_out, d_stats, cost, s, heads, resident, t32p);
         if (le != hipSuccess) { if (heads) (void)hipMemsetAsync(heads, 0, 16 * sizeof(uint32_t), s); return fail(c, CSKY_ERR_HIP, "cloud kernel launch failed: %s", hipGetErrorString(le)); }
     }
     if (kt) HIPCHK(c, hipEventRecord(kt[1], s));
@@ -341,6 +353,7 @@ int csky_device_count(void) {
 }
 
 const char* csky_last_error(const csky_ctx* ctx) { return ctx ? ctx->err : g_err; }
+const char* csky_last_warning(const csky_ctx* ctx) { return ctx ? ctx->warn : ""; }
 
 int csky_create(csky_ctx** out, int device_id) {
     if (!out) return fail(nullptr, CSKY_ERR_INVALID, "csky_create: out is NULL");
@@ -387,7 +400,7 @@ void csky_destroy(csky_ctx* c) {
     (void)hipSetDevice(c->device);
     (void)hipDeviceSynchronize();                              // launches may sit on caller streams too
     void* ptrs[] = {c->d_shape, c->d_detail, c->d_weather, c->d_trans_h, c->d_trans_f, c->sky_h_ring[0], c->sky_h_ring[1], c->sky_f_ring[0], c->sky_f_ring[1],
-                    c->d_stats, c->d_frame, c->d_composite, c->d_raw_large, c->d_raw_small, c->d_raw_weather, c->d_bake_meta, c->d_detail_h, c->d_wg_cost, c->d_lpt_order, c->d_lpt_hist, c->d_heads};
+                    c->d_stats, c->d_frame, c->d_composite, c->d_raw_large, c->d_raw_small, c->d_raw_weather, c->d_bake_meta, c->d_detail_h, c->d_wg_cost, c->d_lpt_order, c->d_lpt_hist, c->d_heads, c->d_shape32, c->d_detail32, c->d_weather32};
     for (void* p : ptrs) if (p) (void)hipFree(p);
     for (int k = 0; k < RING; k++) {
         if (c->fc_ring[k]) (void)hipFree(c->fc_ring[k]);
@@ -468,11 +481,22 @@ static int set_noise_impl(csky_ctx* c, const uint8_t* large_rgba8, const uint8_t
     c->inexact_coeffs = meta.inexact;
     c->detail_lod5 = (float)(5 * t5[0] + 2 * t5[1] + t5[2]) * (1.0f / (8.0f * 255.0f));
     c->w_rmin = meta.range[0] / 255.0; c->w_rmax = meta.range[1] / 255.0; c->w_bmax = meta.range[2] / 255.0; c->win_cov = -1e30f;   // channel ranges for the height-window reject
+    c->warn[0] = 0;
+    // Textures whose cells do not fit fp16 (white noise, checkerboards: csky_noise_inexact_coeffs() > 0) are marched on EXACT cells: the same
+    // polynomial with fp32 coefficients (bake_core.h), twice the bytes per tap, the compact whole-ray kernel on TexSet32.  (Rounds 1-3 marched
+    // them on the rounded fp16 cells and warned)  csky_set_exact_cells(1) asks for them regardless (A/B, tests).
+    c->cell32 = c->inexact_coeffs != 0 || c->exact_cells == 1;
+    if (c->cell32) {
+        if ((rc = dev_alloc(c, &c->d_shape32, shape_total * 4))) return rc;
+        if ((rc = dev_alloc(c, &c->d_detail32, detail_total * 2))) return rc;
+        if ((rc = dev_alloc(c, &c->d_weather32, (size_t)WEATHER_N * WEATHER_N * 2))) return rc;
+        HIPCHK(c, launch_bake32(c->d_raw_large, c->d_raw_small, c->d_raw_weather, c->d_shape32, c->d_detail32, c->d_weather32, s));
+        HIPCHK(c, hipStreamSynchronize(s));
+        if (c->inexact_coeffs)
+            snprintf(c->warn, sizeof c->warn, "csky_set_noise: %llu finite-difference coefficients of these textures do not fit fp16: marching on exact fp32 cells "
+                     "(twice the bytes per tap; the whole-ray compact kernel)", c->inexact_coeffs);
+    }
     c->have_noise = true;
-    c->err[0] = 0;
-    if (c->inexact_coeffs)     // still CSKY_OK (the taps stay within the parity tolerance), but never silent: cloudsky.h csky_noise_inexact_coeffs
-        snprintf(c->err, sizeof c->err, "csky_set_noise: warning: %llu finite-difference coefficients of these textures are not exact in fp16 "
-                 "(|coefficient| > 2048); taps through them carry a relative 2^-11 error", c->inexact_coeffs);
     return CSKY_OK;
 }
 
@@ -598,12 +622,13 @@ int csky_set_frames_in_flight(csky_ctx* c, int frames) {
     if (!c) return fail(nullptr, CSKY_ERR_INVALID, "csky_set_frames_in_flight: ctx is NULL");
     if (frames < 1 || frames > RING) return fail(c, CSKY_ERR_INVALID, "csky_set_frames_in_flight: 1 .. 4 (the rings are four deep)");
     c->frames_in_flight = frames;
-    c->err[0] = 0;
-    if (frames >= 2) {   // still CSKY_OK, but never silent: without enough hardware queues the frames' streams share one and do not overlap
+    c->warn[0] = 0;
+    if (frames >= 2) {   // CSKY_OK, but never silent: without enough hardware queues the frames' streams share one and do not overlap (csky_last_warning)
         const char* q = getenv("GPU_MAX_HW_QUEUES");
-        if (!q || atoi(q) < 8)
-            snprintf(c->err, sizeof c->err, "csky_set_frames_in_flight: warning: GPU_MAX_HW_QUEUES is %s (< 8): streams of consecutive frames may share a hardware "
-                     "queue and not overlap; set it to 8 before the process's first HIP call (libcloudsky does so at load time unless CSKY_NO_ENV=1)", q ? q : "unset");
+        const int qn = q ? atoi(q) : 4;                         // the HIP runtime's default
+        if (qn < frames + 1)                                   // the frames' streams + the prologue stream
+            snprintf(c->warn, sizeof c->warn, "csky_set_frames_in_flight: GPU_MAX_HW_QUEUES is %s: %d streams of consecutive frames plus the prologue stream may share a hardware "
+                     "queue and not overlap; set it (8 is what libcloudsky sets at load time unless CSKY_NO_ENV=1) before the process's first HIP call", q ? q : "unset (4)", frames);
     }
     return CSKY_OK;
 }
@@ -611,6 +636,11 @@ int csky_set_segments(csky_ctx* c, int segments) {
     if (!c) return fail(nullptr, CSKY_ERR_INVALID, "csky_set_segments: ctx is NULL");
     if (segments != 0 && segments != 1 && segments != 2 && segments != 4 && segments != 5) return fail(c, CSKY_ERR_INVALID, "csky_set_segments: 0 (auto), 1, 2, 4 (step ranges) or 5 (4 interleaved)");
     c->segments = segments; return CSKY_OK;
+}
+int csky_set_exact_cells(csky_ctx* c, int mode) {
+    if (!c) return fail(nullptr, CSKY_ERR_INVALID, "csky_set_exact_cells: ctx is NULL");
+    if (mode != 0 && mode != 1) return fail(c, CSKY_ERR_INVALID, "csky_set_exact_cells: 0 (only when a coefficient does not fit fp16) or 1 (always)");
+    c->exact_cells = mode; return CSKY_OK;                     // takes effect at the next csky_set_noise*
 }
 int csky_set_height_window(csky_ctx* c, int enabled) {
     if (!c) return fail(nullptr, CSKY_ERR_INVALID, "csky_set_height_window: ctx is NULL");
@@ -767,20 +797,26 @@ struct csky_external_frame { int device = 0; hipExternalMemory_t mem = nullptr; 
 int csky_external_frame_import_fd(csky_ctx* c, int opaque_fd, size_t allocation_bytes, size_t offset, size_t frame_bytes, csky_external_frame** out, void** d_ptr) {
     if (!c || !out || !d_ptr) return fail(c, CSKY_ERR_INVALID, "csky_external_frame_import_fd: NULL argument");
     *out = nullptr; *d_ptr = nullptr;
-    if (opaque_fd < 0 || frame_bytes == 0 || offset + frame_bytes > allocation_bytes) return fail(c, CSKY_ERR_INVALID, "csky_external_frame_import_fd: bad fd / sizes");
+    if (opaque_fd < 0 || frame_bytes == 0 || frame_bytes > allocation_bytes || offset > allocation_bytes - frame_bytes) return fail(c, CSKY_ERR_INVALID, "csky_external_frame_import_fd: bad fd / sizes");
     int rc; if ((rc = bind(c))) return rc;
     csky_external_frame* f = new (std::nothrow) csky_external_frame();
     if (!f) return fail(c, CSKY_ERR_INVALID, "csky_external_frame_import_fd: out of host memory");
     f->device = c->device; f->bytes = frame_bytes;
     hipExternalMemoryHandleDesc md; memset(&md, 0, sizeof md);
-    md.type = hipExternalMemoryHandleTypeOpaqueFd; md.handle.fd = opaque_fd; md.size = allocation_bytes;   // the runtime takes ownership of the fd on success
+    // The runtime takes ownership of the fd it is given on success and says nothing about failure, so it gets a DUPLICATE: on ANY failure the
+    // caller still owns opaque_fd (and only it); on success the library closes the caller's fd, as documented.
+    const int dfd = dup(opaque_fd);
+    if (dfd < 0) { delete f; return fail(c, CSKY_ERR_INVALID, "csky_external_frame_import_fd: dup(fd) failed"); }
+    md.type = hipExternalMemoryHandleTypeOpaqueFd; md.handle.fd = dfd; md.size = allocation_bytes;
     hipError_t e = hipImportExternalMemory(&f->mem, &md);
+    if (e != hipSuccess) (void)close(dfd);
     if (e == hipSuccess) {
         hipExternalMemoryBufferDesc bd; memset(&bd, 0, sizeof bd);
         bd.offset = offset; bd.size = frame_bytes;
         e = hipExternalMemoryGetMappedBuffer(&f->d_ptr, f->mem, &bd);
     }
     if (e != hipSuccess) { csky_external_frame_release(f); return fail(c, CSKY_ERR_HIP, "csky_external_frame_import_fd: %s", hipGetErrorString(e)); }
+    (void)close(opaque_fd);                                   // success: the library owns the memory object now
     *out = f; *d_ptr = f->d_ptr;
     return CSKY_OK;
 }
@@ -1157,10 +1193,11 @@ int csky_multi_set_staged(csky_multi* m, int staged) {
 }
 int csky_multi_render_sky_lut(csky_multi* m, const csky_sky_params* p) {
     if (!m) return mfail(nullptr, CSKY_ERR_INVALID, "csky_multi_render_sky_lut: handle is NULL");
-    // every device of the group that renders the NEXT frame needs the LUT; with one group that is every device.  With several groups the
-    // LUT is rendered on the devices of the next frame's group only (sky_lut.gd:43-52 is called once per frame, cloud_sky.gd:187).
-    const int n = (int)m->ctx.size(), per = n / m->groups, g = (int)(m->frame_no % (unsigned long long)m->groups);
-    for (int i = g * per; i < (g + 1) * per; i++) { const int rc = csky_render_sky_lut_device(m->ctx[i], p, nullptr); if (rc) return mpass(m, i, rc); }
+    // Every device gets the LUT, whatever the group layout (with several groups it used to go to the NEXT frame's group only, so a
+    // caller with a static sun that rendered it once marched with no / a stale LUT on the other groups).  A sky LUT costs ~33 us of one device
+    // on its prologue stream, overlapped with the previous march (sky_lut.gd:43-52 is called once per frame, cloud_sky.gd:187).
+    const int n = (int)m->ctx.size();
+    for (int i = 0; i < n; i++) { const int rc = csky_render_sky_lut_device(m->ctx[i], p, nullptr); if (rc) return mpass(m, i, rc); }
     return CSKY_OK;
 }
 
@@ -1174,8 +1211,7 @@ int csky_multi_render_clouds_device(csky_multi* m, const csky_cloud_params* p, i
     // Slot = frame number mod (groups x frames in flight): its events, and on every device of the group the stream / ring position
     // slot / groups of that device's frames in flight.
     const int G = m->groups, per = n_all / G, slots = G * m->fif;
-    const int slot = (int)(m->frame_no % (unsigned long long)slots), grp = slot % G, dslot = slot / G;
-    m->frame_no++;
+    const int slot = (int)(m->frame_no % (unsigned long long)slots), grp = slot % G, dslot = slot / G;   // (frame_no advances only when the frame was enqueued: a failed call must not shift the slot / group rotation)
     csky_ctx* c0 = m->ctx[0];
     int rc; if ((rc = bind(c0))) return mpass(m, 0, rc);
     hipStream_t consumer = hip_stream ? (hipStream_t)hip_stream : c0->stream;
@@ -1223,6 +1259,7 @@ int csky_multi_render_clouds_device(csky_multi* m, const csky_cloud_params* p, i
         if (i == 0 || k >= total) continue;
         if (hipStreamWaitEvent(consumer, m->ev_done[slot][i], 0) != hipSuccess) return mfail(m, CSKY_ERR_HIP, "csky_multi_render_clouds_device: hipStreamWaitEvent failed");
     }
+    m->frame_no++;
     return CSKY_OK;
 }
 

@@ -81,4 +81,37 @@ CSKY_HD uint4 bake_weather_texel(const uint8_t* __restrict__ rgb, int x, int y, 
     return q;
 }
 
+
+// ---- exact cells (round 4): the same polynomial cells with fp32 coefficients, for textures some of whose finite differences do not fit fp16
+// (|c| > 2048 and not a multiple of the fp16 spacing there: white noise, checkerboards).  Integers up to 8 x 2040 are exact in fp32, so these
+// cells are exact for ANY 8-bit input; for inputs that also bake exactly in fp16 the two forms filter bit-identically (v_fma_mix_f32 widens
+// exactly what is stored here).  Twice the bytes per tap, so only used when csky_noise_inexact_coeffs() > 0 (or on request, csky_set_exact_cells).
+//   weather: 2 x float4 per texel  {r c0..c3}{b c0..c3};  detail: 2 x float4  {c0..c3}{c4..c7};  shape: 4 x float4  {r c0..c3}{r c4..c7}{f c0..c3}{f c4..c7}
+CSKY_HD void bake_shape_texel32(const uint8_t* __restrict__ src, int n, int x, int y, int z, float4 out[4]) {
+    int vr[8], vf[8], cr[8], cf[8];
+    for (int k = 0; k < 8; k++) {
+        const int xx = (x + (k & 1)) % n, yy = (y + ((k >> 1) & 1)) % n, zz = (z + (k >> 2)) % n;
+        const uint8_t* t = src + (((size_t)zz * n + yy) * n + xx) * 4;
+        vr[k] = t[0]; vf[k] = 5 * t[1] + 2 * t[2] + t[3];
+    }
+    cell_coeffs(vr, cr); cell_coeffs(vf, cf);
+    out[0] = float4{(float)cr[0], (float)cr[1], (float)cr[2], (float)cr[3]}; out[1] = float4{(float)cr[4], (float)cr[5], (float)cr[6], (float)cr[7]};
+    out[2] = float4{(float)cf[0], (float)cf[1], (float)cf[2], (float)cf[3]}; out[3] = float4{(float)cf[4], (float)cf[5], (float)cf[6], (float)cf[7]};
+}
+CSKY_HD void bake_detail_texel32(const uint8_t* __restrict__ src, int n, int x, int y, int z, float4 out[2]) {
+    int v[8], c[8];
+    for (int k = 0; k < 8; k++) v[k] = detail_numerator(src, n, x + (k & 1), y + ((k >> 1) & 1), z + (k >> 2));
+    cell_coeffs(v, c);
+    out[0] = float4{(float)c[0], (float)c[1], (float)c[2], (float)c[3]}; out[1] = float4{(float)c[4], (float)c[5], (float)c[6], (float)c[7]};
+}
+CSKY_HD void bake_weather_texel32(const uint8_t* __restrict__ rgb, int x, int y, float4 out[2]) {
+    const int n = WEATHER_N;
+    for (int c = 0; c < 2; c++) {
+        const int k = 2 * c;
+        const int v00 = rgb[(((size_t)(y % n)) * n + (x % n)) * 3 + k], v10 = rgb[(((size_t)(y % n)) * n + ((x + 1) % n)) * 3 + k];
+        const int v01 = rgb[(((size_t)((y + 1) % n)) * n + (x % n)) * 3 + k], v11 = rgb[(((size_t)((y + 1) % n)) * n + ((x + 1) % n)) * 3 + k];
+        out[c] = float4{(float)v00, (float)(v10 - v00), (float)(v01 - v00), (float)(v11 - v01 - v10 + v00)};
+    }
+}
+
 }  // namespace csky

@@ -264,6 +264,21 @@ CSKY_HD void weather_tap(const uint4* __restrict__ w, float sx, float sy, float&
     weather_fetch(w, sx, sy, q, ax, ay);
     weather_filter(q, ax, ay, wr, wb);
 }
+// the tap of whichever cell form the bound texture set has (TexSet: fp16 pairs; TexSet32: exact fp32 coefficients, bake_core.h): the same
+// polynomial (c0 + c1 fx) + fy (c2 + c3 fx), the x stage a plain FMA instead of v_fma_mix_f32
+template <class TS>
+CSKY_HD void weather_tap_ts(const TS& T, float sx, float sy, float& wr, float& wb) {
+    if constexpr (TS::cell32) {
+        int ix, iy; float ax, ay;
+        split_coord(sx * 512.0f - 0.5f, ix, ax); split_coord(sy * 512.0f - 0.5f, iy, ay);
+        const float4* __restrict__ q = reinterpret_cast<const float4*>(reinterpret_cast<const char*>(T.weather32) + (((((uint32_t)(iy & 511)) << 9) | (uint32_t)(ix & 511)) << 5));
+        const float4 r = q[0], b = q[1];
+        wr = fmaf(ay, fmaf(r.w, ax, r.z), fmaf(r.y, ax, r.x));
+        wb = fmaf(ay, fmaf(b.w, ax, b.z), fmaf(b.y, ax, b.x));
+    } else {
+        weather_tap(T.weather, sx, sy, wr, wb);
+    }
+}
 
 // (float)(1 << e) built from the exponent field: integer SALU work when e is wave-uniform (the light march's LOD), where a cast costs a
 // half-rate v_cvt per tap
@@ -276,13 +291,23 @@ CSKY_HD uint32_t shape_level_offset(int l) { return ((1u << 24) - (1u << (24 - 3
 CSKY_HD uint32_t detail_level_offset(int l) { return ((1u << 18) - (1u << (18 - 3 * l))) / 7u; }
 // REPEAT + LINEAR trilinear tap of the shape volume at integer level `lvl` (clouds.glsl:117).
 // Returns r = n.r and fbm = n.g*0.625 + n.b*0.25 + n.a*0.125 (clouds.glsl:118; exact integer numerators, filtered linearly).
-CSKY_HD void shape_tap(const TexSet& T, int lvl, float sx, float sy, float sz, float& r, float& fbm) {
+template <class TS>
+CSKY_HD void shape_tap(const TS& T, int lvl, float sx, float sy, float sz, float& r, float& fbm) {
     const int n = SHAPE_N >> lvl, m = n - 1;
     const float fn = pow2f(7 - lvl);
     int ix, iy, iz; float ax, ay, az;
     split_coord(sx * fn - 0.5f, ix, ax); split_coord(sy * fn - 0.5f, iy, ay); split_coord(sz * fn - 0.5f, iz, az);
     const int x0 = ix & m, y0 = iy & m, z0 = iz & m;
     const uint32_t sh = (uint32_t)(7 - lvl), base = shape_level_offset(lvl) + (uint32_t)x0;   // n = 1 << sh: shifts, not v_mul_lo_u32 (quarter rate)
+    if constexpr (TS::cell32) {                               // exact cells: 4 x float4 per texel, the xyz polynomial on fp32 coefficients
+        (void)base;
+        const float4* __restrict__ t = reinterpret_cast<const float4*>(reinterpret_cast<const char*>(T.shape32) +
+                                                                       ((size_t)(shape_level_offset(lvl) + shape_cell_offset((uint32_t)x0, (uint32_t)y0, (uint32_t)z0, sh)) << 6));
+        const float4 r0 = t[0], r1 = t[1], f0 = t[2], f1 = t[3];
+        r = fmaf(az, fmaf(ay, fmaf(r1.w, ax, r1.z), fmaf(r1.y, ax, r1.x)), fmaf(ay, fmaf(r0.w, ax, r0.z), fmaf(r0.y, ax, r0.x))) * (1.0f / 255.0f);
+        fbm = fmaf(az, fmaf(ay, fmaf(f1.w, ax, f1.z), fmaf(f1.y, ax, f1.x)), fmaf(ay, fmaf(f0.w, ax, f0.z), fmaf(f0.y, ax, f0.x))) * (1.0f / (8.0f * 255.0f));
+        return;
+    }
     const char* __restrict__ sb = reinterpret_cast<const char*>(T.shape);
 #if CSKY_SHAPE_POLY == 1
     const int y1 = (y0 + 1) & m, z1 = (z0 + 1) & m;
@@ -308,7 +333,8 @@ CSKY_HD void shape_tap(const TexSet& T, int lvl, float sx, float sy, float sz, f
 }
 
 // REPEAT + LINEAR trilinear tap of the oct-packed detail volume (clouds.glsl:132-133): returns hfbm.
-CSKY_HD float detail_tap(const TexSet& T, int lvl, float sx, float sy, float sz) {
+template <class TS>
+CSKY_HD float detail_tap(const TS& T, int lvl, float sx, float sy, float sz) {
     // LOD 5 is 1x1x1: with REPEAT all eight corners are that one texel and a + (a - a)*f = a exactly (what the reference's
     // sampler returns), so light samples j = 5 and the distant sample (clouds.glsl:190,198: textureLod(.., 5.0)) need no tap
     if (lvl == 5) return T.detail_lod5;
@@ -317,6 +343,12 @@ CSKY_HD float detail_tap(const TexSet& T, int lvl, float sx, float sy, float sz)
     int ix, iy, iz; float ax, ay, az;
     split_coord(sx * fn - 0.5f, ix, ax); split_coord(sy * fn - 0.5f, iy, ay); split_coord(sz * fn - 0.5f, iz, az);
     const int x0 = ix & m, y0 = iy & m, z0 = iz & m;
+    if constexpr (TS::cell32) {                               // exact cells: 2 x float4 per texel
+        const uint32_t sh3 = (uint32_t)(5 - lvl), idx3 = detail_level_offset(lvl) + ((((((uint32_t)z0 << sh3) | (uint32_t)y0) << sh3)) | (uint32_t)x0);
+        const float4* __restrict__ t = reinterpret_cast<const float4*>(reinterpret_cast<const char*>(T.detail32) + ((size_t)idx3 << 5));
+        const float4 q0 = t[0], q1 = t[1];
+        return fmaf(az, fmaf(ay, fmaf(q1.w, ax, q1.z), fmaf(q1.y, ax, q1.x)), fmaf(ay, fmaf(q0.w, ax, q0.z), fmaf(q0.y, ax, q0.x))) * (1.0f / (8.0f * 255.0f));
+    }
     if (T.detail_lds) {
         // "lds" variant (north star: noise bricks staged in LDS): the whole detail chain sits in LDS as unpacked fp16 texels, so
         // a tap is eight 2-byte LDS reads assembled into the same x-neighbour pairs the global layout stores pre-packed
@@ -372,7 +404,8 @@ CSKY_HD float density_height_gradient(const FrameConsts& fc, float hf, float ct)
 //      gives 0 and pow(0, e >= 0.5) = 0.  The shape tap is never needed.  wc == 0 (divide by zero -> NaN ->
 //      clamp -> 0 in the oracle) also lands here.
 //  (2) after :125, base_cloud <= 0 makes :135-136 return 0 for the same reason: the detail tap is dead.
-CSKY_HD float density(const TexSet& T, const FrameConsts& fc, float px, float py, float pz, float hf, float wr, float wb,
+template <class TS>
+CSKY_HD float density(const TS& T, const FrameConsts& fc, float px, float py, float pz, float hf, float wr, float wb,
                       int lod_shape, int lod_detail) {
     const float wc = fc.cov255 * wb;                                         // :123 (wb on the texel scale)
     const float g = density_height_gradient(fc, hf, wr);                    // :121
@@ -417,13 +450,14 @@ CSKY_HD float density(const TexSet& T, const FrameConsts& fc, float px, float py
 // for ANY texel of the bound weather map (bake.h height_window: g <= smoothstep(gx,gy,hf) below the cloud body and
 // g <= 1 - smoothstep(gz,gw,hf) above it, maximised over the map's cloud-type range), so reject (1) would fire anyway:
 // the weather tap and the gradient are skipped.  Samples above/below the cloud body cost ~20 VALU instead of ~100.
-CSKY_HD float sample_density(const TexSet& T, const FrameConsts& fc, float px, float py, float pz, float hf, float wx, float wy,
+template <class TS>
+CSKY_HD float sample_density(const TS& T, const FrameConsts& fc, float px, float py, float pz, float hf, float wx, float wy,
                              int lod_shape, int lod_detail) {
     CSKY_STAGE(0);
     if (!(hf > fc.hf_lo && hf < fc.hf_hi)) return 0.0f;
     float wsx, wsy, wr, wb;
     weather_coord(px, pz, wx, wy, wsx, wsy);
-    weather_tap(T.weather, wsx, wsy, wr, wb);
+    weather_tap_ts(T, wsx, wsy, wr, wb);
     CSKY_STAGE(1);
     return density(T, fc, px, py, pz, hf, wr, wb, lod_shape, lod_detail);
 }
@@ -439,9 +473,10 @@ CSKY_HD float sample_density(const TexSet& T, const FrameConsts& fc, float px, f
 #if CSKY_SHAPE_POLY == 3
 // EAGER_DETAIL = false fetches the weather and shape cells together and the detail cell only after reject (2): the form for the
 // primary march, where 77 % of the samples inside the height window reach the shape tap but only 31 % the detail tap.
-template <bool EAGER_DETAIL = true>
-CSKY_HD float sample_density_eager(const TexSet& T, const FrameConsts& fc, float px, float py, float pz, float hf, float wx, float wy,
+template <bool EAGER_DETAIL = true, class TS>
+CSKY_HD float sample_density_eager(const TS& T, const FrameConsts& fc, float px, float py, float pz, float hf, float wx, float wy,
                                    int lod_shape, int lod_detail) {
+    if constexpr (TS::cell32) return sample_density(T, fc, px, py, pz, hf, wx, wy, lod_shape, lod_detail);   // exact cells: the lazy form (not the tuned path)
     if (!(hf > fc.hf_lo && hf < fc.hf_hi)) return 0.0f;
     // ---- addresses + fetches
     float wsx, wsy;
@@ -498,8 +533,8 @@ CSKY_HD float sample_density_eager(const TexSet& T, const FrameConsts& fc, float
     return fast_pow(sat(base), (1.0f - hf) * 0.8f + 0.5f);                  // :136
 }
 #else
-template <bool EAGER_DETAIL = true>
-CSKY_HD float sample_density_eager(const TexSet& T, const FrameConsts& fc, float px, float py, float pz, float hf, float wx, float wy,
+template <bool EAGER_DETAIL = true, class TS>
+CSKY_HD float sample_density_eager(const TS& T, const FrameConsts& fc, float px, float py, float pz, float hf, float wx, float wy,
                                    int lod_shape, int lod_detail) {
     return sample_density(T, fc, px, py, pz, hf, wx, wy, lod_shape, lod_detail);
 }
@@ -546,7 +581,8 @@ CSKY_HD void shade_sample(const FrameConsts& fc, float phase, float t, float hf,
 struct MarchOut { float r, g, b, a, t; uint32_t incloud; };   // L.rgb, alpha, transmittance T, #in-cloud samples
 
 // clouds.glsl:139-215 march() for one ray.
-CSKY_HD MarchOut march(const TexSet& T, const FrameConsts& fc, Ray ray) {
+template <class TS>
+CSKY_HD MarchOut march(const TS& T, const FrameConsts& fc, Ray ray) {
     MarchOut o; o.r = o.g = o.b = o.a = 0.0f; o.t = 1.0f; o.incloud = 0;
     float phase = 0.0f;
     if (ray.above) {

@@ -69,6 +69,7 @@ typedef uint4 ShapeTexel;
 struct ShapeTexel { uint4 r, f; };
 #endif
 struct TexSet {
+    static constexpr bool cell32 = false;   // fp16-pair cells (the layouts above)
     const ShapeTexel* shape;   // all mip levels back to back; level l starts at shape_level_offset(l) texels (cloud_core.h)
     const uint4* detail;    // all mip levels back to back; level l starts at detail_level_offset(l)
     const uint4* weather;   // 512*512
@@ -80,6 +81,14 @@ struct TexSet {
 #ifdef CSKY_BRICK_BOUND
     const float* brick;     // experiment build only (round 3): per 8^3-texel brick of shape level 0 (+1 apron) an upper bound of base_cloud
 #endif
+};
+
+// The same set with EXACT cells (fp32 coefficients, bake_core.h): bound instead of TexSet when some coefficient of the textures does not fit fp16
+struct TexSet32 : TexSet {
+    static constexpr bool cell32 = true;
+    const float4* shape32;     // 4 x float4 per texel, levels packed like `shape`
+    const float4* detail32;    // 2 x float4 per texel
+    const float4* weather32;   // 2 x float4 per texel
 };
 
 // Ray-invariant per-frame constants, computed once per frame by frame_setup() (clouds.glsl:143-170).

@@ -20,7 +20,8 @@ hipError_t launch_frame_setup(const CloudParams& p, const float4* d_sky, int sw,
 // seg = ray segments per ray (1, 2 or 4; variant 1 only): a workgroup covers 4/seg tiles of 8x8 pixels.
 // d_order[grid]: physical workgroup -> workgroup-footprint id (0xffffffff = idle), see api.cpp::build_schedule.
 hipError_t launch_clouds(int variant, int seg, const TexSet& t, const FrameConsts* d_fc, const RenderGeom& g, const uint32_t* d_order, int grid,
-                         uint2* d_out, unsigned long long* d_stats, uint32_t* d_wg_cost, hipStream_t s, uint32_t* d_heads = nullptr, int resident = 0);
+                         uint2* d_out, unsigned long long* d_stats, uint32_t* d_wg_cost, hipStream_t s, uint32_t* d_heads = nullptr, int resident = 0,
+                         const TexSet32* t32 = nullptr);   // t32: march on the exact fp32-coefficient cells (variant 3, seg 1 only)
 // resident 256-thread workgroups per CU of the "compact" kernel (its launch bound): the size of a persistent launch
 int cloud_resident_workgroups_per_cu();
 // next launch's workgroup order from this launch's per-workgroup costs, heaviest first.  d_cost[n] and d_scratch[2048] must be zero
@@ -43,6 +44,9 @@ hipError_t launch_mip_chain(uint8_t* d_chain, int n, int ch, int levels, hipStre
 // weather map (initialise to {255, 0, 0})
 hipError_t launch_bake(const uint8_t* d_large_chain, const uint8_t* d_small_chain, const uint8_t* d_weather, ShapeTexel* d_shape, uint4* d_detail, uint16_t* d_detail_h,
                        uint4* d_weather_out, unsigned long long* d_inexact, int* d_range, hipStream_t s);
+
+// exact cells (bake_core.h): fp32-coefficient layouts of the same three textures
+hipError_t launch_bake32(const uint8_t* d_large_chain, const uint8_t* d_small_chain, const uint8_t* d_weather, float4* d_shape32, float4* d_detail32, float4* d_weather32, hipStream_t s);
 
 // test hook: cloud_core.h::sqrt_shell over an array
 hipError_t launch_sqrt_shell(const float* d_in, float* d_out, size_t n, hipStream_t s);

@@ -191,6 +191,46 @@ hipError_t launch_bake(const uint8_t* d_large_chain, const uint8_t* d_small_chai
     return hipGetLastError();
 }
 
+// exact cells (bake_core.h: fp32 coefficients), built only for textures with coefficients fp16 cannot hold (or on request)
+__global__ __launch_bounds__(256) void bake_shape32_kernel(const uint8_t* __restrict__ chain, float4* __restrict__ out) {
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    int l, n; size_t local;
+    if (level_of<SHAPE_N, SHAPE_LEVELS>(i, l, n, local)) {
+        const int x = (int)(local % n), y = (int)((local / n) % n), z = (int)(local / ((size_t)n * n));
+        float4 c[4];
+        bake_shape_texel32(chain + chain_offset(SHAPE_N, l, 4), n, x, y, z, c);
+        float4* o = out + 4 * ((i - local) + shape_cell_index(n, x, y, z));
+        o[0] = c[0]; o[1] = c[1]; o[2] = c[2]; o[3] = c[3];
+    }
+}
+__global__ __launch_bounds__(256) void bake_detail32_kernel(const uint8_t* __restrict__ chain, float4* __restrict__ out) {
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    int l, n; size_t local;
+    if (level_of<DETAIL_N, DETAIL_LEVELS>(i, l, n, local)) {
+        const int x = (int)(local % n), y = (int)((local / n) % n), z = (int)(local / ((size_t)n * n));
+        float4 c[2];
+        bake_detail_texel32(chain + chain_offset(DETAIL_N, l, 3), n, x, y, z, c);
+        out[2 * i] = c[0]; out[2 * i + 1] = c[1];
+    }
+}
+__global__ __launch_bounds__(256) void bake_weather32_kernel(const uint8_t* __restrict__ rgb, float4* __restrict__ out) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i < WEATHER_N * WEATHER_N) {
+        float4 c[2];
+        bake_weather_texel32(rgb, i % WEATHER_N, i / WEATHER_N, c);
+        out[2 * i] = c[0]; out[2 * i + 1] = c[1];
+    }
+}
+hipError_t launch_bake32(const uint8_t* d_large_chain, const uint8_t* d_small_chain, const uint8_t* d_weather, float4* d_shape32, float4* d_detail32, float4* d_weather32, hipStream_t s) {
+    size_t shape_total = 0, detail_total = 0;
+    for (int l = 0; l < SHAPE_LEVELS; l++) { const size_t n = SHAPE_N >> l; shape_total += n * n * n; }
+    for (int l = 0; l < DETAIL_LEVELS; l++) { const size_t n = DETAIL_N >> l; detail_total += n * n * n; }
+    bake_shape32_kernel<<<(unsigned)((shape_total + 255) / 256), 256, 0, s>>>(d_large_chain, d_shape32);
+    bake_detail32_kernel<<<(unsigned)((detail_total + 255) / 256), 256, 0, s>>>(d_small_chain, d_detail32);
+    bake_weather32_kernel<<<(WEATHER_N * WEATHER_N + 255) / 256, 256, 0, s>>>(d_weather, d_weather32);
+    return hipGetLastError();
+}
+
 // test hook (csky_test_sqrt_shell): cloud_core.h::sqrt_shell over an array, for the exhaustive check against the host's sqrtf
 __global__ __launch_bounds__(256) void sqrt_shell_kernel(const float* __restrict__ in, float* __restrict__ out, size_t n) {
     const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
@@ -397,8 +437,8 @@ constexpr int CQ_FLOATS = 7 * CQ_CAP + 3 * CQ_STEPS;         // pos(3) t hf ss p
 // CUs' wavefronts and got byte-identical frames: see the record further down).
 // `late(et, ehf, ess, eph)` delivers the four inputs the light march itself does not need AFTER it (the owner reads them from its LDS queue
 // then: four registers fewer across the march).
-template <class Late>
-__device__ __forceinline__ void light_march_terms(const TexSet& T, const FrameConsts& fc, const int ls, const float nd, float ex, float ey, float ez, Late&& late,
+template <class TS, class Late>
+__device__ __forceinline__ void light_march_terms(const TS& T, const FrameConsts& fc, const int ls, const float nd, float ex, float ey, float ez, Late&& late,
                                                   float& Dr, float& Dg, float& Db, float& rq, float& dt) {
     float lx = ex, ly = ey, lz = ez, cd = 0.0f;
 #pragma unroll 1                                                 // scalar j: one loop body (unrolling measured no faster, 6x the code)
@@ -421,7 +461,8 @@ __device__ __forceinline__ void light_march_terms(const TexSet& T, const FrameCo
     shade_terms(fc, eph, et, ehf, dt, cd, Dr, Dg, Db, rq);                                             // :202-209
 }
 
-__device__ __forceinline__ MarchOut march_compact(const TexSet& T, const FrameConsts& fc, Ray ray, float* __restrict__ q, int step_begin, int step_end) {
+template <class TS>
+__device__ __forceinline__ MarchOut march_compact(const TS& T, const FrameConsts& fc, Ray ray, float* __restrict__ q, int step_begin, int step_end) {
     float* __restrict__ ev_px = q;
     float* __restrict__ ev_py = q + CQ_CAP;
     float* __restrict__ ev_pz = q + 2 * CQ_CAP;
@@ -765,8 +806,8 @@ __global__ __launch_bounds__(1024) void clouds_kernel_lds(TexSet T, const FrameC
                                // together) 7 waves x 72 VGPRs beat 8 waves x 64 VGPRs + spills: whole frame 1.83 -> 1.80 ms, 1/4 frame 0.49 -> 0.48
 #endif
 // One workgroup's footprint (4 tiles / SEG): `logical` = slab * tiles_x + bx, `rec` = its position in the launch order (timeline build).
-template <int VARIANT, int SEG>
-__device__ __forceinline__ void render_block(TexSet T, const FrameConsts* __restrict__ fcp, const RenderGeom& G, const uint32_t logical, const uint32_t rec,
+template <int VARIANT, int SEG, class TS = TexSet>
+__device__ __forceinline__ void render_block(TS T, const FrameConsts* __restrict__ fcp, const RenderGeom& G, const uint32_t logical, const uint32_t rec,
                                              uint2* __restrict__ out, unsigned long long* __restrict__ stats, uint32_t* __restrict__ wg_cost, const int tile_of_wave = -1) {
     constexpr int BW = 32 / SEG;                               // workgroup footprint width in pixels
     const int tiles_x = (G.tile_w + BW - 1) / BW;
@@ -836,12 +877,12 @@ __device__ __forceinline__ void render_block(TexSet T, const FrameConsts* __rest
     }
 }
 
-template <int VARIANT, int SEG>
-__global__ __launch_bounds__(256, VARIANT == 3 ? CSKY_COMPACT_WAVES : 7) void clouds_kernel(TexSet T, const FrameConsts* __restrict__ fcp, RenderGeom G, const uint32_t* __restrict__ order,
+template <int VARIANT, int SEG, class TS = TexSet>
+__global__ __launch_bounds__(256, VARIANT == 3 ? CSKY_COMPACT_WAVES : 7) void clouds_kernel(TS T, const FrameConsts* __restrict__ fcp, RenderGeom G, const uint32_t* __restrict__ order,
                                                      uint2* __restrict__ out, unsigned long long* __restrict__ stats, uint32_t* __restrict__ wg_cost) {
     const uint32_t logical = order[blockIdx.x];
     if (logical == 0xffffffffu) return;                        // workgroup-uniform
-    render_block<VARIANT, SEG>(T, fcp, G, logical, blockIdx.x, out, stats, wg_cost);
+    render_block<VARIANT, SEG, TS>(T, fcp, G, logical, blockIdx.x, out, stats, wg_cost);
 }
 
 // Persistent form of the whole-ray kernel: the launch is only as large as the chip holds (CUs x resident workgroups) and its
@@ -1023,8 +1064,13 @@ int cloud_variant_count() { return (int)(sizeof(kVariantNames) / sizeof(kVariant
 const char* cloud_variant_name(int v) { return (v >= 0 && v < cloud_variant_count()) ? kVariantNames[v] : nullptr; }
 
 hipError_t launch_clouds(int variant, int seg, const TexSet& t, const FrameConsts* d_fc, const RenderGeom& g, const uint32_t* d_order, int grid,
-                         uint2* d_out, unsigned long long* d_stats, uint32_t* d_wg_cost, hipStream_t s, uint32_t* d_heads, int resident) {
+                         uint2* d_out, unsigned long long* d_stats, uint32_t* d_wg_cost, hipStream_t s, uint32_t* d_heads, int resident, const TexSet32* t32) {
     if (grid <= 0) return hipSuccess;
+    if (t32) {                                                 // exact fp32-coefficient cells: the compact whole-ray kernel on the other texture-set type
+        if (variant != 3 || seg != 1) return hipErrorInvalidValue;
+        clouds_kernel<3, 1, TexSet32><<<grid, 256, 0, s>>>(*t32, d_fc, g, d_order, d_out, d_stats, d_wg_cost);
+        return hipGetLastError();
+    }
     if (d_heads && variant == 3 && seg == 1) {                 // persistent form, see clouds_kernel_persistent
         clouds_kernel_persistent<3><<<grid < resident ? grid : resident, 256, 0, s>>>(t, d_fc, g, d_order, (uint32_t)grid, d_heads, d_out, d_stats, d_wg_cost);
         return hipGetLastError();

@@ -14,7 +14,7 @@
  *
  * Process environment: when libcloudsky.so is LOADED it sets GPU_MAX_HW_QUEUES=8 for the process unless the variable is already set (the HIP
  * runtime reads it at its first call; with the default of 4 the streams of two frames in flight share hardware queues and do not overlap).
- * CSKY_NO_ENV=1 in the environment disables that; csky_set_frames_in_flight(>= 2) then leaves a warning in csky_last_error when the
+ * CSKY_NO_ENV=1 in the environment disables that; csky_set_frames_in_flight(>= 2) then leaves a warning in csky_last_warning when the
  * variable is not in effect.  Other variables read (all optional, A/B switches): CSKY_PERSISTENT, CSKY_PERSISTENT_WGS, CSKY_MULTI_STAGED.
  *
  * Images are tightly packed little-endian RGBA half floats (DATA_FORMAT_R16G16B16A16_SFLOAT,
@@ -35,7 +35,7 @@ extern "C" {
 #define CSKY_ERR_IO (-4)         /* asset file problem                                       */
 #define CSKY_ERR_STATE (-5)      /* e.g. clouds requested before noise / LUTs exist          */
 
-#define CSKY_ABI_VERSION 4  /* 4: csky_submit_* / csky_collect, csky_multi_set_groups / _set_staged, csky_composite_view, csky_external_frame_* (incl. _fence / _ready / _wait); 3: csky_set_noise_mips, csky_decode_bc7, csky_load_ctex[3d]; 2: csky_multi_*, device asset builders */
+#define CSKY_ABI_VERSION 5  /* 5: csky_last_warning (warnings no longer sit in csky_last_error), exact fp32-coefficient texture cells; 4: csky_submit_* / csky_collect, csky_multi_set_groups / _set_staged, csky_composite_view, csky_external_frame_* (incl. _fence / _ready / _wait); 3: csky_set_noise_mips, csky_decode_bc7, csky_load_ctex[3d]; 2: csky_multi_*, device asset builders */
 
 typedef struct csky_ctx csky_ctx; /* opaque: owns every device allocation, the HIP stream and events */
 
@@ -85,6 +85,9 @@ int csky_device_count(void);
 int csky_create(csky_ctx** out, int device_id);
 void csky_destroy(csky_ctx* ctx);
 const char* csky_last_error(const csky_ctx* ctx); /* ctx may be NULL: last create/asset error of this thread */
+/* Text left by the last csky_set_noise* / csky_set_frames_in_flight call that returned CSKY_OK with a caveat ("" if none).  Never mixed into
+ * csky_last_error: a success does not leave text where the cause of the NEXT failure is looked for. */
+const char* csky_last_warning(const csky_ctx* ctx);
 
 /* ---- inputs --------------------------------------------------------------------------------------
  * replaces cloud_sky.gd:298-341 `_create_noise_uniform_set` (REPEAT + LINEAR sampler, three textures).
@@ -99,11 +102,14 @@ int csky_set_noise(csky_ctx* ctx, const uint8_t* large_rgba8, const uint8_t* sma
  * mipmaps/generate=true): the sampler of the reference sees exactly those texels, not a re-derived box filter. */
 int csky_set_noise_mips(csky_ctx* ctx, const uint8_t* large_chain_rgba8, const uint8_t* small_chain_rgb8, const uint8_t* weather_rgb8);
 /* The device layouts store finite differences of neighbouring texels as fp16 (exact for integers up to 2048).  Returns how
- * many coefficients of the textures bound by the last csky_set_noise did NOT fit exactly (0 for natural noise; only
- * adversarial checkerboards of extreme values exceed the range and then carry a relative 2^-11 error on that term).
- * csky_set_noise still returns CSKY_OK in that case but leaves a warning text in csky_last_error(ctx); callers that need the
- * exact-parity guarantee must check this count (the Python binding warns, bench.py and smoke() assert it is 0). */
+ * many coefficients of the textures bound by the last csky_set_noise* do NOT fit fp16 exactly (0 for natural noise; white noise and
+ * checkerboards of extreme values exceed the range).  Such textures are marched on EXACT cells instead -- the same filter polynomial with
+ * fp32 coefficients, twice the bytes per tap, always the whole-ray compact kernel (csky_set_variant / csky_set_segments do not apply) --
+ * so results are exact for ANY 8-bit input; csky_last_warning(ctx) says so, the count stays queryable.  The shipped textures give 0. */
 int csky_noise_inexact_coeffs(csky_ctx* ctx, uint64_t* count);
+/* 1 = build and march the exact fp32-coefficient cells regardless of the count above (A/B and tests: for textures that fit fp16 the two cell
+ * forms filter bit-identically); 0 = only when needed (default).  Takes effect at the next csky_set_noise*. */
+int csky_set_exact_cells(csky_ctx* ctx, int mode);
 /* clouds.glsl:228 (128 primary steps) and clouds.glsl:186 (6 light steps) are literals in the reference;
  * this generalises them (BASELINE config 2 is 64 x 4).  light_steps in [0,6], primary_steps in [1,1024]. */
 int csky_set_march(csky_ctx* ctx, int primary_steps, int light_steps);
@@ -172,7 +178,7 @@ int csky_poll(csky_ctx* ctx, int64_t ticket);
  * gdext/unverified/zero_copy_vulkan.c holds the Vulkan half and the Godot glue (RenderingDevice.texture_create_from_extension -> Texture2DRD); neither
  * Vulkan headers nor an engine exist in this image, so that file is compile-guarded; this half is exercised against a foreign allocator
  * (a hipMemCreate allocation exported as a dma-buf fd: tools/ext_frame_roundtrip.py, tests/test_gpu_round3.py).
- * The library takes ownership of the fds on success.
+ * The library takes ownership of the fds on success; on ANY failure the caller still owns them (the runtime is handed a duplicate).
  * Ordering without a semaphore: ROCm 7.2 on Linux refuses hipImportExternalSemaphore for every handle type (hipErrorNotSupported,
  * tools/ext_semaphore_probe.py; ..._import_semaphore_fd then returns CSKY_ERR_HIP and the frame stays usable).  ..._fence records an event
  * behind the march on its stream; the host polls ..._ready (1 = the frame is complete, 0 = still marching) or blocks in ..._wait before it

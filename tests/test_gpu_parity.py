@@ -387,8 +387,9 @@ def test_polynomial_cell_coefficients_exact_for_shipped_noise(gpu_ctx):
 
 
 def test_white_noise_textures(pkg, oracle, o_trans):
-    """Adversarial inputs: white-noise volumes and weather map (largest texel-to-texel differences; some finite differences
-    leave the exact fp16 range and the library reports how many).  Same tolerance as every other cloud parity test."""
+    """Adversarial inputs: white-noise volumes and weather map (largest texel-to-texel differences; 100 000+ finite differences leave the exact
+    fp16 range).  The library marches such textures on EXACT cells (fp32 coefficients, round 4) and says so; the gate is the tight one of every
+    other cloud parity test (rounds 1-3 marched them on rounded fp16 cells, warned, and were held to the loose SURVEY gate only)."""
     rng = np.random.default_rng(11)
     noise = (rng.integers(0, 256, (128, 128, 128, 4), dtype=np.uint8), rng.integers(0, 256, (32, 32, 32, 3), dtype=np.uint8),
              rng.integers(0, 256, (512, 512, 3), dtype=np.uint8))
@@ -398,19 +399,46 @@ def test_white_noise_textures(pkg, oracle, o_trans):
     ctx = pkg.Context(0)
     try:
         ctx.set_noise(*noise)
-        assert ctx.noise_inexact_coeffs() > 0
+        assert ctx.noise_inexact_coeffs() > 0 and "exact fp32 cells" in ctx.last_warning()
         ctx.render_transmittance(256, 64)
         ctx.render_sky_lut(sun, 200, 100)
         for cov in (0.2, 0.6):
             p = oracle.default_params(128, 64, (1, 1, 0), coverage=cov)
             ref, st = oracle.clouds(otex, p, sk, return_stats=True)
             img = ctx.render_clouds(p)
-            ok, info = cloud_close(img, ref)
+            ok, info = cloud_tight(img, ref)
             assert ok, (cov, info)
             got = int(ctx.cloud_stats()["incloud_samples"])
-            assert got > 0 and abs(got - st["incloud_samples"]) <= 1e-3 * st["incloud_samples"] + 1, cov
+            assert got > 0 and abs(got - st["incloud_samples"]) <= 2e-5 * st["incloud_samples"] + 2, (cov, got, st["incloud_samples"])
+        # rank shares and every variant / segment setting march the same exact cells
+        p = oracle.default_params(128, 64, (1, 1, 0), coverage=0.2)
+        whole = ctx.render_clouds(p)
+        ctx.set_variant(1); ctx.set_segments(4)
+        assert np.array_equal(ctx.render_clouds(p).view(np.uint16), whole.view(np.uint16))
     finally:
         ctx.close()
+
+
+def test_exact_cells_equal_the_fp16_cells_where_those_are_exact(pkg, oracle):
+    """For textures whose cells fit fp16 (the shipped ones: 0 inexact coefficients) the exact fp32-coefficient cells hold the same numbers, so
+    the frame must not differ in a single bit from the product path's (whole-ray compact kernel both times): the exact path is the same filter."""
+    large, small, weather = pkg.assets.load_default_noise()
+    sun = norm((1, 1, 0))
+    p = oracle.default_params(256, 128, sun)
+    frames = []
+    for mode in (0, 1):
+        ctx = pkg.Context(0)
+        try:
+            ctx.set_exact_cells(mode)
+            ctx.set_noise(large, small, weather)
+            assert ctx.noise_inexact_coeffs() == 0 and ctx.last_warning() == ""
+            ctx.set_segments(1)
+            ctx.render_transmittance(256, 64)
+            ctx.render_sky_lut(sun, 200, 100)
+            frames.append((ctx.render_clouds(p).view(np.uint16), ctx.cloud_stats()["incloud_samples"]))
+        finally:
+            ctx.close()
+    assert frames[0][1] == frames[1][1] and np.array_equal(frames[0][0], frames[1][0])
 
 
 def test_fuzz_parameters_vs_oracle(gpu_ctx, oracle, otex, o_trans):

@@ -18,7 +18,7 @@ def product_asm(tmp_path_factory):
 
 def test_scratch_accesses_sit_outside_the_march_loops(product_asm):
     import isa_census as IC
-    for kernel, max_depth in (("_ZN4csky13clouds_kernelILi3ELi1E", 0), ("_ZN4csky24clouds_kernel_persistentILi3E", 2)):
+    for kernel, max_depth in (("_ZN4csky13clouds_kernelILi3ELi1ENS_6TexSetE", 0), ("_ZN4csky24clouds_kernel_persistentILi3E", 2)):
         name, blocks = IC.parse_kernel(product_asm, kernel)
         cen, loops = IC.census(blocks)
         assert len(cen) > 100 and sum(b["n"] for b in cen) > 1500, name
@@ -52,7 +52,7 @@ def test_every_basic_block_gets_a_counter(product_asm):
 
 def test_classification_covers_the_kinds_the_kernel_executes(product_asm):
     import isa_census as IC
-    name, blocks = IC.parse_kernel(product_asm, "_ZN4csky13clouds_kernelILi3ELi1E")
+    name, blocks = IC.parse_kernel(product_asm, "_ZN4csky13clouds_kernelILi3ELi1ENS_6TexSetE")
     kinds = set()
     for b in IC.census(blocks)[0]:
         kinds.update(k for k in b["kinds"] if k.startswith("v_"))

@@ -192,7 +192,7 @@ def census(blocks):
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--kernel", default="clouds_kernelILi3ELi1E")
+    ap.add_argument("--kernel", default="clouds_kernelILi3ELi1ENS_6TexSetE")
     ap.add_argument("--asm", default=None)
     ap.add_argument("--blocks", action="store_true", help="print every basic block")
     ap.add_argument("--json", default=None)

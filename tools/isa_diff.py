@@ -14,7 +14,7 @@ def body(path, name):
             out.append(re.sub(r"\.LBB\d+_", ".LBB_", t))
     return out
 a, b = sys.argv[1], sys.argv[2]
-names = sys.argv[3:] or ["clouds_kernelILi3ELi1E", "clouds_kernel_persistentILi3E", "clouds_kernelILi3ELi2E", "clouds_kernelILi3ELi4E", "clouds_kernelILi1ELi1E", "clouds_kernelILi0ELi1E"]
+names = sys.argv[3:] or ["clouds_kernelILi3ELi1ENS_6TexSetE", "clouds_kernel_persistentILi3E", "clouds_kernelILi3ELi2E", "clouds_kernelILi3ELi4E", "clouds_kernelILi1ELi1E", "clouds_kernelILi0ELi1E"]
 bad = 0
 for k in names:
     x, y = body(a, k), body(b, k)

@@ -34,7 +34,7 @@ import isa_census as IC  # noqa: E402
 
 CSRC = os.path.join(ROOT, "godot-volumetric-cloud-demo-v2_amd", "csrc")
 LLVM = "/opt/rocm/lib/llvm/bin"
-KERNELS = {"plain": "_ZN4csky13clouds_kernelILi3ELi1E", "persistent": "_ZN4csky24clouds_kernel_persistentILi3E"}
+KERNELS = {"plain": "_ZN4csky13clouds_kernelILi3ELi1ENS_6TexSetE", "persistent": "_ZN4csky24clouds_kernel_persistentILi3E"}
 FLAGS = ["-O3", "-std=c++17", "-fPIC", "-fno-slp-vectorize", "--offload-arch=gfx950", "-Wno-unused-function", "-Wno-unknown-pragmas", "-Wno-pass-failed"]
 N_CTR_VGPR = 4                      # 256 block counters per kernel
 CENSUS_BYTE_OFFSET = 16             # the kernel's own two 64-bit tallies come first in the stats buffer
@@ -160,9 +160,12 @@ def instrument(lines, mangled_prefix):
 
 
 def cmd_build(args):
-    work = args.work
-    shutil.rmtree(work, ignore_errors=True)
-    os.makedirs(work)
+    import tempfile
+    own = args.work is None                                    # a private work directory per build: concurrent builds on one box never share one
+    work = tempfile.mkdtemp(prefix="isa_profile_") if own else args.work
+    if not own:
+        shutil.rmtree(work, ignore_errors=True)
+        os.makedirs(work)
     subprocess.check_call(["/opt/rocm/bin/hipcc"] + FLAGS + ["-save-temps", "-c", os.path.join(CSRC, "kernels.hip"), "-o", os.path.join(work, "k.o")], cwd=work,
                           stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
     asm = os.path.join(work, "kernels-hip-amdgcn-amd-amdhsa-gfx950.s")
@@ -195,6 +198,8 @@ def cmd_build(args):
     static["source_hash"] = pmc_collect.source_hash()
     json.dump(static, open(os.path.join(ROOT, "godot-volumetric-cloud-demo-v2_amd", "libcloudsky_census.json"), "w"))
     print("built %s (%s basic blocks instrumented), static census -> libcloudsky_census.json" % (out, info))
+    if own:
+        shutil.rmtree(work, ignore_errors=True)
 
 
 def census_available():
@@ -349,7 +354,7 @@ def cmd_report(args):
 def main():
     ap = argparse.ArgumentParser()
     sub = ap.add_subparsers(dest="cmd", required=True)
-    b = sub.add_parser("build"); b.add_argument("--work", default="/tmp/isa_profile")
+    b = sub.add_parser("build"); b.add_argument("--work", default=None, help="keep the intermediate files here (default: a private temporary directory, removed afterwards)")
     r = sub.add_parser("run"); r.add_argument("--config", default="C3"); r.add_argument("--out", default=os.path.join(ROOT, "gpurun_out", "census_counts.json"))
     p = sub.add_parser("report"); p.add_argument("counts"); p.add_argument("--out", default=None)
     a = ap.parse_args()
