@@ -17,15 +17,18 @@ frame k's launch overlaps the head of frame k+1's and, at N > 1, frame k's gathe
 at a time).  `value` is the pipelined whole-job rate; the same K frames strictly one at a time are timed right after it and
 reported next to it (`value_one_frame_at_a_time`): quote both.
 
-`roofline` (round 3): the path is not HBM-bound (82 MB of baked inputs live in L2 / Infinity Cache) and has no contraction, so
-neither "hbm" nor "mfma" bounds it; the binding unit is VALU issue, with the vector-L1 gather path close behind.  Everything is measured in
-this run, after the timed region: executed instructions = basic-block execution counts of the CENSUS build of the library (the product's own
-assembly with a counter per block, tools/isa_profile.py; its frame is byte-identical) x the static per-block histogram, priced per KIND with issue
-costs measured on gfx950 (profiles/r03/issue_cost_calibration.json) and cross-checked against the hardware totals (rocprofv3 --pmc passes in child
-processes, tools/pmc_collect.py); cycles available = duration x the shader clock SAMPLED while the same loop re-runs (tools/sclk.py).  Top level =
-the timed region (`ms_per_step`); `kernel_alone` = one launch with the GPU to itself.  Nothing is read from a committed counter file: without
-rocprofv3 / the census library the corresponding fields are null.  The contract's algorithmic-bytes figure is kept as `hbm_algorithmic` with
-its ratio to the HBM peak (> 1: the taps are served by L1/L2, it stopped discriminating in round 1).
+`roofline`: the path is not HBM-bound (82 MB of baked inputs live in L2 / Infinity Cache) and has no contraction, so neither "hbm" nor "mfma"
+bounds it; the binding unit is VALU issue, with the vector-L1 gather path close behind.  Everything is measured in this run, after the timed
+region: executed instructions = basic-block execution counts of the CENSUS build of the library (the product's own assembly with a counter per
+block, tools/isa_profile.py; its frame is byte-identical) x the static per-block histogram, cross-checked against the hardware totals (rocprofv3
+--pmc passes in child processes, tools/pmc_collect.py).  Round 4: the TOP LEVEL is the dominant kernel ALONE at the guide's
+issue rates -- achieved = (full x 2 + half x 4 + transcendental x 8) / 1024 SIMDs from `valu_issue.valu_by_class`, peak = `kernel_alone.kernel_ms`
+(HIP events around single launches) x the shader clock sampled while they ran (tools/sclk.py) -- recomputable in one line; `frac_calibrated`
+prices every kind with the TIME it costs in a differential micro-benchmark (profiles/r04/valu_issue_time_gfx950.json, no clock reading);
+`frac_timed_region` is the persistent form's instructions over `ms_per_step` (launches overlap there: a chip-busy figure).  Nothing is read from a
+committed counter file: without rocprofv3 / the census library the fields are null.  The contract's algorithmic-bytes figure is kept as
+`hbm_algorithmic` with its ratio to the HBM peak (> 1); `executed_tap_bytes` next to it is what the kernel's lanes actually request
+(tools/executed_tap_bytes.py: the exact rejects skip 42 % of the algorithmic bytes, the rest is served by L1 / L2 / Infinity Cache).
 
 `value_host_form`: the same frames delivered into PINNED HOST memory through csky_submit_clouds / csky_collect (what the GDExtension's
 submit_clouds() / collect() wrap), with one and two frames in flight: PCIe-inclusive, never the headline `value`.
@@ -256,21 +259,33 @@ def main_single_process(args):
 
 
 def valu_roofline(census, clocks, pmc, vi, k_solo_ms, ms_per_step):
-    """The VALU-issue roofline from the instruction census and the sampled clocks (see the `roofline.note` of the JSON line)."""
-    out = {"achieved": None, "peak": None, "frac": None, "frac_bounds": None, "headline": None, "valu_issue": None, "clocks": clocks}
+    """The VALU-issue roofline from the instruction census and the sampled clocks (see the `roofline.note` of the JSON line).
+
+    Top level = the dominant kernel ALONE at the guide's issue rates:
+        achieved = (full x 2 + half x 4 + transcendental x 8) / 1024 SIMDs        executed wave64 VALU instructions by class (census)
+        peak     = kernel_ms (HIP events around one launch with the GPU to itself) x the shader clock sampled while those launches ran
+        frac     = achieved / peak
+    `frac_calibrated`: the same launch priced with the TIME each instruction kind costs (differential micro-benchmark, ns per instruction,
+    profiles/r04/valu_issue_time_gfx950.json) over kernel_ms: no clock reading in it.  `frac_timed_region` (+ `_calibrated`): the persistent form's
+    instructions over ms_per_step, the effective per-frame time of the timed region where two launches overlap."""
+    out = {"achieved": None, "peak": None, "frac": None, "frac_calibrated": None, "frac_timed_region": None, "frac_timed_region_calibrated": None,
+           "kernel_alone": None, "timed_region": None, "valu_issue": None, "clocks": clocks}
     if not census:
         return out
     kp = census["kernels"].get("plain") or {}
     kq = census["kernels"].get("persistent") or {}
     mix = census.get("mixed_stream_factor") or {}
-    mix_hi = max(mix.values()) if mix else 1.0
-    ach = kp.get("valu_issue_cycles_per_simd")
-    out["valu_issue"] = {"source": "census", "calibration": census.get("calibration"), "mixed_stream_factor": mix,
-                         "executed": kp.get("executed"), "valu_by_class": kp.get("valu_by_class"), "issue_cycles_per_simd": ach,
+    out["valu_issue"] = {"source": "census", "guide_cycles_per_class": census.get("guide_cycles_per_class"), "time_calibration": census.get("time_calibration"),
+                         "round3_calibration": census.get("calibration"), "mixed_stream_factor": mix,
+                         "executed": kp.get("executed"), "valu_by_class": kp.get("valu_by_class"),
+                         "issue_cycles_guide_per_simd": kp.get("valu_issue_cycles_guide_per_simd"), "issue_time_ms_per_simd": kp.get("valu_issue_time_ms_per_simd"),
+                         "issue_cycles_round3_calibration_per_simd": kp.get("valu_issue_cycles_per_simd"),
+                         "persistent_form": {"valu_by_class": kq.get("valu_by_class"), "issue_cycles_guide_per_simd": kq.get("valu_issue_cycles_guide_per_simd"),
+                                             "issue_time_ms_per_simd": kq.get("valu_issue_time_ms_per_simd")},
                          "priced_by_measured_kind_fraction": kp.get("valu_priced_by_measured_kind_fraction"),
                          "frame_identical_to_product": kp.get("frame_identical_to_product"),
                          "scratch_instructions_per_wavefront": {"plain": kp.get("scratch_instructions_per_wavefront"), "persistent": kq.get("scratch_instructions_per_wavefront")},
-                         "persistent_form_issue_cycles_per_simd": kq.get("valu_issue_cycles_per_simd"), "top_kinds": (kp.get("top_kinds") or [])[:12]}
+                         "top_kinds": (kp.get("top_kinds") or [])[:12]}
     cnt = ((pmc or {}).get("counters_per_launch") or {})
     ins = cnt.get("insts") or cnt.get("valu") or {}
     if ins and kp.get("executed"):
@@ -280,29 +295,24 @@ def valu_roofline(census, clocks, pmc, vi, k_solo_ms, ms_per_step):
     ck = (clocks or {}).get("kernel_alone") or {}
     nominal = (clocks or {}).get("nominal_mhz")          # no hwmon node readable: the device's maximum clock (fractions come out LOW, never above 1 by that)
     mhz = (ck.get("sclk") or {}).get("mean_mhz") or nominal
-    sq_cycles = vi.get("kernel_cycles")
-    alone = None
+    ach, ach_ms = kp.get("valu_issue_cycles_guide_per_simd"), kp.get("valu_issue_time_ms_per_simd")
     if ach and mhz:
         k_ms = ck.get("kernel_ms") or k_solo_ms
         peak = k_ms * 1e-3 * mhz * 1e6
-        alone = {"achieved": ach, "peak": peak, "frac": ach / peak, "frac_bounds": [ach / peak, min(1.0, ach * mix_hi / peak)], "kernel_ms": k_ms, "sclk_mhz": mhz,
-                 "peak_source": "kernel alone: %.3f ms x %.0f MHz sampled (SQ_BUSY_CYCLES/32 of the counter pass: %s)" % (k_ms, mhz, "%.4g" % sq_cycles if sq_cycles else "n/a")}
-    elif ach and sq_cycles:
-        alone = {"achieved": ach, "peak": sq_cycles, "frac": ach / sq_cycles, "frac_bounds": [ach / sq_cycles, min(1.0, ach * mix_hi / sq_cycles)], "peak_source": "SQ_BUSY_CYCLES/32 (no clock sample)"}
-    out["kernel_alone"] = alone
+        out["kernel_alone"] = {"kernel": "clouds_kernel<3,1>", "kernel_ms": k_ms, "sclk_mhz": mhz, "achieved": ach, "peak": peak, "frac": ach / peak,
+                               "frac_calibrated": (ach_ms / k_ms) if ach_ms else None,
+                               "recompute": "(full x 2 + half x 4 + trans x 8) / 1024 / (kernel_ms x 1e-3 x sclk_mhz x 1e6) with valu_issue.valu_by_class"}
+        out.update({"achieved": ach, "peak": peak, "frac": ach / peak, "frac_calibrated": out["kernel_alone"]["frac_calibrated"],
+                    "peak_source": "kernel alone: %.4f ms (HIP events around single launches) x %.0f MHz sampled while they ran" % (k_ms, mhz)})
     ch = (clocks or {}).get("headline") or {}
     mhz_h = (ch.get("sclk") or {}).get("mean_mhz") or nominal
-    achq = kq.get("valu_issue_cycles_per_simd") or ach
+    achq, achq_ms = kq.get("valu_issue_cycles_guide_per_simd") or ach, kq.get("valu_issue_time_ms_per_simd") or ach_ms
     if achq and mhz_h:
         peak_h = ms_per_step * 1e-3 * mhz_h * 1e6
-        out["headline"] = {"ms_per_step": ms_per_step, "sclk_mhz": mhz_h, "cycles_per_frame_available": peak_h, "issue_cycles_per_simd": achq, "frac": achq / peak_h,
-                           "frac_bounds": [achq / peak_h, min(1.0, achq * mix_hi / peak_h)], "ms_per_frame_while_sampling": ch.get("ms_per_frame")}
-        # top level = the TIMED REGION: every launch's VALU issue cycles over the cycles the region had (launches overlap there, two frames in flight, so
-        # a per-launch duration means nothing; elapsed / launches = ms_per_step is the effective one).  `kernel_alone` is one launch with the GPU to itself.
-        out.update({"achieved": achq, "peak": peak_h, "frac": achq / peak_h, "frac_bounds": out["headline"]["frac_bounds"],
-                    "peak_source": "timed region: ms_per_step %.4f ms x %.0f MHz sampled while the same loop ran" % (ms_per_step, mhz_h)})
-    elif alone:
-        out.update({k: alone[k] for k in ("achieved", "peak", "frac", "frac_bounds", "peak_source")})
+        out["timed_region"] = {"kernel": "clouds_kernel_persistent<3>, two launches overlapping", "ms_per_step": ms_per_step, "sclk_mhz": mhz_h, "achieved": achq, "peak": peak_h,
+                               "frac": achq / peak_h, "frac_calibrated": (achq_ms / ms_per_step) if achq_ms else None, "ms_per_frame_while_sampling": ch.get("ms_per_frame")}
+        out["frac_timed_region"] = achq / peak_h
+        out["frac_timed_region_calibrated"] = out["timed_region"]["frac_calibrated"]
     return out
 
 
@@ -655,6 +665,15 @@ def main():
                 except BaseException as e:
                     census, census_note = None, "census failed: %s" % str(e)[:200]
         vi = (pmc or {}).get("valu_issue") or {}
+        # the bytes the kernel's lanes REQUEST per frame (its own reject logic walked on the host over every ray: tools/executed_tap_bytes.py), next to
+        # the contractual 80 B/sample: why the algorithmic figure exceeds the HBM peak without any work being skipped
+        executed_taps = None
+        tap_file = os.path.join(ROOT, "profiles", "r04", "executed_tap_bytes_C3.json")
+        if args.config == "C3" and world == 1 and os.path.exists(tap_file):
+            et = json.load(open(tap_file))
+            executed_taps = {"bytes_per_launch": et["executed_tap_bytes"], "over_algorithmic": et["executed_over_algorithmic"], "primary": et["primary"]["bytes"], "light": et["light"]["bytes"],
+                             "achieved_GBps_solo": et["executed_tap_bytes"] / (k_solo * 1e-3) / 1e9, "source": "profiles/r04/executed_tap_bytes_C3.json (host walk of cloud_core.h, lane-level)",
+                             "in_cloud_samples_match_this_run": et["primary"]["in_cloud"] == st["incloud_samples"] or abs(et["primary"]["in_cloud"] - st["incloud_samples"]) <= 64}
         l1 = (pmc or {}).get("l1_gather") or {}
         hb = (pmc or {}).get("hbm_traffic") or {}
         traffic = hb.get("bytes")
@@ -679,7 +698,7 @@ def main():
                        "alpha_mean": alpha_mean, "finite": finite},
             "roofline": dict(valu_roofline(census, clocks, pmc, vi, k_solo, elapsed / args.steps * 1e3), **{
                 # neither "hbm" nor "mfma" binds this path (docstring): the top-level fields are the VALU-issue roof, the one closest to 1
-                "bound": "valu", "kernel": "the cloud march: clouds_kernel_persistent<3> over the timed region (two frames in flight; top level and `headline`), clouds_kernel<3,1> = the same body as a plain launch with the GPU to itself (`kernel_alone`)",
+                "bound": "valu", "kernel": "the cloud march.  Top level: clouds_kernel<3,1> alone (one launch with the GPU to itself) at the guide's issue rates; `timed_region`: the same body as clouds_kernel_persistent<3> over the timed region, two launches overlapping",
                 "unit": "SIMD issue cycles per launch",
                 "traffic": traffic,
                 "kernel_ms_solo": k_solo, "kernel_ms_in_flight": k_inflight, "kernel_launches_timed": k_launches, "frames_in_flight": fif,
@@ -700,14 +719,15 @@ def main():
                                             "for continuity with round 1 only"},
                 "pmc": {"collected": "live in this run (tools/pmc_collect.py)" if pmc else None, "note": pmc_note, "source_hash": (pmc or {}).get("source_hash"),
                         "calibration": (pmc or {}).get("calibration"), "seconds": pmc_s if pmc else None},
-                "note": "achieved = EXECUTED wave64 VALU instructions by kind (basic-block counts of the census build x the static per-block histogram) x the issue cost "
-                        "of each kind measured on gfx950, per SIMD and per launch; peak = the cycles a SIMD had per launch = duration x the shader clock sampled during it.  "
-                        "Top level (= `headline`) is the TIMED REGION: per-frame time ms_per_step (launches overlap there: two frames in flight, persistent form); "
-                        "`kernel_alone` is one launch with the GPU to itself.  frac is the additive pricing (a lower bound of the VALU's busy time); frac_bounds[1] applies "
-                        "the measured mixed-stream factor (a 16-instruction stream in the census's proportions costs 1.06-1.09 x the sum of its kinds).  "
+                "executed_tap_bytes": executed_taps,
+                "note": "achieved = EXECUTED wave64 VALU instructions by class (basic-block counts of the census build x the static per-block histogram: valu_issue.valu_by_class) "
+                        "at the guide's issue rates, full 2 / half 4 / transcendental 8 cycles per instruction on a SIMD-32, per SIMD (/ 1024); peak = the cycles a SIMD had = "
+                        "the launch's duration alone (HIP events) x the shader clock sampled while it ran.  frac_calibrated prices every kind with the time it costs in a "
+                        "differential micro-benchmark (profiles/r04/valu_issue_time_gfx950.json: ns per instruction, no clock reading) over the same duration: an upper "
+                        "estimate, pure streams run the chip at 2.0-2.35 GHz where this kernel runs at 2.38.  frac_timed_region: the persistent form's instructions over ms_per_step "
+                        "(two launches overlap there; a per-launch duration means nothing, elapsed / launches is the effective one): a chip-busy figure, not the kernel's.  "
                         "valu_issue_class_counter_model is round 2's model (hardware class counters, 28 % unclassified) kept for comparison; l1_gather = TA_TA_BUSY / (256 CUs x "
-                        "kernel cycles by SQ_BUSY_CYCLES/32), ~1.0 in every saturated pattern of tools/ubench/gather_rates.hip.  With two frames in flight the next "
-                        "frame fills this launch's tail and the VALU fraction per frame time approaches 1"}),
+                        "kernel cycles by SQ_BUSY_CYCLES/32), ~1.0 in every saturated pattern of tools/ubench/gather_rates.hip"}),
         }
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(large, small, weather, params, sun_n, W, H, primary, light)

@@ -302,9 +302,49 @@ def mixed_stream_factor(cal):
     return {"no_transcendental": pk["mix16"] / ((base + pk["mov"]) / 16.0), "one_transcendental_in_16": pk["mix16_trans"] / ((base + pk["rcp"]) / 16.0)}
 
 
+# ---- the two pricings of round 4
+# (1) the guide's issue rates (/opt/skills/guides/MI355X_MICROARCH.md: a SIMD is 32 lanes wide, a wave64 VALU instruction issues over 2 cycles; half-rate
+#     kinds 4, transcendentals 8), per instruction CLASS: what bench.py's top-level roofline.frac uses, recomputable from the class totals in one line.
+GUIDE_CYCLES = {"full": 2.0, "half": 4.0, "trans": 8.0, "quarter": 8.0, "lane": 4.0}
+# (2) the TIME a kind costs, measured differentially (tools/ubench/valu_rates2 diff -> profiles/r04/valu_issue_time_gfx950.json: slope of the event-timed
+#     launch time between N and 3N loop iterations at 8 waves per SIMD, so launch ramp, prologue and tail drop out).  In nanoseconds per wave64 instruction
+#     per SIMD: no clock reading enters at all -- a pure stream of one kind draws enough power for the chip to run at 2.0-2.35 GHz, lower for the full-rate
+#     kinds, and the hwmon clock node under-reads those states (full-rate kinds come out at 1.8-1.9 "cycles" with it) -- and the denominator of the
+#     fraction is the kernel's own duration in the same unit.  An UPPER estimate of the VALU's busy share: the cloud kernel itself runs at 2.38 GHz.
+def time_calibration_path():
+    p = os.path.join(ROOT, "profiles", "r04", "valu_issue_time_gfx950.json")
+    return p if os.path.exists(p) else None
+
+
+def kind_ns(kind, tcal):
+    ns = {k: v["ns_per_instr"] for k, v in tcal.items()}
+    full = sum(ns[k] for k in ("v_mul_f32", "v_add_f32", "v_fmac_f32", "v_mov_b32", "v_and_b32", "v_fma_f32 3 vgpr src")) / 6.0
+    half = sum(ns[k] for k in ("v_fma_mix_f32", "v_lshlrev_b32", "v_cvt_flr_i32_f32", "v_fract_f32", "v_cndmask_b32 sgpr", "v_lshl_or_b32")) / 6.0
+    trans = sum(ns[k] for k in ("v_rcp_f32", "v_exp_f32", "v_log_f32", "v_sqrt_f32")) / 4.0
+    table = {"v_fma_f32": ns["v_fma_f32 3 vgpr src"], "v_fmac_f32": ns["v_fmac_f32"], "v_mul_f32": ns["v_mul_f32"], "v_add_f32": ns["v_add_f32"], "v_sub_f32": ns["v_sub_f32"],
+             "v_subrev_f32": ns["v_sub_f32"], "v_mov_b32": ns["v_mov_b32"], "v_and_b32": ns["v_and_b32"], "v_or_b32": ns["v_and_b32"], "v_xor_b32": ns["v_and_b32"],
+             "v_add_u32": ns["v_add_u32"], "v_sub_u32": ns["v_add_u32"], "v_subrev_u32": ns["v_add_u32"], "v_fma_mix_f32": ns["v_fma_mix_f32"], "v_max_f32": ns["v_max/min_f32"],
+             "v_min_f32": ns["v_max/min_f32"], "v_med3_f32": ns["v_med3_f32"], "v_lshlrev_b32": ns["v_lshlrev_b32"], "v_lshrrev_b32": ns["v_lshlrev_b32"],
+             "v_lshl_or_b32": ns["v_lshl_or_b32"], "v_and_or_b32": ns["v_and_or_b32"], "v_bfe_u32": ns["v_bfe_u32"], "v_bfi_b32": ns["v_bfi_b32"], "v_lshl_add_u32": ns["v_lshl_add_u32"],
+             "v_cvt_flr_i32_f32": ns["v_cvt_flr_i32_f32"], "v_fract_f32": ns["v_fract_f32"], "v_floor_f32": ns["v_floor_f32"], "v_cvt_f32_i32": ns["v_cvt_f32_i32"],
+             "v_cvt_f32_u32": ns["v_cvt_f32_i32"], "v_cndmask_b32": ns["v_cndmask_b32 sgpr"], "v_rcp_f32": ns["v_rcp_f32"], "v_exp_f32": ns["v_exp_f32"], "v_log_f32": ns["v_log_f32"],
+             "v_sqrt_f32": ns["v_sqrt_f32"], "v_rsq_f32": ns["v_sqrt_f32"], "v_mul_lo_u32": ns["v_mul_lo_u32"], "v_mad_u32_u24": ns["v_mad_u32_u24"], "v_fmaak_f32": ns["v_fmamk_f32"],
+             "v_fmamk_f32": ns["v_fmamk_f32"], "v_add_lshl_u32": ns["v_add_lshl_u32"], "v_or3_b32": ns["v_or3_b32"], "v_readfirstlane_b32": ns["v_readfirstlane_b32"],
+             "v_mbcnt_lo_u32_b32": ns["v_mbcnt_lo/hi"], "v_mbcnt_hi_u32_b32": ns["v_mbcnt_lo/hi"]}
+    if kind in table:
+        return table[kind], "measured"
+    if kind.startswith("v_cmp"):
+        return ns["v_cmp_gt_f32 -> sgpr"], "measured"
+    c = IC.classify(kind)
+    return {"full": full, "half": half, "trans": trans, "quarter": 2 * half, "lane": half}.get(c, half), "class:" + c
+
+
 def report(d, quiet=False):
     cal = json.load(open(calibration_path()))
-    out = {"config": d["config"], "source_hash": d["source_hash"], "calibration": os.path.relpath(calibration_path(), ROOT), "mixed_stream_factor": mixed_stream_factor(cal), "kernels": {}}
+    tpath = time_calibration_path()
+    tcal = json.load(open(tpath)) if tpath else None
+    out = {"config": d["config"], "source_hash": d["source_hash"], "calibration": os.path.relpath(calibration_path(), ROOT), "mixed_stream_factor": mixed_stream_factor(cal),
+           "guide_cycles_per_class": GUIDE_CYCLES, "time_calibration": os.path.relpath(tpath, ROOT) if tpath else None, "kernels": {}}
     for tag, k in d["kernels"].items():
         blocks = d["static"][tag]["blocks"]
         counts = k["counts"]
@@ -324,11 +364,16 @@ def report(d, quiet=False):
             per_kind.append({"kind": kk, "wave_instructions": v, "cycles_each": c, "source": src})
         n_valu = sum(valu.values())
         n_waves = counts[0]
+        by_class = {c: sum(v for kk, v in valu.items() if IC.classify(kk) == c) for c in ("full", "half", "trans", "quarter", "lane")}
+        guide_cycles = sum(GUIDE_CYCLES[c] * v for c, v in by_class.items())
+        time_ns = sum(kind_ns(kk, tcal)[0] * v for kk, v in valu.items()) if tcal else None
         o = {"frame_identical_to_product": k["frame_identical_to_product"], "wavefronts": n_waves, "stats": k["stats"],
              "executed": {"valu": n_valu, "salu": classes["salu"], "smem": classes["smem"], "vmem_load": classes["vmem_load"], "vmem_store": classes["vmem_store"],
                           "vmem_atomic": classes["vmem_atomic"], "lds": classes["lds"], "branch": classes["branch"], "wait": classes["wait"], "scratch": classes["scratch"]},
-             "valu_by_class": {c: sum(v for kk, v in valu.items() if IC.classify(kk) == c) for c in ("full", "half", "trans", "quarter", "lane")},
-             "valu_issue_cycles_total": cycles, "valu_issue_cycles_per_simd": cycles / 1024.0,
+             "valu_by_class": by_class,
+             "valu_issue_cycles_guide_per_simd": guide_cycles / 1024.0,                       # sum over classes of count x (2, 4, 8) / 1024 SIMDs
+             "valu_issue_time_ms_per_simd": (time_ns / 1024.0 * 1e-6) if time_ns is not None else None,   # sum over kinds of count x measured ns / 1024 SIMDs
+             "valu_issue_cycles_total": cycles, "valu_issue_cycles_per_simd": cycles / 1024.0,   # round 3's per-kind cycles (SQ_BUSY_CYCLES/32 of the calibration launches): kept for comparison
              "valu_priced_by_measured_kind_fraction": by_source["measured"] / max(1, n_valu),
              "scratch_instructions_per_wavefront": classes["scratch"] / max(1, n_waves),
              "top_kinds": per_kind[:40]}
@@ -339,8 +384,8 @@ def report(d, quiet=False):
         print("   executed wave-instructions: VALU %.4g (full %.4g, half %.4g, trans %.4g)  SALU %.4g  SMEM %.4g  VMEM loads %.4g  LDS %.4g  branches %.4g  waits %.4g  scratch %.4g (%.1f per wavefront)"
               % (n_valu, o["valu_by_class"]["full"], o["valu_by_class"]["half"], o["valu_by_class"]["trans"], classes["salu"], classes["smem"], classes["vmem_load"], classes["lds"],
                  classes["branch"], classes["wait"], classes["scratch"], o["scratch_instructions_per_wavefront"]))
-        print("   VALU issue cycles per SIMD: %.4g  (%.1f %% of the VALU instructions priced by a per-kind measurement, the rest by their class)"
-              % (cycles / 1024.0, 100 * o["valu_priced_by_measured_kind_fraction"]))
+        print("   VALU issue per SIMD: %.4g cycles at the guide's rates (full 2, half 4, transcendental 8)   %s ms at the measured per-kind times   (round 3's calibrated cycles: %.4g)"
+              % (guide_cycles / 1024.0, "%.4f" % o["valu_issue_time_ms_per_simd"] if time_ns is not None else "n/a", cycles / 1024.0))
     return out
 
 

@@ -14,6 +14,12 @@
 #include <cstring>
 #include <vector>
 #include <algorithm>
+#include <atomic>
+#include <string>
+#include <thread>
+#include <glob.h>
+#include <fcntl.h>
+#include <unistd.h>
 #define CHK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("HIP error %s at line %d\n", hipGetErrorString(e_), __LINE__); return 1; } } while (0)
 
 typedef float f2 __attribute__((ext_vector_type(2)));
@@ -136,9 +142,46 @@ static int run(const Test& t, float* d_out, Stamp* d_st, std::vector<Stamp>& h, 
     return 0;
 }
 
-int main() {
+// ---- round 4: DIFFERENTIAL issue cost ("a full-rate kind must read ~2.0, not 2.3" if loop / launch overhead is what inflates it).
+// Every kind is launched at 8 waves per SIMD with N and 3N loop iterations, timed with HIP events; the cost per instruction is the SLOPE
+//   (t(3N) - t(N)) / (2N x 64 instructions x 8 waves)   x   the shader clock sampled from the amdgpu hwmon node while the 3N launch ran
+// -- launch ramp, prologue, the stamps and the tail drop out of the difference, and the unit (milliseconds x sampled MHz) is exactly the one
+// bench.py's roofline uses for the cycles a SIMD had.  What remains inside the slope is the loop's own 3 scalar instructions per 64 VALU.
+struct Sclk {
+    std::string path; std::atomic<bool> stop{false}; std::vector<double> mhz; std::thread th;
+    void start() { stop = false; mhz.clear(); th = std::thread([this] {
+        int fd = open(path.c_str(), O_RDONLY); if (fd < 0) return;
+        char b[64];
+        while (!stop) { lseek(fd, 0, SEEK_SET); ssize_t n = read(fd, b, 63); if (n > 0) { b[n] = 0; double v = atof(b); if (v > 0) mhz.push_back(v / 1e6); } usleep(250); }
+        close(fd); }); }
+    double finish() { stop = true; if (th.joinable()) th.join(); double a = 0; for (double v : mhz) a += v; return mhz.empty() ? 0.0 : a / mhz.size(); }
+};
+static int run_diff(const Test& t, float* d_out, Stamp* d_st, int cus, Sclk& clk, FILE* js, bool first) {
+    const int W = 8, blocks = cus * W, N = 12000;
+    hipEvent_t e0, e1; CHK(hipEventCreate(&e0)); CHK(hipEventCreate(&e1));
+    float ms[2] = {0, 0}; double mhz = 0.0;
+    t.k<<<blocks, 256>>>(d_out, d_st, 64, 1.0f); CHK(hipDeviceSynchronize());
+    for (int pass = 0; pass < 2; pass++) {
+        const int iters = pass == 0 ? N : 3 * N;
+        if (pass == 1) clk.start();
+        CHK(hipEventRecord(e0)); t.k<<<blocks, 256>>>(d_out, d_st, iters, 1.0f); CHK(hipEventRecord(e1)); CHK(hipEventSynchronize(e1));
+        if (pass == 1) mhz = clk.finish();
+        CHK(hipEventElapsedTime(&ms[pass], e0, e1));
+    }
+    const double instr = 2.0 * N * 8.0 * t.valu_per_8 * W;                       // extra instructions per SIMD in the longer launch
+    const double ns = (ms[1] - ms[0]) * 1e6 / instr, whole = ms[1] * 1e6 / (3.0 * N * 8.0 * t.valu_per_8 * W);
+    printf("%-28s slope %6.4f ns/instr  x %6.1f MHz = %5.3f cycles   (whole launch / instructions: %5.3f cycles; t(N) %.3f ms, t(3N) %.3f ms)\n",
+           t.name, ns, mhz, ns * mhz * 1e-3, whole * mhz * 1e-3, ms[0], ms[1]);
+    if (js) fprintf(js, "%s\n  \"%s\": {\"cycles\": %.4f, \"ns_per_instr\": %.5f, \"sclk_mhz\": %.1f, \"cycles_whole_launch\": %.4f}", first ? "" : ",", t.name, ns * mhz * 1e-3, ns, mhz, whole * mhz * 1e-3);
+    CHK(hipEventDestroy(e0)); CHK(hipEventDestroy(e1));
+    return 0;
+}
+
+int main(int argc, char** argv) {
     hipDeviceProp_t prop; CHK(hipGetDeviceProperties(&prop, 0));
     const int cus = prop.multiProcessorCount;
+    const bool diff = argc > 1 && !strcmp(argv[1], "diff");
+    if (!diff)
     printf("# %s, %d CUs, clockRate %d kHz.  cycles = s_memtime ticks per wave64 VALU instruction per SIMD with W waves resident per SIMD;\n"
            "# MHz = s_memtime / s_memrealtime (100 MHz) over the same interval = the clock the chip actually sustained\n", prop.gcnArchName, cus, prop.clockRate);
     float* d_out; Stamp* d_st;
@@ -159,6 +202,17 @@ int main() {
         {"v_fmamk_f32", k_fmamk, 8}, {"mix16 (census proportions)", k_mix16, 16}, {"mix16 with 1 rcp", k_mix16_trans, 16},
         {"v_pk_fma_f32 3 src", k_pk_fma, 8}, {"v_pk_fma_f32 2 src", k_pk_fma_2src, 8}, {"v_pk_mul_f32", k_pk_mul, 8}, {"v_pk_add_f32", k_pk_add, 8},
     };
+    if (diff) {                                                // valu_rates2 diff [out.json]
+        Sclk clk;
+        glob_t g; if (glob("/sys/class/drm/card*/device/hwmon/hwmon*/freq1_input", 0, nullptr, &g) == 0 && g.gl_pathc > 0) clk.path = g.gl_pathv[0];
+        printf("# %s, %d CUs: differential issue cost at 8 waves per SIMD, clock sampled from %s\n", prop.gcnArchName, cus, clk.path.empty() ? "(no hwmon node: MHz = 0)" : clk.path.c_str());
+        FILE* js = argc > 2 ? fopen(argv[2], "w") : nullptr;
+        if (js) fprintf(js, "{");
+        bool first = true;
+        for (const Test& t : tests) { if (run_diff(t, d_out, d_st, cus, clk, js, first)) return 1; first = false; }
+        if (js) { fprintf(js, "\n}\n"); fclose(js); }
+        return 0;
+    }
     for (const Test& t : tests) if (run(t, d_out, d_st, h, cus)) return 1;
     // the peak the spec sheet quotes: 157.3 TFLOP/s = 256 CUs x 4 SIMDs x 64 FLOP/clk x 2.4 GHz.  64 FLOP/clk/SIMD is reached by
     // a wave64 v_fma_f32 every 2 cycles OR a wave64 v_pk_fma_f32 (2 FMAs per lane) every 4 cycles: compare with the rows above.
