@@ -477,60 +477,65 @@ template <bool EAGER_DETAIL = true, class TS>
 CSKY_HD float sample_density_eager(const TS& T, const FrameConsts& fc, float px, float py, float pz, float hf, float wx, float wy,
                                    int lod_shape, int lod_detail) {
     if constexpr (TS::cell32) return sample_density(T, fc, px, py, pz, hf, wx, wy, lod_shape, lod_detail);   // exact cells: the lazy form (not the tuned path)
-    if (!(hf > fc.hf_lo && hf < fc.hf_hi)) return 0.0f;
-    // ---- addresses + fetches
-    float wsx, wsy;
-    weather_coord(px, pz, wx, wy, wsx, wsy);
-    int wix, wiy; float wax, way;
-    split_coord(wsx * 512.0f - 0.5f, wix, wax); split_coord(wsy * 512.0f - 0.5f, wiy, way);
-    const uint4 wq = *reinterpret_cast<const uint4*>(reinterpret_cast<const char*>(T.weather) + (((((uint32_t)(wiy & 511)) << 9) | (uint32_t)(wix & 511)) << 4));
-    float qx, qy, qz, sx, sy, sz;
-    shape_coord(fc, px, py, pz, qx, qy, qz, sx, sy, sz);
-    const int sn = SHAPE_N >> lod_shape, sm = sn - 1;
-    const float sfn = pow2f(7 - lod_shape);
-    int six, siy, siz; float sax, say, saz;
-    split_coord(sx * sfn - 0.5f, six, sax); split_coord(sy * sfn - 0.5f, siy, say); split_coord(sz * sfn - 0.5f, siz, saz);
-    const uint32_t ssh = (uint32_t)(7 - lod_shape);
-    const uint32_t sidx = shape_level_offset(lod_shape) + shape_cell_offset((uint32_t)(six & sm), (uint32_t)(siy & sm), (uint32_t)(siz & sm), ssh);
-    const uint4* __restrict__ sp = reinterpret_cast<const uint4*>(reinterpret_cast<const char*>(T.shape) + (sidx << 5));
-    const uint4 tr = sp[0], tf = sp[1];
-    float dsx, dsy, dsz;
-    detail_coord(fc, qx, qy, qz, dsx, dsy, dsz);
-    uint4 dq = uint4{0u, 0u, 0u, 0u};
-    float dax = 0.0f, day = 0.0f, daz = 0.0f;
-    if (EAGER_DETAIL && lod_detail != 5) {                    // wave-uniform; LOD 5 is one texel (detail_tap)
-        const int dn = DETAIL_N >> lod_detail, dm = dn - 1;
-        const float dfn = pow2f(5 - lod_detail);
-        int dix, diy, diz;
-        split_coord(dsx * dfn - 0.5f, dix, dax); split_coord(dsy * dfn - 0.5f, diy, day); split_coord(dsz * dfn - 0.5f, diz, daz);
-        const uint32_t dsh = (uint32_t)(5 - lod_detail);
-        const uint32_t didx = detail_level_offset(lod_detail) + ((((((uint32_t)(diz & dm)) << dsh) | (uint32_t)(diy & dm)) << dsh) | (uint32_t)(dix & dm));
-        dq = *reinterpret_cast<const uint4*>(reinterpret_cast<const char*>(T.detail) + (didx << 4));
+    // (round 4: ONE result register written where the sample survives every reject -- three early `return 0` cost a v_mov each per sample -- and
+    // the single-texel LOD 5 of the detail volume as its own wave-uniform case instead of zero-filled tap registers)
+    float d = 0.0f;
+    if (hf > fc.hf_lo && hf < fc.hf_hi) {
+        // ---- addresses + fetches
+        float wsx, wsy;
+        weather_coord(px, pz, wx, wy, wsx, wsy);
+        int wix, wiy; float wax, way;
+        split_coord(wsx * 512.0f - 0.5f, wix, wax); split_coord(wsy * 512.0f - 0.5f, wiy, way);
+        const uint4 wq = *reinterpret_cast<const uint4*>(reinterpret_cast<const char*>(T.weather) + (((((uint32_t)(wiy & 511)) << 9) | (uint32_t)(wix & 511)) << 4));
+        float qx, qy, qz, sx, sy, sz;
+        shape_coord(fc, px, py, pz, qx, qy, qz, sx, sy, sz);
+        const int sn = SHAPE_N >> lod_shape, sm = sn - 1;
+        const float sfn = pow2f(7 - lod_shape);
+        int six, siy, siz; float sax, say, saz;
+        split_coord(sx * sfn - 0.5f, six, sax); split_coord(sy * sfn - 0.5f, siy, say); split_coord(sz * sfn - 0.5f, siz, saz);
+        const uint32_t ssh = (uint32_t)(7 - lod_shape);
+        const uint32_t sidx = shape_level_offset(lod_shape) + shape_cell_offset((uint32_t)(six & sm), (uint32_t)(siy & sm), (uint32_t)(siz & sm), ssh);
+        const uint4* __restrict__ sp = reinterpret_cast<const uint4*>(reinterpret_cast<const char*>(T.shape) + (sidx << 5));
+        const uint4 tr = sp[0], tf = sp[1];
+        float dsx, dsy, dsz;
+        detail_coord(fc, qx, qy, qz, dsx, dsy, dsz);
+        const bool tap = EAGER_DETAIL && lod_detail != 5;         // wave-uniform; LOD 5 is one texel (detail_tap)
+        uint4 dq;
+        float dax, day, daz;
+        if (tap) {
+            const int dn = DETAIL_N >> lod_detail, dm = dn - 1;
+            const float dfn = pow2f(5 - lod_detail);
+            int dix, diy, diz;
+            split_coord(dsx * dfn - 0.5f, dix, dax); split_coord(dsy * dfn - 0.5f, diy, day); split_coord(dsz * dfn - 0.5f, diz, daz);
+            const uint32_t dsh = (uint32_t)(5 - lod_detail);
+            const uint32_t didx = detail_level_offset(lod_detail) + ((((((uint32_t)(diz & dm)) << dsh) | (uint32_t)(diy & dm)) << dsh) | (uint32_t)(dix & dm));
+            dq = *reinterpret_cast<const uint4*>(reinterpret_cast<const char*>(T.detail) + (didx << 4));
+        }
+        // ---- the arithmetic of density() (clouds.glsl:109-137) on the fetched cells
+        const float wr = fmaf(way, lerp_h(wq.y, wax), lerp_h(wq.x, wax));       // texel scale 0..255 (weather_filter)
+        const float wb = fmaf(way, lerp_h(wq.w, wax), lerp_h(wq.z, wax));
+        const float wc = fc.cov255 * wb;                                         // :123 (wb on the texel scale)
+        const float g = density_height_gradient(fc, hf, wr);                    // :121
+        const float omw = 1.0f - wc;
+        if (g > omw) {                                                           // else: exact reject (1)
+            const float nr = fmaf(saz, fmaf(say, lerp_h(tr.w, sax), lerp_h(tr.z, sax)), fmaf(say, lerp_h(tr.y, sax), lerp_h(tr.x, sax))) * (1.0f / 255.0f);
+            const float fbm = fmaf(saz, fmaf(say, lerp_h(tf.w, sax), lerp_h(tf.z, sax)), fmaf(say, lerp_h(tf.y, sax), lerp_h(tf.x, sax))) * (1.0f / (8.0f * 255.0f));
+            const float omf = 1.0f - fbm, den1 = 1.0f + omf;
+            const float num = (nr + omf) * g - omw * den1;                      // :122, :124-125 as numerator / den1 (see density())
+            if (num > 0.0f) {                                                    // else: reject (2)
+                float hfbm;
+                if (tap) hfbm = fmaf(daz, fmaf(day, lerp_h(dq.w, dax), lerp_h(dq.z, dax)), fmaf(day, lerp_h(dq.y, dax), lerp_h(dq.x, dax))) * (1.0f / (8.0f * 255.0f));
+                else if (EAGER_DETAIL) hfbm = T.detail_lod5;
+                else hfbm = detail_tap(T, lod_detail, dsx, dsy, dsz);           // :132-133, fetched now
+                const float k = sat(hf * 4.0f);
+                hfbm = hfbm + k * (1.0f - 2.0f * hfbm);                         // :134
+                const float hm = hfbm * 0.4f * hf, den2 = 1.0f - hm;
+                const float base = (num - hm * den1) * fast_rcp(den1 * den2);   // :135
+                d = fast_pow(sat(base), (1.0f - hf) * 0.8f + 0.5f);             // :136
+            }
+        }
     }
-    // ---- the arithmetic of density() (clouds.glsl:109-137) on the fetched cells
-    const float wr = fmaf(way, lerp_h(wq.y, wax), lerp_h(wq.x, wax));       // texel scale 0..255 (weather_filter)
-    const float wb = fmaf(way, lerp_h(wq.w, wax), lerp_h(wq.z, wax));
-    const float wc = fc.cov255 * wb;                                         // :123 (wb on the texel scale)
-    const float g = density_height_gradient(fc, hf, wr);                    // :121
-    const float omw = 1.0f - wc;
-    if (!(g > omw)) return 0.0f;                                             // exact reject (1)
-    const float nr = fmaf(saz, fmaf(say, lerp_h(tr.w, sax), lerp_h(tr.z, sax)), fmaf(say, lerp_h(tr.y, sax), lerp_h(tr.x, sax))) * (1.0f / 255.0f);
-    const float fbm = fmaf(saz, fmaf(say, lerp_h(tf.w, sax), lerp_h(tf.z, sax)), fmaf(say, lerp_h(tf.y, sax), lerp_h(tf.x, sax))) * (1.0f / (8.0f * 255.0f));
-    const float omf = 1.0f - fbm, den1 = 1.0f + omf;
-    const float num = (nr + omf) * g - omw * den1;                          // :122, :124-125 as numerator / den1 (see density())
-    if (!(num > 0.0f)) return 0.0f;                                         // reject (2)
-    float hfbm;
-    if (EAGER_DETAIL) {
-        hfbm = lod_detail == 5 ? T.detail_lod5
-                               : fmaf(daz, fmaf(day, lerp_h(dq.w, dax), lerp_h(dq.z, dax)), fmaf(day, lerp_h(dq.y, dax), lerp_h(dq.x, dax))) * (1.0f / (8.0f * 255.0f));
-    } else {
-        hfbm = detail_tap(T, lod_detail, dsx, dsy, dsz);                    // :132-133, fetched now
-    }
-    const float k = sat(hf * 4.0f);
-    hfbm = hfbm + k * (1.0f - 2.0f * hfbm);                                 // :134
-    const float hm = hfbm * 0.4f * hf, den2 = 1.0f - hm;
-    const float base = (num - hm * den1) * fast_rcp(den1 * den2);           // :135
-    return fast_pow(sat(base), (1.0f - hf) * 0.8f + 0.5f);                  // :136
+    return d;
 }
 #else
 template <bool EAGER_DETAIL = true, class TS>

@@ -410,7 +410,7 @@ __device__ __forceinline__ MarchOut march_queue(const TexSet& T, const FrameCons
 // the final flush of a ray segment runs with idle lanes.
 constexpr int CQ_CAP = 128;                                  // a flush is taken as soon as 64 samples are queued: count <= 63 + 64
 constexpr int CQ_STEPS = 66;                                 // steps-with-events between flushes: <= 1 carried + 64 (>= 1 event each)
-constexpr int CQ_FLOATS = 7 * CQ_CAP + 3 * CQ_STEPS;         // pos(3) t hf ss phase (after the light march: D(3) q dt) | per-step mask lo/hi + base = 4.4 KB per wavefront
+constexpr int CQ_FLOATS = 7 * CQ_CAP + 3 * CQ_STEPS + 2 + 128;   // pos(3) t hf ss phase (after the light march: D(3) q dt) | per-step mask lo/hi + base | in-cloud tally | per-ray ss, phase = 4.9 KB per wavefront
 
 #ifndef CSKY_EAGER_LIGHT
 #define CSKY_EAGER_LIGHT 1
@@ -487,29 +487,38 @@ __device__ __forceinline__ MarchOut march_compact(const TS& T, const FrameConsts
     const float nd = -fc.density;
     bool live = ray.above;
     int count = 0, cs = 0;                                    // queued samples / steps owning them (uniform)
+    unsigned* __restrict__ tally = st_base + CQ_STEPS;          // in-cloud samples composited by this wavefront, kept in LDS (round 4: neither a per-lane accumulator register
+    if (lane == 0) tally[0] = 0u;                             // in the march loops nor a scalar one in the SGPR-starved persistent form; one ds_add per flush)
+    // the two per-ray constants a queued sample carries (step length, phase value) live in LDS, not in registers held across the whole march: the
+    // persistent form had spilled `phase` to scratch and re-loaded it, behind a vmcnt(0), at every step with an in-cloud sample (round 4 census)
+    float* __restrict__ ray_ss = reinterpret_cast<float*>(tally + 2);
+    float* __restrict__ ray_ph = ray_ss + 64;
+    ray_ss[lane] = ray.ss; ray_ph[lane] = phase;
     if (!__any(live)) return o;
     for (int i = 0; i < step_begin; i++) advance(px, py, pz, ray.sx, ray.sy, ray.sz);   // segment start: replay the fp32 additions (:173)
     int end = step_end;                                       // shrinks when the whole wavefront has left the height window
     for (int i = step_begin;;) {
         // ---- A: one primary sample per lane (none once the segment is exhausted and only carried samples remain)
         if (i < end) {
-            float t = 0.0f, hf = 0.0f;
+            float t, hf;                                     // (meaningful in live lanes only: every use below is guarded by `live` or by `have`)
+            bool have = false, below_top = false;
             if (live) {
                 advance(px, py, pz, ray.sx, ray.sy, ray.sz);                                                   // :173
                 hf = height_fraction(length3_shell(px, py, pz));                                               // :175
                 t = CSKY_PRIMARY_SAMPLE(T, fc, px, py, pz, hf, fc.wpos_x, fc.wpos_y, 0, 0);                    // :174, :177
+                have = t > 0.0f;                                                                               // :184
+                below_top = !(hf >= fc.hf_hi);
             }
             // Exact early end of the march: a ray starts on the inner shell and |p| only grows along it (>= 14 m per step at 128 steps even
             // for a grazing ray, 1.7 m at 1024 steps, against 0.5 m of fp32 noise; every ray of the C3 / C5 frames is walked by
             // tests/test_hostsim_core.py), so once EVERY live ray of the wavefront is above the height window
             // (density() == 0 there, cloud_core.h) all remaining samples are 0 too.  Checked every 4th step: one compare + ballot.
             // 21 % of the wave-steps of the headline view lie above the window (tools/stage_trace).
-            if ((i & 3) == 3 && !__any(live && !(hf >= fc.hf_hi))) end = i + 1;
-            const bool have = t > 0.0f;                                                                        // :184
+            if ((i & 3) == 3 && !__any(below_top)) end = i + 1;
             const unsigned long long m = __ballot(have);
             if (m != 0ull) {
                 const int slot = count + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));
-                if (have) { ev_px[slot] = px; ev_py[slot] = py; ev_pz[slot] = pz; ev_t[slot] = t; ev_hf[slot] = hf; ev_ss[slot] = ray.ss; ev_ph[slot] = phase; }
+                if (have) { ev_px[slot] = px; ev_py[slot] = py; ev_pz[slot] = pz; ev_t[slot] = t; ev_hf[slot] = hf; ev_ss[slot] = ray_ss[lane]; ev_ph[slot] = ray_ph[lane]; }
                 if (lane == 0) { st_lo[cs] = (unsigned)m; st_hi[cs] = (unsigned)(m >> 32); st_base[cs] = (unsigned)count; }
                 count += __popcll(m);
                 cs++;
@@ -525,6 +534,7 @@ __device__ __forceinline__ MarchOut march_compact(const TS& T, const FrameConsts
         wave_lds_fence();
         const int n = count < 64 ? count : 64;
         unsigned long long carry = 0ull;                     // lanes of the last step whose sample is still queued
+        if (lane == 0) tally[0] += (unsigned)n;
         if (lane < n) {
             float Dr, Dg, Db, rq, dt;
             light_march_terms(T, fc, ls, nd, ev_px[lane], ev_py[lane], ev_pz[lane],
@@ -539,7 +549,6 @@ __device__ __forceinline__ MarchOut march_compact(const TS& T, const FrameConsts
             const int slot = (int)st_base[s] + (int)__builtin_amdgcn_mbcnt_hi(hi, __builtin_amdgcn_mbcnt_lo(lo, 0u));
             if (mine && slot < n) {
                 composite_sample(ev_hf[slot], ev_t[slot], ev_px[slot], ev_py[slot], ev_pz[slot], Tr, alpha, Lr, Lg, Lb);
-                o.incloud++;
             }
             if (s == cs - 1) carry = __ballot(mine && slot >= n);
         }
@@ -564,6 +573,8 @@ __device__ __forceinline__ MarchOut march_compact(const TS& T, const FrameConsts
         if (last && count == 0) break;                               // carried samples get one more (partial) flush
     }
     o.r = Lr; o.g = Lg; o.b = Lb; o.a = sat(alpha); o.t = Tr;                                                  // :213-214
+    wave_lds_fence();
+    o.incloud = lane == 0 ? tally[0] : 0u;
     return o;
 }
 
