@@ -494,7 +494,7 @@ __device__ __forceinline__ MarchOut march_compact(const TS& T, const FrameConsts
     float* __restrict__ ray_ss = reinterpret_cast<float*>(tally + 2);
     float* __restrict__ ray_ph = ray_ss + 64;
     ray_ss[lane] = ray.ss; ray_ph[lane] = phase;
-    if (!__any(live)) return o;
+    if (__builtin_amdgcn_ballot_w64(live) == 0ull) return o;   // (the builtin takes the compare's own lane mask: HIP's __any / __ballot wrappers cost a v_cndmask + v_cmp_ne each)
     for (int i = 0; i < step_begin; i++) advance(px, py, pz, ray.sx, ray.sy, ray.sz);   // segment start: replay the fp32 additions (:173)
     int end = step_end;                                       // shrinks when the whole wavefront has left the height window
     for (int i = step_begin;;) {
@@ -514,8 +514,8 @@ __device__ __forceinline__ MarchOut march_compact(const TS& T, const FrameConsts
             // tests/test_hostsim_core.py), so once EVERY live ray of the wavefront is above the height window
             // (density() == 0 there, cloud_core.h) all remaining samples are 0 too.  Checked every 4th step: one compare + ballot.
             // 21 % of the wave-steps of the headline view lie above the window (tools/stage_trace).
-            if ((i & 3) == 3 && !__any(below_top)) end = i + 1;
-            const unsigned long long m = __ballot(have);
+            if ((i & 3) == 3 && __builtin_amdgcn_ballot_w64(below_top) == 0ull) end = i + 1;
+            const unsigned long long m = __builtin_amdgcn_ballot_w64(have);
             if (m != 0ull) {
                 const int slot = count + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));
                 if (have) { ev_px[slot] = px; ev_py[slot] = py; ev_pz[slot] = pz; ev_t[slot] = t; ev_hf[slot] = hf; ev_ss[slot] = ray_ss[lane]; ev_ph[slot] = ray_ph[lane]; }
@@ -544,13 +544,14 @@ __device__ __forceinline__ MarchOut march_compact(const TS& T, const FrameConsts
         wave_lds_fence();
         // ---- C: replay the steps in order; owners of evaluated samples (slot < n) composite (:207-210)
         for (int s = 0; s < cs; s++) {
-            const unsigned lo = st_lo[s], hi = st_hi[s];
-            const bool mine = lane < 32 ? ((lo >> lane) & 1u) : ((hi >> (lane - 32)) & 1u);
+            // the step's lane mask is wave-uniform: as a scalar pair it IS the execution mask of the owners (inverse ballot: no per-lane bit test)
+            const unsigned lo = (unsigned)__builtin_amdgcn_readfirstlane((int)st_lo[s]), hi = (unsigned)__builtin_amdgcn_readfirstlane((int)st_hi[s]);
+            const bool mine = __builtin_amdgcn_inverse_ballot_w64(((unsigned long long)hi << 32) | lo);
             const int slot = (int)st_base[s] + (int)__builtin_amdgcn_mbcnt_hi(hi, __builtin_amdgcn_mbcnt_lo(lo, 0u));
             if (mine && slot < n) {
                 composite_sample(ev_hf[slot], ev_t[slot], ev_px[slot], ev_py[slot], ev_pz[slot], Tr, alpha, Lr, Lg, Lb);
             }
-            if (s == cs - 1) carry = __ballot(mine && slot >= n);
+            if (s == cs - 1) carry = __builtin_amdgcn_ballot_w64(mine && slot >= n);
         }
         wave_lds_fence();
         // ---- keep what was not evaluated: samples n..count-1 move to the front, the last step keeps its unevaluated lanes
@@ -568,7 +569,7 @@ __device__ __forceinline__ MarchOut march_compact(const TS& T, const FrameConsts
         }
         if (fc.early_eps > 0.0f) {                                     // build-side early-out (off by default, bounded error)
             if (Tr < fc.early_eps) live = false;
-            if (!__any(live)) break;
+            if (__builtin_amdgcn_ballot_w64(live) == 0ull) break;
         }
         if (last && count == 0) break;                               // carried samples get one more (partial) flush
     }
