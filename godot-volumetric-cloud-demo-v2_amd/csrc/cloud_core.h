@@ -433,8 +433,11 @@ CSKY_HD float density(const TS& T, const FrameConsts& fc, float px, float py, fl
     // the bracket is 1 + O(6e-8 / wc) in fp32 (1 - (1 - wc) equals wc up to one rounding of 1 - wc) and is left out (section B; the
     // coverage-0.05 sweep frame of tools/parity_sweep.py has the largest 1/wc).  Round 4: the quotient is kept as numerator / den1 through
     // reject (2), whose sign test needs no division, and divided ONCE together with :135's denominator: one v_rcp_f32 less per sample.
-    const float num = (nr + omf) * g - omw * den1;                          // = (base*g - omw) * den1
+    float num = (nr + omf) * g - omw * den1;                                // = (base*g - omw) * den1
     if (!(num > 0.0f)) return 0.0f;                                         // reject (2): base*g - omw <= 0
+#ifdef CSKY_RESTORE_WC_FACTOR
+    num = num * (wc * fast_rcp(1.0f - omw));                                // experiment build (profiles/r04/wc_factor_experiment.txt): the bracket restored
+#endif
     detail_coord(fc, qx, qy, qz, sx, sy, sz);                               // :128-129
     float hfbm = detail_tap(T, lod_detail, sx, sy, sz);                     // :132-133
     CSKY_STAGE(3);
@@ -521,8 +524,11 @@ CSKY_HD float sample_density_eager(const TS& T, const FrameConsts& fc, float px,
             const float nr = fmaf(saz, fmaf(say, lerp_h(tr.w, sax), lerp_h(tr.z, sax)), fmaf(say, lerp_h(tr.y, sax), lerp_h(tr.x, sax))) * (1.0f / 255.0f);
             const float fbm = fmaf(saz, fmaf(say, lerp_h(tf.w, sax), lerp_h(tf.z, sax)), fmaf(say, lerp_h(tf.y, sax), lerp_h(tf.x, sax))) * (1.0f / (8.0f * 255.0f));
             const float omf = 1.0f - fbm, den1 = 1.0f + omf;
-            const float num = (nr + omf) * g - omw * den1;                      // :122, :124-125 as numerator / den1 (see density())
+            float num = (nr + omf) * g - omw * den1;                            // :122, :124-125 as numerator / den1 (see density())
             if (num > 0.0f) {                                                    // else: reject (2)
+#ifdef CSKY_RESTORE_WC_FACTOR
+                num = num * (wc * fast_rcp(1.0f - omw));
+#endif
                 float hfbm;
                 if (tap) hfbm = fmaf(daz, fmaf(day, lerp_h(dq.w, dax), lerp_h(dq.z, dax)), fmaf(day, lerp_h(dq.y, dax), lerp_h(dq.x, dax))) * (1.0f / (8.0f * 255.0f));
                 else if (EAGER_DETAIL) hfbm = T.detail_lod5;
