@@ -410,7 +410,7 @@ __device__ __forceinline__ MarchOut march_queue(const TexSet& T, const FrameCons
 // the final flush of a ray segment runs with idle lanes.
 constexpr int CQ_CAP = 128;                                  // a flush is taken as soon as 64 samples are queued: count <= 63 + 64
 constexpr int CQ_STEPS = 66;                                 // steps-with-events between flushes: <= 1 carried + 64 (>= 1 event each)
-constexpr int CQ_FLOATS = 7 * CQ_CAP + 3 * CQ_STEPS + 2 + 128;   // pos(3) t hf ss phase (after the light march: D(3) q dt) | per-step mask lo/hi + base | in-cloud tally | per-ray ss, phase = 4.9 KB per wavefront
+constexpr int CQ_FLOATS = 5 * CQ_CAP + CQ_CAP / 4 + 3 * CQ_STEPS + 2 + 128 + 320;   // pos(3) t hf (after the light march: D(3) q dt) | owner lane (bytes) | per-step mask lo/hi + base | in-cloud tally | per-ray ss, phase | per-ray T, alpha, L between flushes = 5.2 KB per wavefront
 
 #ifndef CSKY_EAGER_LIGHT
 #define CSKY_EAGER_LIGHT 1
@@ -468,9 +468,8 @@ __device__ __forceinline__ MarchOut march_compact(const TS& T, const FrameConsts
     float* __restrict__ ev_pz = q + 2 * CQ_CAP;
     float* __restrict__ ev_t = q + 3 * CQ_CAP;
     float* __restrict__ ev_hf = q + 4 * CQ_CAP;
-    float* __restrict__ ev_ss = q + 5 * CQ_CAP;                                  // the owner ray's step length and phase value (per-ray constants
-    float* __restrict__ ev_ph = q + 6 * CQ_CAP;                                  // the sample's lane needs for the shading terms)
-    unsigned* __restrict__ st_lo = reinterpret_cast<unsigned*>(q + 7 * CQ_CAP);  // [CQ_STEPS]
+    unsigned char* __restrict__ ev_owner = reinterpret_cast<unsigned char*>(q + 5 * CQ_CAP);   // the sample's owner lane: its step length and phase value are read from ray_ss / ray_ph
+    unsigned* __restrict__ st_lo = reinterpret_cast<unsigned*>(q + 5 * CQ_CAP + CQ_CAP / 4);  // [CQ_STEPS]
     unsigned* __restrict__ st_hi = st_lo + CQ_STEPS;
     unsigned* __restrict__ st_base = st_hi + CQ_STEPS;
 
@@ -482,7 +481,6 @@ __device__ __forceinline__ MarchOut march_compact(const TS& T, const FrameConsts
         const float ct = fc.ldir[0] * ray.dx + fc.ldir[1] * ray.dy + fc.ldir[2] * ray.dz;                       // clouds.glsl:158
         phase = fmaxf(fmaxf(henyey_greenstein(ct, 0.6f), henyey_greenstein(ct, fc.hg_g2)), henyey_greenstein(ct, -0.2f));  // :160
     }
-    float Tr = 1.0f, alpha = 0.0f, Lr = 0.0f, Lg = 0.0f, Lb = 0.0f;
     float px = ray.px, py = ray.py, pz = ray.pz;
     const float nd = -fc.density;
     bool live = ray.above;
@@ -494,6 +492,11 @@ __device__ __forceinline__ MarchOut march_compact(const TS& T, const FrameConsts
     float* __restrict__ ray_ss = reinterpret_cast<float*>(tally + 2);
     float* __restrict__ ray_ph = ray_ss + 64;
     ray_ss[lane] = ray.ss; ray_ph[lane] = phase;
+    // The running state of the ray (T, alpha, L: clouds.glsl:151-153) is touched only while a flush is composited, ~20 times per tile: between
+    // flushes it rests in LDS, not in five registers the allocator had to copy between register sets around every light march (20 M v_mov per
+    // C3 frame, round-4 census) and hold across both march loops.
+    float* __restrict__ acc = ray_ph + 64;                      // [5][64]
+    acc[lane] = 1.0f; acc[64 + lane] = 0.0f; acc[128 + lane] = 0.0f; acc[192 + lane] = 0.0f; acc[256 + lane] = 0.0f;
     if (__builtin_amdgcn_ballot_w64(live) == 0ull) return o;   // (the builtin takes the compare's own lane mask: HIP's __any / __ballot wrappers cost a v_cndmask + v_cmp_ne each)
     for (int i = 0; i < step_begin; i++) advance(px, py, pz, ray.sx, ray.sy, ray.sz);   // segment start: replay the fp32 additions (:173)
     int end = step_end;                                       // shrinks when the whole wavefront has left the height window
@@ -518,7 +521,7 @@ __device__ __forceinline__ MarchOut march_compact(const TS& T, const FrameConsts
             const unsigned long long m = __builtin_amdgcn_ballot_w64(have);
             if (m != 0ull) {
                 const int slot = count + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));
-                if (have) { ev_px[slot] = px; ev_py[slot] = py; ev_pz[slot] = pz; ev_t[slot] = t; ev_hf[slot] = hf; ev_ss[slot] = ray_ss[lane]; ev_ph[slot] = ray_ph[lane]; }
+                if (have) { ev_px[slot] = px; ev_py[slot] = py; ev_pz[slot] = pz; ev_t[slot] = t; ev_hf[slot] = hf; ev_owner[slot] = (unsigned char)lane; }
                 if (lane == 0) { st_lo[cs] = (unsigned)m; st_hi[cs] = (unsigned)(m >> 32); st_base[cs] = (unsigned)count; }
                 count += __popcll(m);
                 cs++;
@@ -538,11 +541,12 @@ __device__ __forceinline__ MarchOut march_compact(const TS& T, const FrameConsts
         if (lane < n) {
             float Dr, Dg, Db, rq, dt;
             light_march_terms(T, fc, ls, nd, ev_px[lane], ev_py[lane], ev_pz[lane],
-                              [&](float& et, float& ehf, float& ess, float& eph) { et = ev_t[lane]; ehf = ev_hf[lane]; ess = ev_ss[lane]; eph = ev_ph[lane]; }, Dr, Dg, Db, rq, dt);
+                              [&](float& et, float& ehf, float& ess, float& eph) { et = ev_t[lane]; ehf = ev_hf[lane]; const int ow = ev_owner[lane]; ess = ray_ss[ow]; eph = ray_ph[ow]; }, Dr, Dg, Db, rq, dt);
             ev_px[lane] = Dr; ev_py[lane] = Dg; ev_pz[lane] = Db; ev_t[lane] = rq; ev_hf[lane] = dt;           // the sample's slot now holds its terms
         }
         wave_lds_fence();
         // ---- C: replay the steps in order; owners of evaluated samples (slot < n) composite (:207-210)
+        float Tr = acc[lane], alpha = acc[64 + lane], Lr = acc[128 + lane], Lg = acc[192 + lane], Lb = acc[256 + lane];
         for (int s = 0; s < cs; s++) {
             // the step's lane mask is wave-uniform: as a scalar pair it IS the execution mask of the owners (inverse ballot: no per-lane bit test)
             const unsigned lo = (unsigned)__builtin_amdgcn_readfirstlane((int)st_lo[s]), hi = (unsigned)__builtin_amdgcn_readfirstlane((int)st_hi[s]);
@@ -553,14 +557,15 @@ __device__ __forceinline__ MarchOut march_compact(const TS& T, const FrameConsts
             }
             if (s == cs - 1) carry = __builtin_amdgcn_ballot_w64(mine && slot >= n);
         }
+        acc[lane] = Tr; acc[64 + lane] = alpha; acc[128 + lane] = Lr; acc[192 + lane] = Lg; acc[256 + lane] = Lb;
         wave_lds_fence();
         // ---- keep what was not evaluated: samples n..count-1 move to the front, the last step keeps its unevaluated lanes
         const int rem = count - n;
         if (rem > 0) {
-            float a0 = 0.0f, a1 = 0.0f, a2 = 0.0f, a3 = 0.0f, a4 = 0.0f, a5 = 0.0f, a6 = 0.0f;
-            if (lane < rem) { a0 = ev_px[n + lane]; a1 = ev_py[n + lane]; a2 = ev_pz[n + lane]; a3 = ev_t[n + lane]; a4 = ev_hf[n + lane]; a5 = ev_ss[n + lane]; a6 = ev_ph[n + lane]; }
+            float a0 = 0.0f, a1 = 0.0f, a2 = 0.0f, a3 = 0.0f, a4 = 0.0f; unsigned char a5 = 0;
+            if (lane < rem) { a0 = ev_px[n + lane]; a1 = ev_py[n + lane]; a2 = ev_pz[n + lane]; a3 = ev_t[n + lane]; a4 = ev_hf[n + lane]; a5 = ev_owner[n + lane]; }
             wave_lds_fence();
-            if (lane < rem) { ev_px[lane] = a0; ev_py[lane] = a1; ev_pz[lane] = a2; ev_t[lane] = a3; ev_hf[lane] = a4; ev_ss[lane] = a5; ev_ph[lane] = a6; }
+            if (lane < rem) { ev_px[lane] = a0; ev_py[lane] = a1; ev_pz[lane] = a2; ev_t[lane] = a3; ev_hf[lane] = a4; ev_owner[lane] = a5; }
             if (lane == 0) { st_lo[0] = (unsigned)carry; st_hi[0] = (unsigned)(carry >> 32); st_base[0] = 0u; }
             wave_lds_fence();
             count = rem; cs = 1;
@@ -573,8 +578,8 @@ __device__ __forceinline__ MarchOut march_compact(const TS& T, const FrameConsts
         }
         if (last && count == 0) break;                               // carried samples get one more (partial) flush
     }
-    o.r = Lr; o.g = Lg; o.b = Lb; o.a = sat(alpha); o.t = Tr;                                                  // :213-214
     wave_lds_fence();
+    o.r = acc[128 + lane]; o.g = acc[192 + lane]; o.b = acc[256 + lane]; o.a = sat(acc[64 + lane]); o.t = acc[lane];   // :213-214
     o.incloud = lane == 0 ? tally[0] : 0u;
     return o;
 }

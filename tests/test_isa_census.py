@@ -25,14 +25,12 @@ def test_scratch_accesses_sit_outside_the_march_loops(product_asm):
         deepest = max(b["depth"] for b in cen)
         assert deepest >= 3                                               # the march loops are there (primary, flush, light march, replay)
         scratch_blocks = [b for b in cen if b["classes"].get("scratch")]
-        # plain kernel: prologue / epilogue, plus (since the shading split) ONE reload of the parked lane index in the preheader of the replay
-        # loop -- a block of register moves executed on 27 % of the flushes, never a block that samples (no texture gather, no
-        # transcendental, no LDS access); persistent form: once per tile (the outer pop loops), never inside the march
-        assert scratch_blocks, name
+        # Round 4: the plain kernel spills NOTHING (69 VGPRs: the per-ray constants and the running state of the ray rest in LDS between flushes);
+        # the persistent form keeps a few spills per TILE (the outer pop loops, depth <= 2), never inside the march
+        if max_depth == 0:
+            assert not scratch_blocks, (name, [(b["depth"], b["classes"]) for b in scratch_blocks])
         inside = [b for b in scratch_blocks if b["depth"] > max_depth]
-        assert len(inside) <= (1 if max_depth == 0 else 0), (name, [(b["depth"], b["classes"]) for b in inside])
-        for b in inside:
-            assert b["classes"].get("scratch") == 1 and not any(b["classes"].get(k) for k in ("vmem_load", "trans", "lds", "vmem_store")), (name, b["classes"])
+        assert not inside, (name, [(b["depth"], b["classes"]) for b in inside])
         assert sum(b["classes"].get("scratch", 0) for b in cen) <= 24
 
 
