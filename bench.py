@@ -338,6 +338,7 @@ def main():
     ap.add_argument("--groups", type=int, default=1,
                     help="frame groups for throughput workloads (single-process form): consecutive frames go to G groups of N/G devices in turn, each "
                          "group splits its frame (N/G)-way; 1 = every device works on every frame (the C4 split)")
+    ap.add_argument("--whole-lut", action="store_true", help="N > 1: every rank renders the whole sky LUT (rounds 1-3) instead of its rows of it")
     ap.add_argument("--staged", action="store_true", help="single-process form: local band buffers + strided peer copies instead of in-place peer stores")
     args = ap.parse_args()
 
@@ -423,10 +424,19 @@ def main():
     # N > 1: the gather of frame k (RCCL, its own stream, ordered behind the stream of frame k at the call) overlaps the march of
     # the following frames on the other streams; wait() orders frame k's stream behind its collective before that buffer set is reused.
     overlap = world > 1 and nbuf > 1
-    local = [torch.zeros((mb * tiling.BAND_ROWS, W, 4), dtype=torch.int16, device=dev) for _ in range(nbuf)]
-    local_b = [t.view(torch.uint8) for t in local]   # collectives move raw bytes (RCCL has no int16 type)
+    # N > 1: each rank renders rows index::per of the 200 x 100 sky LUT instead of all of it (csky_render_sky_lut_rows_device: the LUT costs 33 us
+    # of a whole chip, 12 % of a 1/8 frame share) and its rows ride behind its bands in the same gather; rank 0 interleaves both.
+    # --whole-lut: every rank renders the whole LUT as rounds 1-3 did (A/B).
+    LW, LH = 200, 100
+    split_lut = per > 1 and not args.whole_lut
+    band_bytes = mb * tiling.BAND_ROWS * W * 8
+    lut_bytes = fg.max_lut_rows(LH) * LW * 8 if split_lut else 0
+    local_b = [torch.zeros(band_bytes + lut_bytes, dtype=torch.uint8, device=dev) for _ in range(nbuf)]   # collectives move raw bytes (RCCL has no int16 type)
+    local = [t[:band_bytes].view(torch.int16).view(mb * tiling.BAND_ROWS, W, 4) for t in local_b]
+    lut_rows = fg.lut_rows(LH)
     gdev = "cpu" if debug_one_gpu else dev
-    gathered = [torch.empty((fg.max_members,) + tuple(local[0].shape), dtype=torch.int16, device=gdev) for _ in range(nbuf)] if (world > 1 and rank == 0) else [None] * nbuf
+    gathered = [torch.empty((fg.max_members, band_bytes + lut_bytes), dtype=torch.uint8, device=gdev) for _ in range(nbuf)] if (world > 1 and rank == 0) else [None] * nbuf
+    sky_lut = [None]
     pending = [None] * nbuf
     pend_frame = [0] * nbuf
     frame = [None]
@@ -439,7 +449,10 @@ def main():
             pending[o].wait()
             pending[o] = None
             if rank == 0:
-                frame[0] = fg.assemble(pend_frame[o], gathered[o].to(dev) if debug_one_gpu else gathered[o], H)
+                img, lut = fg.split(gathered[o].to(dev) if debug_one_gpu else gathered[o], H, W, LH if split_lut else 0, LW)
+                frame[0] = fg.assemble(pend_frame[o], img, H)
+                if split_lut:
+                    sky_lut[0] = fg.assemble_lut(pend_frame[o], lut, LH)
 
     def step():
         k = counter[0]
@@ -451,7 +464,10 @@ def main():
         fp, fs = (params, sun_n) if sweep is None else sweep[k % len(sweep)]
         st_k = streams[bset].cuda_stream
         if fg.renders(k):
-            ctx.render_sky_lut_device(fs, 200, 100, st_k)                                          # sky_lut.gd:122-148
+            if split_lut:                                                                          # sky_lut.gd:122-148, this rank's rows, behind its bands
+                ctx.render_sky_lut_rows_device(fs, lut_rows[0], lut_rows[1], local_b[bset].data_ptr() + band_bytes, lut_bytes, LW, LH, st_k)
+            else:
+                ctx.render_sky_lut_device(fs, LW, LH, st_k)                                        # sky_lut.gd:122-148
             ctx.render_clouds_device(fp, W, bands, local[bset].data_ptr(), W * 8, st_k)           # cloud_sky.gd:234-248
         if world == 1:
             frame[0] = local[bset]
@@ -603,6 +619,12 @@ def main():
             print("gathered %d-rank frame vs single-rank frame: max|d| = %.3g, within 1 fp16 ulp-ish: %.6f" % (world, frame_check["max_abs_diff"], ok), file=sys.stderr, flush=True)
             if ok < 0.9999:
                 raise SystemExit("bench.py: multi-rank frame differs from the single-rank frame")
+            if split_lut:                 # ... and the sky LUT interleaved from the ranks' rows must BE the LUT rank 0 has just rendered whole
+                whole = torch.from_numpy(ctx.read_sky_lut().view(np.int16)).to(dev)
+                same = bool((whole == sky_lut[0]).all().item())
+                frame_check["sky_lut"] = {"rows_per_rank": fg.max_lut_rows(LH), "assembled_equals_whole": same}
+                if not same:
+                    raise SystemExit("bench.py: the sky LUT assembled from the ranks' rows differs from the whole LUT")
         # ---- hardware counters of the cloud kernel, collected now (child processes; the timed region is over)
         pmc, pmc_note = None, "not collected: N > 1 or --no-pmc"
         pmc_cfg = "C5frame" if args.config == "C5" else args.config          # the sweep's frames cost the same: profile one of them

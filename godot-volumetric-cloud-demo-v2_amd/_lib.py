@@ -60,6 +60,7 @@ SYMBOLS = [
     ("csky_render_sky_lut_device", C.c_int, [C.c_void_p, C.POINTER(SkyParams), C.c_void_p]),
     ("csky_render_clouds_device", C.c_int, [C.c_void_p, C.POINTER(CloudParams), C.c_int, C.POINTER(Bands), C.c_void_p, C.c_size_t, C.c_void_p]),
     ("csky_copy_sky_lut_device", C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
+    ("csky_render_sky_lut_rows_device", C.c_int, [C.c_void_p, C.POINTER(SkyParams), C.c_int, C.c_int, C.c_void_p, C.c_size_t, C.c_void_p]),
     ("csky_sync", C.c_int, [C.c_void_p]),
     ("csky_set_host_ring", C.c_int, [C.c_void_p, C.c_int]),
     ("csky_submit_clouds", C.c_int, [C.c_void_p, C.POINTER(CloudParams), C.c_int, C.c_int, C.POINTER(C.c_int64)]),
@@ -282,6 +283,15 @@ class Context:
         p.f[0], p.f[1] = float(w), float(h)
         p.f[4], p.f[5], p.f[6] = [float(x) for x in sun_dir]
         self._chk(self._L.csky_render_sky_lut_device(self._h, C.byref(p), C.c_void_p(stream or 0)))
+
+    def render_sky_lut_rows_device(self, sun_dir, first_row, row_stride, d_rows_out, capacity_bytes, w=200, h=100, stream=None):
+        """One rank's rows first_row::row_stride of the sky LUT (N processes splitting a frame), compact RGBA16F into the caller's device buffer
+        on `stream`; the context keeps no LUT, render_clouds_device renders the texels its frame set-up needs itself."""
+        p = SkyParams()
+        p.f[0], p.f[1] = float(w), float(h)
+        p.f[4], p.f[5], p.f[6] = [float(x) for x in sun_dir]
+        self._chk(self._L.csky_render_sky_lut_rows_device(self._h, C.byref(p), int(first_row), int(row_stride), C.c_void_p(int(d_rows_out)),
+                                                          C.c_size_t(int(capacity_bytes)), C.c_void_p(stream or 0)))
 
     def render_clouds_device(self, params, tile_w, bands, d_out, pitch_bytes, stream=None):
         p = cloud_params(params)

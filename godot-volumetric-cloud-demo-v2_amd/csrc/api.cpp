@@ -67,6 +67,9 @@ struct csky_ctx {
     // set-up -> clouds (ev_setup) and clouds -> the next writer of that slot (ev_clouds).  All sky-LUT readers run on `pro`.
     hipStream_t pro = nullptr;
     uint16_t* sky_h_ring[2] = {nullptr, nullptr}; float4* sky_f_ring[2] = {nullptr, nullptr}; int sky_cur = 0;
+    // csky_render_sky_lut_rows_device: the LUT of sun sky_sun exists only as the rows the caller's buffer received (one rank of an N-way frame
+    // split); the texels this context's frame set-up filters are rendered by the set-up kernel itself (clouds_dev)
+    bool sky_partial = false; float sky_sun[3] = {0, 1, 0}; int psw = 0, psh = 0;
     FrameConsts* fc_ring[RING] = {}; int fc_cur = 0;
     hipEvent_t ev_setup[RING] = {}, ev_clouds[RING] = {}; bool clouds_pending[RING] = {};
     unsigned long long* d_stats = nullptr;
@@ -218,7 +221,10 @@ int clouds_dev(csky_ctx* c, const csky_cloud_params* p, int tile_w, const csky_b
         if (c->clouds_pending[f]) HIPCHK(c, hipStreamWaitEvent(c->pro, c->ev_clouds[f], 0));
         // cloud-type range of the weather map (texel values 0..255): all >= 128 or all <= 127 fixes the branch of the height gradient
         const int ctm = !c->use_window ? 0 : (c->w_rmin * 255.0 >= 127.5 ? 1 : (c->w_rmax * 255.0 <= 127.5 ? 2 : 0));
-        HIPCHK(c, launch_frame_setup(cp, c->d_sky_f, c->sw, c->sh, c->primary_steps, c->light_steps, c->early_eps, lo, hi, ctm, c->fc_ring[f], c->pro));
+        if (c->sky_partial)                              // no LUT in memory: the set-up renders the texels of its three taps (clouds.glsl:163-167) itself
+            HIPCHK(c, launch_frame_setup_taps(cp, c->sky_sun, c->d_trans_f, c->tw, c->th, c->psw, c->psh, c->primary_steps, c->light_steps, c->early_eps, lo, hi, ctm, c->fc_ring[f], c->pro));
+        else
+            HIPCHK(c, launch_frame_setup(cp, c->d_sky_f, c->sw, c->sh, c->primary_steps, c->light_steps, c->early_eps, lo, hi, ctm, c->fc_ring[f], c->pro));
         HIPCHK(c, hipEventRecord(c->ev_setup[f], c->pro));
         c->fc_cur = f; c->d_fc = c->fc_ring[f];
         HIPCHK(c, hipStreamWaitEvent(s, c->ev_setup[f], 0));
@@ -679,10 +685,30 @@ int csky_render_sky_lut_device(csky_ctx* c, const csky_sky_params* p, void* hip_
     (void)hip_stream;   // the LUT has no inputs of the caller's: it is rendered on the prologue stream and its consumers are ordered by events
     if (!c->have_trans && (rc = render_trans_dev(c, 256, 64, c->pro))) return rc;   // transmittance_lut.gd:6 default size
     if ((rc = ensure_sky(c, w, h))) return rc;
-    const int k = c->have_sky ? c->sky_cur ^ 1 : c->sky_cur;  // the other ring slot: frame set-ups still reading the current one are ahead on `pro`
+    const int k = (c->have_sky && !c->sky_partial) ? c->sky_cur ^ 1 : c->sky_cur;  // the other ring slot: frame set-ups still reading the current one are ahead on `pro`
     HIPCHK(c, launch_sky_lut(w, h, p->sun_direction, c->d_trans_f, c->tw, c->th, c->sky_h_ring[k], c->sky_f_ring[k], c->pro));
     c->sky_cur = k; c->d_sky_h = c->sky_h_ring[k]; c->d_sky_f = c->sky_f_ring[k];
-    c->have_sky = true;
+    c->have_sky = true; c->sky_partial = false;
+    return CSKY_OK;
+}
+int csky_render_sky_lut_rows_device(csky_ctx* c, const csky_sky_params* p, int first_row, int row_stride, void* d_rows_out, size_t capacity_bytes, void* hip_stream) {
+    if (!c) return fail(nullptr, CSKY_ERR_INVALID, "csky_render_sky_lut_rows_device: ctx is NULL");
+    if (!p || !d_rows_out) return fail(c, CSKY_ERR_INVALID, "csky_render_sky_lut_rows_device: NULL argument");
+    const int w = (int)p->texture_size[0], h = (int)p->texture_size[1];
+    if (w < 1 || h < 1 || w > 8192 || h > 8192) return fail(c, CSKY_ERR_INVALID, "csky_render_sky_lut_rows_device: texture_size out of range");
+    if (first_row < 0 || row_stride < 1 || first_row >= row_stride) return fail(c, CSKY_ERR_INVALID, "csky_render_sky_lut_rows_device: need 0 <= first_row < row_stride");
+    const int n_rows = first_row < h ? (h - first_row + row_stride - 1) / row_stride : 0;
+    if (capacity_bytes < (size_t)n_rows * w * 8) return fail(c, CSKY_ERR_INVALID, "csky_render_sky_lut_rows_device: %zu bytes given, %d rows of %d bytes needed", capacity_bytes, n_rows, w * 8);
+    int rc; if ((rc = bind(c))) return rc;
+    if (!c->have_trans) {                                       // (rendered on the prologue stream: the caller's stream reads it)
+        if ((rc = render_trans_dev(c, 256, 64, c->pro))) return rc;
+        HIPCHK(c, hipStreamSynchronize(c->pro));
+    }
+    // the rows have no consumer inside the library: they are rendered on the CALLER's stream, in order with the bands they travel with
+    hipStream_t s = hip_stream ? (hipStream_t)hip_stream : c->stream;
+    HIPCHK(c, launch_sky_lut_rows(w, h, first_row, row_stride, p->sun_direction, c->d_trans_f, c->tw, c->th, reinterpret_cast<uint2*>(d_rows_out), s));
+    for (int i = 0; i < 3; i++) c->sky_sun[i] = p->sun_direction[i];
+    c->psw = w; c->psh = h; c->sky_partial = true; c->have_sky = true;
     return CSKY_OK;
 }
 
@@ -881,6 +907,7 @@ int csky_read_transmittance(csky_ctx* c, uint16_t* out, int* w, int* h) {
 int csky_read_sky_lut(csky_ctx* c, uint16_t* out, int* w, int* h) {
     if (!c) return fail(nullptr, CSKY_ERR_INVALID, "csky_read_sky_lut: ctx is NULL");
     if (!c->have_sky) return fail(c, CSKY_ERR_STATE, "csky_read_sky_lut: LUT not rendered yet");
+    if (c->sky_partial) return fail(c, CSKY_ERR_STATE, "csky_read_sky_lut: the last LUT went to the caller as rows (csky_render_sky_lut_rows_device), this context holds none");
     int rc; if ((rc = bind(c))) return rc;
     if (w) *w = c->sw; if (h) *h = c->sh;
     if (out) { HIPCHK(c, hipStreamSynchronize(c->pro)); HIPCHK(c, hipMemcpy(out, c->d_sky_h, (size_t)c->sw * c->sh * 8, hipMemcpyDeviceToHost)); }
@@ -1048,6 +1075,7 @@ int csky_copy_sky_lut_device(csky_ctx* c, void* d_out, void* hip_stream) {
     if (!c) return fail(nullptr, CSKY_ERR_INVALID, "csky_copy_sky_lut_device: ctx is NULL");
     if (!d_out) return fail(c, CSKY_ERR_INVALID, "csky_copy_sky_lut_device: d_out is NULL");
     if (!c->have_sky) return fail(c, CSKY_ERR_STATE, "csky_copy_sky_lut_device: LUT not rendered yet");
+    if (c->sky_partial) return fail(c, CSKY_ERR_STATE, "csky_copy_sky_lut_device: the last LUT went to the caller as rows (csky_render_sky_lut_rows_device), this context holds none");
     int rc; if ((rc = bind(c))) return rc;
     hipStream_t s = hip_stream ? (hipStream_t)hip_stream : c->stream;
     // the copy runs on the prologue stream right behind the LUT's render (a later render goes to the other ring slot and, like every

@@ -142,20 +142,38 @@ CSKY_HD void advance(float& x, float& y, float& z, float ix, float iy, float iz)
 CSKY_HD float sky_lut_uv_x(float dz, float dx) { return atan2f(dz, dx) / CLOUD_PI * 0.5f + 0.5f; }
 CSKY_HD float sky_lut_uv_y(float dy) { const float th = asinf(dy); return sqrtf(fabsf(th) / (CLOUD_PI * 0.5f)) * signf(th) * 0.5f + 0.5f; }
 
-CSKY_HD void sky_lut_tap(const float4* sky, int w, int h, float sx, float sy, float out[3]) {  // CLAMP + LINEAR, cloud_sky.gd:381-390
+// cell of one CLAMP + LINEAR tap (cloud_sky.gd:381-390): the four texel coordinates and the two weights
+CSKY_HD void sky_lut_cell(int w, int h, float sx, float sy, int& x0, int& x1, int& y0, int& y1, float& ax, float& ay) {
     const float ux = sx * (float)w - 0.5f, uy = sy * (float)h - 0.5f;
-    const float fx0 = floorf(ux), fy0 = floorf(uy), ax = ux - fx0, ay = uy - fy0;
-    int x0 = (int)fx0, y0 = (int)fy0, x1 = x0 + 1, y1 = y0 + 1;
+    const float fx0 = floorf(ux), fy0 = floorf(uy);
+    ax = ux - fx0; ay = uy - fy0;
+    x0 = (int)fx0; y0 = (int)fy0; x1 = x0 + 1; y1 = y0 + 1;
     x0 = x0 < 0 ? 0 : (x0 > w - 1 ? w - 1 : x0); x1 = x1 < 0 ? 0 : (x1 > w - 1 ? w - 1 : x1);
     y0 = y0 < 0 ? 0 : (y0 > h - 1 ? h - 1 : y0); y1 = y1 < 0 ? 0 : (y1 > h - 1 ? h - 1 : y1);
-    const float4 a = sky[y0 * w + x0], b = sky[y0 * w + x1], c = sky[y1 * w + x0], d = sky[y1 * w + x1];
+}
+// fetch(corner, x, y): the LUT texel (x, y), corner = 0..3 of the cell (x0 y0, x1 y0, x0 y1, x1 y1)
+template <class Fetch> CSKY_HD void sky_lut_tap_f(Fetch fetch, int w, int h, float sx, float sy, float out[3]) {
+    int x0, x1, y0, y1; float ax, ay;
+    sky_lut_cell(w, h, sx, sy, x0, x1, y0, y1, ax, ay);
+    const float4 a = fetch(0, x0, y0), b = fetch(1, x1, y0), c = fetch(2, x0, y1), d = fetch(3, x1, y1);
     out[0] = lerpf(lerpf(a.x, b.x, ax), lerpf(c.x, d.x, ax), ay);
     out[1] = lerpf(lerpf(a.y, b.y, ax), lerpf(c.y, d.y, ax), ay);
     out[2] = lerpf(lerpf(a.z, b.z, ax), lerpf(c.z, d.z, ax), ay);
 }
+CSKY_HD void sky_lut_tap(const float4* sky, int w, int h, float sx, float sy, float out[3]) {
+    sky_lut_tap_f([sky, w](int, int x, int y) { return sky[y * w + x]; }, w, h, sx, sy, out);
+}
+// where the frame set-up samples the sky LUT (clouds.glsl:163,164,166): tap 0 = towards the light (unnormalised direction), 1 / 2 = 45 degrees
+// above / below the horizon.  One place for frame_setup and for the kernel that renders just those texels (kernels.hip frame_setup_taps_kernel).
+CSKY_HD void frame_setup_tap_uv(const float light[3], int tap, float& sx, float& sy) {
+    const float inv = 1.0f / sqrtf(1.0f * 1.0f + 1.0f * 1.0f + 0.0f * 0.0f);               // normalize(vec3(1,+-1,0))
+    if (tap == 0) { sx = sky_lut_uv_x(light[2], light[0]); sy = sky_lut_uv_y(light[1]); }
+    else { sx = sky_lut_uv_x(0.0f, inv); sy = sky_lut_uv_y(tap == 1 ? inv : -inv); }
+}
 
-CSKY_HD void frame_setup(const CloudParams& P, const float4* sky, int sky_w, int sky_h, int primary_steps, int light_steps,
-                         float early_eps, float hf_lo, float hf_hi, FrameConsts& fc) {
+// fetch(tap, corner, x, y): texel (x, y) of the sky LUT, asked for by tap 0..2 (frame_setup_tap_uv) as corner 0..3 of its cell
+template <class Fetch> CSKY_HD void frame_setup_f(const CloudParams& P, Fetch fetch, int sky_w, int sky_h, int primary_steps, int light_steps,
+                                                  float early_eps, float hf_lo, float hf_hi, FrameConsts& fc) {
     const float RV[6][3] = {{0.38051305f, 0.92453449f, -0.02111345f}, {-0.50625799f, -0.03590792f, -0.86163418f},
                             {-0.32509218f, -0.94557439f, 0.01428793f}, {0.09026238f, -0.27376545f, 0.95755165f},
                             {0.28128598f, 0.42443639f, -0.86065785f}, {-0.16852403f, 0.14748697f, 0.97460106f}};  // clouds.glsl:140
@@ -171,15 +189,17 @@ CSKY_HD void frame_setup(const CloudParams& P, const float4* sky, int sky_w, int
     for (int j = 0; j < 6; j++) for (int k = 0; k < 3; k++) fc.linc[j][k] = (fc.ldir[k] + RV[j][k] * (float)j) * lss;
     for (int k = 0; k < 3; k++) fc.ldist[k] = fc.ldir[k] * 18.0f * lss;
     fc.hg_g2 = 0.4f - 1.4f * fc.ldir[1];
-    float s[3];
-    sky_lut_tap(sky, sky_w, sky_h, sky_lut_uv_x(lz, lx), sky_lut_uv_y(ly), s);             // clouds.glsl:163 (unnormalised dir)
+    float s[3], sx, sy;
+    frame_setup_tap_uv(P.LIGHT_DIRECTION, 0, sx, sy);
+    sky_lut_tap_f([&fetch](int c, int x, int y) { return fetch(0, c, x, y); }, sky_w, sky_h, sx, sy, s);   // clouds.glsl:163 (unnormalised dir)
     for (int k = 0; k < 3; k++) fc.sun_c[k] = s[k] * 0.1f * P.LIGHT_ENERGY * P.LIGHT_COLOR[k];
-    const float inv = 1.0f / sqrtf(1.0f * 1.0f + 1.0f * 1.0f + 0.0f * 0.0f);               // normalize(vec3(1,+-1,0))
-    sky_lut_tap(sky, sky_w, sky_h, sky_lut_uv_x(0.0f, inv), sky_lut_uv_y(inv), s);         // clouds.glsl:164
+    frame_setup_tap_uv(P.LIGHT_DIRECTION, 1, sx, sy);
+    sky_lut_tap_f([&fetch](int c, int x, int y) { return fetch(1, c, x, y); }, sky_w, sky_h, sx, sy, s);   // clouds.glsl:164
     for (int k = 0; k < 3; k++) s[k] = s[k] * 0.05f;
     float len = length3_exact(s[0], s[1], s[2]);
     for (int k = 0; k < 3; k++) fc.amb_c[k] = s[k] * (1.0f - 0.5f) + len * 0.5f;           // clouds.glsl:165
-    sky_lut_tap(sky, sky_w, sky_h, sky_lut_uv_x(0.0f, inv), sky_lut_uv_y(-inv), s);        // clouds.glsl:166
+    frame_setup_tap_uv(P.LIGHT_DIRECTION, 2, sx, sy);
+    sky_lut_tap_f([&fetch](int c, int x, int y) { return fetch(2, c, x, y); }, sky_w, sky_h, sx, sy, s);   // clouds.glsl:166
     for (int k = 0; k < 3; k++) s[k] = s[k] * 5.0f * 0.05f;
     len = length3_exact(s[0], s[1], s[2]);
     for (int k = 0; k < 3; k++) fc.gnd_c[k] = s[k] * (1.0f - 0.5f) + (P.ground_color[k] * len) * 0.5f;  // clouds.glsl:167
@@ -188,6 +208,10 @@ CSKY_HD void frame_setup(const CloudParams& P, const float4* sky, int sky_w, int
     fc.early_eps = early_eps;
     fc.hf_lo = hf_lo; fc.hf_hi = hf_hi;
     fc.ct_mode = 0;                   // set by the caller that knows the weather map's range (api.cpp; kernels.hip frame_setup_kernel)
+}
+CSKY_HD void frame_setup(const CloudParams& P, const float4* sky, int sky_w, int sky_h, int primary_steps, int light_steps,
+                         float early_eps, float hf_lo, float hf_hi, FrameConsts& fc) {
+    frame_setup_f(P, [sky, sky_w](int, int, int x, int y) { return sky[y * sky_w + x]; }, sky_w, sky_h, primary_steps, light_steps, early_eps, hf_lo, hf_hi, fc);
 }
 
 // =================================================================================================

@@ -12,9 +12,14 @@ hipError_t launch_transmittance(int w, int h, uint16_t* d_half, float4* d_float,
 // sky-lut.glsl main()
 hipError_t launch_sky_lut(int w, int h, const float sun[3], const float4* d_trans, int tw, int th, uint16_t* d_half,
                           float4* d_float, hipStream_t s);
+// rows row0, row0 + row_stride, ... of that LUT, compact RGBA16F, into d_rows (one rank of an N-way frame split)
+hipError_t launch_sky_lut_rows(int w, int h, int row0, int row_stride, const float sun[3], const float4* d_trans, int tw, int th, uint2* d_rows, hipStream_t s);
 // per-frame constants of clouds.glsl:143-170 (one wave)
 hipError_t launch_frame_setup(const CloudParams& p, const float4* d_sky, int sw, int sh, int primary_steps, int light_steps,
                               float early_eps, float hf_lo, float hf_hi, int ct_mode, FrameConsts* d_fc, hipStream_t s);
+// the same without a sky LUT in memory: renders the <= 12 texels the set-up filters itself (sw x sh LUT of the sun `sun`)
+hipError_t launch_frame_setup_taps(const CloudParams& p, const float sun[3], const float4* d_trans, int tw, int th, int sw, int sh, int primary_steps,
+                                   int light_steps, float early_eps, float hf_lo, float hf_hi, int ct_mode, FrameConsts* d_fc, hipStream_t s);
 // clouds.glsl main() over the rows described by `g`.  d_stats (may be null): [0] += in-cloud samples,
 // [1] += rays above the horizon.
 // seg = ray segments per ray (1, 2 or 4; variant 1 only): a workgroup covers 4/seg tiles of 8x8 pixels.

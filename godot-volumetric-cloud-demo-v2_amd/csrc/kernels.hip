@@ -49,17 +49,13 @@ struct Sun3 { float v[3]; };
 // ~600 VALU with 20 LUT loads and 12 transcendentals and independent of the others), park source term + transmittance
 // in LDS, then lane 0 of the half replays the front-to-back accumulation in the reference's order (bit-identical to the
 // one-lane-per-texel form, 4x shorter critical path: this kernel sits on the critical path of every frame).
-__global__ __launch_bounds__(256) void sky_lut_kernel(int w, int h, Sun3 sun, const float4* __restrict__ trans, int tw, int th,
-                                                     uint16_t* __restrict__ out_h, float4* __restrict__ out_f) {
-    __shared__ float steps[8][IN_SCATTERING_STEPS][8];
-    const int half = threadIdx.x >> 5, sub = threadIdx.x & 31;
-    const int texel = blockIdx.x * 8 + half;                      // rows 100..103 of the reference dispatch are discarded stores (S:281)
-    const bool live = texel < w * h;
-    const int px = live ? texel % w : 0, py = live ? texel / w : 0;
+// One texel; store(px, py, hx, hy, hz, hw) takes the four fp16 values (lane 0 of the half wavefront, live texels only).
+template <class Store> __device__ __forceinline__ void sky_texel(float (*steps)[8], int sub, bool live, int px, int py, int w, int h, const Sun3& sun,
+                                                                 const float4* __restrict__ trans, int tw, int th, Store store) {
     const SkyRay r = sky_ray(px, py, (float)w, (float)h, sun.v);
     if (sub < IN_SCATTERING_STEPS) {
         const SkyStep s = sky_step(r, sub, trans, tw, th);
-        float* d = steps[half][sub];
+        float* d = steps[sub];
         d[0] = s.S_int.x; d[1] = s.S_int.y; d[2] = s.S_int.z; d[3] = s.S_int.w;
         d[4] = s.step_tr.x; d[5] = s.step_tr.y; d[6] = s.step_tr.z; d[7] = s.step_tr.w;
     }
@@ -67,15 +63,41 @@ __global__ __launch_bounds__(256) void sky_lut_kernel(int w, int h, Sun3 sun, co
     if (sub == 0 && live) {
         F4 L = f4(0, 0, 0, 0), Tr = f4(1, 1, 1, 1);
         for (int i = 0; i < IN_SCATTERING_STEPS; ++i) {
-            const float* d = steps[half][i];
+            const float* d = steps[i];
             SkyStep s; s.S_int = f4(d[0], d[1], d[2], d[3]); s.step_tr = f4(d[4], d[5], d[6], d[7]);
             sky_accumulate(L, Tr, s);
         }
         const F4 c = sky_output(L);
-        const uint16_t hx = f2h(c.x), hy = f2h(c.y), hz = f2h(c.z), hw = f2h(c.w);
-        reinterpret_cast<uint2*>(out_h)[texel] = make_uint2((uint32_t)hx | ((uint32_t)hy << 16), (uint32_t)hz | ((uint32_t)hw << 16));
-        out_f[texel] = make_float4(h2f(hx), h2f(hy), h2f(hz), h2f(hw));
+        store(px, py, f2h(c.x), f2h(c.y), f2h(c.z), f2h(c.w));
     }
+}
+__device__ __forceinline__ uint2 pack_half4(uint16_t hx, uint16_t hy, uint16_t hz, uint16_t hw) {
+    return make_uint2((uint32_t)hx | ((uint32_t)hy << 16), (uint32_t)hz | ((uint32_t)hw << 16));
+}
+__global__ __launch_bounds__(256) void sky_lut_kernel(int w, int h, Sun3 sun, const float4* __restrict__ trans, int tw, int th,
+                                                     uint16_t* __restrict__ out_h, float4* __restrict__ out_f) {
+    __shared__ float steps[8][IN_SCATTERING_STEPS][8];
+    const int half = threadIdx.x >> 5, sub = threadIdx.x & 31;
+    const int texel = blockIdx.x * 8 + half;                      // rows 100..103 of the reference dispatch are discarded stores (S:281)
+    const bool live = texel < w * h;
+    const int px = live ? texel % w : 0, py = live ? texel / w : 0;
+    sky_texel(steps[half], sub, live, px, py, w, h, sun, trans, tw, th, [=](int x, int y, uint16_t hx, uint16_t hy, uint16_t hz, uint16_t hw) {
+        reinterpret_cast<uint2*>(out_h)[y * w + x] = pack_half4(hx, hy, hz, hw);
+        out_f[y * w + x] = make_float4(h2f(hx), h2f(hy), h2f(hz), h2f(hw));
+    });
+}
+// One rank's rows of the LUT when N processes split a frame (csky_render_sky_lut_rows_device): rows row0, row0 + row_stride, ... (n_rows of
+// them), stored COMPACT and as RGBA16F only, straight into the buffer that travels to the gathering rank with the rank's bands.
+__global__ __launch_bounds__(256) void sky_lut_rows_kernel(int w, int h, int row0, int row_stride, int n_rows, Sun3 sun, const float4* __restrict__ trans,
+                                                          int tw, int th, uint2* __restrict__ out_rows) {
+    __shared__ float steps[8][IN_SCATTERING_STEPS][8];
+    const int half = threadIdx.x >> 5, sub = threadIdx.x & 31;
+    const int t = blockIdx.x * 8 + half;
+    const bool live = t < w * n_rows;
+    const int px = live ? t % w : 0, py = live ? row0 + (t / w) * row_stride : 0;
+    sky_texel(steps[half], sub, live, px, py, w, h, sun, trans, tw, th, [=](int, int, uint16_t hx, uint16_t hy, uint16_t hz, uint16_t hw) {
+        out_rows[t] = pack_half4(hx, hy, hz, hw);
+    });
 }
 
 hipError_t launch_transmittance(int w, int h, uint16_t* d_half, float4* d_float, hipStream_t s) {
@@ -86,6 +108,12 @@ hipError_t launch_sky_lut(int w, int h, const float sun[3], const float4* d_tran
                           hipStream_t s) {
     Sun3 sv; sv.v[0] = sun[0]; sv.v[1] = sun[1]; sv.v[2] = sun[2];
     sky_lut_kernel<<<(w * h + 7) / 8, 256, 0, s>>>(w, h, sv, d_trans, tw, th, d_half, d_float);
+    return hipGetLastError();
+}
+hipError_t launch_sky_lut_rows(int w, int h, int row0, int row_stride, const float sun[3], const float4* d_trans, int tw, int th, uint2* d_rows, hipStream_t s) {
+    Sun3 sv; sv.v[0] = sun[0]; sv.v[1] = sun[1]; sv.v[2] = sun[2];
+    const int n_rows = row0 < h ? (h - row0 + row_stride - 1) / row_stride : 0;
+    if (n_rows) sky_lut_rows_kernel<<<(w * n_rows + 7) / 8, 256, 0, s>>>(w, h, row0, row_stride, n_rows, sv, d_trans, tw, th, d_rows);
     return hipGetLastError();
 }
 
@@ -268,6 +296,37 @@ __global__ __launch_bounds__(64) void frame_setup_kernel(CloudParams p, const fl
 hipError_t launch_frame_setup(const CloudParams& p, const float4* d_sky, int sw, int sh, int primary_steps, int light_steps, float early_eps,
                               float hf_lo, float hf_hi, int ct_mode, FrameConsts* d_fc, hipStream_t s) {
     frame_setup_kernel<<<1, 64, 0, s>>>(p, d_sky, sw, sh, primary_steps, light_steps, early_eps, hf_lo, hf_hi, ct_mode, d_fc);
+    return hipGetLastError();
+}
+// The same for a context that holds no sky LUT of its own (one rank of an N-way frame split renders only its rows of it, straight into the
+// gather buffer): the <= 12 texels the three taps of clouds.glsl:163-167 filter are rendered here first, one per half wavefront with the
+// per-texel code of sky_lut_kernel (fp16-rounded like the stored LUT), parked in LDS, and lane 0 runs the set-up on them.  The cell
+// arithmetic is sky_lut_cell's in both places, so every texel the set-up asks for is one rendered here: the constants are bit-identical to
+// those filtered from a whole LUT.
+__global__ __launch_bounds__(384) void frame_setup_taps_kernel(CloudParams p, Sun3 sun, const float4* __restrict__ trans, int tw, int th, int sw, int sh,
+                                                              int primary_steps, int light_steps, float early_eps, float hf_lo, float hf_hi, int ct_mode,
+                                                              FrameConsts* __restrict__ out) {
+    __shared__ float steps[12][IN_SCATTERING_STEPS][8];
+    __shared__ float4 texel[12];
+    const int k = threadIdx.x >> 5, sub = threadIdx.x & 31;      // texel k: corner k % 4 of tap k / 4
+    float sx, sy, ax, ay; int x0, x1, y0, y1;
+    frame_setup_tap_uv(p.LIGHT_DIRECTION, k >> 2, sx, sy);
+    sky_lut_cell(sw, sh, sx, sy, x0, x1, y0, y1, ax, ay);
+    sky_texel(steps[k], sub, true, (k & 1) ? x1 : x0, (k & 2) ? y1 : y0, sw, sh, sun, trans, tw, th, [&](int, int, uint16_t hx, uint16_t hy, uint16_t hz, uint16_t hw) {
+        texel[k] = make_float4(h2f(hx), h2f(hy), h2f(hz), h2f(hw));
+    });
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        FrameConsts fc;
+        frame_setup_f(p, [&](int tap, int corner, int, int) { return texel[tap * 4 + corner]; }, sw, sh, primary_steps, light_steps, early_eps, hf_lo, hf_hi, fc);
+        fc.ct_mode = ct_mode;
+        *out = fc;
+    }
+}
+hipError_t launch_frame_setup_taps(const CloudParams& p, const float sun[3], const float4* d_trans, int tw, int th, int sw, int sh, int primary_steps,
+                                   int light_steps, float early_eps, float hf_lo, float hf_hi, int ct_mode, FrameConsts* d_fc, hipStream_t s) {
+    Sun3 sv; sv.v[0] = sun[0]; sv.v[1] = sun[1]; sv.v[2] = sun[2];
+    frame_setup_taps_kernel<<<1, 384, 0, s>>>(p, sv, d_trans, tw, th, sw, sh, primary_steps, light_steps, early_eps, hf_lo, hf_hi, ct_mode, d_fc);
     return hipGetLastError();
 }
 

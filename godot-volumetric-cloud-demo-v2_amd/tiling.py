@@ -37,6 +37,16 @@ def interleave(gathered, height, world, band_rows=BAND_ROWS):
     return np.ascontiguousarray(full[: total * band_rows])
 
 
+def lut_rows_for_rank(lut_h, rank, world):
+    """(first_row, row_stride, n_rows) for csky_render_sky_lut_rows_device: rank r of N renders rows r, r + N, ... of the sky LUT (sky_lut.gd:43-52
+    renders it once per frame; N ranks rendering N identical copies would spend 33 us of a whole chip each, 12 % of a 1/8 frame share)."""
+    return (rank, world, (lut_h - rank + world - 1) // world if rank < lut_h else 0)
+
+
+def max_lut_rows(lut_h, world):
+    return (lut_h + world - 1) // world
+
+
 def render_sharded(render_bands, height, width, rank, world, dist=None, device=None, band_rows=BAND_ROWS):
     """Render this rank's bands and gather the frame on rank 0.
 
@@ -90,6 +100,12 @@ class FrameGroups:
     def max_bands(self, height, band_rows=BAND_ROWS):
         return max_bands(height, self.per, band_rows)
 
+    def lut_rows(self, lut_h):
+        return lut_rows_for_rank(lut_h, self.index, self.per)
+
+    def max_lut_rows(self, lut_h):
+        return max_lut_rows(lut_h, self.per)
+
     def group_of(self, frame_no):
         return frame_no % self.groups
 
@@ -116,3 +132,17 @@ class FrameGroups:
         if self.groups > 1 and g != 0:
             got = got[1:]                                # rank 0's dummy contribution to another group's gather
         return interleave(got, height, self.per, band_rows)
+
+    def split(self, gathered_bytes, height, width, lut_h=0, lut_w=0, band_rows=BAND_ROWS):
+        """Rank 0: a gathered [members, bytes] uint8 tensor whose rows are (compact bands | compact sky-LUT rows) -> the two typed tensors
+        ([members, max_bands*band_rows, W, 4], [members, max_lut_rows, lut_w, 4] int16) that assemble() / assemble_lut() take."""
+        import torch
+        bb = self.max_bands(height, band_rows) * band_rows * width * 8
+        m = gathered_bytes.shape[0]
+        img = gathered_bytes[:, :bb].view(torch.int16).reshape(m, -1, width, 4)
+        lut = gathered_bytes[:, bb: bb + self.max_lut_rows(lut_h) * lut_w * 8].view(torch.int16).reshape(m, -1, lut_w, 4) if lut_h else None
+        return img, lut
+
+    def assemble_lut(self, frame_no, gathered_lut, lut_h):
+        """Rank 0: the members' sky-LUT rows of frame_no ([members, max_lut_rows, w, 4]) -> the [lut_h, w, 4] LUT."""
+        return self.assemble(frame_no, gathered_lut, lut_h, band_rows=1)

@@ -149,6 +149,16 @@ int csky_render_sky_lut_device(csky_ctx* ctx, const csky_sky_params* p, void* hi
  * behind the LUT's render and `hip_stream` is made to wait for it.  What sky_lut.gd:143-146 does by rotating texture_rd[3]: a host
  * that wants the reference's three-deep ring of LUT copies (for clouds.gdshader's sky_blend_from/to) keeps them with this. */
 int csky_copy_sky_lut_device(csky_ctx* ctx, void* d_out_rgba16f, void* hip_stream);
+/* One rank's part of the sky LUT when N processes split a frame (sky_lut.gd:43-52 renders the LUT once per frame, cloud_sky.gd:187:
+ * on N ranks that would be N identical copies of a kernel that costs 33 us of a whole chip, 12 % of a 1/8 frame share).  Renders rows
+ * first_row, first_row + row_stride, ... (0 <= first_row < row_stride) of the p->texture_size LUT, COMPACT (ceil((h - first_row) / row_stride)
+ * rows of w RGBA16F texels), straight into the caller's DEVICE buffer on `hip_stream` (the context's own stream if NULL): the buffer that
+ * travels to the gathering rank behind the rank's bands, where the rows are interleaved (tiling.py / bench.py).  The context keeps no LUT:
+ * the (at most 12) texels its frame set-up filters (clouds.glsl:163-167) are rendered by the set-up of each following csky_render_clouds*
+ * call, for THAT call's light direction and with the same per-texel code, so frames are byte-identical to those marched with a whole LUT.
+ * csky_read_sky_lut / csky_copy_sky_lut_device return CSKY_ERR_STATE until the next csky_render_sky_lut*. */
+int csky_render_sky_lut_rows_device(csky_ctx* ctx, const csky_sky_params* p, int first_row, int row_stride, void* d_rows_out_rgba16f,
+                                    size_t capacity_bytes, void* hip_stream);
 int csky_render_clouds_device(csky_ctx* ctx, const csky_cloud_params* p, int tile_w, const csky_bands* bands,
                               void* d_out_rgba16f, size_t row_pitch_bytes, void* hip_stream);
 int csky_sync(csky_ctx* ctx); /* wait for the context's own streams (work on caller streams is the caller's to wait for) */

@@ -96,3 +96,77 @@ def test_multi_groups_render_the_sky_lut_on_every_device(pkg, noise, oracle, ora
             assert ok, (k, info)
     finally:
         m.close()
+
+
+def _lut_rows(ctx, torch, sun, r, n, w=200, h=100):
+    """rank r of n: its rows of the LUT, compact, as [rows, w, 4] uint16"""
+    rows = len(range(r, h, n))
+    buf = torch.zeros(max(1, rows) * w * 8, dtype=torch.uint8, device="cuda")
+    st = torch.cuda.Stream()
+    ctx.render_sky_lut_rows_device(sun, r, n, buf.data_ptr(), buf.numel(), w, h, st.cuda_stream)
+    st.synchronize()
+    return buf.cpu().numpy().view(np.uint16).reshape(-1, w, 4)[:rows]
+
+
+@pytest.mark.parametrize("n", [2, 8, 3])
+def test_sky_lut_rows_interleave_to_the_whole_lut(gpu_ctx, n):
+    """csky_render_sky_lut_rows_device (sky_lut.gd:43-52 split over the ranks of a frame split): rows r::n of every rank, interleaved, are the LUT
+    one context renders whole, to the byte (ragged for n = 3 / 8: 100 rows)."""
+    import torch
+    sun = norm(SUNS["demo"])
+    whole = gpu_ctx.render_sky_lut(sun, 200, 100).view(np.uint16)
+    got = np.zeros_like(whole)
+    for r in range(n):
+        got[r::n] = _lut_rows(gpu_ctx, torch, sun, r, n)
+    assert np.array_equal(got, whole)
+    gpu_ctx.render_sky_lut(sun, 200, 100)          # leave the shared context with a whole LUT
+
+
+@pytest.mark.parametrize("sun_key,light", [("deg45", None), ("zenith", None), ("demo", None), ("deg45", (-0.3, -0.8, 0.5)), ("demo", (0.0, 1.0, 0.0))])
+def test_frames_marched_on_a_rows_only_lut_are_byte_identical(gpu_ctx, oracle, sun_key, light):
+    """A context whose LUT went to the caller as rows keeps none: its frame set-up renders the <= 12 texels it filters itself, for the light
+    direction of each frame (clouds.glsl:163-167; frame_setup_taps_kernel) -- also when LIGHT_DIRECTION is not the sky LUT's sun, below the
+    horizon (v clamps at row 0) or straight up (atan2(0, 0), top row): this rank's bands are byte-identical to the ones marched on the whole LUT."""
+    import torch
+    W, H = 512, 256
+    sun = norm(SUNS[sun_key])
+    params = oracle.default_params(W, H, light if light is not None else SUNS[sun_key])
+    bands = (8, 3, 8, H // 8 // 8)
+    out = [torch.zeros((bands[3] * 8, W, 4), dtype=torch.int16, device="cuda") for _ in range(2)]
+    st = torch.cuda.Stream()
+    other = norm((-0.2, 0.15, 0.9))                # both slots of the context's LUT ring hold ANOTHER sun's texels when the rows-only frame is marched
+    rows = torch.zeros(13 * 200 * 8, dtype=torch.uint8, device="cuda")
+    gpu_ctx.render_sky_lut_device(sun, 200, 100, st.cuda_stream)
+    gpu_ctx.render_clouds_device(params, W, bands, out[0].data_ptr(), W * 8, st.cuda_stream)
+    gpu_ctx.render_sky_lut_device(other, 200, 100, st.cuda_stream)
+    gpu_ctx.render_sky_lut_device(other, 200, 100, st.cuda_stream)
+    gpu_ctx.render_sky_lut_rows_device(sun, 3, 8, rows.data_ptr(), rows.numel(), 200, 100, st.cuda_stream)
+    gpu_ctx.render_clouds_device(params, W, bands, out[1].data_ptr(), W * 8, st.cuda_stream)
+    st.synchronize()
+    assert bool((out[0] == out[1]).all().item()) and float(out[0].view(torch.float16)[..., 3].float().mean().item()) > 0.0
+    gpu_ctx.render_sky_lut(sun, 200, 100)
+
+
+def test_a_rows_only_lut_cannot_be_read_as_a_whole_one(gpu_ctx, pkg):
+    import torch
+    sun = norm(SUNS["deg45"])
+    buf = torch.zeros(200 * 100 * 8, dtype=torch.uint8, device="cuda")
+    gpu_ctx.render_sky_lut_rows_device(sun, 1, 4, buf.data_ptr(), buf.numel(), 200, 100, None)
+    with pytest.raises(pkg.CloudSkyError) as e:
+        gpu_ctx.read_sky_lut()
+    assert e.value.code == pkg._lib.ERR_STATE
+    with pytest.raises(pkg.CloudSkyError) as e:
+        gpu_ctx.copy_sky_lut_device(buf.data_ptr(), None)
+    assert e.value.code == pkg._lib.ERR_STATE
+    with pytest.raises(pkg.CloudSkyError) as e:
+        gpu_ctx.render_sky_lut_rows_device(sun, 1, 4, buf.data_ptr(), 25 * 200 * 8 - 1, 200, 100, None)      # 25 rows of 1600 bytes needed
+    assert e.value.code == pkg._lib.ERR_INVALID
+    with pytest.raises(pkg.CloudSkyError) as e:
+        gpu_ctx.render_sky_lut_rows_device(sun, 4, 4, buf.data_ptr(), buf.numel(), 200, 100, None)            # first_row < row_stride
+    assert e.value.code == pkg._lib.ERR_INVALID
+    whole = gpu_ctx.render_sky_lut(sun, 200, 100)
+    assert gpu_ctx.read_sky_lut().shape == (100, 200, 4)
+    gpu_ctx.render_sky_lut_rows_device(sun, 0, 1, buf.data_ptr(), buf.numel(), 200, 100, None)                # stride 1: every row
+    gpu_ctx.sync()
+    assert np.array_equal(buf.cpu().numpy().view(np.uint16).reshape(100, 200, 4), whole.view(np.uint16))
+    gpu_ctx.render_sky_lut(sun, 200, 100)

@@ -84,7 +84,8 @@ def test_band_partition_is_exact():
 
 def _group_worker(rank, world, groups, port, H, W, frames, q):
     """tiling.FrameGroups (the dealing bench.py --groups uses): frame f goes to group f % groups, the group's ranks split its bands, rank 0
-    receives every frame over that group's communicator.  Synthetic bands (value = a function of frame and pixel row), two gathers in flight."""
+    receives every frame over that group's communicator.  Synthetic bands (value = a function of frame and pixel row), two gathers in flight.
+    Behind its bands every rank sends its rows index::per of a (ragged: 10 rows) sky LUT, the byte layout bench.py uses at N > 1."""
     sys.path.insert(0, ROOT)
     import torch
     import torch.distributed as dist
@@ -97,15 +98,26 @@ def _group_worker(rank, world, groups, port, H, W, frames, q):
     br, first, stride, n = fg.bands(H)
     mb = fg.max_bands(H)
     nbuf = 2 * (groups if rank == 0 else 1)
-    local = [torch.zeros((mb * br, W, 4), dtype=torch.int16) for _ in range(nbuf)]
-    gathered = [torch.empty((fg.max_members,) + tuple(local[0].shape), dtype=torch.int16) for _ in range(nbuf)] if rank == 0 else [None] * nbuf
+    LH, LW = 10, 6
+    band_bytes, lut_bytes = mb * br * W * 8, fg.max_lut_rows(LH) * LW * 8
+    local_b = [torch.zeros(band_bytes + lut_bytes, dtype=torch.uint8) for _ in range(nbuf)]
+    local = [t[:band_bytes].view(torch.int16).view(mb * br, W, 4) for t in local_b]
+    local_lut = [t[band_bytes:].view(torch.int16).view(-1, LW, 4) for t in local_b]
+    gathered = [torch.empty((fg.max_members, band_bytes + lut_bytes), dtype=torch.uint8) for _ in range(nbuf)] if rank == 0 else [None] * nbuf
     pending, ok, taken = [], True, 0
+    r0, rs, rn = fg.lut_rows(LH)
+
+    def lut_value(f, rows):
+        return ((f * 11 + rows.view(-1, 1, 1) * 5 + torch.arange(LW, dtype=torch.int32).view(1, LW, 1)) % 30000).to(torch.int16).expand(rows.numel(), LW, 4)
 
     def check(f, b):
-        frame = fg.assemble(f, gathered[b], H)
+        img, lut = fg.split(gathered[b], H, W, LH, LW)
+        frame = fg.assemble(f, img, H)
         rows = torch.arange(H, dtype=torch.int32).view(H, 1, 1)
         want = ((f * 37 + rows * 3) % 30000).to(torch.int16).expand(H, W, 4)
-        return bool((frame == want).all()) and tuple(frame.shape) == (H, W, 4)
+        sky = fg.assemble_lut(f, lut, LH)
+        return bool((frame == want).all()) and tuple(frame.shape) == (H, W, 4) and tuple(sky.shape) == (LH, LW, 4) and \
+            bool((sky == lut_value(f, torch.arange(LH, dtype=torch.int32))).all())
 
     for f in range(frames):
         if not fg.takes_part(f):
@@ -117,9 +129,10 @@ def _group_worker(rank, world, groups, port, H, W, frames, q):
                 y0 = (first + k * stride) * br
                 rows = torch.arange(y0, y0 + br, dtype=torch.int32).view(br, 1, 1)
                 local[b][k * br:(k + 1) * br] = ((f * 37 + rows * 3) % 30000).to(torch.int16).expand(br, W, 4)
+            local_lut[b][:rn] = lut_value(f, torch.arange(r0, LH, rs, dtype=torch.int32))
         else:
-            local[b].fill_(-1)                        # rank 0's dummy for another group's frame: must never show up
-        pending.append((fg.gather(f, local[b].view(torch.uint8), gathered[b], async_op=True), f, b))
+            local_b[b].fill_(255)                     # rank 0's dummy for another group's frame: must never show up
+        pending.append((fg.gather(f, local_b[b], gathered[b], async_op=True), f, b))
         if len(pending) == nbuf:                      # the oldest gather ran while the younger frames were produced
             w, f0, b0 = pending.pop(0)
             w.wait()
@@ -165,5 +178,12 @@ def test_frame_groups_partition():
                     seen.setdefault(f, []).extend(first + k * stride for k in range(n))
                 assert fg.takes_part(f) == (fg.renders(f) or r == 0)
         assert all(sorted(v) == list(range(8)) for v in seen.values()) and len(seen) == 2 * G     # every band of every frame exactly once
+    for world in (1, 2, 3, 8, 128):                       # sky-LUT rows: every row of the 100 exactly once, whatever the split
+        rows = []
+        for r in range(world):
+            r0, rs, rn = T.lut_rows_for_rank(100, r, world)
+            assert rn == len(range(r0, 100, rs)) <= T.max_lut_rows(100, world)
+            rows.extend(range(r0, 100, rs))
+        assert sorted(rows) == list(range(100))
     with pytest.raises(ValueError):
         T.FrameGroups(0, 8, 3)

@@ -1,5 +1,7 @@
 #!/usr/bin/env python
-"""One rank's share of the frame (1/4, 1/8): ms per frame for ray segments x schedule x frames in flight."""
+"""One rank's share of the frame (1/4, 1/8): ms per frame for ray segments x schedule x frames in flight.
+LUT=rows (default for shares < 1: the rank's rows of the sky LUT, as bench.py does at N > 1) | whole (every rank the whole LUT, rounds 1-3) |
+none (no per-frame LUT at all: what the LUT costs a share)."""
 import os, sys, time
 os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 import numpy as np
@@ -13,6 +15,9 @@ p = np.array([W, H, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0.270588, 0.188235, 0.027451, 
 ctx = gvcd_amd.Context(0)
 ctx.set_noise(*gvcd_amd.assets.load_default_noise())
 ctx.render_transmittance(256, 64)
+ctx.render_sky_lut(s, 200, 100, readback=False)
+LUT = os.environ.get("LUT", "rows")
+lut_out = torch.zeros(200 * 100 * 8, dtype=torch.uint8, device="cuda")
 NS = [int(a) for a in os.environ.get("NS", "1,2").split(",")]   # frames in flight to try (the rings are four deep)
 pool = [torch.cuda.Stream() for _ in range(max(NS))]
 for share in [int(a) for a in sys.argv[1:]] or (2, 4, 8):
@@ -25,7 +30,10 @@ for share in [int(a) for a in sys.argv[1:]] or (2, 4, 8):
                 ctx.set_segments(seg); ctx.set_schedule(sched); ctx.set_frames_in_flight(ns)
                 def step(k):
                     i = k % ns
-                    ctx.render_sky_lut_device(s, 200, 100, pool[i].cuda_stream)
+                    if LUT == "rows" and share > 1:     # the rank's rows of the LUT, into the buffer that rides with its bands (bench.py at N > 1)
+                        ctx.render_sky_lut_rows_device(s, 0, share, lut_out.data_ptr(), lut_out.numel(), 200, 100, pool[i].cuda_stream)
+                    elif LUT != "none":
+                        ctx.render_sky_lut_device(s, 200, 100, pool[i].cuda_stream)
                     ctx.render_clouds_device(p, W, bands, outs[i].data_ptr(), W * 8, pool[i].cuda_stream)
                 for k in range(12):
                     step(k)
@@ -35,4 +43,4 @@ for share in [int(a) for a in sys.argv[1:]] or (2, 4, 8):
                     step(k)
                 torch.cuda.synchronize()
                 row.append("s%d/x%d %.3f" % (sched, ns, (time.perf_counter() - t0) / 60 * 1e3))
-        print("%s1/%d frame, seg %d: %s" % (os.environ.get("TAG", ""), share, seg, "  ".join(row)), flush=True)
+        print("%sLUT %s, 1/%d frame, seg %d: %s" % (os.environ.get("TAG", ""), LUT if share > 1 or LUT == "none" else "whole", share, seg, "  ".join(row)), flush=True)
