@@ -50,7 +50,7 @@ import numpy as np
 # onto GPU_MAX_HW_QUEUES (default 4) queues, in first-use order; with torch's default stream, the library's two internal streams
 # and the two frame streams, four are not enough to keep the frame streams apart (measured: no overlap at 4, overlap at 8).  Must
 # be set before the HIP runtime initialises, i.e. before torch / libcloudsky are imported.
-os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")   # (8 until round 4: a rank share keeps up to eight frames in flight now)
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
@@ -398,8 +398,8 @@ def main():
     # frame's workgroups fill that tail (the library keeps per-frame state in four-deep rings ordered by events).  Measured on one
     # GPU: whole frame 2.19 -> 1.90 ms; one rank's 1/2, 1/4, 1/8 share 1.09 -> 0.96, 0.67 -> 0.52, 0.43 -> 0.34 ms per frame
     # (tools/share_matrix.py).  Buffer set b = frame number mod frames in flight: band buffer, stream, gather target.
-    # The rings are four deep; more than two frames in flight only pay for small rank shares (a 1/8 share of C3: 0.32 -> 0.28 ms per
-    # frame as whole rays), so the default is 4 for 3072..6143 tiles per rank at N > 1 and 2 everywhere else.
+    # The rings are eight deep; more than two frames in flight only pay for small rank shares (a 1/8 share of C3: 0.31 -> 0.25 -> 0.22 ms per
+    # frame as whole rays with 2 -> 4 -> 8), so the default is 8 for 3072..12287 tiles per rank at N > 1 and 2 everywhere else.
     # Frame groups (--groups G, throughput workloads such as C5's 64-frame sweep): the ranks are split into G groups of world / G; consecutive
     # frames go to the groups in turn and the ranks of a group split THEIR frame's bands (world / G)-way.  A rank's share is G times larger
     # (fewer, fuller launches), every frame is still gathered on rank 0: group g's collective runs on a communicator of {0} + its ranks, to
@@ -411,8 +411,10 @@ def main():
     per = fg.per
     bands = fg.bands(H)
     tiles_per_rank = ((W + 7) // 8) * bands[3]
-    fif_default = 4 if (per > 1 and 3072 <= tiles_per_rank < 6144) else 2    # measured per frame, x2 / x4: 1/4 share 0.485 / 0.512, 1/8 share 0.316 / 0.283, 1/16 share 0.191 / 0.250
-    fif = max(1, min(4, args.frames_in_flight if args.frames_in_flight is not None else fif_default))
+    # measured per frame (round 4, rings eight deep, 16 hardware queues; profiles/r04/frames_in_flight_depth.txt), x2 / x4 / x8:
+    # 1/2 share 0.82 / 0.82 / 0.82, 1/4 share 0.487 / 0.446 / 0.415, 1/8 share 0.31 / 0.247 / 0.224 (round 3, x2 / x4: 1/16 share 0.191 / 0.250)
+    fif_default = 8 if (per > 1 and 3072 <= tiles_per_rank < 12288) else 2
+    fif = max(1, min(8, args.frames_in_flight if args.frames_in_flight is not None else fif_default))
     if os.environ.get("CSKY_BENCH_SYNC_GATHER") == "1":
         fif = 1                                      # debugging aid: gather-then-render, one frame at a time
     ctx.set_frames_in_flight(fif)

@@ -524,7 +524,7 @@ class MultiContext:
         self._chk(self._L.csky_multi_set_march(self._h, primary_steps, light_steps))
 
     def set_frames_in_flight(self, frames):
-        """2..4: consecutive render_clouds_device calls rotate that many consumer streams (per frame group); every device does too."""
+        """2..8: consecutive render_clouds_device calls rotate that many consumer streams (per frame group); every device does too."""
         self._chk(self._L.csky_multi_set_frames_in_flight(self._h, int(frames)))
 
     def set_groups(self, groups):

@@ -31,14 +31,14 @@ using namespace csky;
 __attribute__((constructor)) static void csky_runtime_defaults() {
     const char* no = getenv("CSKY_NO_ENV");
     if (no && no[0] && no[0] != '0') return;
-    if (!getenv("GPU_MAX_HW_QUEUES")) setenv("GPU_MAX_HW_QUEUES", "8", /*overwrite=*/0);
+    if (!getenv("GPU_MAX_HW_QUEUES")) setenv("GPU_MAX_HW_QUEUES", "16", /*overwrite=*/0);
 }
 
 static_assert(sizeof(csky_cloud_params) == sizeof(CloudParams), "ABI struct mismatch");
 
 // Depth of the per-frame rings (frame constants, launch order, cost feedback, pop counters, events): the number of frames a caller may keep
 // in flight on as many streams (csky_set_frames_in_flight).  The slots rotate over all RING entries whatever that number is.
-constexpr int RING = 4;
+constexpr int RING = 8;
 constexpr int HOST_RING = 8;   // pinned host frames of the asynchronous host form (a single context uses up to RING of them, csky_multi up to groups x frames in flight)
 
 struct csky_ctx {
@@ -254,9 +254,12 @@ int clouds_dev(csky_ctx* c, const csky_cloud_params* p, int tile_w, const csky_b
         //   seg 1: 0.96 (s5) 0.52 (s7) 0.42 0.35    seg 2: 1.18 0.61 0.34 (s7) 0.29    seg 4: 1.27 0.75 0.39 0.22 (s7)
         // With three or four frames in flight (the rings are four deep) a 1/8 share is best marched as whole rays:
         //   1/8 frame, cost feedback, x2 / x3 / x4:  seg 1 0.330 0.284 0.279   seg 2 0.313 0.352 0.355   (1/4 frame and larger: no gain over x2)
+        // Round 4, rings eight deep (16 hardware queues): a 1/8 share x4 / x6 / x8: 0.247 / 0.228 / 0.224 ms (whole rays, static order; cost
+        // feedback 0.242 / 0.226 / 0.222 once every ring slot has its previous launch's costs: not in a short run), a 1/4 share x2 / x4 / x8:
+        // 0.487 / 0.446 / 0.415 static, 0.444 / 0.436 / 0.428 feedback; 1/2 and whole frames gain nothing beyond x2 (profiles/r04/frames_in_flight_depth.txt).
         const int whole_from = c->frames_in_flight >= 3 ? 3072 : 6144;
         if (queued && seg == 0) seg = waves >= whole_from ? 1 : (waves >= 3072 ? 2 : (waves >= 768 ? 4 : 5));
-        auto_mode = waves >= 12288 ? 5 : (waves >= 768 ? 7 : 2);
+        auto_mode = (waves >= 12288 || (c->frames_in_flight >= 6 && waves >= 3072)) ? 5 : (waves >= 768 ? 7 : 2);
     } else if (c->variant == 3) {
         if (queued && seg == 0) seg = waves >= 12288 ? 1 : (waves >= 6144 ? 2 : (waves >= 768 ? 4 : 5));
         auto_mode = waves >= 24576 ? 5 : (waves >= 1536 ? 7 : 2);
@@ -626,7 +629,7 @@ int csky_set_schedule(csky_ctx* c, int mode) {
 }
 int csky_set_frames_in_flight(csky_ctx* c, int frames) {
     if (!c) return fail(nullptr, CSKY_ERR_INVALID, "csky_set_frames_in_flight: ctx is NULL");
-    if (frames < 1 || frames > RING) return fail(c, CSKY_ERR_INVALID, "csky_set_frames_in_flight: 1 .. 4 (the rings are four deep)");
+    if (frames < 1 || frames > RING) return fail(c, CSKY_ERR_INVALID, "csky_set_frames_in_flight: 1 .. 8 (the rings are eight deep)");
     c->frames_in_flight = frames;
     c->warn[0] = 0;
     if (frames >= 2) {   // CSKY_OK, but never silent: without enough hardware queues the frames' streams share one and do not overlap (csky_last_warning)
@@ -634,7 +637,7 @@ int csky_set_frames_in_flight(csky_ctx* c, int frames) {
         const int qn = q ? atoi(q) : 4;                         // the HIP runtime's default
         if (qn < frames + 1)                                   // the frames' streams + the prologue stream
             snprintf(c->warn, sizeof c->warn, "csky_set_frames_in_flight: GPU_MAX_HW_QUEUES is %s: %d streams of consecutive frames plus the prologue stream may share a hardware "
-                     "queue and not overlap; set it (8 is what libcloudsky sets at load time unless CSKY_NO_ENV=1) before the process's first HIP call", q ? q : "unset (4)", frames);
+                     "queue and not overlap; set it (16 is what libcloudsky sets at load time unless CSKY_NO_ENV=1) before the process's first HIP call", q ? q : "unset (4)", frames);
     }
     return CSKY_OK;
 }
@@ -767,7 +770,7 @@ int host_slot_prepare(csky_ctx* c, csky_ctx::HostSlot& hs, size_t px, bool need_
 
 int csky_set_host_ring(csky_ctx* c, int slots) {
     if (!c) return fail(nullptr, CSKY_ERR_INVALID, "csky_set_host_ring: ctx is NULL");
-    if (slots < 1 || slots > RING) return fail(c, CSKY_ERR_INVALID, "csky_set_host_ring: 1 .. 4 frames");
+    if (slots < 1 || slots > RING) return fail(c, CSKY_ERR_INVALID, "csky_set_host_ring: 1 .. 8 frames");
     for (auto& hs : c->hring) if (hs.busy) return fail(c, CSKY_ERR_STATE, "csky_set_host_ring: collect the outstanding tickets first");
     c->hslots = slots;
     return csky_set_frames_in_flight(c, slots >= 2 ? 2 : 1);    // launch policy: two frames in flight is the best choice for whole frames (csky_set_frames_in_flight)
@@ -1198,7 +1201,7 @@ int csky_multi_set_march(csky_multi* m, int primary_steps, int light_steps) {
 }
 int csky_multi_set_frames_in_flight(csky_multi* m, int frames) {
     if (!m) return mfail(nullptr, CSKY_ERR_INVALID, "csky_multi_set_frames_in_flight: handle is NULL");
-    if (frames < 1 || frames > RING) return mfail(m, CSKY_ERR_INVALID, "csky_multi_set_frames_in_flight: 1 .. 4 per frame group (the per-device rings are four deep)");
+    if (frames < 1 || frames > RING) return mfail(m, CSKY_ERR_INVALID, "csky_multi_set_frames_in_flight: 1 .. 8 per frame group (the per-device rings are eight deep)");
     if (frames * m->groups > MULTI_SLOTS) return mfail(m, CSKY_ERR_INVALID, "csky_multi_set_frames_in_flight: frames x groups must be <= %d", MULTI_SLOTS);
     for (size_t i = 0; i < m->ctx.size(); i++) { const int rc = csky_set_frames_in_flight(m->ctx[i], frames); if (rc) return mpass(m, (int)i, rc); }
     m->fif = frames;
@@ -1315,7 +1318,7 @@ int csky_multi_render_clouds(csky_multi* m, const csky_cloud_params* p, int tile
 // asynchronous host form over the multi-device handle: the first context's pinned ring and streams serve as consumer streams
 int csky_multi_set_host_ring(csky_multi* m, int slots) {
     if (!m) return mfail(nullptr, CSKY_ERR_INVALID, "csky_multi_set_host_ring: handle is NULL");
-    if (slots < 1 || slots > HOST_RING || slots > m->groups * RING || slots % m->groups) return mfail(m, CSKY_ERR_INVALID, "csky_multi_set_host_ring: 1 .. 8 frames, a multiple of the group count, at most 4 per group");
+    if (slots < 1 || slots > HOST_RING || slots > m->groups * RING || slots % m->groups) return mfail(m, CSKY_ERR_INVALID, "csky_multi_set_host_ring: 1 .. 8 frames, a multiple of the group count, at most 8 per group");
     csky_ctx* c0 = m->ctx[0];
     for (auto& hs : c0->hring) if (hs.busy) return mfail(m, CSKY_ERR_STATE, "csky_multi_set_host_ring: collect the outstanding tickets first");
     const int rc = csky_multi_set_frames_in_flight(m, slots / m->groups); if (rc) return rc;

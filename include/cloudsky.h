@@ -12,8 +12,9 @@
  * every RenderingDevice call onto the single render thread: cloud_sky.gd:118,154).  There is NO CPU
  * fallback: without a usable HIP device csky_create fails with CSKY_ERR_NO_DEVICE.
  *
- * Process environment: when libcloudsky.so is LOADED it sets GPU_MAX_HW_QUEUES=8 for the process unless the variable is already set (the HIP
- * runtime reads it at its first call; with the default of 4 the streams of two frames in flight share hardware queues and do not overlap).
+ * Process environment: when libcloudsky.so is LOADED it sets GPU_MAX_HW_QUEUES=16 for the process unless the variable is already set (the HIP
+ * runtime reads it at its first call; with the default of 4 the streams of two frames in flight share hardware queues and do not overlap; a rank share with eight frames
+ * in flight needs more than 8: 0.30 ms per frame with 8 queues, 0.23 with 16).
  * CSKY_NO_ENV=1 in the environment disables that; csky_set_frames_in_flight(>= 2) then leaves a warning in csky_last_warning when the
  * variable is not in effect.  Other variables read (all optional, A/B switches): CSKY_PERSISTENT, CSKY_PERSISTENT_WGS, CSKY_MULTI_STAGED.
  *
@@ -141,7 +142,7 @@ int csky_render_clouds(csky_ctx* ctx, const csky_cloud_params* p, int tile_w, in
  * The LUT inputs of later calls are
  * always the context's internal copies, so the chain transmittance -> sky -> clouds needs no host hop.
  * The sky LUT and the per-frame constants derived from it are rendered on an internal "prologue" stream into rings (the
- * LUT two deep: all its readers run on that stream; the per-frame constants four deep; like the reference's texture rings, sky_lut.gd:143-146): when frames are enqueued back to back, the prologue of
+ * LUT two deep: all its readers run on that stream; the per-frame constants eight deep; like the reference's texture rings, sky_lut.gd:143-146): when frames are enqueued back to back, the prologue of
  * frame k+1 overlaps the march of frame k.  The library orders prologue -> march -> reuse of a ring slot with events, so a
  * caller only has to order its own reads of d_out behind `hip_stream`; csky_render_sky_lut_device ignores `hip_stream`. */
 int csky_render_sky_lut_device(csky_ctx* ctx, const csky_sky_params* p, void* hip_stream);
@@ -266,11 +267,12 @@ int csky_set_schedule(csky_ctx* ctx, int mode);
  * step ranges for one GPU's share of a split frame, 4 interleaved step sets for tile-sized launches such as the
  * reference's 96x96 temporal tiles), 1, 2, 4 (step ranges) or 5 (4 interleaved). */
 int csky_set_segments(csky_ctx* ctx, int segments);
-/* Policy hint for the automatic segment / schedule choice: n = 2..4: the caller keeps n frames in flight by rotating n streams
- * between consecutive csky_render_*_device calls (always safe: per-frame state lives in four-deep rings ordered by events); the
- * next frame then fills the tail of this one and fewer, longer wavefronts are the better choice for partial frames.  Default 1;
- * 2 is the best choice for whole frames down to quarter frames, 3-4 only pay for one GPU's 1/8 share (0.32 -> 0.28 ms per frame).
- * The two streams must map to different hardware queues: the library sets GPU_MAX_HW_QUEUES=8 at load time unless the host already set it
+/* Policy hint for the automatic segment / schedule choice: n = 2..8: the caller keeps n frames in flight by rotating n streams
+ * between consecutive csky_render_*_device calls (always safe: per-frame state lives in eight-deep rings ordered by events); the
+ * next frames then fill the tail of this one and fewer, longer wavefronts are the better choice for partial frames.  Default 1;
+ * 2 is the best choice for whole and half frames; more only pays for one GPU's share of a split frame (1/4 share 0.49 -> 0.45 -> 0.42 ms,
+ * 1/8 share 0.31 -> 0.25 -> 0.22 ms per frame with 2 -> 4 -> 8; profiles/r04/frames_in_flight_depth.txt).
+ * The streams must map to different hardware queues: the library sets GPU_MAX_HW_QUEUES=16 at load time unless the host already set it
  * (the HIP runtime's default of 4 loses part of the overlap); that works when the library is loaded before the process's first HIP call.
  * With 2, whole-ray launches of 12 Ki - 64 Ki wavefronts (a 2048x1024 frame, half of it) run in the persistent form: one workgroup per
  * resident slot, wavefronts pop tiles from per-XCD sequences of the schedule and steal from the other XCDs at the end (kernels.hip,
@@ -297,9 +299,9 @@ csky_ctx* csky_multi_ctx(csky_multi* m, int i);
 const char* csky_multi_last_error(const csky_multi* m);
 int csky_multi_set_noise(csky_multi* m, const uint8_t* large_rgba8, const uint8_t* small_rgb8, const uint8_t* weather_rgb8);
 int csky_multi_set_noise_mips(csky_multi* m, const uint8_t* large_chain_rgba8, const uint8_t* small_chain_rgb8, const uint8_t* weather_rgb8);
-/* n = 2..4: the caller keeps n frames in flight (per frame group) by rotating n consumer streams between consecutive
+/* n = 2..8: the caller keeps n frames in flight (per frame group) by rotating n consumer streams between consecutive
  * csky_multi_render_clouds_device calls: every device then rotates n streams / event sets as well (csky_set_frames_in_flight on every
- * context; the per-device rings are four deep).  Default 1.  frames x groups <= 8. */
+ * context; the per-device rings are eight deep).  Default 1.  frames x groups <= 8. */
 int csky_multi_set_frames_in_flight(csky_multi* m, int frames);
 /* Frame groups, for THROUGHPUT workloads (a sequence of independent frames: BASELINE config 5's 64-frame sun sweep): the n devices are
  * split into `groups` groups of n/groups devices; consecutive csky_multi_render_clouds_device calls go to the groups in turn and the

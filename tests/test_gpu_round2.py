@@ -142,7 +142,7 @@ def test_multi_device_handle_matches_single_context(pkg, noise, gpu_ctx, oracle)
                 assert (bufs[1].cpu().numpy().view(np.uint16) == ref).all(), ids
                 m.set_frames_in_flight(1)
                 with pytest.raises(pkg.CloudSkyError):
-                    m.set_frames_in_flight(5)            # the per-device rings are four deep
+                    m.set_frames_in_flight(9)            # the per-device rings are eight deep
             with pytest.raises(pkg.CloudSkyError):
                 m.render_clouds(p, W, 12)            # bands are 8 rows
         finally:
@@ -355,7 +355,8 @@ def test_four_frames_in_flight_rotate_the_four_deep_rings(pkg, noise, gpu_ctx, o
         refs.append(o.cpu().numpy().view(np.uint16).copy())
     assert all(r.any() for r in refs) and (refs[0] != refs[1]).any()
     try:
-        for fif in (3, 4):
+        lut_rows = torch.zeros(13 * 200 * 8, dtype=torch.uint8, device="cuda")
+        for fif in (3, 4, 8):                                                 # (8: round 4, rings eight deep; that run sends the sky LUT out as rows)
             gpu_ctx.set_frames_in_flight(fif)
             streams = [torch.cuda.Stream() for _ in range(fif)]
             outs = [torch.zeros((rows, W, 4), dtype=torch.int16, device="cuda") for _ in range(fif)]
@@ -367,13 +368,16 @@ def test_four_frames_in_flight_rotate_the_four_deep_rings(pkg, noise, gpu_ctx, o
                     streams[i].synchronize()
                     assert (outs[i].cpu().numpy().view(np.uint16) == refs[which[i]]).all(), (share, fif, k)
                 sun = suns[k % len(suns)]
-                gpu_ctx.render_sky_lut_device(norm(sun), 200, 100, streams[i].cuda_stream)
+                if fif == 8:
+                    gpu_ctx.render_sky_lut_rows_device(norm(sun), 3, 8, lut_rows.data_ptr(), lut_rows.numel(), 200, 100, streams[i].cuda_stream)
+                else:
+                    gpu_ctx.render_sky_lut_device(norm(sun), 200, 100, streams[i].cuda_stream)
                 gpu_ctx.render_clouds_device(oracle.default_params(W, H, sun), W, bands, outs[i].data_ptr(), W * 8, streams[i].cuda_stream)
                 which[i] = k % len(suns)
             torch.cuda.synchronize()
             for i in range(fif):
                 assert (outs[i].cpu().numpy().view(np.uint16) == refs[which[i]]).all(), (share, fif, "drain", i)
         with pytest.raises(pkg.CloudSkyError):
-            gpu_ctx.set_frames_in_flight(5)
+            gpu_ctx.set_frames_in_flight(9)
     finally:
         gpu_ctx.set_frames_in_flight(1); gpu_ctx.set_segments(0)

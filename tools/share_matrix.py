@@ -3,7 +3,7 @@
 LUT=rows (default for shares < 1: the rank's rows of the sky LUT, as bench.py does at N > 1) | whole (every rank the whole LUT, rounds 1-3) |
 none (no per-frame LUT at all: what the LUT costs a share)."""
 import os, sys, time
-os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
