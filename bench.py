@@ -10,11 +10,13 @@ default clouds_sky.tres parameters, sun = (1,1,0)/sqrt(2), wind frozen (SURVEY Â
 
 N > 1: one process per GPU (torch.distributed, backend nccl = RCCL); the frame's 8-row bands are interleaved over
 the ranks with no collective during the march and ONE gather to rank 0 per frame ("scaling": "strong": the frame
-is fixed, each rank renders 1/N of it).
+is fixed, each rank renders 1/N of it).  The 200x100 sky LUT is split the same way (rank r renders rows r, r+N, ... into the
+tail of its band buffer; rank 0 interleaves both out of the one gather): N identical LUTs would cost every rank 33 us of a
+whole chip per frame.
 
-Consecutive frames are independent, so by default every rank keeps two frames in flight (alternating streams): the tail of
-frame k's launch overlaps the head of frame k+1's and, at N > 1, frame k's gather (`--frames-in-flight 1` = strictly one frame
-at a time).  `value` is the pipelined whole-job rate; the same K frames strictly one at a time are timed right after it and
+Consecutive frames are independent, so by default every rank keeps two frames in flight (alternating streams; EIGHT for a
+rank share of a quarter frame or less, whose launches do not fill the chip): the tail of frame k's launch overlaps the head of
+the following ones and, at N > 1, frame k's gather (`--frames-in-flight 1` = strictly one frame at a time).  `value` is the pipelined whole-job rate; the same K frames strictly one at a time are timed right after it and
 reported next to it (`value_one_frame_at_a_time`): quote both.
 
 `roofline`: the path is not HBM-bound (82 MB of baked inputs live in L2 / Infinity Cache) and has no contraction, so neither "hbm" nor "mfma"
@@ -179,8 +181,8 @@ def main_single_process(args):
         c.render_transmittance(256, 64)
     per = n // G
     tiles_per_dev = ((W + 7) // 8) * ((H // 8 + per - 1) // per)
-    fif_default = 4 if (per > 1 and 3072 <= tiles_per_dev < 6144) else 2
-    fif = max(1, min(4, args.frames_in_flight if args.frames_in_flight is not None else fif_default))
+    fif_default = max(2, 8 // G) if (per > 1 and 3072 <= tiles_per_dev < 12288) else 2    # (frames in flight x groups <= 8 behind one handle)
+    fif = max(1, min(8 // G, args.frames_in_flight if args.frames_in_flight is not None else fif_default))
     m.set_groups(G)
     m.set_frames_in_flight(fif)
     if args.staged:
@@ -330,8 +332,8 @@ def main():
     ap.add_argument("--no-pmc", action="store_true", help="skip the live rocprofv3 counter passes (roofline fractions become null)")
     ap.add_argument("--no-host-form", action="store_true", help="skip the value_host_form leg (frames delivered to pinned host memory): for profiling the timed region alone")
     ap.add_argument("--frames-in-flight", type=int, default=None,
-                    help="consecutive frames rotate over this many streams per rank, 1..4 (default 2: the tail of frame k overlaps the head of "
-                         "frame k+1 and, at N > 1, its gather; 4 for rank shares of 3072..6143 tiles; 1 = strictly one frame at a time)")
+                    help="consecutive frames rotate over this many streams per rank, 1..8 (default 2: the tail of frame k overlaps the head of "
+                         "frame k+1 and, at N > 1, its gather; 8 for rank shares of 3072..12287 tiles; 1 = strictly one frame at a time)")
     ap.add_argument("--single-process", action="store_true",
                     help="N > 1 behind the C ABI: ONE process, one host thread, csky_multi_* over the N devices (every device stores its bands straight "
                          "into the frame on device 0 over xGMI; no torch.distributed, no RCCL): the form a GDExtension host can use")
