@@ -18,7 +18,7 @@ echo "== single-process form, 8 contexts on this one GPU (CSKY_BENCH_ONE_GPU_DEB
 CSKY_BENCH_ONE_GPU_DEBUG=1 timeout -s KILL 300 python bench.py --gpus 8 --single-process --steps 40 2>&1 | tail -2
 echo "== variants"; timeout -s KILL 120 python tools/prof_kernel.py --time --frames 20 2>/dev/null
 } > $O/secondary_numbers.log
-NS=1,2,4 timeout -s KILL 400 python tools/share_matrix.py 1 2 4 8 2>/dev/null > $O/share_matrix.txt
+NS=1,2,4,8 timeout -s KILL 500 python tools/share_matrix.py 1 2 4 8 2>/dev/null > $O/share_matrix.txt
 python tools/isa_profile.py run --config C3 --out $O/census_counts_C3.json 2>&1 | tail -3 > $O/census_run.log
 python tools/isa_profile.py report $O/census_counts_C3.json --out $O/census_report_C3.json > $O/census_report_C3.txt 2>&1
 timeout -s KILL 300 python tools/parity_stats.py 2>&1 | grep '^{' > $O/parity_stats.txt
