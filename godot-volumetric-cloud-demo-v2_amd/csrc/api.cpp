@@ -186,10 +186,17 @@ int ensure_order(csky_ctx* c, int slot, int mode, int tile_w, int tiles_x, int s
     const long long key[4] = {tile_w, slabs, mode, grid};
     if (c->d_order_ring[slot] && memcmp(key, c->order_key_ring[slot], sizeof key) == 0) return CSKY_OK;
     if (c->order_cap[slot] < (size_t)grid) {
-        HIPCHK(c, hipDeviceSynchronize());                   // growing the table is rare; an older launch may still read the old one
-        if (c->d_order_ring[slot]) { (void)hipFree(c->d_order_ring[slot]); c->d_order_ring[slot] = nullptr; c->order_cap[slot] = 0; }
-        HIPCHK(c, hipMalloc(reinterpret_cast<void**>(&c->d_order_ring[slot]), (size_t)grid * sizeof(uint32_t)));
-        c->order_cap[slot] = (size_t)grid;
+        // growing is rare and costs a device-wide wait (an older launch may still read the old table): grow EVERY slot's table now, so that it
+        // happens once, at the first frame of a geometry, and not again at the first use of each of the other ring slots (with rings eight deep
+        // and a five-frame warm-up that was three synchronisations inside a timed region)
+        HIPCHK(c, hipDeviceSynchronize());
+        for (int k = 0; k < RING; k++) {
+            if (c->order_cap[k] >= (size_t)grid) continue;
+            if (c->d_order_ring[k]) { (void)hipFree(c->d_order_ring[k]); c->d_order_ring[k] = nullptr; c->order_cap[k] = 0; }
+            HIPCHK(c, hipMalloc(reinterpret_cast<void**>(&c->d_order_ring[k]), (size_t)grid * sizeof(uint32_t)));
+            c->order_cap[k] = (size_t)grid;
+            for (long long& v : c->order_key_ring[k]) v = -1;
+        }
     }
     // the last reader of this slot's table is the march of two frames ago; the caller has already ordered `s` behind it (ev_clouds -> pro ->
     // ev_setup -> s), exactly like the frame constants of the slot

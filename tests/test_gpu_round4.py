@@ -89,7 +89,7 @@ def test_multi_groups_render_the_sky_lut_on_every_device(pkg, noise, oracle, ora
         p = oracle.default_params(W, H, sun)
         out = torch.zeros((H, W, 4), dtype=torch.int16, device="cuda")
         for k in range(4):                                                  # frames alternate between the two groups
-            out.zero_()
+            out.zero_(); torch.cuda.synchronize()                            # (torch's stream and the handle's own are not ordered against each other)
             m.render_clouds_device(p, W, H, out.data_ptr(), W * 8)
             m.sync(); torch.cuda.synchronize()
             ok, info = cloud_tight(out.cpu().numpy().view(np.float16), ref)
@@ -102,6 +102,7 @@ def _lut_rows(ctx, torch, sun, r, n, w=200, h=100):
     """rank r of n: its rows of the LUT, compact, as [rows, w, 4] uint16"""
     rows = len(range(r, h, n))
     buf = torch.zeros(max(1, rows) * w * 8, dtype=torch.uint8, device="cuda")
+    torch.cuda.synchronize()                       # (the fill runs on torch's stream, the render on `st`: nothing else orders them)
     st = torch.cuda.Stream()
     ctx.render_sky_lut_rows_device(sun, r, n, buf.data_ptr(), buf.numel(), w, h, st.cuda_stream)
     st.synchronize()
@@ -136,6 +137,7 @@ def test_frames_marched_on_a_rows_only_lut_are_byte_identical(gpu_ctx, oracle, s
     st = torch.cuda.Stream()
     other = norm((-0.2, 0.15, 0.9))                # both slots of the context's LUT ring hold ANOTHER sun's texels when the rows-only frame is marched
     rows = torch.zeros(13 * 200 * 8, dtype=torch.uint8, device="cuda")
+    torch.cuda.synchronize()                       # the fills above run on torch's stream, the renders on `st`
     gpu_ctx.render_sky_lut_device(sun, 200, 100, st.cuda_stream)
     gpu_ctx.render_clouds_device(params, W, bands, out[0].data_ptr(), W * 8, st.cuda_stream)
     gpu_ctx.render_sky_lut_device(other, 200, 100, st.cuda_stream)
@@ -151,6 +153,7 @@ def test_a_rows_only_lut_cannot_be_read_as_a_whole_one(gpu_ctx, pkg):
     import torch
     sun = norm(SUNS["deg45"])
     buf = torch.zeros(200 * 100 * 8, dtype=torch.uint8, device="cuda")
+    torch.cuda.synchronize()
     gpu_ctx.render_sky_lut_rows_device(sun, 1, 4, buf.data_ptr(), buf.numel(), 200, 100, None)
     with pytest.raises(pkg.CloudSkyError) as e:
         gpu_ctx.read_sky_lut()

@@ -1,7 +1,7 @@
 #!/bin/bash
 # Round-4 validation + evidence run (GPU box).  usage: bash tools/gpu_full_r04.sh   -> everything lands under gpurun_out/r04final/
 R=$PWD; O=$R/gpurun_out/r04final; mkdir -p $O
-timeout -s KILL 900 python -m pytest tests -m gpu -q 2>&1 | tail -6 | tee $O/pytest_gpu.log
+timeout -s KILL 900 python -m pytest tests -m gpu -q > $O/pytest_gpu_full.log 2>&1; tail -6 $O/pytest_gpu_full.log | tee $O/pytest_gpu.log
 timeout -s KILL 200 python __graft_entry__.py smoke 2>&1 | tail -1 | tee $O/smoke.log
 timeout -s KILL 400 python bench.py > $O/bench_C3_n1.json 2> $O/bench_C3_n1.err
 cp gpurun_out/bench_pmc_C3.json $O/clouds_C3_pmc_live_from_bench.json 2>/dev/null
