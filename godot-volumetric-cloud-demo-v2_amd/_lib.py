@@ -52,6 +52,7 @@ SYMBOLS = [
     ("csky_set_noise", C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     ("csky_set_noise_mips", C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     ("csky_noise_inexact_coeffs", C.c_int, [C.c_void_p, C.POINTER(C.c_uint64)]),
+    ("csky_encode_bc7", C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]),
     ("csky_set_march", C.c_int, [C.c_void_p, C.c_int, C.c_int]),
     ("csky_set_early_out", C.c_int, [C.c_void_p, C.c_float]),
     ("csky_render_transmittance", C.c_int, [C.c_void_p, C.POINTER(TransParams), C.c_void_p]),
@@ -221,6 +222,18 @@ class Context:
         if a.size != self._L.csky_mip_offset(128, 8, 4) or b.size != self._L.csky_mip_offset(32, 6, 3) or c.size != 512 * 512 * 3:
             raise ValueError("set_noise_mips: expected the 8-level 128^3 RGBA8 chain, the 6-level 32^3 RGB8 chain, 512^2 RGB8")
         self._chk(self._L.csky_set_noise_mips(self._h, _ptr(a), _ptr(b), _ptr(c)))
+
+    def encode_bc7(self, images):
+        """csky_encode_bc7: [n, h, w, 4] (or [h, w, 4]) uint8 -> [n, ceil(h/4), ceil(w/4), 16] uint8 BC7 blocks, encoded on the GPU."""
+        a = np.ascontiguousarray(images, np.uint8)
+        if a.ndim == 3:
+            a = a[None]
+        if a.ndim != 4 or a.shape[3] != 4:
+            raise ValueError("encode_bc7: expected [n, h, w, 4] uint8")
+        n, h, w = a.shape[:3]
+        out = np.zeros((n, (h + 3) // 4, (w + 3) // 4, 16), np.uint8)
+        self._chk(self._L.csky_encode_bc7(self._h, _ptr(a), w, h, n, _ptr(out)))
+        return out
 
     def noise_inexact_coeffs(self):
         """Finite-difference coefficients of the bound textures that fp16 could not hold exactly (0 for natural noise)."""

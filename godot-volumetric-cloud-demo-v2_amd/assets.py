@@ -131,6 +131,41 @@ def chains_from_godot_import(large_ctex3d, small_ctex3d, weather_ctex):
     return (np.concatenate([l.reshape(-1) for l in large]), np.concatenate([l[..., :3].reshape(-1) for l in small]), np.ascontiguousarray(weather[..., :3]))
 
 
+def vram_compressed_chains(ctx, large, small, weather):
+    """What compress/mode=2 of the three *.import files does to the inputs, with THIS library's encoder in the importer's place (it is not the
+    engine's: see csky_encode_bc7): the box-filtered mip chains of the two volumes (mipmaps/generate=true) and the weather map, every level
+    BC7-encoded slice by slice on the GPU of `ctx` and decoded again -> (large chain RGBA8, small chain RGB8, weather RGB8) for
+    Context.set_noise_mips, plus the per-texture PSNR of the round trip."""
+    def psnr(a, b):
+        d = a.astype(np.float64) - b.astype(np.float64)
+        m = float((d * d).mean())
+        return float("inf") if m == 0 else 10.0 * np.log10(255.0 * 255.0 / m)
+
+    def roundtrip(img4):                                        # [n, h, w, 4]
+        n, h, w = img4.shape[:3]
+        blocks = ctx.encode_bc7(img4)
+        return np.stack([decode_bc7(blocks[i], w, h) for i in range(n)])
+
+    def volume_chain(level0, levels, ch):
+        n = level0.shape[0]
+        chain = build_mips(level0, levels)
+        out, o = [], 0
+        for l in range(levels):
+            m = n >> l
+            lv = chain[o:o + m * m * m * ch].reshape(m, m, m, ch); o += m * m * m * ch
+            rgba = np.concatenate([lv, np.full((m, m, m, 1), 255, np.uint8)], -1) if ch == 3 else lv
+            out.append((lv, roundtrip(rgba)[..., :ch]))
+        return out
+
+    big = volume_chain(np.ascontiguousarray(large, np.uint8), 8, 4)
+    sml = volume_chain(np.ascontiguousarray(small, np.uint8), 6, 3)
+    w0 = np.ascontiguousarray(weather, np.uint8)
+    w4 = np.concatenate([w0, np.full(w0.shape[:2] + (1,), 255, np.uint8)], -1)
+    wq = roundtrip(w4[None])[0][..., :3]
+    stats = {"large_psnr_level0": psnr(*big[0]), "small_psnr_level0": psnr(*sml[0]), "weather_psnr": psnr(w0, wq)}
+    return (np.concatenate([q.reshape(-1) for _, q in big]), np.concatenate([q.reshape(-1) for _, q in sml]), np.ascontiguousarray(wq)), stats
+
+
 _CACHE = {}
 
 

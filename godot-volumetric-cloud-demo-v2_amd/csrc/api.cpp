@@ -603,6 +603,25 @@ int csky_generate_detail_noise_device(csky_ctx* c, uint32_t seed, int n, uint8_t
     return CSKY_OK;
 }
 
+int csky_encode_bc7(csky_ctx* c, const uint8_t* rgba8, int w, int h, int n_images, uint8_t* blocks_out) {
+    if (!c) return fail(nullptr, CSKY_ERR_INVALID, "csky_encode_bc7: ctx is NULL");
+    if (!rgba8 || !blocks_out || w < 1 || h < 1 || n_images < 1 || w > 16384 || h > 16384 || n_images > 16384) return fail(c, CSKY_ERR_INVALID, "csky_encode_bc7: NULL argument or size out of range");
+    int rc; if ((rc = bind(c))) return rc;
+    const size_t in_bytes = (size_t)w * h * 4 * (size_t)n_images, out_bytes = (size_t)((w + 3) / 4) * ((h + 3) / 4) * 16 * (size_t)n_images;
+    const size_t in_pad = (in_bytes + 15) & ~(size_t)15;        // the blocks follow the texels, 16-byte aligned
+    uint8_t* d = nullptr;
+    HIPCHK(c, hipMalloc(reinterpret_cast<void**>(&d), in_pad + out_bytes));
+    uint8_t* d_out = d + in_pad;
+    hipError_t e = hipSuccess;
+    if (e == hipSuccess) e = hipMemcpyAsync(d, rgba8, in_bytes, hipMemcpyHostToDevice, c->stream);
+    if (e == hipSuccess) e = launch_bc7_encode(d, w, h, n_images, reinterpret_cast<uint4*>(d_out), c->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(blocks_out, d_out, out_bytes, hipMemcpyDeviceToHost, c->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+    (void)hipFree(d);
+    if (e != hipSuccess) return fail(c, CSKY_ERR_HIP, "csky_encode_bc7: %s", hipGetErrorString(e));
+    return CSKY_OK;
+}
+
 int csky_noise_inexact_coeffs(csky_ctx* c, uint64_t* n) {
     if (!c || !n) return CSKY_ERR_INVALID;
     if (!c->have_noise) return fail(c, CSKY_ERR_STATE, "csky_noise_inexact_coeffs: csky_set_noise has not been called");

@@ -10,6 +10,8 @@
 #include "../../godot-volumetric-cloud-demo-v2_amd/csrc/lut_core.h"
 #include "../../godot-volumetric-cloud-demo-v2_amd/csrc/bake.h"
 #include "../../godot-volumetric-cloud-demo-v2_amd/csrc/composite_core.h"
+#include "../../godot-volumetric-cloud-demo-v2_amd/csrc/bc7enc_core.h"
+#include "../../godot-volumetric-cloud-demo-v2_amd/csrc/bc7_tables.h"
 
 using namespace csky;
 
@@ -185,5 +187,27 @@ size_t csky_mip_offset(int n, int level, int ch) {  // same definition as assets
     size_t off = 0;
     for (int l = 0; l < level; l++) { size_t m = (size_t)(n >> l); off += m * m * m * (size_t)ch; }
     return off;
+}
+}
+
+extern "C" {
+// the BC7 encoder core on the host: n_img images of w x h RGBA8 -> blocks, exactly what bc7enc.hip's lanes run
+void hostsim_bc7_encode(const uint8_t* img, int w, int h, int n_img, uint8_t* blocks) {
+    const int bw = (w + 3) / 4, bh = (h + 3) / 4;
+    for (int im = 0; im < n_img; im++) for (int by = 0; by < bh; by++) for (int bx = 0; bx < bw; bx++) {
+        unsigned char px[16][4]; uint32_t blk[4];
+        bc7_gather_block(img + (size_t)im * w * h * 4, w, h, bx, by, px);
+        bc7_encode_block(px, blk);
+        memcpy(blocks + (((size_t)im * bh + by) * bw + bx) * 16, blk, 16);
+    }
+}
+// the encoder's compact tables against the decoder's (bc7_tables.h, derived independently by tools/derive_bc7_tables.py): number of mismatches
+int hostsim_bc7_table_mismatches() {
+    int bad = 0;
+    for (int p = 0; p < 64; p++) {
+        for (int i = 0; i < 16; i++) bad += (int)((bc7_part2_mask(p) >> i) & 1u) != (int)kBc7Partition2[p][i];
+        bad += bc7_anchor2(p) != (int)kBc7Anchor2[p];
+    }
+    return bad;
 }
 }

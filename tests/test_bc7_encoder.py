@@ -1,0 +1,109 @@
+"""The BC7 encoder (csrc/bc7enc_core.h: the per-block code of bc7enc.hip, here compiled for the host by tests/hostsim): SURVEY 8f row 4,
+"BC7 encode/decode".  The reference's inputs are imported with compress/mode=2, high_quality=true (weather.bmp.import:19-20,
+worlnoise.bmp.import:19-20, perlworlnoise.tga.import:19-20).  What can be pinned: every emitted block is a VALID BC7 block that an independent
+decoder (Pillow) and csky_decode_bc7 expand to the same texels, and those texels are close to the input.  What cannot: agreement with the
+engine's own encoder."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+
+def _enc(hostsim, img):
+    img = np.ascontiguousarray(img, np.uint8)
+    if img.ndim == 3:
+        img = img[None]
+    n, h, w = img.shape[:3]
+    out = np.zeros((n, (h + 3) // 4, (w + 3) // 4, 16), np.uint8)
+    hostsim.hostsim_bc7_encode(img.ctypes.data_as(C.c_void_p), w, h, n, out.ctypes.data_as(C.c_void_p))
+    return out
+
+
+def _psnr(a, b):
+    d = a.astype(np.float64) - b.astype(np.float64)
+    m = float((d * d).mean())
+    return 99.0 if m == 0 else 10.0 * np.log10(255.0 * 255.0 / m)
+
+
+def _modes(blocks):
+    first = blocks.reshape(-1, 16)[:, 0].astype(np.int32)
+    assert (first != 0).all()                                               # a mode bit in the first byte: never the reserved encoding
+    return np.bincount(np.log2(first & -first).astype(np.int64), minlength=8)
+
+
+def _opaque(rgb):
+    return np.concatenate([rgb, np.full(rgb.shape[:-1] + (1,), 255, np.uint8)], -1)
+
+
+def test_encoder_tables_are_the_decoders(hostsim):
+    """the encoder's compact partition masks / anchors (bc7enc_core.h) against bc7_tables.h (tools/derive_bc7_tables.py)"""
+    assert hostsim.hostsim_bc7_table_mismatches() == 0
+
+
+def test_blocks_decode_the_same_everywhere_and_close_to_the_input(pkg, hostsim, noise):
+    """weather map, shape slices (RGBA with an independent fourth channel), detail slices: Pillow's decoder and csky_decode_bc7 agree on every
+    block, the round trip stays within what BC7 can do for such data, and the modes used are the ones the block class calls for."""
+    Image = pytest.importorskip("PIL.Image")
+    large, small, weather = noise
+    cases = [("weather", _opaque(weather[128:256, 64:320])[None], 48.0, {1, 6}),
+             ("shape", large[40:42], 33.0, {5, 6}),
+             ("detail", _opaque(small[:6]), 33.0, {1, 6})]
+    for name, img, floor, allowed in cases:
+        n, h, w = img.shape[:3]
+        blocks = _enc(hostsim, img)
+        used = _modes(blocks)
+        assert set(np.nonzero(used)[0]) <= allowed, (name, used)
+        for i in range(n):
+            mine = pkg.assets.decode_bc7(blocks[i], w, h)
+            theirs = np.asarray(Image.frombytes("RGBA", (w, h), blocks[i].tobytes(), "bcn", (7,)))
+            assert (mine == theirs).all(), (name, i)
+        dec = np.stack([pkg.assets.decode_bc7(blocks[i], w, h) for i in range(n)])
+        p = _psnr(dec[..., :3], img[..., :3]) if name != "shape" else _psnr(dec, img)
+        assert p >= floor, (name, p)
+        if name != "shape":
+            assert (dec[..., 3] >= 254).all()                                # (mode 6 carries alpha with a p-bit: 254 or 255)
+
+
+def test_easy_blocks_are_near_exact(pkg, hostsim):
+    rng = np.random.default_rng(5)
+    # solid colours, any alpha: every channel within one level
+    solid = np.zeros((64, 4, 4, 4), np.uint8)
+    solid[:] = rng.integers(0, 256, size=(64, 1, 1, 4), dtype=np.uint8)
+    b = _enc(hostsim, solid)
+    for i in range(64):
+        assert np.abs(pkg.assets.decode_bc7(b[i], 4, 4).astype(int) - solid[i]).max() <= 1
+    # a smooth two-channel ramp: well inside one subset's reach
+    g = np.zeros((16, 16, 4), np.uint8)
+    g[..., 0] = np.arange(16)[None, :] * 16; g[..., 1] = np.arange(16)[:, None] * 8; g[..., 2] = 77; g[..., 3] = 255
+    d = pkg.assets.decode_bc7(_enc(hostsim, g)[0], 16, 16)
+    assert _psnr(d, g) >= 40.0 and np.abs(d.astype(int) - g).max() <= 5
+    # two regions, each with its own pair of colours (four colours, not on one line), split along a partition shape (left / right halves of a
+    # block = partition 0): only the two-subset mode can do that well, and it must find the shape
+    e = np.zeros((4, 8, 4), np.uint8)
+    for x in range(8):
+        for y in range(4):
+            left = (x % 4) < 2
+            a, b2 = ((200, 30, 40), (160, 90, 40)) if left else ((20, 180, 220), (70, 200, 150))
+            e[y, x, :3] = a if (x + y) % 2 == 0 else b2
+    e[..., 3] = 255
+    blocks = _enc(hostsim, e)
+    d = pkg.assets.decode_bc7(blocks[0], 8, 4)
+    assert np.abs(d[..., :3].astype(int) - e[..., :3]).max() <= 3 and _modes(blocks)[1] == 2, (_modes(blocks), np.abs(d.astype(int) - e).max())
+    # an alpha ramp over a flat colour: the scalar channel of mode 5 (or mode 6's fourth component) carries it
+    a = np.zeros((4, 8, 4), np.uint8)
+    a[...] = (90, 90, 200, 0); a[..., 3] = (np.arange(8) * 36)[None, :]
+    d = pkg.assets.decode_bc7(_enc(hostsim, a)[0], 8, 4)
+    assert np.abs(d.astype(int) - a).max() <= 8 and np.abs(d[..., :3].astype(int) - a[..., :3]).max() <= 2
+
+
+def test_ragged_sizes_pad_with_the_edge_texels(pkg, hostsim):
+    """a 10 x 7 image is 3 x 2 blocks; the texels outside repeat the last column / row (so they pull no end point away from the image)"""
+    yy, xx = np.mgrid[0:7, 0:10]
+    t = xx + yy                                                             # one direction in colour space: within a single subset's reach
+    img = np.stack([10 + 9 * t, 200 - 7 * t, 3 + 5 * t, np.full_like(xx, 255)], -1).astype(np.uint8)
+    b = _enc(hostsim, img)
+    assert b.shape == (1, 2, 3, 16)
+    d = pkg.assets.decode_bc7(b[0], 10, 7)
+    full = pkg.assets.decode_bc7(b[0], 12, 8)
+    assert (d == full[:7, :10]).all() and _psnr(d[..., :3], img[..., :3]) >= 38.0
+    assert np.abs(full[:7, 10:, :3].astype(int) - full[:7, 9:10, :3].astype(int)).max() <= 6 and np.abs(full[7, :10, :3].astype(int) - full[6, :10, :3].astype(int)).max() <= 6

@@ -173,3 +173,46 @@ def test_a_rows_only_lut_cannot_be_read_as_a_whole_one(gpu_ctx, pkg):
     gpu_ctx.sync()
     assert np.array_equal(buf.cpu().numpy().view(np.uint16).reshape(100, 200, 4), whole.view(np.uint16))
     gpu_ctx.render_sky_lut(sun, 200, 100)
+
+
+def test_gpu_bc7_encoder_is_the_host_twin_to_the_byte(gpu_ctx, hostsim, noise):
+    """bc7enc.hip (one block per lane) against the same per-block code compiled for the host (tests/hostsim): the fits use IEEE + - * / only,
+    everything else is integer, so the 16 bytes of every block must agree -- weather map, shape slices, the whole detail volume, a ragged size."""
+    import ctypes as C
+    large, small, weather = noise
+    def opaque(rgb):
+        return np.concatenate([rgb, np.full(rgb.shape[:-1] + (1,), 255, np.uint8)], -1)
+    rng = np.random.default_rng(2)
+    ragged = np.clip(rng.normal(128, 30, size=(3, 13, 22, 4)), 0, 255).astype(np.uint8)
+    for name, img in (("weather", opaque(weather)[None]), ("shape", large[30:38]), ("detail", opaque(small)), ("ragged", ragged)):
+        img = np.ascontiguousarray(img)
+        n, h, w = img.shape[:3]
+        want = np.zeros((n, (h + 3) // 4, (w + 3) // 4, 16), np.uint8)
+        hostsim.hostsim_bc7_encode(img.ctypes.data_as(C.c_void_p), w, h, n, want.ctypes.data_as(C.c_void_p))
+        got = gpu_ctx.encode_bc7(img)
+        assert got.shape == want.shape and (got == want).all(), (name, int((got != want).any(-1).sum()))
+
+
+def test_frame_marched_on_bc7_round_tripped_textures_vs_oracle(pkg, gpu_ctx, noise, oracle, o_trans):
+    """assets.vram_compressed_chains: the inputs as compress/mode=2 of the *.import files would leave them (with this library's encoder in the
+    importer's place), bound with csky_set_noise_mips.  The HIP path must march exactly those texels -- the oracle is fed the same chains, tight
+    gate -- and the frame must differ from the uncompressed one (that difference is what tools/bc7_sensitivity.py reports)."""
+    large, small, weather = noise
+    (lc, sc, wq), stats = pkg.assets.vram_compressed_chains(gpu_ctx, large, small, weather)
+    assert 30.0 < stats["large_psnr_level0"] < 60.0 and 30.0 < stats["small_psnr_level0"] < 60.0 and stats["weather_psnr"] > 45.0, stats
+    sun = (1, 1, 0)
+    sk_o = oracle.sky_lut(norm(sun), o_trans, 200, 100)
+    p = oracle.default_params(256, 128, sun)
+    ref, st_o = oracle.clouds(oracle.OracleTextures.from_chains(lc, sc, wq), p, sk_o, nthreads=oracle.max_threads(), return_stats=True)
+    ref_raw, _ = oracle.clouds(oracle.OracleTextures(large, small, weather), p, sk_o, nthreads=oracle.max_threads(), return_stats=True)
+    ctx = pkg.Context(0)
+    try:
+        ctx.set_noise_mips(lc, sc, wq)                     # (cells that do not fit fp16 pairs, if any, are marched as exact fp32 cells)
+        ctx.set_march(128, 6); ctx.render_transmittance(256, 64); ctx.render_sky_lut(norm(sun), 200, 100)
+        img = ctx.render_clouds(p)
+        ok, info = cloud_tight(img, ref)
+        assert ok, info
+        assert ctx.cloud_stats()["primary_samples"] == st_o["primary_samples"]
+        assert float(np.abs(ref.astype(np.float32) - ref_raw.astype(np.float32)).max()) > 1e-2      # compression is visible at this precision
+    finally:
+        ctx.close()

@@ -184,7 +184,7 @@ def cmd_build(args):
          "-input=dev.out", "-output=dev.hipfb"])
     run(["/opt/rocm/bin/hipcc"] + FLAGS + ["--cuda-host-only", "-Xclang", "-fcuda-include-gpubinary", "-Xclang", "dev.hipfb", "-c", os.path.join(CSRC, "kernels.hip"), "-o", "kernels_host.o"])
     out = os.path.join(ROOT, "godot-volumetric-cloud-demo-v2_amd", "libcloudsky_census.so")
-    subprocess.check_call(["/opt/rocm/bin/hipcc"] + FLAGS + ["-shared", "-o", out, os.path.join(work, "kernels_host.o"), "api.cpp", "assets.cpp", "godot_import.cpp"], cwd=CSRC)
+    subprocess.check_call(["/opt/rocm/bin/hipcc"] + FLAGS + ["-shared", "-o", out, os.path.join(work, "kernels_host.o"), "bc7enc.hip", "api.cpp", "assets.cpp", "godot_import.cpp"], cwd=CSRC)
     # static census of the PRODUCT assembly (block indices are shared with the instrumentation: same splitting rule)
     static = {}
     for tag, pre in KERNELS.items():
