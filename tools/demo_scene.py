@@ -56,7 +56,11 @@ def render(ctx, sun, coverage, name):
     Image.fromarray((img * 255.0 + 0.5).astype(np.uint8)).save(out)
     s = stats(img)
     s.update({"sun": [float(v) for v in sun], "cloud_coverage": coverage, "hemisphere_alpha_mean": float(cl[..., 3].astype(np.float32).mean()), "png": os.path.relpath(out, ROOT)})
+    _IMAGES[name] = (img * 255.0 + 0.5).astype(np.uint8)
     return s
+
+
+_IMAGES = {}
 
 
 def main():
@@ -72,11 +76,25 @@ def main():
            "expected_horizon_row": float(0.5 + np.tan(np.arcsin(fwd[1])) / (2.0 * np.tan(np.radians(FOV / 2)))),
            "scene_as_committed": render(ctx, SCENE_SUN, 0.2, "demo_scene_as_committed"),
            "high_sun_coverage_0.35": render(ctx, high, 0.35, "demo_scene_high_sun")}
+    # (c) render (b) again from the inputs as compress/mode=2 of the *.import files would leave them (this library's BC7 encoder in the importer's place,
+    # DESIGN.md 3): what the texture compression the reference runs with does to the picture on screen
+    large, small, weather = gvcd_amd.assets.load_default_noise()
+    (lq, sq, wq), tex = gvcd_amd.assets.vram_compressed_chains(ctx, large, small, weather)
+    ctx.set_noise_mips(lq, sq, wq)
+    res["high_sun_coverage_0.35_bc7_inputs"] = render(ctx, high, 0.35, "demo_scene_high_sun_bc7_inputs")
+    a, b = _IMAGES["demo_scene_high_sun"].astype(np.float64), _IMAGES["demo_scene_high_sun_bc7_inputs"].astype(np.float64)
+    d = np.abs(a - b)
+    res["high_sun_coverage_0.35_bc7_inputs"]["vs_uncompressed_inputs_8bit_srgb"] = {
+        "psnr_db": float(10 * np.log10(255.0 ** 2 / max(1e-12, (d ** 2).mean()))), "mean_abs_levels": float(d.mean()), "max_abs_levels": float(d.max()),
+        "pixels_off_by_more_than_2_levels": float((d.max(-1) > 2).mean()), "texture_round_trip_psnr_db": tex}
     ref = os.path.join(ROOT, "profiles", "r04", "reference_screenshot_stats.json")
     if os.path.exists(ref):
         res["reference_screenshots"] = json.load(open(ref))
     json.dump(res, open(os.path.join(ROOT, "profiles", "r04", "demo_scene_stats.json"), "w"), indent=1)
-    for k in ("scene_as_committed", "high_sun_coverage_0.35"):
+    v = res["high_sun_coverage_0.35_bc7_inputs"]["vs_uncompressed_inputs_8bit_srgb"]
+    print("BC7-compressed inputs vs uncompressed, 8-bit sRGB picture: PSNR %.1f dB, mean |d| %.2f levels, max %d, %.1f %% of the pixels off by more than 2 levels" % (
+        v["psnr_db"], v["mean_abs_levels"], v["max_abs_levels"], 100 * v["pixels_off_by_more_than_2_levels"]))
+    for k in ("scene_as_committed", "high_sun_coverage_0.35", "high_sun_coverage_0.35_bc7_inputs"):
         s = res[k]
         print("%-24s horizon row %s (camera geometry: %.3f)   glow at (%.2f, %.2f) luminance %.2f   cloud cover %.2f   -> %s" % (
             k, "%.3f" % s["horizon_row"] if s["horizon_row"] else "none", res["expected_horizon_row"], s["glow"]["x"], s["glow"]["y"], s["glow"]["mean_luminance"], s["cloud_cover"], s["png"]))
