@@ -70,6 +70,9 @@ struct csky_ctx {
     // csky_render_sky_lut_rows_device: the LUT of sun sky_sun exists only as the rows the caller's buffer received (one rank of an N-way frame
     // split); the texels this context's frame set-up filters are rendered by the set-up kernel itself (clouds_dev)
     bool sky_partial = false; float sky_sun[3] = {0, 1, 0}; int psw = 0, psh = 0;
+    // csky_multi_render_sky_lut: the whole LUT IS in this context's memory (ring slot sky_cur), written row by row by the devices of the handle;
+    // readers of the memory copy wait for those writers first.  (sky_partial stays set: the frame set-ups never read the memory copy.)
+    bool sky_in_memory = false; std::vector<hipEvent_t> lut_writers;
     FrameConsts* fc_ring[RING] = {}; int fc_cur = 0;
     hipEvent_t ev_setup[RING] = {}, ev_clouds[RING] = {}; bool clouds_pending[RING] = {};
     unsigned long long* d_stats = nullptr;
@@ -714,10 +717,10 @@ int csky_render_sky_lut_device(csky_ctx* c, const csky_sky_params* p, void* hip_
     (void)hip_stream;   // the LUT has no inputs of the caller's: it is rendered on the prologue stream and its consumers are ordered by events
     if (!c->have_trans && (rc = render_trans_dev(c, 256, 64, c->pro))) return rc;   // transmittance_lut.gd:6 default size
     if ((rc = ensure_sky(c, w, h))) return rc;
-    const int k = (c->have_sky && !c->sky_partial) ? c->sky_cur ^ 1 : c->sky_cur;  // the other ring slot: frame set-ups still reading the current one are ahead on `pro`
+    const int k = (c->have_sky && c->sky_in_memory) ? c->sky_cur ^ 1 : c->sky_cur;  // the other ring slot: frame set-ups still reading the current one are ahead on `pro`
     HIPCHK(c, launch_sky_lut(w, h, p->sun_direction, c->d_trans_f, c->tw, c->th, c->sky_h_ring[k], c->sky_f_ring[k], c->pro));
     c->sky_cur = k; c->d_sky_h = c->sky_h_ring[k]; c->d_sky_f = c->sky_f_ring[k];
-    c->have_sky = true; c->sky_partial = false;
+    c->have_sky = true; c->sky_partial = false; c->sky_in_memory = true; c->lut_writers.clear();
     return CSKY_OK;
 }
 int csky_render_sky_lut_rows_device(csky_ctx* c, const csky_sky_params* p, int first_row, int row_stride, void* d_rows_out, size_t capacity_bytes, void* hip_stream) {
@@ -735,9 +738,9 @@ int csky_render_sky_lut_rows_device(csky_ctx* c, const csky_sky_params* p, int f
     }
     // the rows have no consumer inside the library: they are rendered on the CALLER's stream, in order with the bands they travel with
     hipStream_t s = hip_stream ? (hipStream_t)hip_stream : c->stream;
-    HIPCHK(c, launch_sky_lut_rows(w, h, first_row, row_stride, p->sun_direction, c->d_trans_f, c->tw, c->th, reinterpret_cast<uint2*>(d_rows_out), s));
+    HIPCHK(c, launch_sky_lut_rows(w, h, first_row, row_stride, p->sun_direction, c->d_trans_f, c->tw, c->th, reinterpret_cast<uint2*>(d_rows_out), nullptr, s));
     for (int i = 0; i < 3; i++) c->sky_sun[i] = p->sun_direction[i];
-    c->psw = w; c->psh = h; c->sky_partial = true; c->have_sky = true;
+    c->psw = w; c->psh = h; c->sky_partial = true; c->have_sky = true; c->sky_in_memory = false; c->lut_writers.clear();
     return CSKY_OK;
 }
 
@@ -936,10 +939,14 @@ int csky_read_transmittance(csky_ctx* c, uint16_t* out, int* w, int* h) {
 int csky_read_sky_lut(csky_ctx* c, uint16_t* out, int* w, int* h) {
     if (!c) return fail(nullptr, CSKY_ERR_INVALID, "csky_read_sky_lut: ctx is NULL");
     if (!c->have_sky) return fail(c, CSKY_ERR_STATE, "csky_read_sky_lut: LUT not rendered yet");
-    if (c->sky_partial) return fail(c, CSKY_ERR_STATE, "csky_read_sky_lut: the last LUT went to the caller as rows (csky_render_sky_lut_rows_device), this context holds none");
+    if (!c->sky_in_memory) return fail(c, CSKY_ERR_STATE, "csky_read_sky_lut: the last LUT went to the caller as rows (csky_render_sky_lut_rows_device), this context holds none");
     int rc; if ((rc = bind(c))) return rc;
     if (w) *w = c->sw; if (h) *h = c->sh;
-    if (out) { HIPCHK(c, hipStreamSynchronize(c->pro)); HIPCHK(c, hipMemcpy(out, c->d_sky_h, (size_t)c->sw * c->sh * 8, hipMemcpyDeviceToHost)); }
+    if (out) {
+        HIPCHK(c, hipStreamSynchronize(c->pro));
+        for (hipEvent_t ev : c->lut_writers) HIPCHK(c, hipEventSynchronize(ev));       // rows written by the other devices of a csky_multi handle
+        HIPCHK(c, hipMemcpy(out, c->d_sky_h, (size_t)c->sw * c->sh * 8, hipMemcpyDeviceToHost));
+    }
     return CSKY_OK;
 }
 
@@ -1104,11 +1111,12 @@ int csky_copy_sky_lut_device(csky_ctx* c, void* d_out, void* hip_stream) {
     if (!c) return fail(nullptr, CSKY_ERR_INVALID, "csky_copy_sky_lut_device: ctx is NULL");
     if (!d_out) return fail(c, CSKY_ERR_INVALID, "csky_copy_sky_lut_device: d_out is NULL");
     if (!c->have_sky) return fail(c, CSKY_ERR_STATE, "csky_copy_sky_lut_device: LUT not rendered yet");
-    if (c->sky_partial) return fail(c, CSKY_ERR_STATE, "csky_copy_sky_lut_device: the last LUT went to the caller as rows (csky_render_sky_lut_rows_device), this context holds none");
+    if (!c->sky_in_memory) return fail(c, CSKY_ERR_STATE, "csky_copy_sky_lut_device: the last LUT went to the caller as rows (csky_render_sky_lut_rows_device), this context holds none");
     int rc; if ((rc = bind(c))) return rc;
     hipStream_t s = hip_stream ? (hipStream_t)hip_stream : c->stream;
     // the copy runs on the prologue stream right behind the LUT's render (a later render goes to the other ring slot and, like every
     // writer of a slot, is queued behind this reader on the same stream); the caller's stream then waits for it
+    for (hipEvent_t ev : c->lut_writers) HIPCHK(c, hipStreamWaitEvent(c->pro, ev, 0));   // rows written by the other devices of a csky_multi handle
     HIPCHK(c, hipMemcpyAsync(d_out, c->d_sky_h, (size_t)c->sw * c->sh * 8, hipMemcpyDeviceToDevice, c->pro));
     HIPCHK(c, hipEventRecord(c->ev_copy, c->pro));
     HIPCHK(c, hipStreamWaitEvent(s, c->ev_copy, 0));
@@ -1128,6 +1136,8 @@ struct csky_multi {
     std::vector<uint2*> d_stage[RING];    // [per-device frame slot][device]: compact band buffer on that device (staged form)
     std::vector<size_t> stage_px[RING];
     uint2* d_frame = nullptr; size_t frame_px = 0;   // host-buffer form: internal frame on the first device
+    std::vector<hipEvent_t> ev_lut;       // [device]: its rows of the sky LUT have been stored into the first device's LUT (csky_multi_render_sky_lut)
+    hipEvent_t ev_lut_begin = nullptr;    // on the first device's prologue stream: the readers of the LUT slot about to be rewritten are behind this
     char err[512] = {0};
 };
 namespace {
@@ -1171,6 +1181,7 @@ int csky_multi_create(csky_multi** out, const int* device_ids, int n) {
             m->side[k].push_back(st);
         }
         for (int k = 0; k < RING; k++) { m->d_stage[k].push_back(nullptr); m->stage_px[k].push_back(0); }
+        { hipEvent_t ev = nullptr; if ((e = hipEventCreateWithFlags(&ev, hipEventDisableTiming)) != hipSuccess) return bail(CSKY_ERR_HIP, "hipEventCreate", e); m->ev_lut.push_back(ev); }
         if (di != d0) {                                          // the march on device di stores into the frame on d0: xGMI peer access
             int can = 0;
             if ((e = hipDeviceCanAccessPeer(&can, di, d0)) != hipSuccess) return bail(CSKY_ERR_HIP, "hipDeviceCanAccessPeer", e);
@@ -1183,6 +1194,7 @@ int csky_multi_create(csky_multi** out, const int* device_ids, int n) {
     if ((e = hipSetDevice(d0)) != hipSuccess) return bail(CSKY_ERR_HIP, "hipSetDevice", e);
     for (int sl = 0; sl < MULTI_SLOTS; sl++)
         if ((e = hipEventCreateWithFlags(&m->ev_begin[sl], hipEventDisableTiming)) != hipSuccess) return bail(CSKY_ERR_HIP, "hipEventCreate", e);
+    if ((e = hipEventCreateWithFlags(&m->ev_lut_begin, hipEventDisableTiming)) != hipSuccess) return bail(CSKY_ERR_HIP, "hipEventCreate", e);
     if (const char* se = getenv("CSKY_MULTI_STAGED")) m->staged = atoi(se) != 0;   // A/B switch for the driver's 8-GPU node
     *out = m;
     return CSKY_OK;
@@ -1196,10 +1208,13 @@ void csky_multi_destroy(csky_multi* m) {
         for (int sl = 0; sl < MULTI_SLOTS; sl++) if (i < m->ev_done[sl].size() && m->ev_done[sl][i]) (void)hipEventDestroy(m->ev_done[sl][i]);
         for (int k = 0; k < RING - 1; k++) if (i < m->side[k].size() && m->side[k][i]) (void)hipStreamDestroy(m->side[k][i]);
         for (int k = 0; k < RING; k++) if (i < m->d_stage[k].size() && m->d_stage[k][i]) (void)hipFree(m->d_stage[k][i]);
+        if (i < m->ev_lut.size() && m->ev_lut[i]) (void)hipEventDestroy(m->ev_lut[i]);
     }
     if (!m->ctx.empty()) {
         (void)hipSetDevice(m->ctx[0]->device);
         for (int sl = 0; sl < MULTI_SLOTS; sl++) if (m->ev_begin[sl]) (void)hipEventDestroy(m->ev_begin[sl]);
+        if (m->ev_lut_begin) (void)hipEventDestroy(m->ev_lut_begin);
+        m->ctx[0]->lut_writers.clear();
         if (m->d_frame) (void)hipFree(m->d_frame);
     }
     for (csky_ctx* c : m->ctx) csky_destroy(c);
@@ -1250,11 +1265,35 @@ int csky_multi_set_staged(csky_multi* m, int staged) {
 }
 int csky_multi_render_sky_lut(csky_multi* m, const csky_sky_params* p) {
     if (!m) return mfail(nullptr, CSKY_ERR_INVALID, "csky_multi_render_sky_lut: handle is NULL");
-    // Every device gets the LUT, whatever the group layout (with several groups it used to go to the NEXT frame's group only, so a
-    // caller with a static sun that rendered it once marched with no / a stale LUT on the other groups).  A sky LUT costs ~33 us of one device
-    // on its prologue stream, overlapped with the previous march (sky_lut.gd:43-52 is called once per frame, cloud_sky.gd:187).
+    if (!p) return mfail(m, CSKY_ERR_INVALID, "csky_multi_render_sky_lut: params is NULL");
+    const int w = (int)p->texture_size[0], h = (int)p->texture_size[1];
+    if (w < 1 || h < 1 || w > 8192 || h > 8192) return mfail(m, CSKY_ERR_INVALID, "csky_multi_render_sky_lut: texture_size out of range");
+    // sky_lut.gd:43-52 renders the LUT once per frame (cloud_sky.gd:187); n devices rendering n whole copies would each spend 33 us of a chip on it,
+    // 12 % of a 1/8 frame share.  Device i renders rows i, i + n, ... and stores them, like its bands, straight into the LUT on the first device
+    // (the copy a consumer reads: csky_read_sky_lut / csky_copy_sky_lut_device on csky_multi_ctx(m, 0) wait for every writer).  No device's frame
+    // set-up reads that copy: each renders the <= 12 texels it filters itself (frame_setup_taps_kernel), for the sun recorded here -- on EVERY
+    // device, whatever the group layout (a caller with a static sun renders the LUT once and then frames on all groups).
     const int n = (int)m->ctx.size();
-    for (int i = 0; i < n; i++) { const int rc = csky_render_sky_lut_device(m->ctx[i], p, nullptr); if (rc) return mpass(m, i, rc); }
+    csky_ctx* c0 = m->ctx[0];
+    int rc; if ((rc = bind(c0))) return mpass(m, 0, rc);
+    if ((rc = ensure_sky(c0, w, h))) return mpass(m, 0, rc);
+    const int k = (c0->have_sky && c0->sky_in_memory) ? c0->sky_cur ^ 1 : c0->sky_cur;     // the other ring slot, as in csky_render_sky_lut_device
+    // the readers of slot k (device copies of the LUT before last) sit on the first device's prologue stream: every writer queues behind them
+    if (hipEventRecord(m->ev_lut_begin, c0->pro) != hipSuccess) return mfail(m, CSKY_ERR_HIP, "csky_multi_render_sky_lut: hipEventRecord failed");
+    for (int i = 0; i < n; i++) {
+        csky_ctx* c = m->ctx[i];
+        if ((rc = bind(c))) return mpass(m, i, rc);
+        if (!c->have_trans && (rc = render_trans_dev(c, 256, 64, c->pro))) return mpass(m, i, rc);   // transmittance_lut.gd:6 default size
+        hipError_t e = i ? hipStreamWaitEvent(c->pro, m->ev_lut_begin, 0) : hipSuccess;
+        if (e == hipSuccess) e = launch_sky_lut_rows(w, h, i, n, p->sun_direction, c->d_trans_f, c->tw, c->th, reinterpret_cast<uint2*>(c0->sky_h_ring[k]), c0->sky_f_ring[k], c->pro);
+        if (e == hipSuccess) e = hipEventRecord(m->ev_lut[i], c->pro);
+        if (e != hipSuccess) return mfail(m, CSKY_ERR_HIP, "csky_multi_render_sky_lut: device index %d: %s", i, hipGetErrorString(e));
+        for (int q = 0; q < 3; q++) c->sky_sun[q] = p->sun_direction[q];
+        c->psw = w; c->psh = h; c->sky_partial = true; c->have_sky = true;
+        if (i) { c->sky_in_memory = false; c->lut_writers.clear(); }
+    }
+    c0->sky_cur = k; c0->d_sky_h = c0->sky_h_ring[k]; c0->d_sky_f = c0->sky_f_ring[k]; c0->sky_in_memory = true;
+    c0->lut_writers.assign(m->ev_lut.begin() + 1, m->ev_lut.end());      // (its own rows are on its prologue stream, ahead of any reader)
     return CSKY_OK;
 }
 

@@ -12,8 +12,10 @@ hipError_t launch_transmittance(int w, int h, uint16_t* d_half, float4* d_float,
 // sky-lut.glsl main()
 hipError_t launch_sky_lut(int w, int h, const float sun[3], const float4* d_trans, int tw, int th, uint16_t* d_half,
                           float4* d_float, hipStream_t s);
-// rows row0, row0 + row_stride, ... of that LUT, compact RGBA16F, into d_rows (one rank of an N-way frame split)
-hipError_t launch_sky_lut_rows(int w, int h, int row0, int row_stride, const float sun[3], const float4* d_trans, int tw, int th, uint2* d_rows, hipStream_t s);
+// rows row0, row0 + row_stride, ... of that LUT (one rank / device of an N-way frame split): d_whole_f == nullptr: compact RGBA16F into d_rows;
+// otherwise at their own place in the whole LUT d_rows (RGBA16F) + d_whole_f (the float copy)
+hipError_t launch_sky_lut_rows(int w, int h, int row0, int row_stride, const float sun[3], const float4* d_trans, int tw, int th, uint2* d_rows, float4* d_whole_f,
+                               hipStream_t s);
 // per-frame constants of clouds.glsl:143-170 (one wave)
 hipError_t launch_frame_setup(const CloudParams& p, const float4* d_sky, int sw, int sh, int primary_steps, int light_steps,
                               float early_eps, float hf_lo, float hf_hi, int ct_mode, FrameConsts* d_fc, hipStream_t s);

@@ -86,17 +86,20 @@ __global__ __launch_bounds__(256) void sky_lut_kernel(int w, int h, Sun3 sun, co
         out_f[y * w + x] = make_float4(h2f(hx), h2f(hy), h2f(hz), h2f(hw));
     });
 }
-// One rank's rows of the LUT when N processes split a frame (csky_render_sky_lut_rows_device): rows row0, row0 + row_stride, ... (n_rows of
-// them), stored COMPACT and as RGBA16F only, straight into the buffer that travels to the gathering rank with the rank's bands.
+// One rank's rows of the LUT when N ranks / devices split a frame: rows row0, row0 + row_stride, ... (n_rows of them).  out_f == nullptr
+// (csky_render_sky_lut_rows_device): stored COMPACT and as RGBA16F only, straight into the buffer that travels to the gathering rank with the
+// rank's bands.  out_f != nullptr (csky_multi_render_sky_lut): stored at the texel's own place in the whole LUT (half + float copies) of the
+// handle's first device, over xGMI peer access, like the frame's bands.
 __global__ __launch_bounds__(256) void sky_lut_rows_kernel(int w, int h, int row0, int row_stride, int n_rows, Sun3 sun, const float4* __restrict__ trans,
-                                                          int tw, int th, uint2* __restrict__ out_rows) {
+                                                          int tw, int th, uint2* __restrict__ out_h, float4* __restrict__ out_f) {
     __shared__ float steps[8][IN_SCATTERING_STEPS][8];
     const int half = threadIdx.x >> 5, sub = threadIdx.x & 31;
     const int t = blockIdx.x * 8 + half;
     const bool live = t < w * n_rows;
     const int px = live ? t % w : 0, py = live ? row0 + (t / w) * row_stride : 0;
-    sky_texel(steps[half], sub, live, px, py, w, h, sun, trans, tw, th, [=](int, int, uint16_t hx, uint16_t hy, uint16_t hz, uint16_t hw) {
-        out_rows[t] = pack_half4(hx, hy, hz, hw);
+    sky_texel(steps[half], sub, live, px, py, w, h, sun, trans, tw, th, [=](int x, int y, uint16_t hx, uint16_t hy, uint16_t hz, uint16_t hw) {
+        if (out_f) { out_h[y * w + x] = pack_half4(hx, hy, hz, hw); out_f[y * w + x] = make_float4(h2f(hx), h2f(hy), h2f(hz), h2f(hw)); }
+        else out_h[t] = pack_half4(hx, hy, hz, hw);
     });
 }
 
@@ -110,10 +113,11 @@ hipError_t launch_sky_lut(int w, int h, const float sun[3], const float4* d_tran
     sky_lut_kernel<<<(w * h + 7) / 8, 256, 0, s>>>(w, h, sv, d_trans, tw, th, d_half, d_float);
     return hipGetLastError();
 }
-hipError_t launch_sky_lut_rows(int w, int h, int row0, int row_stride, const float sun[3], const float4* d_trans, int tw, int th, uint2* d_rows, hipStream_t s) {
+hipError_t launch_sky_lut_rows(int w, int h, int row0, int row_stride, const float sun[3], const float4* d_trans, int tw, int th, uint2* d_rows, float4* d_whole_f,
+                               hipStream_t s) {
     Sun3 sv; sv.v[0] = sun[0]; sv.v[1] = sun[1]; sv.v[2] = sun[2];
     const int n_rows = row0 < h ? (h - row0 + row_stride - 1) / row_stride : 0;
-    if (n_rows) sky_lut_rows_kernel<<<(w * n_rows + 7) / 8, 256, 0, s>>>(w, h, row0, row_stride, n_rows, sv, d_trans, tw, th, d_rows);
+    if (n_rows) sky_lut_rows_kernel<<<(w * n_rows + 7) / 8, 256, 0, s>>>(w, h, row0, row_stride, n_rows, sv, d_trans, tw, th, d_rows, d_whole_f);
     return hipGetLastError();
 }
 

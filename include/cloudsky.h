@@ -318,6 +318,10 @@ int csky_multi_set_groups(csky_multi* m, int groups);
  * environment at csky_multi_create.  Default 0. */
 int csky_multi_set_staged(csky_multi* m, int staged);
 int csky_multi_set_march(csky_multi* m, int primary_steps, int light_steps);
+/* sky_lut.gd:122-148 for the handle: device i renders rows i, i + n, ... of the LUT and stores them, like its bands, straight into the LUT of the
+ * first device (csky_read_sky_lut / csky_copy_sky_lut_device on csky_multi_ctx(m, 0) give the whole LUT and wait for every writer); no device's
+ * frame set-up reads that copy, each renders the few texels it filters itself (see csky_render_sky_lut_rows_device), on every device whatever the
+ * group layout.  The other contexts of the handle hold no LUT (CSKY_ERR_STATE from their csky_read_sky_lut). */
 int csky_multi_render_sky_lut(csky_multi* m, const csky_sky_params* p);
 /* Whole tile [0,tile_w) x [0,tile_h) into d_out on the FIRST device (row pitch in bytes), asynchronously: `hip_stream` (a stream of
  * the first device; NULL = that context's own stream) is ordered behind every device's march.  tile_h must be a multiple of 8 (bands are

@@ -216,3 +216,29 @@ def test_frame_marched_on_bc7_round_tripped_textures_vs_oracle(pkg, gpu_ctx, noi
         assert float(np.abs(ref.astype(np.float32) - ref_raw.astype(np.float32)).max()) > 1e-2      # compression is visible at this precision
     finally:
         ctx.close()
+
+
+def test_multi_handle_sky_lut_is_assembled_on_the_first_device(pkg, noise):
+    """csky_multi_render_sky_lut: device i stores rows i::n into the LUT of the first device (4 contexts on device 0 here, which runs the same
+    peer-store code); read through context 0 it is the whole LUT of a single context to the byte, also as a device copy, two suns in a row
+    (both ring slots); the other contexts hold none."""
+    import torch
+    ref_ctx = pkg.Context(0)
+    m = pkg.MultiContext([0, 0, 0, 0])
+    try:
+        m.set_noise(*noise)
+        buf = torch.zeros(200 * 100 * 8, dtype=torch.uint8, device="cuda")
+        torch.cuda.synchronize()
+        for sun in (SUNS["deg45"], SUNS["demo"], SUNS["zenith"]):
+            want = ref_ctx.render_sky_lut(norm(sun), 200, 100).view(np.uint16)
+            m.render_sky_lut(norm(sun), 200, 100)
+            c0 = m.ctx(0)
+            assert np.array_equal(c0.read_sky_lut().view(np.uint16), want)
+            c0.copy_sky_lut_device(buf.data_ptr(), None)
+            c0.sync()
+            assert np.array_equal(buf.cpu().numpy().view(np.uint16).reshape(100, 200, 4), want)
+            with pytest.raises(pkg.CloudSkyError) as e:
+                m.ctx(2).read_sky_lut()
+            assert e.value.code == pkg._lib.ERR_STATE
+    finally:
+        m.close(); ref_ctx.close()
