@@ -441,6 +441,10 @@ def main():
     gdev = "cpu" if debug_one_gpu else dev
     gathered = [torch.empty((fg.max_members, band_bytes + lut_bytes), dtype=torch.uint8, device=gdev) for _ in range(nbuf)] if (world > 1 and rank == 0) else [None] * nbuf
     sky_lut = [None]
+    # rank 0's delivered textures, one per buffer set: the interleave of the gathered bands / LUT rows writes into them (csky_interleave_bands_device)
+    frame_out = [torch.zeros((H, W, 4), dtype=torch.int16, device=dev) for _ in range(nbuf)] if (world > 1 and rank == 0) else []
+    lut_out = [torch.zeros((LH, LW, 4), dtype=torch.int16, device=dev) for _ in range(nbuf)] if (world > 1 and rank == 0 and split_lut) else []
+    staged_g = [None] * nbuf
     pending = [None] * nbuf
     pend_frame = [0] * nbuf
     frame = [None]
@@ -453,10 +457,11 @@ def main():
             pending[o].wait()
             pending[o] = None
             if rank == 0:
-                img, lut = fg.split(gathered[o].to(dev) if debug_one_gpu else gathered[o], H, W, LH if split_lut else 0, LW)
-                frame[0] = fg.assemble(pend_frame[o], img, H)
+                staged_g[o] = gathered[o].to(dev) if debug_one_gpu else gathered[o]      # (kept alive until the buffer set comes round again)
+                fg.assemble_device(pend_frame[o], staged_g[o], ctx, streams[o].cuda_stream, H, W, frame_out[o], LH if split_lut else 0, LW, lut_out[o] if split_lut else None)
+                frame[0] = frame_out[o]
                 if split_lut:
-                    sky_lut[0] = fg.assemble_lut(pend_frame[o], lut, LH)
+                    sky_lut[0] = lut_out[o]
 
     def step():
         k = counter[0]

@@ -62,6 +62,7 @@ SYMBOLS = [
     ("csky_render_clouds_device", C.c_int, [C.c_void_p, C.POINTER(CloudParams), C.c_int, C.POINTER(Bands), C.c_void_p, C.c_size_t, C.c_void_p]),
     ("csky_copy_sky_lut_device", C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
     ("csky_render_sky_lut_rows_device", C.c_int, [C.c_void_p, C.POINTER(SkyParams), C.c_int, C.c_int, C.c_void_p, C.c_size_t, C.c_void_p]),
+    ("csky_interleave_bands_device", C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_size_t, C.c_int, C.c_void_p, C.c_void_p]),
     ("csky_sync", C.c_int, [C.c_void_p]),
     ("csky_set_host_ring", C.c_int, [C.c_void_p, C.c_int]),
     ("csky_submit_clouds", C.c_int, [C.c_void_p, C.POINTER(CloudParams), C.c_int, C.c_int, C.POINTER(C.c_int64)]),
@@ -311,6 +312,11 @@ class Context:
         b = Bands(*[int(x) for x in bands])
         self._chk(self._L.csky_render_clouds_device(self._h, C.byref(p), int(tile_w), C.byref(b), C.c_void_p(int(d_out)), int(pitch_bytes),
                                                     C.c_void_p(stream or 0)))
+
+    def interleave_bands_device(self, d_gathered, member_stride_bytes, members, band_bytes, total_bands, d_frame, stream=None):
+        """The gathering rank's interleave: frame band k = member k % members, local band k // members of the gathered rank-major buffer."""
+        self._chk(self._L.csky_interleave_bands_device(self._h, C.c_void_p(int(d_gathered)), C.c_size_t(int(member_stride_bytes)), int(members), C.c_size_t(int(band_bytes)),
+                                                       int(total_bands), C.c_void_p(int(d_frame)), C.c_void_p(stream or 0)))
 
     def copy_sky_lut_device(self, d_out, stream=None):
         """Async device copy of the sky LUT rendered last (w*h*8 bytes of RGBA16F) into a caller-owned device buffer."""

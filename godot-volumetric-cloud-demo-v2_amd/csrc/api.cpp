@@ -1123,6 +1123,18 @@ int csky_copy_sky_lut_device(csky_ctx* c, void* d_out, void* hip_stream) {
     return CSKY_OK;
 }
 
+int csky_interleave_bands_device(csky_ctx* c, const void* d_gathered, size_t member_stride_bytes, int members, size_t band_bytes, int total_bands, void* d_frame, void* hip_stream) {
+    if (!c) return fail(nullptr, CSKY_ERR_INVALID, "csky_interleave_bands_device: ctx is NULL");
+    if (!d_gathered || !d_frame || members < 1 || total_bands < 0) return fail(c, CSKY_ERR_INVALID, "csky_interleave_bands_device: NULL argument or bad counts");
+    if (band_bytes % 16 || member_stride_bytes % 16 || ((uintptr_t)d_gathered & 15) || ((uintptr_t)d_frame & 15))
+        return fail(c, CSKY_ERR_INVALID, "csky_interleave_bands_device: band size, member stride and both pointers must be multiples of 16 bytes");
+    const size_t local = ((size_t)total_bands + members - 1) / members;
+    if (local * band_bytes > member_stride_bytes) return fail(c, CSKY_ERR_INVALID, "csky_interleave_bands_device: a member's %zu bands of %zu bytes do not fit its stride of %zu", local, band_bytes, member_stride_bytes);
+    int rc; if ((rc = bind(c))) return rc;
+    HIPCHK(c, launch_interleave_bands(d_gathered, member_stride_bytes, members, band_bytes, total_bands, d_frame, hip_stream ? (hipStream_t)hip_stream : c->stream));
+    return CSKY_OK;
+}
+
 // ---- multi-GPU: n contexts, one frame on the first device written by peer stores (cloudsky.h) ----------------------------
 constexpr int MULTI_SLOTS = 8;            // frames in flight over all groups (csky_multi_set_frames_in_flight x csky_multi_set_groups)
 struct csky_multi {

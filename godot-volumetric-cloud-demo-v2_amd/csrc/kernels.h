@@ -45,6 +45,8 @@ hipError_t launch_shape_noise(uint32_t seed, int n, uint32_t* d_out, hipStream_t
 
 // generated 32^3 RGB detail volume (noise_core.h::detail_voxel), 3 bytes per voxel
 hipError_t launch_detail_noise(uint32_t seed, int n, uint8_t* d_out, hipStream_t s);
+// frame band k (band_bytes each, total_bands of them) = member k % members, local band k / members of a gathered rank-major buffer
+hipError_t launch_interleave_bands(const void* d_gathered, size_t member_stride_bytes, int members, size_t band_bytes, int total_bands, void* d_frame, hipStream_t s);
 // BC7 (BPTC) blocks of n_img images of w x h RGBA8 texels (bc7enc.hip; what compress/mode=2 of the *.import files asks the importer for)
 hipError_t launch_bc7_encode(const uint8_t* d_img, int w, int h, int n_img, uint4* d_blocks, hipStream_t s);
 // 2x2x2 box mips of a device chain whose level 0 is filled (level l at chain_offset(n, l, ch))

@@ -121,6 +121,27 @@ hipError_t launch_sky_lut_rows(int w, int h, int row0, int row_stride, const flo
     return hipGetLastError();
 }
 
+// ------------------------------------------------------------------------------------------------ band interleave (gathering rank, N > 1)
+// The gather leaves rank-major compact bands ([member][local band][rows]); the frame wants band k = member k % n, local band k / n.  A plain
+// strided copy, deliberately on FEW workgroups: it is HBM-bound (32 MiB per 2048x1024 frame) beside marches that are not, so 48 workgroups
+// streaming 16-byte chunks take it off the critical path instead of sweeping the whole chip for 15 us per frame (torch's permute + copy).
+__global__ __launch_bounds__(256) void interleave_bands_kernel(const uint4* __restrict__ src, size_t member_stride16, int members, uint32_t band16, uint32_t total_bands,
+                                                              uint4* __restrict__ dst) {
+    const size_t total = (size_t)band16 * total_bands;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+        const uint32_t k = (uint32_t)(i / band16), c = (uint32_t)(i - (size_t)k * band16);
+        dst[i] = src[(size_t)(k % members) * member_stride16 + (size_t)(k / members) * band16 + c];
+    }
+}
+hipError_t launch_interleave_bands(const void* d_gathered, size_t member_stride_bytes, int members, size_t band_bytes, int total_bands, void* d_frame, hipStream_t s) {
+    const size_t chunks = band_bytes / 16 * (size_t)total_bands;
+    if (!chunks) return hipSuccess;
+    const unsigned grid = (unsigned)(chunks / 256 + 1 < 48 ? chunks / 256 + 1 : 48);
+    interleave_bands_kernel<<<grid, 256, 0, s>>>(reinterpret_cast<const uint4*>(d_gathered), member_stride_bytes / 16, members, (uint32_t)(band_bytes / 16), (uint32_t)total_bands,
+                                                 reinterpret_cast<uint4*>(d_frame));
+    return hipGetLastError();
+}
+
 // ------------------------------------------------------------------------------------------------ shape-noise bake
 // The stand-in 128^3 RGBA shape volume, one voxel per lane (bit-identical to the host generator: noise_core.h).
 __global__ __launch_bounds__(256) void shape_noise_kernel(uint32_t seed, int n, uint32_t* __restrict__ out) {

@@ -143,6 +143,19 @@ class FrameGroups:
         lut = gathered_bytes[:, bb: bb + self.max_lut_rows(lut_h) * lut_w * 8].view(torch.int16).reshape(m, -1, lut_w, 4) if lut_h else None
         return img, lut
 
+    def assemble_device(self, frame_no, gathered_bytes, ctx, stream, height, width, out_frame, lut_h=0, lut_w=0, out_lut=None, band_rows=BAND_ROWS):
+        """Rank 0, device tensors: the same as split() + assemble() (+ assemble_lut()) with the library's narrow copy kernel
+        (csky_interleave_bands_device) on `stream` (a raw HIP stream handle) into the caller's out_frame [height, W, 4] int16 (and out_lut):
+        an HBM-bound pass that runs beside the following frames' marches instead of sweeping the whole chip."""
+        g = self.group_of(frame_no)
+        skip = 1 if (self.groups > 1 and g != 0) else 0          # rank 0's dummy contribution to another group's gather
+        stride = gathered_bytes.stride(0) * gathered_bytes.element_size()
+        base = gathered_bytes.data_ptr() + skip * stride
+        bb = self.max_bands(height, band_rows) * band_rows * width * 8
+        ctx.interleave_bands_device(base, stride, self.per, band_rows * width * 8, height // band_rows, out_frame.data_ptr(), stream)
+        if lut_h:
+            ctx.interleave_bands_device(base + bb, stride, self.per, lut_w * 8, lut_h, out_lut.data_ptr(), stream)
+
     def assemble_lut(self, frame_no, gathered_lut, lut_h):
         """Rank 0: the members' sky-LUT rows of frame_no ([members, max_lut_rows, w, 4]) -> the [lut_h, w, 4] LUT."""
         return self.assemble(frame_no, gathered_lut, lut_h, band_rows=1)

@@ -160,6 +160,12 @@ int csky_copy_sky_lut_device(csky_ctx* ctx, void* d_out_rgba16f, void* hip_strea
  * csky_read_sky_lut / csky_copy_sky_lut_device return CSKY_ERR_STATE until the next csky_render_sky_lut*. */
 int csky_render_sky_lut_rows_device(csky_ctx* ctx, const csky_sky_params* p, int first_row, int row_stride, void* d_rows_out_rgba16f,
                                     size_t capacity_bytes, void* hip_stream);
+/* The gathering rank's last step when N processes split a frame (one gather to rank 0): the gather leaves every member's compact
+ * bands back to back (member m at d_gathered + m * member_stride_bytes); frame band k (band_bytes each: band_rows x row bytes; total_bands of
+ * them) = member k % members, local band k / members.  Asynchronous on `hip_stream`; a deliberately narrow, HBM-bound copy that runs beside the
+ * marches of the following frames.  Also used for the sky-LUT rows (band = one row).  Sizes and pointers: multiples of 16 bytes. */
+int csky_interleave_bands_device(csky_ctx* ctx, const void* d_gathered, size_t member_stride_bytes, int members, size_t band_bytes, int total_bands,
+                                 void* d_frame, void* hip_stream);
 int csky_render_clouds_device(csky_ctx* ctx, const csky_cloud_params* p, int tile_w, const csky_bands* bands,
                               void* d_out_rgba16f, size_t row_pitch_bytes, void* hip_stream);
 int csky_sync(csky_ctx* ctx); /* wait for the context's own streams (work on caller streams is the caller's to wait for) */

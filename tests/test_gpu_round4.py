@@ -242,3 +242,24 @@ def test_multi_handle_sky_lut_is_assembled_on_the_first_device(pkg, noise):
             assert e.value.code == pkg._lib.ERR_STATE
     finally:
         m.close(); ref_ctx.close()
+
+
+@pytest.mark.parametrize("world,groups", [(8, 1), (3, 1), (8, 2)])
+def test_library_interleave_is_tilings_interleave(gpu_ctx, pkg, world, groups):
+    """csky_interleave_bands_device (rank 0's last step at N > 1) against tiling.FrameGroups.split / assemble / assemble_lut in torch: frame and
+    sky LUT byte-identical, ragged splits (3 ranks: 43 + 43 + 42 bands, 34 + 33 + 33 LUT rows) and a group whose gather starts with rank 0's dummy."""
+    import torch
+    T = pkg.tiling
+    H, W, LH, LW = 1024, 256, 100, 200
+    fg = T.FrameGroups(0, world, groups)
+    bb, lb = fg.max_bands(H) * 8 * W * 8, fg.max_lut_rows(LH) * LW * 8
+    g = torch.randint(0, 256, (fg.max_members, bb + lb), dtype=torch.uint8, device="cuda")
+    for frame_no in range(groups):
+        img, lut = fg.split(g, H, W, LH, LW)
+        want_f, want_l = fg.assemble(frame_no, img, H), fg.assemble_lut(frame_no, lut, LH)
+        out_f = torch.zeros((H, W, 4), dtype=torch.int16, device="cuda"); out_l = torch.zeros((LH, LW, 4), dtype=torch.int16, device="cuda")
+        st = torch.cuda.Stream()
+        torch.cuda.synchronize()
+        fg.assemble_device(frame_no, g, gpu_ctx, st.cuda_stream, H, W, out_f, LH, LW, out_l)
+        st.synchronize()
+        assert bool((out_f == want_f).all().item()) and bool((out_l == want_l).all().item()), (world, groups, frame_no)

@@ -41,18 +41,34 @@ dev = torch.device("cuda", 0)
 streams = [torch.cuda.Stream(device=dev) for _ in range(FIF)]
 local_b = [torch.zeros(band_bytes + lut_bytes, dtype=torch.uint8, device=dev) for _ in range(FIF)]
 gathered = [torch.zeros((WORLD, band_bytes + lut_bytes), dtype=torch.uint8, device=dev) for _ in range(FIF)]
+frame_out = [torch.zeros((H, W, 4), dtype=torch.int16, device=dev) for _ in range(FIF)]
+lut_out = [torch.zeros((LH, LW, 4), dtype=torch.int16, device=dev) for _ in range(FIF)]
 pending = [None] * FIF
 T = {"render": 0.0, "gather": 0.0, "finish": 0.0}
 out = [None, None]
+
+
+SKIP = os.environ.get("SKIP", "")          # "gather", "interleave" or "gather,interleave": leave that part out (what does rank 0's extra time consist of?)
+
+
+class Done:
+    def wait(self):
+        pass
 
 
 def finish(o):
     t = time.perf_counter()
     with torch.cuda.stream(streams[o]):
         pending[o].wait(); pending[o] = None
-        img, lut = fg.split(gathered[o], H, W, LH, LW)
-        out[0] = fg.assemble(0, img, H)
-        out[1] = fg.assemble_lut(0, lut, LH)
+        if "interleave" in SKIP:
+            T["finish"] += time.perf_counter() - t
+            return
+        if os.environ.get("TORCH_INTERLEAVE"):                   # what round 4 started with: permute + copy on the whole chip
+            img, lut = fg.split(gathered[o], H, W, LH, LW)
+            out[0] = fg.assemble(0, img, H)
+            out[1] = fg.assemble_lut(0, lut, LH)
+        else:
+            fg.assemble_device(0, gathered[o], ctx, streams[o].cuda_stream, H, W, frame_out[o], LH, LW, lut_out[o])
     T["finish"] += time.perf_counter() - t
 
 
@@ -64,7 +80,7 @@ def step(k):
     ctx.render_clouds_device(p, W, bands, local_b[b].data_ptr(), W * 8, st)
     t1 = time.perf_counter(); T["render"] += t1 - t
     with torch.cuda.stream(streams[b]):
-        pending[b] = fg.gather(k, local_b[b], gathered[b], async_op=True)
+        pending[b] = Done() if "gather" in SKIP else fg.gather(k, local_b[b], gathered[b], async_op=True)
     T["gather"] += time.perf_counter() - t1
     o = (b + 1) % FIF
     if pending[o] is not None:
@@ -84,6 +100,6 @@ for o in range(FIF):
     if pending[o] is not None: finish(o)
 torch.cuda.synchronize()
 total = time.perf_counter() - t0
-print("rank 0 of %d, %d frames in flight: %.3f ms per frame in all, host loop alone %.3f ms per frame (render calls %.3f, gather call %.3f, wait + interleave calls %.3f)"
-      % (WORLD, FIF, total / N * 1e3, host / N * 1e3, T["render"] / N * 1e3, T["gather"] / N * 1e3, T["finish"] / N * 1e3))
+print("%srank 0 of %d, %d frames in flight: %.3f ms per frame in all, host loop alone %.3f ms per frame (render calls %.3f, gather call %.3f, wait + interleave calls %.3f)"
+      % ("[without %s] " % SKIP if SKIP else "", WORLD, FIF, total / N * 1e3, host / N * 1e3, T["render"] / N * 1e3, T["gather"] / N * 1e3, T["finish"] / N * 1e3))
 dist.destroy_process_group()
