@@ -954,6 +954,10 @@ int csky_set_kernel_timing(csky_ctx* c, int enabled) {
     if (!c) return fail(nullptr, CSKY_ERR_INVALID, "csky_set_kernel_timing: ctx is NULL");
     int rc; if ((rc = bind(c))) return rc;
     c->kt_on = enabled != 0; c->kt_count = 0;
+    if (c->kt_on && c->kt_ev.empty()) {      // the first pool is made HERE, not by the first timed launch: 512 hipEventCreate calls are ~1 ms of host time, 3 % of a 20-frame timed region
+        c->kt_ev.resize(512, nullptr);
+        for (hipEvent_t& ev : c->kt_ev) HIPCHK(c, hipEventCreate(&ev));
+    }
     return CSKY_OK;
 }
 

@@ -6,7 +6,7 @@ The driver runs `bench.py --gpus 1 --steps 20 --warmup 5`; the builder's numbers
 prologue: sky LUT -> frame set-up -> march), the second fills its tail, and from the fourth frame on one frame completes every ~1.64 ms.  One fill of ~0.7-1 ms
 is 0.2 % of 200 steps and 2-3 % of 20; the first two or three frames after an idle period also run a few per cent slow.  Steady state is the same on both boxes."""
 import os, sys, time
-os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
 import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch, gvcd_amd
