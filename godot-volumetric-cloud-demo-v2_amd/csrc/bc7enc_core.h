@@ -7,9 +7,10 @@
 // an encoder of this class gives is the SIZE of that difference: textures passed through encode -> csky_decode_bc7 (the decoder is pinned against an
 // independent one, tests/test_godot_import.py) and marched, next to the same frame from the uncompressed bytes (tools/bc7_sensitivity.py).
 //
-// Modes: 6 (one subset, RGBA 7777 + p-bit per end point, 4-bit indices), 1 (two subsets out of 64 partitions, RGB 666 + shared p-bit, 3-bit
-// indices; opaque blocks only) and 5 (RGB 777 with 2-bit indices + a separately indexed 8-bit scalar, four channel rotations; blocks whose alpha
-// varies) -- the three a quality encoder spends most blocks on for smooth RGB and for RGBA with an independent fourth channel.  Per candidate:
+// Modes: 6 (one subset, RGBA 7777 + p-bit per end point, 4-bit indices); for opaque blocks 1 and 3 (two subsets out of 64 partitions: RGB 666 +
+// shared p-bit with 3-bit indices, RGB 777 + p-bits with 2-bit indices); for blocks whose alpha varies 5 (RGB 777 with 2-bit indices + a separately
+// indexed 8-bit scalar, four channel rotations) and 7 (two subsets, RGBA 5555 + p-bits, 2-bit indices) -- five of the eight; the three-subset
+// modes 0 and 2 and the 5/6-bit separate-alpha mode 4 are not tried.  Per candidate:
 // principal axis of the subset's texels (covariance, power iteration), end points at the extreme projections, quantisation to the mode's
 // precision over the p-bit choices, exhaustive index search against the palette THE DECODER builds (integer, bit for bit), up to three least-squares
 // refits of the end points for those indices; the candidate with the smallest summed squared error over the four channels wins.
@@ -218,7 +219,9 @@ CSKY_HD void bc7_encode_block(const unsigned char px[16][4], uint32_t out[4]) {
             best_err = err; best = b;
         }
     }
-    if (best_err != 0 && opaque) {    // ---- mode 1: every partition estimated with a plain fit, the best few fitted in full
+    if (best_err != 0) {   // ---- two subsets: every partition estimated with a plain fit, the best few fitted in full in the modes the block class allows:
+        //      opaque: 1 (RGB 666 + shared p-bit, 3-bit indices) and 3 (RGB 777 + p-bit per end point, 2-bit indices); else 7 (RGBA 5555 + p-bits, 2-bit indices)
+        const int D = opaque ? 3 : 4;
         int cand[BC7_PARTITIONS_TRIED]; unsigned cerr[BC7_PARTITIONS_TRIED];
         for (int k = 0; k < BC7_PARTITIONS_TRIED; k++) { cand[k] = 0; cerr[k] = 0xffffffffu; }
         for (int p = 0; p < 64; p++) {
@@ -227,16 +230,16 @@ CSKY_HD void bc7_encode_block(const unsigned char px[16][4], uint32_t out[4]) {
             for (int sub = 0; sub < 2; sub++) {
                 int sel[16], n = 0;
                 for (int i = 0; i < 16; i++) if ((int)((mask >> i) & 1u) == sub) sel[n++] = i;
-                int lo[3] = {255, 255, 255}, hi[3] = {0, 0, 0};
-                for (int i = 0; i < n; i++) for (int c = 0; c < 3; c++) { const int x = px[sel[i]][c]; lo[c] = x < lo[c] ? x : lo[c]; hi[c] = x > hi[c] ? x : hi[c]; }
+                int lo[4] = {255, 255, 255, 255}, hi[4] = {0, 0, 0, 0};
+                for (int i = 0; i < n; i++) for (int c = 0; c < D; c++) { const int x = px[sel[i]][c]; lo[c] = x < lo[c] ? x : lo[c]; hi[c] = x > hi[c] ? x : hi[c]; }
                 // squared distance of every texel to the box diagonal: what a line fit cannot remove
-                float d[3], dd = 0.0f;
-                for (int c = 0; c < 3; c++) { d[c] = (float)(hi[c] - lo[c]); dd += d[c] * d[c]; }
+                float d[4] = {0, 0, 0, 0}, dd = 0.0f;
+                for (int c = 0; c < D; c++) { d[c] = (float)(hi[c] - lo[c]); dd += d[c] * d[c]; }
                 for (int i = 0; i < n; i++) {
-                    float t = 0.0f, r2 = 0.0f, r[3];
-                    for (int c = 0; c < 3; c++) { r[c] = (float)(px[sel[i]][c] - lo[c]); t += r[c] * d[c]; }
+                    float t = 0.0f, r2 = 0.0f, r[4] = {0, 0, 0, 0};
+                    for (int c = 0; c < D; c++) { r[c] = (float)(px[sel[i]][c] - lo[c]); t += r[c] * d[c]; }
                     t = dd > 0.0f ? t / dd : 0.0f;
-                    for (int c = 0; c < 3; c++) { const float q = r[c] - t * d[c]; r2 += q * q; }
+                    for (int c = 0; c < D; c++) { const float q = r[c] - t * d[c]; r2 += q * q; }
                     est += (unsigned)(r2 + 0.5f);
                 }
             }
@@ -245,26 +248,36 @@ CSKY_HD void bc7_encode_block(const unsigned char px[16][4], uint32_t out[4]) {
                 cerr[k] = est; cand[k] = p; break;
             }
         }
-        for (int k = 0; k < BC7_PARTITIONS_TRIED; k++) {
-            const int p = cand[k];
-            const unsigned mask = bc7_part2_mask(p);
-            Bc7Subset s[2]; int sel[2][16], n[2] = {0, 0}, apos[2] = {0, 0};
-            for (int i = 0; i < 16; i++) { const int sub = (int)((mask >> i) & 1u); if (i == (sub ? bc7_anchor2(p) : 0)) apos[sub] = n[sub]; sel[sub][n[sub]++] = i; }
-            unsigned err = 0;
-            for (int sub = 0; sub < 2; sub++) { bc7_fit_subset<3>(px, v, sel[sub], n[sub], 0, 6, 2, 3, s[sub]); err += s[sub].err; }
-            if (err >= best_err) continue;
-            for (int sub = 0; sub < 2; sub++) bc7_fix_anchor(s[sub], n[sub], apos[sub], 3, 0, 3);
-            Bc7Bits b; b.pos = 0; for (int q = 0; q < 4; q++) b.w[q] = 0;
-            b.put(1u << 1, 2); b.put((uint32_t)p, 6);
-            for (int c = 0; c < 3; c++) for (int sub = 0; sub < 2; sub++) { b.put((uint32_t)s[sub].q0[c], 6); b.put((uint32_t)s[sub].q1[c], 6); }
-            b.put((uint32_t)s[0].p0, 1); b.put((uint32_t)s[1].p0, 1);
-            int pos[2] = {0, 0};
-            for (int i = 0; i < 16; i++) {
-                const int sub = (int)((mask >> i) & 1u);
-                const bool anchor = i == (sub ? bc7_anchor2(p) : 0);
-                b.put((uint32_t)s[sub].idx[pos[sub]++], anchor ? 2 : 3);
+        const int n_modes = opaque ? 2 : 1;
+        for (int mi = 0; mi < n_modes; mi++) {
+            const int mode = opaque ? (mi == 0 ? 1 : 3) : 7;
+            const int bits = mode == 1 ? 6 : (mode == 3 ? 7 : 5), pmode = mode == 1 ? 2 : 1, ibits = mode == 1 ? 3 : 2;
+            for (int k = 0; k < BC7_PARTITIONS_TRIED; k++) {
+                const int p = cand[k];
+                const unsigned mask = bc7_part2_mask(p);
+                Bc7Subset s[2]; int sel[2][16], n[2] = {0, 0}, apos[2] = {0, 0};
+                for (int i = 0; i < 16; i++) { const int sub = (int)((mask >> i) & 1u); if (i == (sub ? bc7_anchor2(p) : 0)) apos[sub] = n[sub]; sel[sub][n[sub]++] = i; }
+                unsigned err = 0;
+                for (int sub = 0; sub < 2; sub++) {
+                    if (opaque) bc7_fit_subset<3>(px, v, sel[sub], n[sub], 0, bits, pmode, ibits, s[sub]);
+                    else bc7_fit_subset<4>(px, v, sel[sub], n[sub], 0, bits, pmode, ibits, s[sub]);
+                    err += s[sub].err;
+                }
+                if (err >= best_err) continue;
+                for (int sub = 0; sub < 2; sub++) bc7_fix_anchor(s[sub], n[sub], apos[sub], ibits, 0, D);
+                Bc7Bits b; b.pos = 0; for (int q = 0; q < 4; q++) b.w[q] = 0;
+                b.put(1u << mode, mode + 1); b.put((uint32_t)p, 6);
+                for (int c = 0; c < D; c++) for (int sub = 0; sub < 2; sub++) { b.put((uint32_t)s[sub].q0[c], bits); b.put((uint32_t)s[sub].q1[c], bits); }
+                if (pmode == 2) { b.put((uint32_t)s[0].p0, 1); b.put((uint32_t)s[1].p0, 1); }
+                else for (int sub = 0; sub < 2; sub++) { b.put((uint32_t)s[sub].p0, 1); b.put((uint32_t)s[sub].p1, 1); }
+                int pos[2] = {0, 0};
+                for (int i = 0; i < 16; i++) {
+                    const int sub = (int)((mask >> i) & 1u);
+                    const bool anchor = i == (sub ? bc7_anchor2(p) : 0);
+                    b.put((uint32_t)s[sub].idx[pos[sub]++], anchor ? ibits - 1 : ibits);
+                }
+                best_err = err; best = b;
             }
-            best_err = err; best = b;
         }
     }
     for (int k = 0; k < 4; k++) out[k] = best.w[k];
