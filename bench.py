@@ -520,7 +520,7 @@ def main():
     # W warm-up steps and the K timed steps run exactly as asked.
     prewarm_frames = 0
     if not args.no_prewarm:
-        est_ms = 1.7 * tiles_per_rank / 32768.0 * primary / 128.0
+        est_ms = 1.7 * (((W + 7) // 8) * mb) / 32768.0 * primary / 128.0       # from the LARGEST rank share: every rank must run the same number of frames (collectives)
         prewarm_frames = int(min(1024, max(16, np.ceil(120.0 / max(est_ms, 1e-3))))) * G
         for _ in range(prewarm_frames):
             step()
