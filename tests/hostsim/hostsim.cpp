@@ -211,3 +211,28 @@ int hostsim_bc7_table_mismatches() {
     return bad;
 }
 }
+
+extern "C" {
+// The frame constants filtered from a whole sky LUT (frame_setup, what frame_setup_kernel runs) and from just the <= 12 texels the three taps touch,
+// parked tap-major as frame_setup_taps_kernel parks them in LDS (frame_setup_f with the LDS fetch): both FrameConsts, byte for byte.  Returns
+// sizeof(FrameConsts); `touched` receives the 12 texel indices (y * w + x) the second form asked for.
+int hostsim_frame_setup_two_ways(const float params[28], const uint16_t* sky_h, int sw, int sh, uint8_t* fc_whole, uint8_t* fc_taps, int touched[12]) {
+    const std::vector<float4> sky = widen(sky_h, sw, sh);
+    CloudParams P; memcpy(&P, params, sizeof P);
+    FrameConsts a, b;
+    memset(&a, 0, sizeof a); memset(&b, 0, sizeof b);
+    frame_setup(P, sky.data(), sw, sh, 128, 6, 0.0f, -1.0f, 2.0f, a);
+    float4 texel[12];
+    for (int k = 0; k < 12; k++) {                               // frame_setup_taps_kernel: texel k = corner k % 4 of tap k / 4
+        float sx, sy, ax, ay; int x0, x1, y0, y1;
+        frame_setup_tap_uv(P.LIGHT_DIRECTION, k >> 2, sx, sy);
+        sky_lut_cell(sw, sh, sx, sy, x0, x1, y0, y1, ax, ay);
+        const int x = (k & 1) ? x1 : x0, y = (k & 2) ? y1 : y0;
+        touched[k] = y * sw + x;
+        texel[k] = sky[(size_t)y * sw + x];
+    }
+    frame_setup_f(P, [&](int tap, int corner, int, int) { return texel[tap * 4 + corner]; }, sw, sh, 128, 6, 0.0f, -1.0f, 2.0f, b);
+    memcpy(fc_whole, &a, sizeof a); memcpy(fc_taps, &b, sizeof b);
+    return (int)sizeof(FrameConsts);
+}
+}

@@ -217,3 +217,20 @@ def test_eager_fetch_density_is_the_same_function(hostsim, pkg, oracle, noise, o
     lazy, eager = out[0::2], out[1::2]
     assert (lazy.view(np.uint32) == eager.view(np.uint32)).all()
     assert (lazy > 0).mean() > 0.02 and (lazy == 0).mean() > 0.05            # both outcomes are exercised
+
+
+def test_frame_constants_from_twelve_texels_equal_those_from_the_whole_lut(hostsim, oracle, o_trans):
+    """What a rank of an N-way frame split does (csky_render_sky_lut_rows_device: no whole LUT in memory): the frame set-up filters the LUT at three
+    places (clouds.glsl:163-167) and gets the <= 12 texels involved handed over tap-major, as frame_setup_taps_kernel parks them in LDS.  The
+    constants must be those of the whole-LUT set-up to the byte, for lights towards every octant, straight up / down (atan2(0, 0), clamped rows),
+    below the horizon and unnormalised; and the texels asked for are inside the LUT."""
+    import ctypes as C
+    sk = oracle.sky_lut(norm((1, 1, 0)), o_trans, 200, 100).view(np.uint16)
+    lights = [(1, 1, 0), (0, 1, 0), (0, -1, 0), (-1, 0.05, 0.3), (0.3, -0.2, -1), (-0.998773, 0.0495291, 2.69869e-07), (5, 3, -4), (0, 0.999, 1e-4), (1e-3, 0.2, 0)]
+    for l in lights:
+        p = oracle.default_params(256, 128, l)
+        p = np.ascontiguousarray(p, np.float32)
+        a = np.zeros(1024, np.uint8); b = np.zeros(1024, np.uint8); t = (C.c_int * 12)()
+        n = hostsim.hostsim_frame_setup_two_ways(p.ctypes.data_as(C.c_void_p), sk.ctypes.data_as(C.c_void_p), 200, 100, a.ctypes.data_as(C.c_void_p), b.ctypes.data_as(C.c_void_p), t)
+        assert 0 < n <= 1024 and (a[:n] == b[:n]).all(), l
+        assert all(0 <= v < 200 * 100 for v in t), (l, list(t))
