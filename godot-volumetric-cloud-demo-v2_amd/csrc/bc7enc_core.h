@@ -7,10 +7,11 @@
 // an encoder of this class gives is the SIZE of that difference: textures passed through encode -> csky_decode_bc7 (the decoder is pinned against an
 // independent one, tests/test_godot_import.py) and marched, next to the same frame from the uncompressed bytes (tools/bc7_sensitivity.py).
 //
-// Modes: 6 (one subset, RGBA 7777 + p-bit per end point, 4-bit indices); for opaque blocks 1 and 3 (two subsets out of 64 partitions: RGB 666 +
-// shared p-bit with 3-bit indices, RGB 777 + p-bits with 2-bit indices); for blocks whose alpha varies 5 (RGB 777 with 2-bit indices + a separately
-// indexed 8-bit scalar, four channel rotations) and 7 (two subsets, RGBA 5555 + p-bits, 2-bit indices) -- five of the eight; the three-subset
-// modes 0 and 2 and the 5/6-bit separate-alpha mode 4 are not tried.  Per candidate:
+// All eight modes: 6 (one subset, RGBA 7777 + p-bit per end point, 4-bit indices); for opaque blocks 1 and 3 (two subsets out of 64 partitions:
+// RGB 666 + shared p-bit with 3-bit indices, RGB 777 + p-bits with 2-bit indices) and 0 and 2 (three subsets: RGB 444 + p-bits with 3-bit indices out
+// of 16 partitions, RGB 555 with 2-bit indices out of 64); for blocks whose alpha varies 5 and 4 (RGB + a separately indexed scalar, four channel
+// rotations: 777 / 8 with two 2-bit index sets; 555 / 6 with a 2-bit and a 3-bit set either way round) and 7 (two subsets, RGBA 5555 + p-bits,
+// 2-bit indices).  Per candidate:
 // principal axis of the subset's texels (covariance, power iteration), end points at the extreme projections, quantisation to the mode's
 // precision over the p-bit choices, exhaustive index search against the palette THE DECODER builds (integer, bit for bit), up to three least-squares
 // refits of the end points for those indices; the candidate with the smallest summed squared error over the four channels wins.
@@ -40,6 +41,26 @@ CSKY_HD int bc7_anchor2(int p) {
                                  15, 15, 6, 8, 2, 8, 15, 15, 2, 8, 2, 2, 2, 15, 15, 6, 6, 2, 6, 8, 15, 15, 2, 2, 15, 15, 15, 15, 15, 2, 2, 15};
     return t[p];
 }
+// two bits per texel: its subset in three-subset partition p (kBc7Partition3), and the anchors of subsets 1 and 2 (kBc7Anchor3a / 3b)
+CSKY_HD unsigned bc7_part3_mask(int p) {
+    const unsigned t[64] = {0xAA685050u, 0x6A5A5040u, 0x5A5A4200u, 0x5450A0A8u, 0xA5A50000u, 0xA0A05050u, 0x5555A0A0u, 0x5A5A5050u, 0xAA550000u, 0xAA555500u, 0xAAAA5500u, 0x90909090u,
+                            0x94949494u, 0xA4A4A4A4u, 0xA9A59450u, 0x2A0A4250u, 0xA5945040u, 0x0A425054u, 0xA5A5A500u, 0x55A0A0A0u, 0xA8A85454u, 0x6A6A4040u, 0xA4A45000u, 0x1A1A0500u,
+                            0x0050A4A4u, 0xAAA59090u, 0x14696914u, 0x69691400u, 0xA08585A0u, 0xAA821414u, 0x50A4A450u, 0x6A5A0200u, 0xA9A58000u, 0x5090A0A8u, 0xA8A09050u, 0x24242424u,
+                            0x00AA5500u, 0x24924924u, 0x24499224u, 0x50A50A50u, 0x500AA550u, 0xAAAA4444u, 0x66660000u, 0xA5A0A5A0u, 0x50A050A0u, 0x69286928u, 0x44AAAA44u, 0x66666600u,
+                            0xAA444444u, 0x54A854A8u, 0x95809580u, 0x96969600u, 0xA85454A8u, 0x80959580u, 0xAA141414u, 0x96960000u, 0xAAAA1414u, 0xA05050A0u, 0xA0A5A5A0u, 0x96000000u,
+                            0x40804080u, 0xA9A8A9A8u, 0xAAAAAA44u, 0x2A4A5254u};
+    return t[p];
+}
+CSKY_HD int bc7_anchor3(int p, int sub) {
+    const unsigned char a[64] = {3, 3, 15, 15, 8, 3, 15, 15, 8, 8, 6, 6, 6, 5, 3, 3, 3, 3, 8, 15, 3, 3, 6, 10, 5, 8, 8, 6, 8, 5, 15, 15,
+                                 8, 15, 3, 5, 6, 10, 8, 15, 15, 3, 15, 5, 15, 15, 15, 15, 3, 15, 5, 5, 5, 8, 5, 10, 5, 10, 8, 13, 15, 12, 3, 3};
+    const unsigned char b[64] = {15, 8, 8, 3, 15, 15, 3, 8, 15, 15, 15, 15, 15, 15, 15, 8, 15, 8, 15, 3, 15, 8, 15, 8, 3, 15, 6, 10, 15, 15, 10, 8,
+                                 15, 3, 15, 10, 10, 8, 9, 10, 6, 15, 8, 15, 3, 6, 6, 8, 15, 3, 15, 15, 15, 15, 15, 15, 15, 15, 15, 15, 3, 15, 15, 8};
+    return sub == 0 ? 0 : (sub == 1 ? a[p] : b[p]);
+}
+// subset of texel i / anchor texel of subset `sub` in partition p of an ns-subset mode
+CSKY_HD int bc7_subset_of(int ns, int p, int i) { return ns == 2 ? (int)((bc7_part2_mask(p) >> i) & 1u) : (int)((bc7_part3_mask(p) >> (2 * i)) & 3u); }
+CSKY_HD int bc7_anchor_of(int ns, int p, int sub) { return ns == 2 ? (sub ? bc7_anchor2(p) : 0) : bc7_anchor3(p, sub); }
 CSKY_HD int bc7_lerp6(int a, int b, int w) { return ((64 - w) * a + w * b + 32) >> 6; }
 
 struct Bc7Bits {
@@ -219,17 +240,47 @@ CSKY_HD void bc7_encode_block(const unsigned char px[16][4], uint32_t out[4]) {
             best_err = err; best = b;
         }
     }
-    if (best_err != 0) {   // ---- two subsets: every partition estimated with a plain fit, the best few fitted in full in the modes the block class allows:
-        //      opaque: 1 (RGB 666 + shared p-bit, 3-bit indices) and 3 (RGB 777 + p-bit per end point, 2-bit indices); else 7 (RGBA 5555 + p-bits, 2-bit indices)
+    if (best_err != 0 && !opaque) {   // ---- mode 4: like 5 with RGB 555 / A 6 and a 2-bit + a 3-bit index set, either of which may serve the colour (index selector)
+        for (int rot = 0; rot < 4; rot++) {
+            unsigned char rp[16][4]; float rv[16][4];
+            for (int i = 0; i < 16; i++) {
+                for (int c = 0; c < 4; c++) rp[i][c] = px[i][c];
+                if (rot) { const unsigned char t = rp[i][3]; rp[i][3] = rp[i][rot - 1]; rp[i][rot - 1] = t; }
+                for (int c = 0; c < 4; c++) rv[i][c] = (float)rp[i][c];
+            }
+            for (int isel = 0; isel < 2; isel++) {
+                const int cb = isel ? 3 : 2, ab = isel ? 2 : 3;
+                Bc7Subset col, sc;
+                bc7_fit_subset<3>(rp, rv, all, 16, 0, 5, 0, cb, col);
+                bc7_fit_subset<1>(rp, rv, all, 16, 3, 6, 0, ab, sc);
+                const unsigned err = col.err + sc.err;
+                if (err >= best_err) continue;
+                bc7_fix_anchor(col, 16, 0, cb, 0, 3);
+                bc7_fix_anchor(sc, 16, 0, ab, 3, 4);
+                Bc7Bits b; b.pos = 0; for (int k = 0; k < 4; k++) b.w[k] = 0;
+                b.put(1u << 4, 5); b.put((uint32_t)rot, 2); b.put((uint32_t)isel, 1);
+                for (int c = 0; c < 3; c++) { b.put((uint32_t)col.q0[c], 5); b.put((uint32_t)col.q1[c], 5); }
+                b.put((uint32_t)sc.q0[3], 6); b.put((uint32_t)sc.q1[3], 6);
+                const Bc7Subset& two = isel ? sc : col;            // the 2-bit set is stored first, then the 3-bit one
+                const Bc7Subset& three = isel ? col : sc;
+                for (int i = 0; i < 16; i++) b.put((uint32_t)two.idx[i], i == 0 ? 1 : 2);
+                for (int i = 0; i < 16; i++) b.put((uint32_t)three.idx[i], i == 0 ? 2 : 3);
+                best_err = err; best = b;
+            }
+        }
+    }
+    // ---- two and three subsets: every partition estimated with a plain fit, the best few fitted in full in the modes the block class allows:
+    //      opaque: 1 (two subsets, RGB 666 + shared p-bit, 3-bit indices), 3 (two, RGB 777 + p-bit per end point, 2-bit), 0 (three subsets out of the
+    //      first 16 partitions, RGB 444 + p-bits, 3-bit), 2 (three, RGB 555, 2-bit); blocks whose alpha varies: 7 (two subsets, RGBA 5555 + p-bits, 2-bit)
+    for (int ns = 2; ns <= (opaque ? 3 : 2) && best_err != 0; ns++) {
         const int D = opaque ? 3 : 4;
-        int cand[BC7_PARTITIONS_TRIED]; unsigned cerr[BC7_PARTITIONS_TRIED];
-        for (int k = 0; k < BC7_PARTITIONS_TRIED; k++) { cand[k] = 0; cerr[k] = 0xffffffffu; }
+        int cand[BC7_PARTITIONS_TRIED], cand16[BC7_PARTITIONS_TRIED]; unsigned cerr[BC7_PARTITIONS_TRIED], cerr16[BC7_PARTITIONS_TRIED];
+        for (int k = 0; k < BC7_PARTITIONS_TRIED; k++) { cand[k] = cand16[k] = 0; cerr[k] = cerr16[k] = 0xffffffffu; }
         for (int p = 0; p < 64; p++) {
-            const unsigned mask = bc7_part2_mask(p);
             unsigned est = 0;
-            for (int sub = 0; sub < 2; sub++) {
+            for (int sub = 0; sub < ns; sub++) {
                 int sel[16], n = 0;
-                for (int i = 0; i < 16; i++) if ((int)((mask >> i) & 1u) == sub) sel[n++] = i;
+                for (int i = 0; i < 16; i++) if (bc7_subset_of(ns, p, i) == sub) sel[n++] = i;
                 int lo[4] = {255, 255, 255, 255}, hi[4] = {0, 0, 0, 0};
                 for (int i = 0; i < n; i++) for (int c = 0; c < D; c++) { const int x = px[sel[i]][c]; lo[c] = x < lo[c] ? x : lo[c]; hi[c] = x > hi[c] ? x : hi[c]; }
                 // squared distance of every texel to the box diagonal: what a line fit cannot remove
@@ -247,34 +298,36 @@ CSKY_HD void bc7_encode_block(const unsigned char px[16][4], uint32_t out[4]) {
                 for (int j = BC7_PARTITIONS_TRIED - 1; j > k; j--) { cerr[j] = cerr[j - 1]; cand[j] = cand[j - 1]; }
                 cerr[k] = est; cand[k] = p; break;
             }
+            if (p < 16) for (int k = 0; k < BC7_PARTITIONS_TRIED; k++) if (est < cerr16[k]) {   // mode 0 stores four partition bits
+                for (int j = BC7_PARTITIONS_TRIED - 1; j > k; j--) { cerr16[j] = cerr16[j - 1]; cand16[j] = cand16[j - 1]; }
+                cerr16[k] = est; cand16[k] = p; break;
+            }
         }
         const int n_modes = opaque ? 2 : 1;
         for (int mi = 0; mi < n_modes; mi++) {
-            const int mode = opaque ? (mi == 0 ? 1 : 3) : 7;
-            const int bits = mode == 1 ? 6 : (mode == 3 ? 7 : 5), pmode = mode == 1 ? 2 : 1, ibits = mode == 1 ? 3 : 2;
+            const int mode = !opaque ? 7 : (ns == 2 ? (mi == 0 ? 1 : 3) : (mi == 0 ? 0 : 2));
+            const int bits = mode == 1 ? 6 : (mode == 3 ? 7 : (mode == 0 ? 4 : 5)), pmode = mode == 1 ? 2 : (mode == 2 ? 0 : 1), ibits = (mode == 1 || mode == 0) ? 3 : 2;
             for (int k = 0; k < BC7_PARTITIONS_TRIED; k++) {
-                const int p = cand[k];
-                const unsigned mask = bc7_part2_mask(p);
-                Bc7Subset s[2]; int sel[2][16], n[2] = {0, 0}, apos[2] = {0, 0};
-                for (int i = 0; i < 16; i++) { const int sub = (int)((mask >> i) & 1u); if (i == (sub ? bc7_anchor2(p) : 0)) apos[sub] = n[sub]; sel[sub][n[sub]++] = i; }
+                const int p = mode == 0 ? cand16[k] : cand[k];
+                Bc7Subset s[3]; int sel[3][16], n[3] = {0, 0, 0}, apos[3] = {0, 0, 0};
+                for (int i = 0; i < 16; i++) { const int sub = bc7_subset_of(ns, p, i); if (i == bc7_anchor_of(ns, p, sub)) apos[sub] = n[sub]; sel[sub][n[sub]++] = i; }
                 unsigned err = 0;
-                for (int sub = 0; sub < 2; sub++) {
+                for (int sub = 0; sub < ns; sub++) {
                     if (opaque) bc7_fit_subset<3>(px, v, sel[sub], n[sub], 0, bits, pmode, ibits, s[sub]);
                     else bc7_fit_subset<4>(px, v, sel[sub], n[sub], 0, bits, pmode, ibits, s[sub]);
                     err += s[sub].err;
                 }
                 if (err >= best_err) continue;
-                for (int sub = 0; sub < 2; sub++) bc7_fix_anchor(s[sub], n[sub], apos[sub], ibits, 0, D);
+                for (int sub = 0; sub < ns; sub++) bc7_fix_anchor(s[sub], n[sub], apos[sub], ibits, 0, D);
                 Bc7Bits b; b.pos = 0; for (int q = 0; q < 4; q++) b.w[q] = 0;
-                b.put(1u << mode, mode + 1); b.put((uint32_t)p, 6);
-                for (int c = 0; c < D; c++) for (int sub = 0; sub < 2; sub++) { b.put((uint32_t)s[sub].q0[c], bits); b.put((uint32_t)s[sub].q1[c], bits); }
-                if (pmode == 2) { b.put((uint32_t)s[0].p0, 1); b.put((uint32_t)s[1].p0, 1); }
-                else for (int sub = 0; sub < 2; sub++) { b.put((uint32_t)s[sub].p0, 1); b.put((uint32_t)s[sub].p1, 1); }
-                int pos[2] = {0, 0};
+                b.put(1u << mode, mode + 1); b.put((uint32_t)p, mode == 0 ? 4 : 6);
+                for (int c = 0; c < D; c++) for (int sub = 0; sub < ns; sub++) { b.put((uint32_t)s[sub].q0[c], bits); b.put((uint32_t)s[sub].q1[c], bits); }
+                if (pmode == 2) { for (int sub = 0; sub < ns; sub++) b.put((uint32_t)s[sub].p0, 1); }
+                else if (pmode == 1) for (int sub = 0; sub < ns; sub++) { b.put((uint32_t)s[sub].p0, 1); b.put((uint32_t)s[sub].p1, 1); }
+                int pos[3] = {0, 0, 0};
                 for (int i = 0; i < 16; i++) {
-                    const int sub = (int)((mask >> i) & 1u);
-                    const bool anchor = i == (sub ? bc7_anchor2(p) : 0);
-                    b.put((uint32_t)s[sub].idx[pos[sub]++], anchor ? ibits - 1 : ibits);
+                    const int sub = bc7_subset_of(ns, p, i);
+                    b.put((uint32_t)s[sub].idx[pos[sub]++], i == bc7_anchor_of(ns, p, sub) ? ibits - 1 : ibits);
                 }
                 best_err = err; best = b;
             }

@@ -389,7 +389,7 @@ int csky_census_clouds(csky_ctx* ctx, const csky_cloud_params* p, int tile_w, co
 int csky_decode_bc7(const uint8_t* blocks, int w, int h, uint8_t* out_rgba8);
 /* The other direction, on the GPU (bc7enc.hip, one block per lane): n_images images of w x h RGBA8 texels back to back -> per image
  * ceil(h/4) x ceil(w/4) blocks of 16 bytes, row-major (a 3-D texture is its slices: one image per slice, every mip level its own call, as the
- * importer stores them).  Modes 6, 1 and 3 (opaque blocks), 5 and 7 (blocks whose alpha varies); principal-axis fit + least-squares refits, smallest
+ * importer stores them).  All eight modes (6; 0-3 for opaque blocks; 4, 5 and 7 for blocks whose alpha varies); principal-axis fit + least-squares refits, smallest
  * squared error wins.  It is NOT the engine's encoder (that one cannot be reproduced): textures passed through this and csky_decode_bc7 show the
  * SIZE of what compress/mode=2 does to a frame (tools/bc7_sensitivity.py), not the reference's exact texels. */
 int csky_encode_bc7(csky_ctx* ctx, const uint8_t* rgba8, int w, int h, int n_images, uint8_t* blocks_out);

@@ -207,6 +207,9 @@ int hostsim_bc7_table_mismatches() {
     for (int p = 0; p < 64; p++) {
         for (int i = 0; i < 16; i++) bad += (int)((bc7_part2_mask(p) >> i) & 1u) != (int)kBc7Partition2[p][i];
         bad += bc7_anchor2(p) != (int)kBc7Anchor2[p];
+        for (int i = 0; i < 16; i++) bad += bc7_subset_of(3, p, i) != (int)kBc7Partition3[p][i];
+        bad += bc7_anchor3(p, 1) != (int)kBc7Anchor3a[p];
+        bad += bc7_anchor3(p, 2) != (int)kBc7Anchor3b[p];
     }
     return bad;
 }
