@@ -198,3 +198,45 @@ def test_import_entry_points_refuse_bad_arguments_without_a_gpu(pkg, tmp_path):
     assert not small.any() and (w.value, h.value, n.value) == (4, 4, 1)
     assert L.csky_set_noise_mips(None, buf, buf, buf) == -1                   # NULL context
     assert L.csky_multi_set_noise_mips(None, buf, buf, buf) == -1 and L.csky_multi_set_frames_in_flight(None, 2) == -1
+
+
+def test_importer_shaped_files_with_real_bc7_payloads(pkg, hostsim, noise, tmp_path):
+    """The readers above are fed random blocks; here the payload is what an importer would actually store: the detail volume and a weather crop,
+    mip levels box-filtered, every slice BC7-encoded by the library's encoder (host twin of bc7enc.hip), wrapped in .ctex3d / .ctex containers.
+    Reading them back gives texels close to the source and exactly the decoded blocks; chains_from_godot_import would hand them to set_noise_mips."""
+    import ctypes as C
+    _, small, weather = noise
+
+    def enc(img4):
+        img4 = np.ascontiguousarray(img4, np.uint8)
+        n, h, w = img4.shape[:3]
+        out = np.zeros((n, (h + 3) // 4, (w + 3) // 4, 16), np.uint8)
+        hostsim.hostsim_bc7_encode(img4.ctypes.data_as(C.c_void_p), w, h, n, out.ctypes.data_as(C.c_void_p))
+        return out
+
+    chain = pkg.assets.build_mips(small, 6)
+    recs, levels, nm, o = [], [], 0, 0
+    for l in range(6):
+        m = 32 >> l
+        lv = chain[o:o + m ** 3 * 3].reshape(m, m, m, 3); o += m ** 3 * 3
+        rgba = np.concatenate([lv, np.full((m, m, m, 1), 255, np.uint8)], -1)
+        blocks = enc(rgba)
+        for z in range(m):
+            recs.append(image_record(m, m, FMT_BPTC, [blocks[z].tobytes()]))
+            nm += l > 0
+        levels.append((lv, blocks))
+    p3 = str(tmp_path / "worlnoise.bmp-0.bptc.ctex3d")
+    write_ctex3d(p3, 32, recs, nm)
+    got = pkg.assets.load_ctex3d(p3)
+    assert [g.shape for g in got] == [(32 >> l,) * 3 + (4,) for l in range(6)]
+    for l, (lv, blocks) in enumerate(levels):
+        m = 32 >> l
+        assert all((got[l][z] == pkg.assets.decode_bc7(blocks[z], m, m)).all() for z in range(m))
+        d = got[l][..., :3].astype(np.float64) - lv
+        assert 10 * np.log10(255.0 ** 2 / max(1e-9, (d * d).mean())) >= (33.0 if l == 0 else 28.0), l   # (coarser levels vary faster per block; the 1- and 2-texel levels are one padded block each)
+    crop = np.concatenate([weather[:64, :128], np.full((64, 128, 1), 255, np.uint8)], -1)
+    pw = str(tmp_path / "weather.bmp-0.bptc.ctex")
+    write_ctex(pw, image_record(128, 64, FMT_BPTC, [enc(crop)[0].tobytes()]))
+    (w0,) = pkg.assets.load_ctex(pw)
+    d = w0[..., :3].astype(np.float64) - crop[..., :3]
+    assert w0.shape == (64, 128, 4) and 10 * np.log10(255.0 ** 2 / (d * d).mean()) >= 45.0
