@@ -236,7 +236,7 @@ def test_importer_shaped_files_with_real_bc7_payloads(pkg, hostsim, noise, tmp_p
         assert 10 * np.log10(255.0 ** 2 / max(1e-9, (d * d).mean())) >= (33.0 if l == 0 else 28.0), l   # (coarser levels vary faster per block; the 1- and 2-texel levels are one padded block each)
     crop = np.concatenate([weather[:64, :128], np.full((64, 128, 1), 255, np.uint8)], -1)
     pw = str(tmp_path / "weather.bmp-0.bptc.ctex")
-    write_ctex(pw, image_record(128, 64, FMT_BPTC, [enc(crop)[0].tobytes()]))
+    write_ctex(pw, image_record(128, 64, FMT_BPTC, [enc(crop[None])[0].tobytes()]))
     (w0,) = pkg.assets.load_ctex(pw)
     d = w0[..., :3].astype(np.float64) - crop[..., :3]
     assert w0.shape == (64, 128, 4) and 10 * np.log10(255.0 ** 2 / (d * d).mean()) >= 45.0
