@@ -701,7 +701,9 @@ int csky_render_transmittance(csky_ctx* c, const csky_transmittance_params* p, u
     const int w = (int)p->texture_size[0], h = (int)p->texture_size[1];
     if (w < 1 || h < 1 || w > 8192 || h > 8192) return fail(c, CSKY_ERR_INVALID, "csky_render_transmittance: texture_size out of range");
     int rc; if ((rc = bind(c))) return rc;
-    HIPCHK(c, hipStreamSynchronize(c->pro));                 // sky LUTs in flight read the old transmittance LUT
+    // sky LUTs in flight read the old transmittance LUT: whole ones and the set-ups' own texels on the prologue stream, a rank's rows
+    // (csky_render_sky_lut_rows_device) on CALLER streams; the LUT is rendered once at load (transmittance_lut.gd:15-18), so wait for the device
+    HIPCHK(c, hipDeviceSynchronize());
     if ((rc = render_trans_dev(c, w, h, c->stream))) return rc;
     if (out) HIPCHK(c, hipMemcpyAsync(out, c->d_trans_h, (size_t)w * h * 8, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
@@ -1291,7 +1293,10 @@ int csky_multi_render_sky_lut(csky_multi* m, const csky_sky_params* p) {
     // device, whatever the group layout (a caller with a static sun renders the LUT once and then frames on all groups).
     const int n = (int)m->ctx.size();
     csky_ctx* c0 = m->ctx[0];
-    int rc; if ((rc = bind(c0))) return mpass(m, 0, rc);
+    int rc;
+    if (c0->d_sky_h && (c0->sw != w || c0->sh != h))            // a size change re-allocates the first device's LUT slots: no device may still be storing rows into them
+        for (int i = 0; i < n; i++) { if ((rc = bind(m->ctx[i]))) return mpass(m, i, rc); if (hipStreamSynchronize(m->ctx[i]->pro) != hipSuccess) return mfail(m, CSKY_ERR_HIP, "csky_multi_render_sky_lut: hipStreamSynchronize failed"); }
+    if ((rc = bind(c0))) return mpass(m, 0, rc);
     if ((rc = ensure_sky(c0, w, h))) return mpass(m, 0, rc);
     const int k = (c0->have_sky && c0->sky_in_memory) ? c0->sky_cur ^ 1 : c0->sky_cur;     // the other ring slot, as in csky_render_sky_lut_device
     // the readers of slot k (device copies of the LUT before last) sit on the first device's prologue stream: every writer queues behind them
