@@ -411,7 +411,7 @@ def main():
     ctx.render_transmittance(256, 64)               # once at load, transmittance_lut.gd:15-18
 
     # Frames are independent and a launch ends in a tail of few, long wavefronts; with two frames in flight on two streams the next
-    # frame's workgroups fill that tail (the library keeps per-frame state in four-deep rings ordered by events).  Measured on one
+    # frame's workgroups fill that tail (the library keeps per-frame state in eight-deep rings ordered by events).  Measured on one
     # GPU: whole frame 2.19 -> 1.90 ms; one rank's 1/2, 1/4, 1/8 share 1.09 -> 0.96, 0.67 -> 0.52, 0.43 -> 0.34 ms per frame
     # (tools/share_matrix.py).  Buffer set b = frame number mod frames in flight: band buffer, stream, gather target.
     # The rings are eight deep; more than two frames in flight only pay for small rank shares (a 1/8 share of C3: 0.31 -> 0.25 -> 0.22 ms per

@@ -20,7 +20,7 @@
  *   create_multi(device_ids: PackedInt32Array) -> int               the GPUs of the node behind this one object (csky_multi_*): every device
  *                                                                   renders its bands of each frame straight into the frame on the first one
  *   set_noise_mips(large_chain, small_chain, weather) -> int        explicit form of set_noise() with all mip levels back to back (the importer's own chains)
- *   set_frames(slots: int) -> int                                   frames kept in flight by submit/collect (1..4; default 2)
+ *   set_frames(slots: int) -> int                                   frames kept in flight by submit/collect (1..8; default 2)
  *   submit_clouds(pc: PackedFloat32Array, tile_w, tile_h: int) -> int   enqueue march + copy into a pinned ring slot, return a ticket (>= 0) at once, < 0 = error
  *   collect(ticket: int) -> PackedByteArray                         wait for that frame, return its bytes for rd.texture_update()
  *   is_ready(ticket: int) -> int                                    1 ready, 0 in flight, < 0 error

@@ -181,7 +181,7 @@ int csky_sync(csky_ctx* ctx); /* wait for the context's own streams (work on cal
  * submit_clouds() / collect() wrap (gdext/cloudsky_gdextension.c): the reference's frame loop (cloud_sky.gd:129-187 on frame_pre_draw,
  * rd.texture_update into the ring textures of :368-378) has a frame of slack by construction -- the cloud texture it draws with is the
  * one finished in an EARLIER update pass (:137-148). */
-int csky_set_host_ring(csky_ctx* ctx, int slots);   /* 1..4, default 2 */
+int csky_set_host_ring(csky_ctx* ctx, int slots);   /* 1..8, default 2 */
 int csky_submit_clouds(csky_ctx* ctx, const csky_cloud_params* p, int tile_w, int tile_h, int64_t* ticket);
 int csky_collect(csky_ctx* ctx, int64_t ticket, const uint16_t** frame_rgba16f, size_t* bytes);
 int csky_poll(csky_ctx* ctx, int64_t ticket);
