@@ -132,7 +132,7 @@ def test_submit_collect_over_the_pinned_ring(pkg, noise, gpu_ctx, oracle):
     ctx = pkg.Context(0)
     try:
         ctx.set_noise(*noise); ctx.set_march(128, 6); ctx.set_segments(1); ctx.render_transmittance(256, 64)
-        for slots in (1, 2, 3, 4):
+        for slots in (1, 2, 3, 4, 8):                                  # (8: round 4, rings eight deep)
             ctx.set_host_ring(slots)
             pending = []
             for k in range(3 * slots + 2):
