@@ -42,6 +42,23 @@ class CloudStats(C.Structure):
     _fields_ = [("rays", C.c_uint64), ("primary_samples", C.c_uint64), ("incloud_samples", C.c_uint64)]
 
 
+class ShapeNoiseParams(C.Structure):
+    """csky_shape_noise_params (include/cloudsky.h): the knobs of the stand-in shape-noise generator."""
+    _fields_ = [("perlin_freq", C.c_int32), ("perlin_octaves", C.c_int32), ("worley_freq", C.c_int32), ("perlin_gain", C.c_float), ("dilate", C.c_float),
+                ("centre", C.c_float), ("contrast", C.c_float), ("offset", C.c_float)]
+
+
+def shape_noise_params(**knobs):
+    """The generator's defaults with the given fields replaced."""
+    p = ShapeNoiseParams()
+    lib().csky_shape_noise_default_params(C.byref(p))
+    for k, v in knobs.items():
+        if k not in dict(ShapeNoiseParams._fields_):
+            raise TypeError("unknown shape-noise knob %r" % k)
+        setattr(p, k, v)
+    return p
+
+
 # every symbol include/cloudsky.h declares: (name, restype, argtypes)
 SYMBOLS = [
     ("csky_abi_version", C.c_int, []),
@@ -115,6 +132,10 @@ SYMBOLS = [
     ("csky_strip_to_volume", C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
     ("csky_generate_shape_noise", C.c_int, [C.c_uint32, C.c_int, C.c_void_p]),
     ("csky_generate_shape_noise_device", C.c_int, [C.c_void_p, C.c_uint32, C.c_int, C.c_void_p]),
+    ("csky_shape_noise_default_params", None, [C.c_void_p]),
+    ("csky_check_shape_noise_params", C.c_int, [C.c_void_p, C.c_int]),
+    ("csky_generate_shape_noise_tuned", C.c_int, [C.c_uint32, C.c_int, C.c_void_p, C.c_void_p]),
+    ("csky_generate_shape_noise_tuned_device", C.c_int, [C.c_void_p, C.c_uint32, C.c_int, C.c_void_p, C.c_void_p]),
     ("csky_generate_detail_noise", C.c_int, [C.c_uint32, C.c_int, C.c_void_p]),
     ("csky_generate_detail_noise_device", C.c_int, [C.c_void_p, C.c_uint32, C.c_int, C.c_void_p]),
     ("csky_build_mips_device", C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int]),
@@ -405,10 +426,11 @@ class Context:
         self._chk(self._L.csky_composite_view(self._h, C.byref(p), C.cast(v, C.c_void_p), _ptr(a[0]), _ptr(a[1]), _ptr(a[2]), _ptr(a[3]), _ptr(out)))
         return out.view(np.float16)
 
-    def generate_shape_noise(self, seed=1, n=128):
-        """GPU bake of the stand-in shape volume: uint8 [n, n, n, 4], byte-identical to assets.generate_shape_noise."""
+    def generate_shape_noise(self, seed=1, n=128, **knobs):
+        """GPU bake of the stand-in shape volume: uint8 [n, n, n, 4], byte-identical to assets.generate_shape_noise (knobs: ShapeNoiseParams fields)."""
         vol = np.zeros((n, n, n, 4), np.uint8)
-        self._chk(self._L.csky_generate_shape_noise_device(self._h, seed, n, _ptr(vol)))
+        p = shape_noise_params(**knobs)
+        self._chk(self._L.csky_generate_shape_noise_tuned_device(self._h, seed, n, C.byref(p), _ptr(vol)))
         return vol
 
     def generate_detail_noise(self, seed=1, n=32):

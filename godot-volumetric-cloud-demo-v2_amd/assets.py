@@ -55,10 +55,12 @@ def strip_to_volume(strip, n):
     return vol
 
 
-def generate_shape_noise(seed=SHAPE_SEED, n=128):
-    """Deterministic stand-in for the missing cloud_sky/perlworlnoise.tga: [z,y,x,4] uint8."""
+def generate_shape_noise(seed=SHAPE_SEED, n=128, **knobs):
+    """Deterministic stand-in for the missing cloud_sky/perlworlnoise.tga: [z,y,x,4] uint8.  knobs: fields of _lib.ShapeNoiseParams (README.md:30
+    TODO 3, a generator that can be tweaked); none = the calibration every benchmark and parity input uses."""
     vol = np.zeros((n, n, n, 4), np.uint8)
-    _chk(_lib.lib().csky_generate_shape_noise(seed, n, vol.ctypes.data_as(C.c_void_p)))
+    p = _lib.shape_noise_params(**knobs)
+    _chk(_lib.lib().csky_generate_shape_noise_tuned(seed, n, C.byref(p), vol.ctypes.data_as(C.c_void_p)))
     return vol
 
 

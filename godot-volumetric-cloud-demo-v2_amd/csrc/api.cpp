@@ -210,6 +210,23 @@ int ensure_order(csky_ctx* c, int slot, int mode, int tile_w, int tiles_x, int s
 }
 
 // frame_setup + clouds on stream s into d_out (compact rows).  stats: optional device counters.
+
+// The event pool of csky_set_kernel_timing grows to `want` events.  All or nothing: a hipEventCreate failing part-way used to leave null
+// entries in the pool for later timed launches to record on; now the new events made so far are destroyed and the pool keeps its old size.
+static int grow_timing_pool(csky_ctx* c, size_t want) {
+    const size_t old_n = c->kt_ev.size();
+    if (want <= old_n) return CSKY_OK;
+    c->kt_ev.resize(want, nullptr);
+    for (size_t i = old_n; i < want; i++) {
+        const hipError_t e = hipEventCreate(&c->kt_ev[i]);
+        if (e != hipSuccess) {
+            for (size_t j = old_n; j < i; j++) (void)hipEventDestroy(c->kt_ev[j]);
+            c->kt_ev.resize(old_n);
+            return fail(c, CSKY_ERR_HIP, "kernel timing: hipEventCreate: %s", hipGetErrorString(e));
+        }
+    }
+    return CSKY_OK;
+}
 int clouds_dev(csky_ctx* c, const csky_cloud_params* p, int tile_w, const csky_bands* b, uint2* d_out, size_t pitch_bytes, hipStream_t s,
                unsigned long long* d_stats, bool setup, bool out_full = false) {
     if (!p) return fail(c, CSKY_ERR_INVALID, "render_clouds: params is NULL");
@@ -300,9 +317,7 @@ int clouds_dev(csky_ctx* c, const csky_cloud_params* p, int tile_w, const csky_b
     hipEvent_t* kt = nullptr;                                    // timing pair of this launch (csky_set_kernel_timing)
     if (c->kt_on) {
         if ((size_t)c->kt_count * 2 + 2 > c->kt_ev.size()) {    // the pool grows on demand: no launch is ever dropped from the sum
-            const size_t old_n = c->kt_ev.size();
-            c->kt_ev.resize(old_n ? old_n * 2 : 512, nullptr);
-            for (size_t i = old_n; i < c->kt_ev.size(); i++) HIPCHK(c, hipEventCreate(&c->kt_ev[i]));
+            if ((rc = grow_timing_pool(c, c->kt_ev.empty() ? 512 : c->kt_ev.size() * 2))) return rc;
         }
         kt = &c->kt_ev[(size_t)c->kt_count * 2]; c->kt_count++;
     }
@@ -957,8 +972,7 @@ int csky_set_kernel_timing(csky_ctx* c, int enabled) {
     int rc; if ((rc = bind(c))) return rc;
     c->kt_on = enabled != 0; c->kt_count = 0;
     if (c->kt_on && c->kt_ev.empty()) {      // the first pool is made HERE, not by the first timed launch: 512 hipEventCreate calls are ~1 ms of host time, 3 % of a 20-frame timed region
-        c->kt_ev.resize(512, nullptr);
-        for (hipEvent_t& ev : c->kt_ev) HIPCHK(c, hipEventCreate(&ev));
+        if ((rc = grow_timing_pool(c, 512))) { c->kt_on = false; return rc; }
     }
     return CSKY_OK;
 }
@@ -1092,14 +1106,20 @@ static int composite_impl(csky_ctx* c, const csky_composite_params* p, const csk
     return CSKY_OK;
 }
 
-int csky_generate_shape_noise_device(csky_ctx* c, uint32_t seed, int n, uint8_t* out_rgba8) {
+int csky_generate_shape_noise_device(csky_ctx* c, uint32_t seed, int n, uint8_t* out_rgba8) { return csky_generate_shape_noise_tuned_device(c, seed, n, nullptr, out_rgba8); }
+int csky_generate_shape_noise_tuned_device(csky_ctx* c, uint32_t seed, int n, const csky_shape_noise_params* params, uint8_t* out_rgba8) {
     if (!c) return fail(nullptr, CSKY_ERR_INVALID, "csky_generate_shape_noise_device: ctx is NULL");
     if (!out_rgba8 || n < 8 || n > 512 || (n & (n - 1))) return fail(c, CSKY_ERR_INVALID, "csky_generate_shape_noise_device: n must be a power of two in [8, 512]");
+    ShapeNoiseParams P = shape_noise_defaults();
+    if (params) {
+        if (n >= 64 && csky_check_shape_noise_params(params, n)) return fail(c, CSKY_ERR_INVALID, "csky_generate_shape_noise_tuned_device: %s", csky_assets_last_error());
+        memcpy(&P, params, sizeof P);
+    }
     int rc; if ((rc = bind(c))) return rc;
     const size_t bytes = (size_t)n * n * n * 4;
     uint32_t* d = nullptr;
     HIPCHK(c, hipMalloc(reinterpret_cast<void**>(&d), bytes));
-    hipError_t e = launch_shape_noise(seed, n, d, c->stream);
+    hipError_t e = launch_shape_noise(seed, n, P, d, c->stream);
     if (e == hipSuccess) e = hipMemcpyAsync(out_rgba8, d, bytes, hipMemcpyDeviceToHost, c->stream);
     if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
     (void)hipFree(d);

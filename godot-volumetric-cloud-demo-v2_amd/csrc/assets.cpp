@@ -22,9 +22,9 @@
 
 namespace {
 
-void shape_rows(uint32_t seed, int n, int z0, int z1, uint8_t* out) {
+void shape_rows(uint32_t seed, int n, csky::ShapeNoiseParams P, int z0, int z1, uint8_t* out) {
     for (int z = z0; z < z1; z++) for (int y = 0; y < n; y++) for (int x = 0; x < n; x++)
-        csky::shape_voxel(seed, n, x, y, z, out + ((((size_t)z * n + y) * n + x) * 4));
+        csky::shape_voxel(seed, n, x, y, z, P, out + ((((size_t)z * n + y) * n + x) * 4));
 }
 
 }  // namespace
@@ -35,15 +35,36 @@ extern "C" {
 
 const char* csky_assets_last_error(void) { return g_asset_err; }
 
+void csky_shape_noise_default_params(csky_shape_noise_params* p) {
+    if (!p) return;
+    const csky::ShapeNoiseParams d = csky::shape_noise_defaults();
+    static_assert(sizeof(csky_shape_noise_params) == sizeof(csky::ShapeNoiseParams), "csky_shape_noise_params mirrors noise_core.h::ShapeNoiseParams");
+    memcpy(p, &d, sizeof d);
+}
+int csky_check_shape_noise_params(const csky_shape_noise_params* p, int n) {
+    // every octave needs at least one texel per cell (freq << octave <= n) or the lattice aliases; the curve's slope must be finite and positive
+    if (!p || p->perlin_freq < 1 || p->perlin_octaves < 1 || p->perlin_octaves > 8 || (p->perlin_freq << (p->perlin_octaves - 1)) > n || p->worley_freq < 1 || p->worley_freq * 16 > n ||
+        !(p->perlin_gain > 0.0f) || !(p->dilate >= 0.0f && p->dilate <= 1.0f) || !(p->contrast > 0.0f) || !(p->centre == p->centre) || !(p->offset == p->offset)) {
+        snprintf(g_asset_err, sizeof g_asset_err, "shape noise parameters out of range (perlin_freq << (octaves - 1) <= n, worley_freq * 16 <= n, gain > 0, 0 <= dilate <= 1, contrast > 0)");
+        return CSKY_ERR_INVALID;
+    }
+    return CSKY_OK;
+}
 int csky_generate_shape_noise(uint32_t seed, int n, uint8_t* out_rgba8) {
+    csky_shape_noise_params p; csky_shape_noise_default_params(&p);
+    return csky_generate_shape_noise_tuned(seed, n, &p, out_rgba8);
+}
+int csky_generate_shape_noise_tuned(uint32_t seed, int n, const csky_shape_noise_params* params, uint8_t* out_rgba8) {
     if (!out_rgba8 || n < 8 || (n & (n - 1))) { snprintf(g_asset_err, sizeof g_asset_err, "generate_shape_noise: n must be a power of two >= 8"); return CSKY_ERR_INVALID; }
+    csky::ShapeNoiseParams P = csky::shape_noise_defaults();
+    if (params) { if (n >= 64) { int rc = csky_check_shape_noise_params(params, n); if (rc) return rc; } memcpy(&P, params, sizeof P); }
     unsigned hw = std::thread::hardware_concurrency();
     int nt = (int)(hw == 0 ? 1 : (hw > 32 ? 32 : hw));
     if (nt > n) nt = n;
     std::vector<std::thread> th;
     for (int t = 0; t < nt; t++) {
         int z0 = (int)((long)n * t / nt), z1 = (int)((long)n * (t + 1) / nt);
-        th.emplace_back(shape_rows, seed, n, z0, z1, out_rgba8);
+        th.emplace_back(shape_rows, seed, n, P, z0, z1, out_rgba8);
     }
     for (auto& t : th) t.join();
     return CSKY_OK;

@@ -3,6 +3,7 @@
 #include <hip/hip_runtime_api.h>
 #include "csky_common.h"
 #include "composite_core.h"
+#include "noise_core.h"
 
 namespace csky {
 
@@ -41,7 +42,7 @@ hipError_t launch_static_order(int mode, int tiles_x, int slabs, int grid, uint3
 hipError_t launch_composite(const CompositeArgs& a, uint2* d_out, hipStream_t s);
 
 // stand-in shape noise bake: n^3 RGBA8 voxels (little-endian u32 = r | g<<8 | b<<16 | a<<24)
-hipError_t launch_shape_noise(uint32_t seed, int n, uint32_t* d_out, hipStream_t s);
+hipError_t launch_shape_noise(uint32_t seed, int n, const ShapeNoiseParams& P, uint32_t* d_out, hipStream_t s);
 
 // generated 32^3 RGB detail volume (noise_core.h::detail_voxel), 3 bytes per voxel
 hipError_t launch_detail_noise(uint32_t seed, int n, uint8_t* d_out, hipStream_t s);

@@ -144,17 +144,17 @@ hipError_t launch_interleave_bands(const void* d_gathered, size_t member_stride_
 
 // ------------------------------------------------------------------------------------------------ shape-noise bake
 // The stand-in 128^3 RGBA shape volume, one voxel per lane (bit-identical to the host generator: noise_core.h).
-__global__ __launch_bounds__(256) void shape_noise_kernel(uint32_t seed, int n, uint32_t* __restrict__ out) {
+__global__ __launch_bounds__(256) void shape_noise_kernel(uint32_t seed, int n, ShapeNoiseParams P, uint32_t* __restrict__ out) {
     const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
     if (i >= (size_t)n * n * n) return;
     const int x = (int)(i % n), y = (int)((i / n) % n), z = (int)(i / ((size_t)n * n));
     uint8_t o[4];
-    shape_voxel(seed, n, x, y, z, o);
+    shape_voxel(seed, n, x, y, z, P, o);
     out[i] = (uint32_t)o[0] | ((uint32_t)o[1] << 8) | ((uint32_t)o[2] << 16) | ((uint32_t)o[3] << 24);
 }
-hipError_t launch_shape_noise(uint32_t seed, int n, uint32_t* d_out, hipStream_t s) {
+hipError_t launch_shape_noise(uint32_t seed, int n, const ShapeNoiseParams& P, uint32_t* d_out, hipStream_t s) {
     const size_t total = (size_t)n * n * n;
-    shape_noise_kernel<<<(unsigned)((total + 255) / 256), 256, 0, s>>>(seed, n, d_out);
+    shape_noise_kernel<<<(unsigned)((total + 255) / 256), 256, 0, s>>>(seed, n, P, d_out);
     return hipGetLastError();
 }
 

@@ -70,24 +70,39 @@ CSKY_HD float remapf(float v, float omin, float omax, float nmin, float nmax) { 
 CSKY_HD float clamp01(float v) { return v < 0.0f ? 0.0f : (v > 1.0f ? 1.0f : v); }
 CSKY_HD uint8_t unorm8(float v) { return (uint8_t)(int)(clamp01(v) * 255.0f + 0.5f); }
 
+// The knobs of the stand-in shape generator (README.md:30 TODO 3: "a noise generator so custom noise can be created and tweaked").  The defaults
+// are the calibration every benchmark and parity input uses (seed 1: tests/golden/INPUTS.txt pins its SHA-256); tools/demo_scene.py sweeps them to
+// say which one moves which statistic of the rendered sky towards the reference's screenshots (profiles/r05/demo_scene_fit.txt).
+// == csky_shape_noise_params of include/cloudsky.h, field for field.
+struct ShapeNoiseParams {
+    int perlin_freq;        // base period of the R channel's Perlin fBm in cells per volume edge (4: ~3 km features at 97.66 m per texel)
+    int perlin_octaves;     // octaves of that fBm (5), amplitude halving per octave
+    int worley_freq;        // base frequency of the G channel's Worley fBm (4); B and A use 2x and 4x of it
+    float perlin_gain;      // p01 = clamp(fBm * gain + 0.5)                                   (0.9)
+    float dilate;           // R = remap(p01, 0, 1, G * dilate, 1): how far the Worley cells carve the Perlin field  (0.55)
+    float centre, contrast, offset;   // R = clamp((R - centre) * contrast + offset): the contrast curve        (0.38, 1.75, 0.32)
+};
+CSKY_HD ShapeNoiseParams shape_noise_defaults() { ShapeNoiseParams p; p.perlin_freq = 4; p.perlin_octaves = 5; p.worley_freq = 4; p.perlin_gain = 0.9f; p.dilate = 0.55f; p.centre = 0.38f; p.contrast = 1.75f; p.offset = 0.32f; return p; }
+
 // One voxel of the stand-in shape volume (R = Perlin-Worley, G/B/A = Worley fBm octaves).  Integer hashing + IEEE
 // +,-,*,/,sqrt only, FP contraction off: bit-identical on the host and on the GPU.
-CSKY_HD void shape_voxel(uint32_t seed, int n, int x, int y, int z, uint8_t o[4]) {
+CSKY_HD void shape_voxel(uint32_t seed, int n, int x, int y, int z, const ShapeNoiseParams& P, uint8_t o[4]) {
     const float inv = 1.0f / (float)n;
     const float u = ((float)x + 0.5f) * inv, v = ((float)y + 0.5f) * inv, w = ((float)z + 0.5f) * inv;
     // G/B/A: inverted Worley fBm at rising base frequency (Schneider / "Nubis" layout)
-    const float g = worley_fbm(u, v, w, 4, seed * 101U + 11U);
-    const float b = worley_fbm(u, v, w, 8, seed * 101U + 23U);
-    const float a = worley_fbm(u, v, w, 16, seed * 101U + 37U);
-    // R: low-frequency Perlin fBm dilated by the first Worley fBm ("Perlin-Worley"), then a fixed contrast curve
+    const float g = worley_fbm(u, v, w, P.worley_freq, seed * 101U + 11U);
+    const float b = worley_fbm(u, v, w, P.worley_freq * 2, seed * 101U + 23U);
+    const float a = worley_fbm(u, v, w, P.worley_freq * 4, seed * 101U + 37U);
+    // R: low-frequency Perlin fBm dilated by the first Worley fBm ("Perlin-Worley"), then a contrast curve whose defaults were
     // calibrated so that the default coverage (0.2) gives mean alpha in 0.3-0.6 (the original asset is
     // missing so this is a calibration, not a reconstruction).
-    const float pf = perlin_fbm(u, v, w, 4, 5, seed * 101U + 53U);        // ~[-0.6, 0.6]
-    const float p01 = clamp01(pf * 0.9f + 0.5f);
-    const float pw = remapf(p01, 0.0f, 1.0f, g * 0.55f, 1.0f);            // dilate towards the worley cells
-    const float r = clamp01((pw - 0.38f) * 1.75f + 0.32f);
+    const float pf = perlin_fbm(u, v, w, P.perlin_freq, P.perlin_octaves, seed * 101U + 53U);   // ~[-0.6, 0.6]
+    const float p01 = clamp01(pf * P.perlin_gain + 0.5f);
+    const float pw = remapf(p01, 0.0f, 1.0f, g * P.dilate, 1.0f);         // dilate towards the worley cells
+    const float r = clamp01((pw - P.centre) * P.contrast + P.offset);
     o[0] = unorm8(r); o[1] = unorm8(g); o[2] = unorm8(b); o[3] = unorm8(a);
 }
+CSKY_HD void shape_voxel(uint32_t seed, int n, int x, int y, int z, uint8_t o[4]) { shape_voxel(seed, n, x, y, z, shape_noise_defaults(), o); }
 
 // One voxel of a generated 32^3 RGB detail volume in the role of cloud_sky/worlnoise.bmp (README.md:30 TODO 3: "generate the noise on
 // the GPU"): three tileable inverted-Worley fBm channels of rising frequency.  Calibrated against the shipped worlnoise.bmp (SURVEY A.8;

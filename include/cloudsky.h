@@ -352,6 +352,18 @@ int csky_load_bmp_rgb8(const char* path, int* w, int* h, uint8_t* out_rgb8, size
 int csky_load_tga_rgba8(const char* path, int* w, int* h, uint8_t* out_rgba8, size_t out_capacity);
 int csky_strip_to_volume(const uint8_t* strip, int n, int ch, uint8_t* vol);
 int csky_generate_shape_noise(uint32_t seed, int n, uint8_t* out_rgba8);
+/* The generator's knobs (README.md:30 TODO 3: "a noise generator so custom noise can be created and tweaked").  csky_generate_shape_noise uses
+ * csky_shape_noise_default_params, the calibration every benchmark and parity input is made with; other settings are for looking at what the
+ * missing asset's character does to the picture (tools/demo_scene.py).  R = clamp((remap(clamp(perlin_fbm * perlin_gain + 0.5), 0, 1,
+ * G * dilate, 1) - centre) * contrast + offset); G / B / A = inverted Worley fBm at worley_freq x 1 / 2 / 4. */
+typedef struct csky_shape_noise_params {
+    int32_t perlin_freq, perlin_octaves, worley_freq;
+    float perlin_gain, dilate, centre, contrast, offset;
+} csky_shape_noise_params;
+void csky_shape_noise_default_params(csky_shape_noise_params* p);
+int csky_check_shape_noise_params(const csky_shape_noise_params* p, int n);
+int csky_generate_shape_noise_tuned(uint32_t seed, int n, const csky_shape_noise_params* params, uint8_t* out_rgba8);
+int csky_generate_shape_noise_tuned_device(csky_ctx* ctx, uint32_t seed, int n, const csky_shape_noise_params* params, uint8_t* out_rgba8);
 /* The same generator as a HIP kernel (one voxel per lane): byte-identical output, ~1 ms for 128^3 (README.md:30 TODO 3). */
 int csky_generate_shape_noise_device(csky_ctx* ctx, uint32_t seed, int n, uint8_t* out_rgba8);
 /* A generated 32^3 RGB detail volume in the role of worlnoise.bmp (three tileable inverted-Worley fBm channels calibrated on the asset's

@@ -134,3 +134,22 @@ def test_tga_loader_matches_pil(pkg, tmp_path):
     bad.write_bytes(bytes(18))
     with pytest.raises(pkg.CloudSkyError):
         pkg.assets.load_tga_rgba8(str(bad))
+
+
+def test_tuned_shape_generator_defaults_are_the_benchmark_volume_and_knobs_move_only_their_channels(pkg):
+    """csky_generate_shape_noise_tuned (README.md:30 TODO 3: a generator that can be tweaked): with csky_shape_noise_default_params it IS
+    csky_generate_shape_noise; the R-channel knobs leave G / B / A alone; out-of-range settings are refused, not rendered."""
+    import pytest
+    base = pkg.assets.generate_shape_noise(3, 64)
+    assert (pkg.assets.generate_shape_noise(3, 64, **{}) == base).all()
+    p = pkg._lib.shape_noise_params()
+    assert (p.perlin_freq, p.perlin_octaves, p.worley_freq) == (4, 5, 4) and abs(p.dilate - 0.55) < 1e-7 and abs(p.contrast - 1.75) < 1e-7
+    finer = pkg.assets.generate_shape_noise(3, 64, perlin_freq=8, perlin_octaves=4, dilate=0.8)
+    assert (finer[..., 1:] == base[..., 1:]).all() and (finer[..., 0] != base[..., 0]).mean() > 0.5
+    w8 = pkg.assets.generate_shape_noise(3, 128, worley_freq=8)
+    assert (w8[..., 1] != pkg.assets.generate_shape_noise(3, 128)[..., 1]).mean() > 0.5
+    for bad in (dict(perlin_freq=0), dict(perlin_freq=32, perlin_octaves=4), dict(worley_freq=16), dict(contrast=0.0), dict(dilate=1.5), dict(perlin_gain=float("nan"))):
+        with pytest.raises(pkg.CloudSkyError):
+            pkg.assets.generate_shape_noise(3, 64, **bad)
+    with pytest.raises(TypeError):
+        pkg.assets.generate_shape_noise(3, 64, no_such_knob=1)

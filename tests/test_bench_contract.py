@@ -44,6 +44,9 @@ def test_bench_line_contract_single_gpu():
     assert d["config"]["workload"].startswith("C3: 2048x1024") and d["config"]["finite"] is True
     assert abs(d["value"] - 2048 * 1024 / d["ms_per_step"] / 1e3) < 1e-6 * d["value"]
     assert 100.0 < d["value"] < 1e5 and d["value_one_frame_at_a_time"]["value"] <= d["value"] * 1.15
+    # both protocols in the one line: the W + K steps exactly as asked, run first and cold, next to the same region after the clock pre-warm
+    assert abs(d["value_as_asked"] - 2048 * 1024 / d["ms_per_step_as_asked"] / 1e3) < 1e-6 * d["value_as_asked"] and d["as_asked"]["value"] == d["value_as_asked"]
+    assert d["config"]["clock_prewarm_frames"] > 0 and 0.5 * d["value"] < d["value_as_asked"] < 1.1 * d["value"]
     for k in ("value_host_form", "ranks_seen", "per_rank_share_ms"):
         assert k in d, k
     assert d["value_host_form"]["2_in_flight"]["Mrays_per_s"] > d["value_host_form"]["1_in_flight"]["Mrays_per_s"] > 100.0
@@ -61,7 +64,8 @@ def test_bench_line_contract_single_gpu():
     assert abs(guide - r["achieved"]) < 1e-6 * guide
     assert abs(r["frac"] - guide / (ka["kernel_ms"] * 1e-3 * ka["sclk_mhz"] * 1e6)) < 1e-9 and r["frac"] == ka["frac"]
     assert 0.3 < r["frac"] <= 1.0 and r["frac"] <= r["frac_calibrated"] <= 1.0 and 1500 < ka["sclk_mhz"] < 2600
-    assert r["frac"] <= 1.1 * r["frac_timed_region"] and r["frac_timed_region"] <= 1.0 and r["frac_timed_region"] == tr["frac"] and tr["frac"] <= tr["frac_calibrated"] <= 1.05   # (only 6 timed steps here: fill and drain weigh on ms_per_step)
+    assert r["frac"] <= 1.1 * r["frac_timed_region"] and r["frac_timed_region"] <= 1.0 and r["frac_timed_region"] == tr["frac"] and tr["frac"] <= tr["frac_calibrated"] <= 1.05   # (only 6 timed steps here: fill and drain weigh on ms_per_step; the 5 % of slack on the time-priced
+    # fraction: its per-kind costs were measured on pure instruction streams, which run the chip at 2.0-2.35 GHz where this kernel runs at 2.38 -- an upper estimate by that ratio, bench.py roofline.note)
     assert 0.5 * d["ms_per_step"] < tr["ms_per_frame_while_sampling"] <= 1.25 * d["ms_per_step"]   # (6 timed steps pay the pipeline's fill and drain; the sampled loop runs >= 0.4 s)
     et = r["executed_tap_bytes"]
     assert et["in_cloud_samples_match_this_run"] and 0.4 < et["over_algorithmic"] < 0.8 and et["bytes_per_launch"] < r["hbm_algorithmic"]["bytes_per_launch_incl_light_march"]
@@ -72,9 +76,10 @@ def test_bench_line_contract_single_gpu():
     assert c["kind"] == "port" and c["cores"] >= 1 and c["value"] > 0 and "sample" in c
 
 
-@pytest.mark.parametrize("fif", [4])                         # (one case per mode; the default rotation of two is what test_bench_gpus_2_starts_its_own_ranks runs)
+@pytest.mark.parametrize("fif", [4, 8])                      # (the default rotation of two is what test_bench_gpus_2_starts_its_own_ranks runs)
 def test_bench_two_ranks_on_one_gpu_through_gloo(fif):
-    """fif = 4: the buffer-set rotation of small rank shares (the default at N = 8), steps chosen so that the drain starts mid-rotation."""
+    """fif = 4 / 8: the buffer-set rotation of small rank shares (8 = the default at N = 8, the depth of the rings: ADVICE r4), steps chosen so that
+    the drain starts mid-rotation (7 steps: 7 mod 4 = 3, 7 mod 8 = 7)."""
     env = dict(os.environ, CSKY_BENCH_ONE_GPU_DEBUG="1")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", str(_free_port()),
            os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "4" if fif is None else "7", "--warmup", "1", "--no-cpu-baseline"]

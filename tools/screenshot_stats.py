@@ -2,12 +2,12 @@
 """screenshot_stats.py -- three coarse statistics of a tonemapped sky image, shared by tools/demo_scene.py (our renders) and the reference's
 screenshots (screenshots/*.png: the only image evidence the reference holds; tonemapped, camera-projected, sun / wind / coverage unknown).
 
-    horizon_row        fraction of the image height at which the strongest horizontal luminance edge of the lower half sits (column median)
+    horizon_row        fraction of the image height at which the strongest luminance edge spanning the whole width sits in the lower half (row of the largest column-median vertical gradient)
     glow               centroid (x, y as fractions) and mean luminance of the brightest 0.5 % of the pixels: where the sun's glow is, if in view
     cloud_cover        above the horizon: share of pixels that are cloud rather than clear sky (saturation (max - min) / max below 0.30 at
                        luminance above 0.25: white / grey versus blue)
 
-Run with no arguments IN THE BUILD CONTAINER it reads /root/reference/screenshots/*.png and writes profiles/r04/reference_screenshot_stats.json
+Run with no arguments IN THE BUILD CONTAINER it reads /root/reference/screenshots/*.png and writes profiles/r05/reference_screenshot_stats.json
 (data derived from the reference's images; the images themselves are not copied).  Qualitative: what it can catch is a shared misreading of an
 axis or row order (clouds below the horizon, a mirrored sun, the hemisphere upside down), not a per-pixel difference."""
 import json
@@ -17,6 +17,28 @@ import sys
 import numpy as np
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def mask_spectrum(mask, full_width):
+    """Radially averaged power spectrum of the cloud / clear-sky mask, so that "blobby" versus "billowy" is a number: the share of the mask's
+    variance in three bands of spatial frequency (cycles per image WIDTH, so that renders of different resolution compare) and the power-weighted
+    mean frequency.  The mask is the above-horizon crop, mean removed, Hann-windowed; frequencies above 64 cycles per width are left out (the
+    screenshots are 1147 wide, TAA-blurred; the tool's own renders can be narrower)."""
+    m = np.asarray(mask, np.float64)
+    h, w = m.shape
+    if h < 16 or w < 16 or m.std() == 0:
+        return None
+    m = (m - m.mean()) * np.hanning(h)[:, None] * np.hanning(w)[None, :]
+    p = np.abs(np.fft.fft2(m)) ** 2
+    ky = np.fft.fftfreq(h)[:, None] * h * (full_width / h)     # cycles per image width (square pixels)
+    kx = np.fft.fftfreq(w)[None, :] * w * (full_width / w)
+    k = np.hypot(kx, ky)
+    keep = (k >= 1.0) & (k <= 64.0)
+    tot = p[keep].sum()
+    if tot <= 0:
+        return None
+    bands = {"1-4": (1, 4), "4-16": (4, 16), "16-64": (16, 64.0001)}
+    return {"power_share": {n: float(p[(k >= a) & (k < b)].sum() / tot) for n, (a, b) in bands.items()}, "mean_cycles_per_width": float((p[keep] * k[keep]).sum() / tot)}
 
 
 def stats(rgb):
@@ -29,9 +51,14 @@ def stats(rgb):
     blur = (c[2 * k + 1:] - c[:-(2 * k + 1)]) / (2 * k + 1)     # rows k .. h-k-1
     g = np.abs(blur[2:] - blur[:-2])                            # rows k+1 .. h-k-2
     lo = h // 2 - (k + 1)
-    rows = np.argmax(g[lo:], 0) + lo + k + 1
-    horizon = float(np.median(rows) / h)
-    edge_strength = float(np.median(np.max(g[lo:], 0)))
+    # the horizon is ONE straight row: score every row by the column MEDIAN of its vertical gradient and take the best row of the lower half.
+    # (Round 4 took each column's own strongest edge and then the median of those rows: in a dusk picture the cloud edges are stronger than the
+    # dim horizon, most columns latch onto a cloud and the median lands in the clouds -- 0.612 for the scene as committed against 0.915 from
+    # the camera's geometry.  A cloud edge crosses a given row in few columns, so it cannot win a column median.)
+    rowscore = np.median(g[lo:], 1)
+    best = int(np.argmax(rowscore))
+    horizon = float((best + lo + k + 1) / h)
+    edge_strength = float(rowscore[best])
     thr = np.quantile(lum, 0.995)
     yy, xx = np.nonzero(lum >= thr)
     glow = {"x": float(xx.mean() / w), "y": float(yy.mean() / h), "mean_luminance": float(lum[lum >= thr].mean()), "spread": float(np.hypot(xx.std() / w, yy.std() / h))}
@@ -40,7 +67,8 @@ def stats(rgb):
     mx, mn = sky.max(-1), sky.min(-1)
     sat = (mx - mn) / np.maximum(mx, 1e-6)
     cloud = (sat < 0.30) & (sky @ np.array([0.2126, 0.7152, 0.0722]) > 0.25)
-    return {"size": [w, h], "horizon_row": horizon if edge_strength > 0.01 else None, "horizon_edge_strength": edge_strength, "glow": glow,
+    spec = mask_spectrum(cloud, w)
+    return {"cloud_mask_spectrum": spec, "size": [w, h], "horizon_row": horizon if edge_strength > 0.01 else None, "horizon_edge_strength": edge_strength, "glow": glow,
             "cloud_cover": float(cloud.mean()), "mean_rgb_above_horizon": [float(v) for v in sky.reshape(-1, 3).mean(0)]}
 
 
@@ -55,8 +83,8 @@ if __name__ == "__main__":
         for n in sorted(os.listdir(src)):
             if n.endswith(".png"):
                 out["screenshots/" + n] = stats(np.asarray(Image.open(os.path.join(src, n)).convert("RGB"), np.float64) / 255.0)
-        os.makedirs(os.path.join(ROOT, "profiles", "r04"), exist_ok=True)
-        json.dump(out, open(os.path.join(ROOT, "profiles", "r04", "reference_screenshot_stats.json"), "w"), indent=1)
+        os.makedirs(os.path.join(ROOT, "profiles", "r05"), exist_ok=True)
+        json.dump(out, open(os.path.join(ROOT, "profiles", "r05", "reference_screenshot_stats.json"), "w"), indent=1)
         print(json.dumps(out, indent=1))
     else:
         print("no screenshots here: pass image files")
