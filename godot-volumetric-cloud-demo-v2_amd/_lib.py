@@ -59,7 +59,7 @@ def shape_noise_params(**knobs):
     return p
 
 
-# every symbol include/cloudsky.h declares: (name, restype, argtypes)
+# every symbol include/cloudsky.h and include/cloudsky_internal.h declare: (name, restype, argtypes); INTERNAL names the second header's (the lab bench)
 SYMBOLS = [
     ("csky_abi_version", C.c_int, []),
     ("csky_device_count", C.c_int, []),
@@ -152,7 +152,7 @@ SYMBOLS = [
 
 
 DEFAULT_VARIANT = 3   # include/cloudsky.h CSKY_DEFAULT_VARIANT ("compact"); set_variant(-1) selects it
-ABI_VERSION = 5       # include/cloudsky.h CSKY_ABI_VERSION
+ABI_VERSION = 6       # include/cloudsky.h CSKY_ABI_VERSION
 
 
 def library_path():

@@ -1,4 +1,4 @@
-// api.cpp -- the C ABI of libcloudsky (include/cloudsky.h): context, device memory, texture baking, launches.
+// api.cpp -- the C ABI of libcloudsky (include/cloudsky.h; the measurement / tuning / test entry points: include/cloudsky_internal.h): context, device memory, texture baking, launches.
 // Mirrors the resource ownership of the reference's GDScript drivers: cloud_sky.gd (`_initialize_compute_code`,
 // `_render_process`, `cleanup`), sky_lut.gd (`render_lut`), transmittance_lut.gd (`_initialize_compute_code`).
 // There is no CPU render path here: every render entry point needs a live HIP device.
@@ -13,7 +13,8 @@
 #include <string>
 #include <vector>
 #include <unistd.h>
-#include "../../include/cloudsky.h"
+#include <sys/stat.h>
+#include "../../include/cloudsky_internal.h"
 #include "kernels.h"
 #include "bake.h"
 #include "bake_core.h"
@@ -275,7 +276,8 @@ int clouds_dev(csky_ctx* c, const csky_cloud_params* p, int tile_w, const csky_b
     const bool queued = variant == 1 || variant == 3;
     int seg = c->cell32 ? 1 : (queued ? c->segments : 1);
     int auto_mode;
-    if (c->variant == 3 && c->frames_in_flight >= 2) {
+    // (the policy below is written for the kernel that RUNS: `variant`, not c->variant -- exact cells always march with the compact whole-ray kernel)
+    if (variant == 3 && c->frames_in_flight >= 2) {
         // the caller keeps two frames in flight on two streams (csky_set_frames_in_flight): the next frame's workgroups fill this
         // launch's tail, so fewer, longer wavefronts win (tools/share_matrix.py, ms per frame at 1/2, 1/4, 1/8, 1/16 of the frame):
         //   seg 1: 0.96 (s5) 0.52 (s7) 0.42 0.35    seg 2: 1.18 0.61 0.34 (s7) 0.29    seg 4: 1.27 0.75 0.39 0.22 (s7)
@@ -287,7 +289,7 @@ int clouds_dev(csky_ctx* c, const csky_cloud_params* p, int tile_w, const csky_b
         const int whole_from = c->frames_in_flight >= 3 ? 3072 : 6144;
         if (queued && seg == 0) seg = waves >= whole_from ? 1 : (waves >= 3072 ? 2 : (waves >= 768 ? 4 : 5));
         auto_mode = (waves >= 12288 || (c->frames_in_flight >= 6 && waves >= 3072)) ? 5 : (waves >= 768 ? 7 : 2);
-    } else if (c->variant == 3) {
+    } else if (variant == 3) {
         if (queued && seg == 0) seg = waves >= 12288 ? 1 : (waves >= 6144 ? 2 : (waves >= 768 ? 4 : 5));
         auto_mode = waves >= 24576 ? 5 : (waves >= 1536 ? 7 : 2);
     } else {
@@ -529,6 +531,11 @@ static int set_noise_impl(csky_ctx* c, const uint8_t* large_rgba8, const uint8_t
         if (c->inexact_coeffs)
             snprintf(c->warn, sizeof c->warn, "csky_set_noise: %llu finite-difference coefficients of these textures do not fit fp16: marching on exact fp32 cells "
                      "(twice the bytes per tap; the whole-ray compact kernel)", c->inexact_coeffs);
+    } else {
+        // textures that fit fp16 again: the ~150 MB of exact cells of an earlier bind are not kept until csky_destroy (nothing is in flight: the device was synchronised above)
+        if (c->d_shape32) { (void)hipFree(c->d_shape32); c->d_shape32 = nullptr; }
+        if (c->d_detail32) { (void)hipFree(c->d_detail32); c->d_detail32 = nullptr; }
+        if (c->d_weather32) { (void)hipFree(c->d_weather32); c->d_weather32 = nullptr; }
     }
     c->have_noise = true;
     return CSKY_OK;
@@ -867,7 +874,8 @@ int csky_poll(csky_ctx* c, int64_t ticket) {
 }
 
 // ---- zero-copy interop: a frame that lives in memory another API allocated (cloudsky.h; gdext/unverified/zero_copy_vulkan.c is the Vulkan half) ----
-struct csky_external_frame { int device = 0; hipExternalMemory_t mem = nullptr; void* d_ptr = nullptr; size_t bytes = 0; hipExternalSemaphore_t sem = nullptr; hipEvent_t fence = nullptr; bool fenced = false; };
+struct csky_external_frame { int device = 0; hipExternalMemory_t mem = nullptr; void* d_ptr = nullptr; size_t bytes = 0; hipExternalSemaphore_t sem = nullptr; hipEvent_t fence = nullptr; bool fenced = false;
+                             int dfd = -1; dev_t dfd_dev = 0; ino_t dfd_ino = 0; };   // the duplicate handed to the runtime and what it pointed at (see csky_external_frame_release)
 
 int csky_external_frame_import_fd(csky_ctx* c, int opaque_fd, size_t allocation_bytes, size_t offset, size_t frame_bytes, csky_external_frame** out, void** d_ptr) {
     if (!c || !out || !d_ptr) return fail(c, CSKY_ERR_INVALID, "csky_external_frame_import_fd: NULL argument");
@@ -883,8 +891,9 @@ int csky_external_frame_import_fd(csky_ctx* c, int opaque_fd, size_t allocation_
     const int dfd = dup(opaque_fd);
     if (dfd < 0) { delete f; return fail(c, CSKY_ERR_INVALID, "csky_external_frame_import_fd: dup(fd) failed"); }
     md.type = hipExternalMemoryHandleTypeOpaqueFd; md.handle.fd = dfd; md.size = allocation_bytes;
+    { struct stat st; if (fstat(dfd, &st) == 0) { f->dfd_dev = st.st_dev; f->dfd_ino = st.st_ino; } }
     hipError_t e = hipImportExternalMemory(&f->mem, &md);
-    if (e != hipSuccess) (void)close(dfd);
+    if (e != hipSuccess) (void)close(dfd); else f->dfd = dfd;
     if (e == hipSuccess) {
         hipExternalMemoryBufferDesc bd; memset(&bd, 0, sizeof bd);
         bd.offset = offset; bd.size = frame_bytes;
@@ -942,6 +951,13 @@ void csky_external_frame_release(csky_external_frame* f) {
     if (f->fence) { (void)hipEventSynchronize(f->fence); (void)hipEventDestroy(f->fence); }   // never unmap memory a march may still be writing
     if (f->sem) (void)hipDestroyExternalSemaphore(f->sem);
     if (f->mem) (void)hipDestroyExternalMemory(f->mem);      // unmaps d_ptr
+    // The duplicate fd the runtime was handed: CUDA-style import takes the fd over, ROCm's documentation does not say, and a runtime
+    // that neither closes it at import nor at destroy would leak one fd per imported frame.  So: if the number still names the SAME object it
+    // named at import (device + inode; a number the runtime closed and someone else re-opened names another), nobody has closed it: do it here.
+    if (f->dfd >= 0) {
+        struct stat st;
+        if (fstat(f->dfd, &st) == 0 && st.st_dev == f->dfd_dev && st.st_ino == f->dfd_ino) (void)close(f->dfd);
+    }
     delete f;
 }
 

@@ -7,6 +7,10 @@
  * reference call site (file:line, relative to the reference root) it replaces; INTEGRATION.md shows the
  * GDExtension / GDScript-side binding a maintainer would add.
  *
+ * This header is the PRODUCT surface: exactly the rows of INTEGRATION.md's table.  The measurement, tuning and test entry points the benchmarks and
+ * the test-suite use (kernel variants, schedules, ray segments, per-kernel timing, the instruction census, texture read-back, the BC7 encoder of
+ * the sensitivity study) are exported by the same library and declared in cloudsky_internal.h; a host binds this file alone.
+ *
  * Conventions: plain C types only; 0 = success, < 0 = error (csky_last_error() gives the text); nothing
  * throws or aborts across the ABI.  One context = one GPU = one caller thread (the reference marshals
  * every RenderingDevice call onto the single render thread: cloud_sky.gd:118,154).  There is NO CPU
@@ -36,7 +40,7 @@ extern "C" {
 #define CSKY_ERR_IO (-4)         /* asset file problem                                       */
 #define CSKY_ERR_STATE (-5)      /* e.g. clouds requested before noise / LUTs exist          */
 
-#define CSKY_ABI_VERSION 5  /* 5: csky_last_warning (warnings no longer sit in csky_last_error), exact fp32-coefficient texture cells, csky_render_sky_lut_rows_device, csky_interleave_bands_device, csky_encode_bc7, rings eight deep; 4: csky_submit_* / csky_collect, csky_multi_set_groups / _set_staged, csky_composite_view, csky_external_frame_* (incl. _fence / _ready / _wait); 3: csky_set_noise_mips, csky_decode_bc7, csky_load_ctex[3d]; 2: csky_multi_*, device asset builders */
+#define CSKY_ABI_VERSION 6  /* 6: the measurement / tuning / test entry points moved to cloudsky_internal.h (same library), csky_generate_shape_noise_tuned[_device]; 5: csky_last_warning (warnings no longer sit in csky_last_error), exact fp32-coefficient texture cells, csky_render_sky_lut_rows_device, csky_interleave_bands_device, csky_encode_bc7, rings eight deep; 4: csky_submit_* / csky_collect, csky_multi_set_groups / _set_staged, csky_composite_view, csky_external_frame_* (incl. _fence / _ready / _wait); 3: csky_set_noise_mips, csky_decode_bc7, csky_load_ctex[3d]; 2: csky_multi_*, device asset builders */
 
 typedef struct csky_ctx csky_ctx; /* opaque: owns every device allocation, the HIP stream and events */
 
@@ -105,7 +109,7 @@ int csky_set_noise_mips(csky_ctx* ctx, const uint8_t* large_chain_rgba8, const u
 /* The device layouts store finite differences of neighbouring texels as fp16 (exact for integers up to 2048).  Returns how
  * many coefficients of the textures bound by the last csky_set_noise* do NOT fit fp16 exactly (0 for natural noise; white noise and
  * checkerboards of extreme values exceed the range).  Such textures are marched on EXACT cells instead -- the same filter polynomial with
- * fp32 coefficients, twice the bytes per tap, always the whole-ray compact kernel (csky_set_variant / csky_set_segments do not apply) --
+ * fp32 coefficients, twice the bytes per tap, always the whole-ray compact kernel (the tuning knobs of cloudsky_internal.h do not apply) --
  * so results are exact for ANY 8-bit input; csky_last_warning(ctx) says so, the count stays queryable.  The shipped textures give 0. */
 int csky_noise_inexact_coeffs(csky_ctx* ctx, uint64_t* count);
 /* 1 = build and march the exact fp32-coefficient cells regardless of the count above (A/B and tests: for textures that fit fp16 the two cell
@@ -156,7 +160,9 @@ int csky_copy_sky_lut_device(csky_ctx* ctx, void* d_out_rgba16f, void* hip_strea
  * rows of w RGBA16F texels), straight into the caller's DEVICE buffer on `hip_stream` (the context's own stream if NULL): the buffer that
  * travels to the gathering rank behind the rank's bands, where the rows are interleaved (tiling.py / bench.py).  The context keeps no LUT:
  * the (at most 12) texels its frame set-up filters (clouds.glsl:163-167) are rendered by the set-up of each following csky_render_clouds*
- * call, for THAT call's light direction and with the same per-texel code, so frames are byte-identical to those marched with a whole LUT.
+ * call with the same per-texel code -- WHERE it taps comes from that call's LIGHT_DIRECTION, but the sun the texels are rendered for is the one
+ * recorded by THIS call (p->sun_direction), exactly as with a whole LUT (cloud_sky.gd:242 binds the LUT rendered last): after a sun change,
+ * render the rows again before the next frame, or its sun colours are the old sun's.  Frames are byte-identical to those marched with a whole LUT.
  * csky_read_sky_lut / csky_copy_sky_lut_device return CSKY_ERR_STATE until the next csky_render_sky_lut*. */
 int csky_render_sky_lut_rows_device(csky_ctx* ctx, const csky_sky_params* p, int first_row, int row_stride, void* d_rows_out_rgba16f,
                                     size_t capacity_bytes, void* hip_stream);
@@ -239,40 +245,7 @@ typedef struct { float basis[9]; float fov_y_degrees; } csky_view;
 int csky_composite_view(csky_ctx* ctx, const csky_composite_params* p, const csky_view* view, const uint16_t* cloud_from, const uint16_t* cloud_to,
                         const uint16_t* sky_from, const uint16_t* sky_to, uint16_t* out_rgba16f);
 
-/* ---- measurement ---------------------------------------------------------------------------------
- * Times `iters` back-to-back launches of the cloud kernel alone with HIP events on the context's stream
- * (after `warmup` untimed launches) and returns the mean per-launch milliseconds.  Also fills the
- * sample counters of one launch (the kernel's own tallies). */
-int csky_time_clouds(csky_ctx* ctx, const csky_cloud_params* p, int tile_w, const csky_bands* bands, int warmup,
-                     int iters, float* mean_ms, csky_cloud_stats* stats);
-int csky_get_cloud_stats(csky_ctx* ctx, csky_cloud_stats* stats); /* tallies of the last stats-enabled launch */
-/* Per-launch timing of the cloud kernel inside the caller's own frame loop: while enabled, every csky_render_clouds* launch is
- * bracketed by a pair of HIP events recorded on the stream the kernel is launched on.  csky_get_kernel_ms waits for the launches
- * recorded since the last call (all of them: the event pool grows on demand), returns the sum of their durations and their
- * number, and resets. */
-int csky_set_kernel_timing(csky_ctx* ctx, int enabled);
-int csky_get_kernel_ms(csky_ctx* ctx, float* total_ms, int* launches);
-/* Kernel variant selector for A/B measurement (csky_variant_name lists them).  -1 = the default = the fastest measured
- * (CSKY_DEFAULT_VARIANT, "compact").  Unknown ids -> CSKY_ERR_INVALID. */
-#define CSKY_DEFAULT_VARIANT 3
-int csky_set_variant(csky_ctx* ctx, int variant);
-/* Exact height-window reject (density() provably 0 above/below the cloud body for the bound weather map): on by default;
- * 0 disables it (A/B measurement, identical results). */
-int csky_set_height_window(csky_ctx* ctx, int enabled);
-int csky_variant_count(void);
-/* Workgroup -> XCD schedule (tuning knob, results are identical): -1 = auto (see api.cpp::clouds_dev for the launch-size policy);
- * 5 = slab rows round-robin over the XCDs; 1 = contiguous eighths; 2 = natural order (all three written on the device);
- * 7 = cost feedback: every launch records a cost per workgroup (in-cloud samples) and the next launch of the same geometry
- *     and view starts its workgroups heaviest first (the first launch runs in a static order);
- *     Only the ORDER comes from the previous launch; every sample is recomputed.
- * (0, 3, 4, 6 were azimuth-wedge / horizon-first orders of round 1; 8 / 9 the 'deadline' reorder and per-workgroup adaptive ray
- *  segments of round 2: all measured, no gain, removed -- kernels.hip keeps the numbers.) */
-int csky_set_schedule(csky_ctx* ctx, int mode);
-/* Ray segments: the primary march of every ray is cut into `segments` pieces marched by different wavefronts of one
- * workgroup and composited front to back (T and L are associative).  0 = auto (whole rays for large launches, 2 or 4
- * step ranges for one GPU's share of a split frame, 4 interleaved step sets for tile-sized launches such as the
- * reference's 96x96 temporal tiles), 1, 2, 4 (step ranges) or 5 (4 interleaved). */
-int csky_set_segments(csky_ctx* ctx, int segments);
+/* ---- frames in flight ---------------------------------------------------------------------------- */
 /* Policy hint for the automatic segment / schedule choice: n = 2..8: the caller keeps n frames in flight by rotating n streams
  * between consecutive csky_render_*_device calls (always safe: per-frame state lives in eight-deep rings ordered by events); the
  * next frames then fill the tail of this one and fewer, longer wavefronts are the better choice for partial frames.  Default 1;
@@ -285,7 +258,6 @@ int csky_set_segments(csky_ctx* ctx, int segments);
  * clouds_kernel_persistent); frames are byte-identical either way.  Environment variable CSKY_PERSISTENT, read by csky_create, is the A/B
  * switch: 0 = never, 1 = this policy (default), 2 = every whole-ray launch. */
 int csky_set_frames_in_flight(csky_ctx* ctx, int frames);
-const char* csky_variant_name(int variant);
 
 /* ---- multi-GPU: the devices of one node behind one handle ------------------------------
  * One host thread drives n devices.  Rays are independent and the reference already renders disjoint tiles addressed by
@@ -295,7 +267,7 @@ const char* csky_variant_name(int variant);
  * buffer, no gather step and no host hop.  Every device renders its own copy of the two LUTs (36 K texels: cheaper than a
  * broadcast).  Events order the consumer stream on the first device behind all marches.  A device id may appear more than once
  * (two contexts sharing one GPU): meaningless for speed, it lets a single-GPU box exercise the n > 1 path.
- * csky_multi_ctx(m, i) gives the per-device context for the per-context settings (csky_set_march, csky_set_variant, ...);
+ * csky_multi_ctx(m, i) gives the per-device context for the per-context settings (csky_set_march, csky_set_early_out, ...);
  * csky_multi_set_* apply one setting to all of them. */
 typedef struct csky_multi csky_multi;
 int csky_multi_create(csky_multi** out, const int* device_ids, int n_devices);
@@ -376,16 +348,6 @@ size_t csky_mip_offset(int n, int level, int ch);
  * csky_set_noise builds its chains and its device layouts on the GPU itself (kernels.hip::launch_mip_chain / launch_bake). */
 int csky_build_mips(uint8_t* vol, int n, int ch, int levels);
 int csky_build_mips_device(csky_ctx* ctx, uint8_t* vol, int n, int ch, int levels);
-/* Test hook: read back what csky_set_noise built on the device.  which: 0 shape layout, 1 detail layout, 2 weather layout (csky_common.h),
- * 3 / 4 the 8-bit mip chains of the large / small volume.  out may be NULL to query the size. */
-int csky_read_baked_texture(csky_ctx* ctx, int which, void* out, size_t capacity, size_t* bytes);
-/* Test hook: the march's range-restricted exact square root (cloud_core.h::sqrt_shell, |p|^2 of sample positions) over an array, so that
- * a test can check it EXHAUSTIVELY against IEEE sqrtf on the range it is used on (all 30 067 floats in [3.597e13, 3.6097e13]). */
-int csky_test_sqrt_shell(csky_ctx* ctx, const float* in, float* out, size_t n);
-/* Measurement hook of tools/isa_profile.py: one launch of the cloud kernel over `bands` with the statistics buffer bound, then the first n
- * (<= 256) 32-bit basic-block execution counters behind the kernel's own tallies.  The counters are written only by the CENSUS build of the
- * library (the product assembly with a counter per basic block, made by that tool); the product build leaves them zero. */
-int csky_census_clouds(csky_ctx* ctx, const csky_cloud_params* p, int tile_w, const csky_bands* bands, uint32_t* counts, int n);
 /* ---- what Godot's importer wrote (godot_import.cpp; host only) ------------------------------------
  * The reference's noise textures are imported with compress/mode=2, compress/high_quality=true (weather.bmp.import:19-20,
  * worlnoise.bmp.import:19-20, perlworlnoise.tga.import:19-20), i.e. as BPTC (BC7) blocks in .godot/imported/<name>-<md5>.bptc.ctex
@@ -399,12 +361,6 @@ int csky_census_clouds(csky_ctx* ctx, const csky_cloud_params* p, int tile_w, co
  * sizes.  The container layout follows the engine's loader (Godot 4.2 scene/resources/compressed_texture.cpp); no imported file
  * ships with the reference, so only the BC7 decoder is pinned by an outside implementation. */
 int csky_decode_bc7(const uint8_t* blocks, int w, int h, uint8_t* out_rgba8);
-/* The other direction, on the GPU (bc7enc.hip, one block per lane): n_images images of w x h RGBA8 texels back to back -> per image
- * ceil(h/4) x ceil(w/4) blocks of 16 bytes, row-major (a 3-D texture is its slices: one image per slice, every mip level its own call, as the
- * importer stores them).  All eight modes (6; 0-3 for opaque blocks; 4, 5 and 7 for blocks whose alpha varies); principal-axis fit + least-squares refits, smallest
- * squared error wins.  It is NOT the engine's encoder (that one cannot be reproduced): textures passed through this and csky_decode_bc7 show the
- * SIZE of what compress/mode=2 does to a frame (tools/bc7_sensitivity.py), not the reference's exact texels. */
-int csky_encode_bc7(csky_ctx* ctx, const uint8_t* rgba8, int w, int h, int n_images, uint8_t* blocks_out);
 int csky_load_ctex(const char* path, int* w, int* h, int* levels, uint8_t* out_rgba8, size_t out_capacity);
 int csky_load_ctex3d(const char* path, int* w, int* h, int* d, int* levels, uint8_t* out_rgba8, size_t out_capacity);
 const char* csky_assets_last_error(void);

@@ -1,4 +1,5 @@
-"""The C-ABI library loads and exports every symbol include/cloudsky.h declares (no compute without a GPU)."""
+"""The C-ABI library loads and exports every symbol include/cloudsky.h (the product surface) and include/cloudsky_internal.h (measurement, tuning and
+test entry points of the same library) declare (no compute without a GPU)."""
 import ctypes as C
 import os
 import re
@@ -8,23 +9,39 @@ import pytest
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def header_symbols():
-    txt = open(os.path.join(ROOT, "include", "cloudsky.h")).read()
+def header_symbols(name="cloudsky.h"):
+    txt = open(os.path.join(ROOT, "include", name)).read()
     txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
     return sorted(set(re.findall(r"\b(csky_[a-z_0-9]+)\s*\(", txt)))
 
 
+# the lab bench: what a host binding the product header must NOT see
+LAB_BENCH = {"csky_time_clouds", "csky_get_cloud_stats", "csky_set_kernel_timing", "csky_get_kernel_ms", "csky_set_variant", "csky_variant_count", "csky_variant_name",
+             "csky_set_height_window", "csky_set_schedule", "csky_set_segments", "csky_read_baked_texture", "csky_test_sqrt_shell", "csky_census_clouds", "csky_encode_bc7"}
+
+
 def test_header_symbols_exported(pkg):
     L = C.CDLL(pkg.library_path())
-    names = header_symbols()
+    names = header_symbols() + header_symbols("cloudsky_internal.h")
     assert len(names) >= 25
     for n in names:
         assert hasattr(L, n), "libcloudsky.so does not export %s" % n
 
 
+def test_public_header_has_no_lab_bench_and_the_two_headers_are_disjoint():
+    pub, internal = set(header_symbols()), set(header_symbols("cloudsky_internal.h"))
+    assert not (pub & internal), pub & internal
+    assert internal == LAB_BENCH, internal ^ LAB_BENCH
+    assert not [n for n in pub if n.startswith(("csky_test_", "csky_census_", "csky_time_"))]
+    src = open(os.path.join(ROOT, "gdext", "cloudsky_gdextension.c")).read() + open(os.path.join(ROOT, "tests", "c_abi_check.c")).read()
+    assert "cloudsky_internal.h" not in src                       # the shim and the plain C client build against the product header alone
+    for n in LAB_BENCH:
+        assert n + "(" not in src, n
+
+
 def test_binding_table_covers_header(pkg):
     bound = {s[0] for s in pkg._lib.SYMBOLS}
-    assert bound == set(header_symbols())
+    assert bound == set(header_symbols()) | set(header_symbols("cloudsky_internal.h"))
 
 
 def test_push_constant_layouts(pkg):
