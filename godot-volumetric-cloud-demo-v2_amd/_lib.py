@@ -70,6 +70,7 @@ SYMBOLS = [
     ("csky_set_noise_mips", C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     ("csky_noise_inexact_coeffs", C.c_int, [C.c_void_p, C.POINTER(C.c_uint64)]),
     ("csky_encode_bc7", C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]),
+    ("csky_encode_bc7_quality", C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]),
     ("csky_set_march", C.c_int, [C.c_void_p, C.c_int, C.c_int]),
     ("csky_set_early_out", C.c_int, [C.c_void_p, C.c_float]),
     ("csky_render_transmittance", C.c_int, [C.c_void_p, C.POINTER(TransParams), C.c_void_p]),
@@ -79,6 +80,7 @@ SYMBOLS = [
     ("csky_render_clouds_device", C.c_int, [C.c_void_p, C.POINTER(CloudParams), C.c_int, C.POINTER(Bands), C.c_void_p, C.c_size_t, C.c_void_p]),
     ("csky_copy_sky_lut_device", C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
     ("csky_render_sky_lut_rows_device", C.c_int, [C.c_void_p, C.POINTER(SkyParams), C.c_int, C.c_int, C.c_void_p, C.c_size_t, C.c_void_p]),
+    ("csky_set_lut_rows_overlap", C.c_int, [C.c_void_p, C.c_int]),
     ("csky_interleave_bands_device", C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_size_t, C.c_int, C.c_void_p, C.c_void_p]),
     ("csky_sync", C.c_int, [C.c_void_p]),
     ("csky_set_host_ring", C.c_int, [C.c_void_p, C.c_int]),
@@ -245,8 +247,9 @@ class Context:
             raise ValueError("set_noise_mips: expected the 8-level 128^3 RGBA8 chain, the 6-level 32^3 RGB8 chain, 512^2 RGB8")
         self._chk(self._L.csky_set_noise_mips(self._h, _ptr(a), _ptr(b), _ptr(c)))
 
-    def encode_bc7(self, images):
-        """csky_encode_bc7: [n, h, w, 4] (or [h, w, 4]) uint8 -> [n, ceil(h/4), ceil(w/4), 16] uint8 BC7 blocks, encoded on the GPU."""
+    def encode_bc7(self, images, quality=0):
+        """csky_encode_bc7[_quality]: [n, h, w, 4] (or [h, w, 4]) uint8 -> [n, ceil(h/4), ceil(w/4), 16] uint8 BC7 blocks, encoded on the GPU
+        (quality 1: more partitions + end-point coordinate descent, the sensitivity study's second encoder)."""
         a = np.ascontiguousarray(images, np.uint8)
         if a.ndim == 3:
             a = a[None]
@@ -254,7 +257,7 @@ class Context:
             raise ValueError("encode_bc7: expected [n, h, w, 4] uint8")
         n, h, w = a.shape[:3]
         out = np.zeros((n, (h + 3) // 4, (w + 3) // 4, 16), np.uint8)
-        self._chk(self._L.csky_encode_bc7(self._h, _ptr(a), w, h, n, _ptr(out)))
+        self._chk(self._L.csky_encode_bc7_quality(self._h, _ptr(a), w, h, n, int(quality), _ptr(out)))
         return out
 
     def noise_inexact_coeffs(self):
@@ -327,6 +330,10 @@ class Context:
         p.f[4], p.f[5], p.f[6] = [float(x) for x in sun_dir]
         self._chk(self._L.csky_render_sky_lut_rows_device(self._h, C.byref(p), int(first_row), int(row_stride), C.c_void_p(int(d_rows_out)),
                                                           C.c_size_t(int(capacity_bytes)), C.c_void_p(stream or 0)))
+
+    def set_lut_rows_overlap(self, enabled):
+        """1: a rank's LUT rows run beside the march that follows them on the stream instead of in front of it (csky_set_lut_rows_overlap)."""
+        self._chk(self._L.csky_set_lut_rows_overlap(self._h, int(bool(enabled))))
 
     def render_clouds_device(self, params, tile_w, bands, d_out, pitch_bytes, stream=None):
         p = cloud_params(params)

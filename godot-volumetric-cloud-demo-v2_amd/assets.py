@@ -133,7 +133,7 @@ def chains_from_godot_import(large_ctex3d, small_ctex3d, weather_ctex):
     return (np.concatenate([l.reshape(-1) for l in large]), np.concatenate([l[..., :3].reshape(-1) for l in small]), np.ascontiguousarray(weather[..., :3]))
 
 
-def vram_compressed_chains(ctx, large, small, weather):
+def vram_compressed_chains(ctx, large, small, weather, quality=0):
     """What compress/mode=2 of the three *.import files does to the inputs, with THIS library's encoder in the importer's place (it is not the
     engine's: see csky_encode_bc7): the box-filtered mip chains of the two volumes (mipmaps/generate=true) and the weather map, every level
     BC7-encoded slice by slice on the GPU of `ctx` and decoded again -> (large chain RGBA8, small chain RGB8, weather RGB8) for
@@ -145,7 +145,7 @@ def vram_compressed_chains(ctx, large, small, weather):
 
     def roundtrip(img4):                                        # [n, h, w, 4]
         n, h, w = img4.shape[:3]
-        blocks = ctx.encode_bc7(img4)
+        blocks = ctx.encode_bc7(img4, quality)
         return np.stack([decode_bc7(blocks[i], w, h) for i in range(n)])
 
     def volume_chain(level0, levels, ch):

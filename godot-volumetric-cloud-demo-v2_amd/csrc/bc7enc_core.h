@@ -153,12 +153,13 @@ CSKY_HD unsigned bc7_indices(const unsigned char px[16][4], const int* sel, int 
 }
 
 constexpr int BC7_PARTITIONS_TRIED = 4;                          // mode 1: partitions fitted in full, after a plain estimate of all 64
+constexpr int BC7_PARTITIONS_MAX = 8;                            // ... at quality 1
 constexpr int BC7_REFITS = 3;                                   // least-squares refits of the end points per candidate
 // A fitted subset: stored end points q0 / q1 (+ their 8-bit expansions), p-bits, indices, error.  Channels [c0, c1) of `px`.
 struct Bc7Subset { int q0[4] = {0, 0, 0, 0}, q1[4] = {0, 0, 0, 0}, a8[4] = {0, 0, 0, 0}, b8[4] = {0, 0, 0, 0}, p0 = 0, p1 = 0, idx[16] = {}; unsigned err = 0xffffffffu; };
 
 // fit, quantise over the p-bit choices, index, refit once.  pmode: 0 none, 1 one p-bit per end point, 2 one shared by both end points
-template <int D> CSKY_HD void bc7_fit_subset(const unsigned char px[16][4], const float v[16][4], const int* sel, int n, int c0, int bits, int pmode, int ibits, Bc7Subset& out) {
+template <int D> CSKY_HD void bc7_fit_subset(const unsigned char px[16][4], const float v[16][4], const int* sel, int n, int c0, int bits, int pmode, int ibits, Bc7Subset& out, bool refine = false) {
     float e0[4] = {0, 0, 0, 0}, e1[4] = {0, 0, 0, 0};
     float vv[16][4];
     for (int i = 0; i < 16; i++) for (int c = 0; c < D; c++) vv[i][c] = v[i][c0 + c];
@@ -187,6 +188,27 @@ template <int D> CSKY_HD void bc7_fit_subset(const unsigned char px[16][4], cons
         for (int c = 0; c < D && ok; c++) ok = bc7_lsq(vv, sel, wt, n, c, e0[c], e1[c]);
         if (!ok) break;
     }
+    // quality 1 (round 5: the second row of the sensitivity study, tools/bc7_sensitivity.py): coordinate descent on the STORED end points -- every
+    // channel of either end moved by -2 .. +2 steps with the p-bits kept, indices searched again against the decoder's palette, a move kept when the
+    // subset's squared error drops; until a whole sweep improves nothing (at most four sweeps).  Integer throughout.
+    if (refine && out.err != 0u && out.err != 0xffffffffu) {
+        const int total = bits + (pmode != 0 ? 1 : 0), top = (1 << bits) - 1;
+        for (int sweep = 0; sweep < 4; sweep++) {
+            bool improved = false;
+            for (int c = c0; c < c0 + D; c++) for (int end = 0; end < 2; end++) for (int d = -2; d <= 2; d++) {
+                if (d == 0) continue;
+                Bc7Subset t = out;
+                const int q = (end ? t.q1[c] : t.q0[c]) + d;
+                if (q < 0 || q > top) continue;
+                const int raw = pmode != 0 ? ((q << 1) | (end ? t.p1 : t.p0)) : q;
+                const int v8 = ((raw << (8 - total)) | (raw >> (2 * total - 8))) & 255;
+                if (end) { t.q1[c] = q; t.b8[c] = v8; } else { t.q0[c] = q; t.a8[c] = v8; }
+                t.err = bc7_indices(px, sel, n, t.a8, t.b8, c0, c0 + D, ibits, t.idx);
+                if (t.err < out.err) { out = t; improved = true; }
+            }
+            if (!improved || out.err == 0u) break;
+        }
+    }
 }
 // the anchor texel's index must have a clear top bit: swap the end points and mirror the subset's indices
 CSKY_HD void bc7_fix_anchor(Bc7Subset& s, int n, int anchor_pos, int ibits, int c0, int c1) {
@@ -196,7 +218,9 @@ CSKY_HD void bc7_fix_anchor(Bc7Subset& s, int n, int anchor_pos, int ibits, int 
     for (int i = 0; i < n; i++) s.idx[i] = ((1 << ibits) - 1) - s.idx[i];
 }
 
-CSKY_HD void bc7_encode_block(const unsigned char px[16][4], uint32_t out[4]) {
+CSKY_HD void bc7_encode_block(const unsigned char px[16][4], uint32_t out[4], int quality = 0) {
+    const bool refine = quality >= 1;
+    const int ntry = quality >= 1 ? BC7_PARTITIONS_MAX : BC7_PARTITIONS_TRIED;   // partitions fitted in full per two- / three-subset mode
     float v[16][4];
     bool opaque = true;
     for (int i = 0; i < 16; i++) { for (int c = 0; c < 4; c++) v[i][c] = (float)px[i][c]; opaque = opaque && px[i][3] == 255; }
@@ -207,7 +231,7 @@ CSKY_HD void bc7_encode_block(const unsigned char px[16][4], uint32_t out[4]) {
 
     {   // ---- mode 6
         Bc7Subset s;
-        bc7_fit_subset<4>(px, v, all, 16, 0, 7, 1, 4, s);
+        bc7_fit_subset<4>(px, v, all, 16, 0, 7, 1, 4, s, refine);
         bc7_fix_anchor(s, 16, 0, 4, 0, 4);
         Bc7Bits b; b.pos = 0; for (int k = 0; k < 4; k++) b.w[k] = 0;
         b.put(1u << 6, 7);
@@ -225,8 +249,8 @@ CSKY_HD void bc7_encode_block(const unsigned char px[16][4], uint32_t out[4]) {
                 for (int c = 0; c < 4; c++) rv[i][c] = (float)rp[i][c];
             }
             Bc7Subset col, sc;
-            bc7_fit_subset<3>(rp, rv, all, 16, 0, 7, 0, 2, col);
-            bc7_fit_subset<1>(rp, rv, all, 16, 3, 8, 0, 2, sc);
+            bc7_fit_subset<3>(rp, rv, all, 16, 0, 7, 0, 2, col, refine);
+            bc7_fit_subset<1>(rp, rv, all, 16, 3, 8, 0, 2, sc, refine);
             const unsigned err = col.err + sc.err;
             if (err >= best_err) continue;
             bc7_fix_anchor(col, 16, 0, 2, 0, 3);
@@ -251,8 +275,8 @@ CSKY_HD void bc7_encode_block(const unsigned char px[16][4], uint32_t out[4]) {
             for (int isel = 0; isel < 2; isel++) {
                 const int cb = isel ? 3 : 2, ab = isel ? 2 : 3;
                 Bc7Subset col, sc;
-                bc7_fit_subset<3>(rp, rv, all, 16, 0, 5, 0, cb, col);
-                bc7_fit_subset<1>(rp, rv, all, 16, 3, 6, 0, ab, sc);
+                bc7_fit_subset<3>(rp, rv, all, 16, 0, 5, 0, cb, col, refine);
+                bc7_fit_subset<1>(rp, rv, all, 16, 3, 6, 0, ab, sc, refine);
                 const unsigned err = col.err + sc.err;
                 if (err >= best_err) continue;
                 bc7_fix_anchor(col, 16, 0, cb, 0, 3);
@@ -274,8 +298,8 @@ CSKY_HD void bc7_encode_block(const unsigned char px[16][4], uint32_t out[4]) {
     //      first 16 partitions, RGB 444 + p-bits, 3-bit), 2 (three, RGB 555, 2-bit); blocks whose alpha varies: 7 (two subsets, RGBA 5555 + p-bits, 2-bit)
     for (int ns = 2; ns <= (opaque ? 3 : 2) && best_err != 0; ns++) {
         const int D = opaque ? 3 : 4;
-        int cand[BC7_PARTITIONS_TRIED], cand16[BC7_PARTITIONS_TRIED]; unsigned cerr[BC7_PARTITIONS_TRIED], cerr16[BC7_PARTITIONS_TRIED];
-        for (int k = 0; k < BC7_PARTITIONS_TRIED; k++) { cand[k] = cand16[k] = 0; cerr[k] = cerr16[k] = 0xffffffffu; }
+        int cand[BC7_PARTITIONS_MAX], cand16[BC7_PARTITIONS_MAX]; unsigned cerr[BC7_PARTITIONS_MAX], cerr16[BC7_PARTITIONS_MAX];
+        for (int k = 0; k < BC7_PARTITIONS_MAX; k++) { cand[k] = cand16[k] = 0; cerr[k] = cerr16[k] = 0xffffffffu; }
         for (int p = 0; p < 64; p++) {
             unsigned est = 0;
             for (int sub = 0; sub < ns; sub++) {
@@ -294,12 +318,12 @@ CSKY_HD void bc7_encode_block(const unsigned char px[16][4], uint32_t out[4]) {
                     est += (unsigned)(r2 + 0.5f);
                 }
             }
-            for (int k = 0; k < BC7_PARTITIONS_TRIED; k++) if (est < cerr[k]) {         // insertion into the short list
-                for (int j = BC7_PARTITIONS_TRIED - 1; j > k; j--) { cerr[j] = cerr[j - 1]; cand[j] = cand[j - 1]; }
+            for (int k = 0; k < ntry; k++) if (est < cerr[k]) {         // insertion into the short list
+                for (int j = ntry - 1; j > k; j--) { cerr[j] = cerr[j - 1]; cand[j] = cand[j - 1]; }
                 cerr[k] = est; cand[k] = p; break;
             }
-            if (p < 16) for (int k = 0; k < BC7_PARTITIONS_TRIED; k++) if (est < cerr16[k]) {   // mode 0 stores four partition bits
-                for (int j = BC7_PARTITIONS_TRIED - 1; j > k; j--) { cerr16[j] = cerr16[j - 1]; cand16[j] = cand16[j - 1]; }
+            if (p < 16) for (int k = 0; k < ntry; k++) if (est < cerr16[k]) {   // mode 0 stores four partition bits
+                for (int j = ntry - 1; j > k; j--) { cerr16[j] = cerr16[j - 1]; cand16[j] = cand16[j - 1]; }
                 cerr16[k] = est; cand16[k] = p; break;
             }
         }
@@ -307,14 +331,14 @@ CSKY_HD void bc7_encode_block(const unsigned char px[16][4], uint32_t out[4]) {
         for (int mi = 0; mi < n_modes; mi++) {
             const int mode = !opaque ? 7 : (ns == 2 ? (mi == 0 ? 1 : 3) : (mi == 0 ? 0 : 2));
             const int bits = mode == 1 ? 6 : (mode == 3 ? 7 : (mode == 0 ? 4 : 5)), pmode = mode == 1 ? 2 : (mode == 2 ? 0 : 1), ibits = (mode == 1 || mode == 0) ? 3 : 2;
-            for (int k = 0; k < BC7_PARTITIONS_TRIED; k++) {
+            for (int k = 0; k < ntry; k++) {
                 const int p = mode == 0 ? cand16[k] : cand[k];
                 Bc7Subset s[3]; int sel[3][16], n[3] = {0, 0, 0}, apos[3] = {0, 0, 0};
                 for (int i = 0; i < 16; i++) { const int sub = bc7_subset_of(ns, p, i); if (i == bc7_anchor_of(ns, p, sub)) apos[sub] = n[sub]; sel[sub][n[sub]++] = i; }
                 unsigned err = 0;
                 for (int sub = 0; sub < ns; sub++) {
-                    if (opaque) bc7_fit_subset<3>(px, v, sel[sub], n[sub], 0, bits, pmode, ibits, s[sub]);
-                    else bc7_fit_subset<4>(px, v, sel[sub], n[sub], 0, bits, pmode, ibits, s[sub]);
+                    if (opaque) bc7_fit_subset<3>(px, v, sel[sub], n[sub], 0, bits, pmode, ibits, s[sub], refine);
+                    else bc7_fit_subset<4>(px, v, sel[sub], n[sub], 0, bits, pmode, ibits, s[sub], refine);
                     err += s[sub].err;
                 }
                 if (err >= best_err) continue;

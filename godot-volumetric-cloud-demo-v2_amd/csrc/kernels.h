@@ -49,7 +49,7 @@ hipError_t launch_detail_noise(uint32_t seed, int n, uint8_t* d_out, hipStream_t
 // frame band k (band_bytes each, total_bands of them) = member k % members, local band k / members of a gathered rank-major buffer
 hipError_t launch_interleave_bands(const void* d_gathered, size_t member_stride_bytes, int members, size_t band_bytes, int total_bands, void* d_frame, hipStream_t s);
 // BC7 (BPTC) blocks of n_img images of w x h RGBA8 texels (bc7enc.hip; what compress/mode=2 of the *.import files asks the importer for)
-hipError_t launch_bc7_encode(const uint8_t* d_img, int w, int h, int n_img, uint4* d_blocks, hipStream_t s);
+hipError_t launch_bc7_encode(const uint8_t* d_img, int w, int h, int n_img, int quality, uint4* d_blocks, hipStream_t s);
 // 2x2x2 box mips of a device chain whose level 0 is filled (level l at chain_offset(n, l, ch))
 hipError_t launch_mip_chain(uint8_t* d_chain, int n, int ch, int levels, hipStream_t s);
 // the three device texture layouts from the 8-bit chains; *d_inexact += coefficients not exact in fp16; d_range = {min R, max R, max B} of the

@@ -66,6 +66,10 @@ int csky_census_clouds(csky_ctx* ctx, const csky_cloud_params* p, int tile_w, co
  * squared error wins.  It is NOT the engine's encoder (that one cannot be reproduced): textures passed through this and csky_decode_bc7 show the
  * SIZE of what compress/mode=2 does to a frame (tools/bc7_sensitivity.py), not the reference's exact texels. */
 int csky_encode_bc7(csky_ctx* ctx, const uint8_t* rgba8, int w, int h, int n_images, uint8_t* blocks_out);
+/* quality 0 = csky_encode_bc7; 1 = eight instead of four partitions fitted in full per multi-subset mode and, per subset, coordinate descent on the
+ * stored end points (every channel of either end -2 .. +2 steps, indices searched again, until a sweep improves nothing): the second encoder of the
+ * sensitivity study's error bar (profiles/r05/bc7_sensitivity.txt).  Frozen there: a sensitivity tool, not a product feature. */
+int csky_encode_bc7_quality(csky_ctx* ctx, const uint8_t* rgba8, int w, int h, int n_images, int quality, uint8_t* blocks_out);
 
 #ifdef __cplusplus
 }

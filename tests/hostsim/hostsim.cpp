@@ -192,12 +192,14 @@ size_t csky_mip_offset(int n, int level, int ch) {  // same definition as assets
 
 extern "C" {
 // the BC7 encoder core on the host: n_img images of w x h RGBA8 -> blocks, exactly what bc7enc.hip's lanes run
-void hostsim_bc7_encode(const uint8_t* img, int w, int h, int n_img, uint8_t* blocks) {
+void hostsim_bc7_encode_quality(const uint8_t* img, int w, int h, int n_img, int quality, uint8_t* blocks);
+void hostsim_bc7_encode(const uint8_t* img, int w, int h, int n_img, uint8_t* blocks) { hostsim_bc7_encode_quality(img, w, h, n_img, 0, blocks); }
+void hostsim_bc7_encode_quality(const uint8_t* img, int w, int h, int n_img, int quality, uint8_t* blocks) {
     const int bw = (w + 3) / 4, bh = (h + 3) / 4;
     for (int im = 0; im < n_img; im++) for (int by = 0; by < bh; by++) for (int bx = 0; bx < bw; bx++) {
         unsigned char px[16][4]; uint32_t blk[4];
         bc7_gather_block(img + (size_t)im * w * h * 4, w, h, bx, by, px);
-        bc7_encode_block(px, blk);
+        bc7_encode_block(px, blk, quality);
         memcpy(blocks + (((size_t)im * bh + by) * bw + bx) * 16, blk, 16);
     }
 }

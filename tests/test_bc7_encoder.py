@@ -127,3 +127,32 @@ def test_no_block_is_off_by_its_own_range(pkg, hostsim, noise):
         span = (tiles(img).max(axis=(2, 4)).astype(np.int32) - tiles(img).min(axis=(2, 4))).max(-1)
         worst = (err / np.maximum(span, 8)).max()
         assert worst <= 0.75, (name, float(worst), int(err.max()))
+
+
+def test_quality_one_is_never_worse_block_by_block_and_still_decodes_everywhere(pkg, hostsim, noise):
+    """The sensitivity study's second encoder (bc7_encode_block quality 1: eight partitions fitted in full, coordinate descent on the stored end points):
+    it only ever ACCEPTS a move that lowers a subset's squared error, so no block may come out worse than at quality 0; Pillow's decoder and
+    csky_decode_bc7 agree on its blocks too; and on the shape volume's slices (four independent channels, the hard case) it gains measurably."""
+    Image = pytest.importorskip("PIL.Image")
+    large, small, weather = noise
+    img = np.ascontiguousarray(large[40:44, :64, :64])                       # four 64 x 64 RGBA slices of the shape volume
+    n, h, w = img.shape[:3]
+
+    def enc(q):
+        out = np.zeros((n, h // 4, w // 4, 16), np.uint8)
+        hostsim.hostsim_bc7_encode_quality(img.ctypes.data_as(C.c_void_p), w, h, n, q, out.ctypes.data_as(C.c_void_p))
+        return out
+
+    b0, b1 = enc(0), enc(1)
+    d0 = np.stack([pkg.assets.decode_bc7(b0[i], w, h) for i in range(n)]).astype(np.int64)
+    d1 = np.stack([pkg.assets.decode_bc7(b1[i], w, h) for i in range(n)]).astype(np.int64)
+    for i in range(n):
+        assert (np.asarray(Image.frombytes("RGBA", (w, h), b1[i].tobytes(), "bcn", (7,))) == d1[i]).all()
+
+    def block_err(d):
+        e = ((d - img.astype(np.int64)) ** 2).sum(-1)                        # [n, h, w]
+        return e.reshape(n, h // 4, 4, w // 4, 4).sum((2, 4))
+
+    e0, e1 = block_err(d0), block_err(d1)
+    assert (e1 <= e0).all(), int((e1 > e0).sum())
+    assert _psnr(d1, img) > _psnr(d0, img) + 0.2, (_psnr(d0, img), _psnr(d1, img))
