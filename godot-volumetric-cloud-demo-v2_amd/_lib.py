@@ -80,7 +80,6 @@ SYMBOLS = [
     ("csky_render_clouds_device", C.c_int, [C.c_void_p, C.POINTER(CloudParams), C.c_int, C.POINTER(Bands), C.c_void_p, C.c_size_t, C.c_void_p]),
     ("csky_copy_sky_lut_device", C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
     ("csky_render_sky_lut_rows_device", C.c_int, [C.c_void_p, C.POINTER(SkyParams), C.c_int, C.c_int, C.c_void_p, C.c_size_t, C.c_void_p]),
-    ("csky_set_lut_rows_overlap", C.c_int, [C.c_void_p, C.c_int]),
     ("csky_interleave_bands_device", C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_size_t, C.c_int, C.c_void_p, C.c_void_p]),
     ("csky_sync", C.c_int, [C.c_void_p]),
     ("csky_set_host_ring", C.c_int, [C.c_void_p, C.c_int]),
@@ -330,10 +329,6 @@ class Context:
         p.f[4], p.f[5], p.f[6] = [float(x) for x in sun_dir]
         self._chk(self._L.csky_render_sky_lut_rows_device(self._h, C.byref(p), int(first_row), int(row_stride), C.c_void_p(int(d_rows_out)),
                                                           C.c_size_t(int(capacity_bytes)), C.c_void_p(stream or 0)))
-
-    def set_lut_rows_overlap(self, enabled):
-        """1: a rank's LUT rows run beside the march that follows them on the stream instead of in front of it (csky_set_lut_rows_overlap)."""
-        self._chk(self._L.csky_set_lut_rows_overlap(self._h, int(bool(enabled))))
 
     def render_clouds_device(self, params, tile_w, bands, d_out, pitch_bytes, stream=None):
         p = cloud_params(params)

@@ -71,10 +71,6 @@ struct csky_ctx {
     // csky_render_sky_lut_rows_device: the LUT of sun sky_sun exists only as the rows the caller's buffer received (one rank of an N-way frame
     // split); the texels this context's frame set-up filters are rendered by the set-up kernel itself (clouds_dev)
     bool sky_partial = false; float sky_sun[3] = {0, 1, 0}; int psw = 0, psh = 0;
-    // csky_set_lut_rows_overlap (round 5): a rank's LUT rows have no reader on this device, so they need not sit in front of the march on its
-    // stream: they run on `side` and the caller's stream is ordered behind them AFTER the march has been enqueued (clouds_dev)
-    bool rows_overlap = false; hipStream_t side = nullptr; hipEvent_t ev_rows_begin[RING] = {}, ev_rows_done[RING] = {}; int rows_n = 0;
-    bool rows_join_pending = false; hipStream_t rows_join_stream = nullptr; hipEvent_t rows_join_ev = nullptr;
     // csky_multi_render_sky_lut: the whole LUT IS in this context's memory (ring slot sky_cur), written row by row by the devices of the handle;
     // readers of the memory copy wait for those writers first.  (sky_partial stays set: the frame set-ups never read the memory copy.)
     bool sky_in_memory = false; std::vector<hipEvent_t> lut_writers;
@@ -232,15 +228,6 @@ static int grow_timing_pool(csky_ctx* c, size_t want) {
     }
     return CSKY_OK;
 }
-// Orders the stream the last csky_render_sky_lut_rows_device call was given (and `also`, the stream of the march just enqueued, if it is another one)
-// behind those rows when they ran on the side stream (csky_set_lut_rows_overlap).
-int join_lut_rows(csky_ctx* c, hipStream_t also) {
-    if (!c->rows_join_pending) return CSKY_OK;
-    HIPCHK(c, hipStreamWaitEvent(c->rows_join_stream, c->rows_join_ev, 0));
-    if (also && also != c->rows_join_stream) HIPCHK(c, hipStreamWaitEvent(also, c->rows_join_ev, 0));
-    c->rows_join_pending = false;
-    return CSKY_OK;
-}
 int clouds_dev(csky_ctx* c, const csky_cloud_params* p, int tile_w, const csky_bands* b, uint2* d_out, size_t pitch_bytes, hipStream_t s,
                unsigned long long* d_stats, bool setup, bool out_full = false) {
     if (!p) return fail(c, CSKY_ERR_INVALID, "render_clouds: params is NULL");
@@ -347,7 +334,7 @@ int clouds_dev(csky_ctx* c, const csky_cloud_params* p, int tile_w, const csky_b
         }
         if (kt) HIPCHK(c, hipEventRecord(kt[1], s));
         HIPCHK(c, hipEventRecord(c->ev_clouds[c->fc_cur], s)); c->clouds_pending[c->fc_cur] = true;
-        return join_lut_rows(c, s);
+        return CSKY_OK;
     }
     // mode 7: this launch runs in the order derived from the costs of the previous launch ON THE SAME RING SLOT (same geometry and
     // view), records its own costs and derives the next order from them.  The first launch of a geometry uses the static order.  Costs,
@@ -386,7 +373,7 @@ int clouds_dev(csky_ctx* c, const csky_cloud_params* p, int tile_w, const csky_b
     HIPCHK(c, launch_lpt_order(cost, nblocks, shift, c->d_lpt_hist + slot * 2048, lorder, s));
     c->lpt_valid[slot] = true;
     HIPCHK(c, hipEventRecord(c->ev_clouds[c->fc_cur], s)); c->clouds_pending[c->fc_cur] = true;
-    return join_lut_rows(c, s);
+    return CSKY_OK;
 }
 
 }  // namespace
@@ -425,12 +412,6 @@ int csky_create(csky_ctx** out, int device_id) {
     // (a HIGH-PRIORITY prologue stream was measured in round 2: whole frames with two frames in flight 1.78 -> 2.02 ms, one rank's 1/8 share
     // 0.329 -> 0.335 ms: the priority queue breaks the overlap of the two frame streams.  Plain stream.)
     if ((e = hipStreamCreateWithFlags(&c->pro, hipStreamNonBlocking)) != hipSuccess) return bail("hipStreamCreate", e);
-    if ((e = hipStreamCreateWithFlags(&c->side, hipStreamNonBlocking)) != hipSuccess) return bail("hipStreamCreate", e);
-    for (int k = 0; k < RING; k++) {
-        if ((e = hipEventCreateWithFlags(&c->ev_rows_begin[k], hipEventDisableTiming)) != hipSuccess) return bail("hipEventCreate", e);
-        if ((e = hipEventCreateWithFlags(&c->ev_rows_done[k], hipEventDisableTiming)) != hipSuccess) return bail("hipEventCreate", e);
-    }
-    if (const char* pe = getenv("CSKY_ROWS_OVERLAP")) c->rows_overlap = atoi(pe) != 0;      // A/B switch (tools/share_matrix.py); the API is csky_set_lut_rows_overlap
     for (int k = 0; k < RING; k++) {
         for (long long& v : c->order_key_ring[k]) v = -1;
         for (long long& v : c->lpt_key[k]) v = -1;
@@ -473,8 +454,6 @@ void csky_destroy(csky_ctx* c) {
     for (hipEvent_t ev : evs) if (ev) (void)hipEventDestroy(ev);
     for (hipEvent_t ev : c->kt_ev) if (ev) (void)hipEventDestroy(ev);
     if (c->pro) (void)hipStreamDestroy(c->pro);
-    if (c->side) (void)hipStreamDestroy(c->side);
-    for (int k = 0; k < RING; k++) { if (c->ev_rows_begin[k]) (void)hipEventDestroy(c->ev_rows_begin[k]); if (c->ev_rows_done[k]) (void)hipEventDestroy(c->ev_rows_done[k]); }
     if (c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
 }
@@ -736,15 +715,7 @@ int csky_sync(csky_ctx* c) {
     if (!c) return fail(nullptr, CSKY_ERR_INVALID, "csky_sync: ctx is NULL");
     int rc; if ((rc = bind(c))) return rc;
     HIPCHK(c, hipStreamSynchronize(c->pro));
-    HIPCHK(c, hipStreamSynchronize(c->side));
     HIPCHK(c, hipStreamSynchronize(c->stream));
-    return CSKY_OK;
-}
-int csky_set_lut_rows_overlap(csky_ctx* c, int enabled) {
-    if (!c) return fail(nullptr, CSKY_ERR_INVALID, "csky_set_lut_rows_overlap: ctx is NULL");
-    int rc; if ((rc = bind(c))) return rc;
-    if ((rc = join_lut_rows(c, nullptr))) return rc;
-    c->rows_overlap = enabled != 0;
     return CSKY_OK;
 }
 
@@ -791,21 +762,11 @@ int csky_render_sky_lut_rows_device(csky_ctx* c, const csky_sky_params* p, int f
         if ((rc = render_trans_dev(c, 256, 64, c->pro))) return rc;
         HIPCHK(c, hipStreamSynchronize(c->pro));
     }
-    // the rows have no consumer inside the library: they are rendered on the CALLER's stream, in order with the bands they travel with --
+    // the rows have no consumer inside the library: they are rendered on the CALLER's stream, in order with the bands they travel with.
+    // (Round 5 measured them on a side stream BESIDE the march that follows, joined behind it: a 1/8 share one frame at a time 0.409 -> 0.460 ms, eight
+    // in flight 0.241 -> 0.244: two more cross-stream hops cost more than the rows they take off the critical path; profiles/r05/rows_overlap_ab.txt.)
     hipStream_t s = hip_stream ? (hipStream_t)hip_stream : c->stream;
-    if ((rc = join_lut_rows(c, nullptr))) return rc;          // (rows of an earlier call that no march followed: ordered now)
-    if (c->rows_overlap) {
-        // -- or, with csky_set_lut_rows_overlap, BESIDE the march that follows on that stream: the side stream starts where the caller's stream stands
-        // (the buffer's previous reader, the gather of an earlier frame, is ordered there), and the caller's stream waits for the rows behind the march
-        const int k = c->rows_n++ % RING;
-        HIPCHK(c, hipEventRecord(c->ev_rows_begin[k], s));
-        HIPCHK(c, hipStreamWaitEvent(c->side, c->ev_rows_begin[k], 0));
-        HIPCHK(c, launch_sky_lut_rows(w, h, first_row, row_stride, p->sun_direction, c->d_trans_f, c->tw, c->th, reinterpret_cast<uint2*>(d_rows_out), nullptr, c->side));
-        HIPCHK(c, hipEventRecord(c->ev_rows_done[k], c->side));
-        c->rows_join_pending = true; c->rows_join_stream = s; c->rows_join_ev = c->ev_rows_done[k];
-    } else {
-        HIPCHK(c, launch_sky_lut_rows(w, h, first_row, row_stride, p->sun_direction, c->d_trans_f, c->tw, c->th, reinterpret_cast<uint2*>(d_rows_out), nullptr, s));
-    }
+    HIPCHK(c, launch_sky_lut_rows(w, h, first_row, row_stride, p->sun_direction, c->d_trans_f, c->tw, c->th, reinterpret_cast<uint2*>(d_rows_out), nullptr, s));
     for (int i = 0; i < 3; i++) c->sky_sun[i] = p->sun_direction[i];
     c->psw = w; c->psh = h; c->sky_partial = true; c->have_sky = true; c->sky_in_memory = false; c->lut_writers.clear();
     return CSKY_OK;

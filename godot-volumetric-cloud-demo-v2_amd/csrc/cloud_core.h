@@ -25,28 +25,6 @@ CSKY_HD float fast_exp2(float x) { return exp2f(x); }
 CSKY_HD float fast_log2(float x) { return log2f(x); }
 #define CSKY_WAVE_ALL(x) (x)
 #endif
-// two fp32 lanes in one even-aligned register pair: the operand form of gfx950's v_pk_fma_f32 / v_pk_mul_f32 / v_pk_add_f32 (IEEE per component).
-// Experiment builds only (CSKY_PK_FILTER / CSKY_PK_COORD, round 5; clang vector extension: the g++ host build of tests/hostsim never sees them).
-#if !defined(__clang__)
-#undef CSKY_PK_FILTER
-#undef CSKY_PK_COORD
-#endif
-#ifndef CSKY_PK_FILTER
-#define CSKY_PK_FILTER 0
-#endif
-#ifndef CSKY_PK_COORD
-#define CSKY_PK_COORD 0
-#endif
-#if defined(__clang__)
-typedef float v2f __attribute__((ext_vector_type(2)));
-CSKY_HD v2f pk_fma(v2f a, v2f b, v2f c) {
-#if defined(__HIP_DEVICE_COMPILE__)
-    return __builtin_elementwise_fma(a, b, c);
-#else
-    return v2f{fmaf(a.x, b.x, c.x), fmaf(a.y, b.y, c.y)};
-#endif
-}
-#endif
 CSKY_HD float fast_exp(float x) { return fast_exp2(x * 1.44269504088896f); }
 CSKY_HD float fast_pow(float x, float y) { return fast_exp2(y * fast_log2(x)); }  // x >= 0; pow(0,y>0) = 0
 
@@ -172,19 +150,6 @@ CSKY_HD void detail_coord(const FrameConsts& fc, float qx, float qy, float qz, f
     sx = (qx - fc.det_off_x) * 0.001f; sy = (qy - fc.det_off_y) * 0.001f; sz = (qz - fc.det_off_z) * 0.001f;
 }
 CSKY_HD void advance(float& x, float& y, float& z, float ix, float iy, float iz) { x = x + ix; y = y + iy; z = z + iz; }
-// packed (x, z) forms of the coordinate chains above for the CSKY_PK_COORD experiment: the same IEEE operations per component, two per instruction
-#if defined(__clang__)
-typedef float v2f_a __attribute__((ext_vector_type(2)));
-CSKY_HD v2f_a pk_add_nc(v2f_a a, v2f_a b) { return a + b; }
-CSKY_HD v2f_a pk_sub_nc(v2f_a a, v2f_a b) { return a - b; }
-CSKY_HD v2f_a pk_mul_nc(v2f_a a, v2f_a b) { return a * b; }
-CSKY_HD v2f_a pk_weather_uv(v2f_a pxz, v2f_a wpos) {         // weather_coord, then the texel coordinate u * 512 - 0.5 (x 512 is exact: the fused form rounds once, to the same value)
-    const v2f_a uv = pxz * v2f_a{0.00006f, 0.00006f} + v2f_a{0.5f, 0.5f} + wpos;
-    return uv * v2f_a{512.0f, 512.0f} - v2f_a{0.5f, 0.5f};
-}
-CSKY_HD v2f_a pk_scale_half(v2f_a s, float fn) { return s * v2f_a{fn, fn} - v2f_a{0.5f, 0.5f}; }   // fn is a power of two: s * fn is exact
-#endif
-CSKY_HD float detail_coord_y(const FrameConsts& fc, float qy) { return (qy - fc.det_off_y) * 0.001f; }
 
 // Per-frame constants (clouds.glsl:114,128-129,148-150,160-170,187,195).  Runs once per frame (one lane).
 CSKY_HD float sky_lut_uv_x(float dz, float dx) { return atan2f(dz, dx) / CLOUD_PI * 0.5f + 0.5f; }
@@ -540,6 +505,8 @@ CSKY_HD float sample_density(const TS& T, const FrameConsts& fc, float px, float
 // (Round-2 experiment, measured and removed: the cells of detail LODs 2..4 / 3..4 staged in LDS per workgroup and served to the light march
 // with one ds_read_b128 per tap: frames bit-identical, C3 2.16 / 2.08 ms against 2.05 ms (LODs 2..4 need 9.3 KB and cost a wavefront per SIMD;
 // LODs 3..4 remove 2 of 28 gathers per in-cloud sample and add a workgroup barrier + staging): profiles/r02/layout_lds_ab.txt.)
+// (Round 5, measured and removed, profiles/r05/kernel_experiments.txt: v_pk_fma_f32 for the y / z stages of the cell pairs: no gain; packed (x, z)
+// coordinate chains, v_pk_mul / v_pk_add: frame identical, +4.6 % time.)
 // sample_density() with all of a sample's texture fetches issued up front ("eager"): the addresses of the weather, shape and detail
 // cells depend only on the sample position, not on each other's results, so the three gathers can be in flight together instead of
 // one after the other (one memory latency per sample instead of three; the kernel is as sensitive to latency as to VALU issue:
@@ -558,43 +525,23 @@ CSKY_HD float sample_density_eager(const TS& T, const FrameConsts& fc, float px,
     if (hf > fc.hf_lo && hf < fc.hf_hi) {
         // ---- addresses + fetches
         CSKY_PRIO(0);
-        int wix, wiy; float wax, way;
-#if CSKY_PK_COORD
-        // experiment (round 5): the (x, z) halves of the coordinate chains as packed fp32 (v_pk_mul_f32 / v_pk_add_f32: IEEE per component, no
-        // contraction, so every rounding of section A is kept); y stays scalar.  pk_xz_* are compiled with contraction off (section A, above).
-        const v2f pxz = v2f{px, pz};
-        const v2f wuv = pk_weather_uv(pxz, v2f{wx, wy});
-        split_coord(wuv.x, wix, wax); split_coord(wuv.y, wiy, way);
-#else
         float wsx, wsy;
         weather_coord(px, pz, wx, wy, wsx, wsy);
+        int wix, wiy; float wax, way;
         split_coord(wsx * 512.0f - 0.5f, wix, wax); split_coord(wsy * 512.0f - 0.5f, wiy, way);
-#endif
         const uint4 wq = *reinterpret_cast<const uint4*>(reinterpret_cast<const char*>(T.weather) + (((((uint32_t)(wiy & 511)) << 9) | (uint32_t)(wix & 511)) << 4));
+        float qx, qy, qz, sx, sy, sz;
+        shape_coord(fc, px, py, pz, qx, qy, qz, sx, sy, sz);
         const int sn = SHAPE_N >> lod_shape, sm = sn - 1;
         const float sfn = pow2f(7 - lod_shape);
         int six, siy, siz; float sax, say, saz;
-#if CSKY_PK_COORD
-        const v2f qxz = pk_add_nc(pxz, v2f{fc.cloud_off_x, fc.cloud_off_z});
-        const float qy = py;
-        const v2f suw = pk_scale_half(pk_mul_nc(qxz, v2f{0.00008f, 0.00008f}), sfn);
-        split_coord(suw.x, six, sax); split_coord((qy * 0.00008f) * sfn - 0.5f, siy, say); split_coord(suw.y, siz, saz);
-#else
-        float qx, qy, qz, sx, sy, sz;
-        shape_coord(fc, px, py, pz, qx, qy, qz, sx, sy, sz);
         split_coord(sx * sfn - 0.5f, six, sax); split_coord(sy * sfn - 0.5f, siy, say); split_coord(sz * sfn - 0.5f, siz, saz);
-#endif
         const uint32_t ssh = (uint32_t)(7 - lod_shape);
         const uint32_t sidx = shape_level_offset(lod_shape) + shape_cell_offset((uint32_t)(six & sm), (uint32_t)(siy & sm), (uint32_t)(siz & sm), ssh);
         const uint4* __restrict__ sp = reinterpret_cast<const uint4*>(reinterpret_cast<const char*>(T.shape) + (sidx << 5));
         const uint4 tr = sp[0], tf = sp[1];
         float dsx, dsy, dsz;
-#if CSKY_PK_COORD
-        const v2f dxz = pk_mul_nc(pk_sub_nc(qxz, v2f{fc.det_off_x, fc.det_off_z}), v2f{0.001f, 0.001f});
-        dsx = dxz.x; dsz = dxz.y; dsy = detail_coord_y(fc, qy);
-#else
         detail_coord(fc, qx, qy, qz, dsx, dsy, dsz);
-#endif
         const bool tap = EAGER_DETAIL && lod_detail != 5;         // wave-uniform; LOD 5 is one texel (detail_tap)
         uint4 dq;
         float dax, day, daz;
@@ -602,41 +549,21 @@ CSKY_HD float sample_density_eager(const TS& T, const FrameConsts& fc, float px,
             const int dn = DETAIL_N >> lod_detail, dm = dn - 1;
             const float dfn = pow2f(5 - lod_detail);
             int dix, diy, diz;
-#if CSKY_PK_COORD
-            const v2f duw = pk_scale_half(dxz, dfn);
-            split_coord(duw.x, dix, dax); split_coord(dsy * dfn - 0.5f, diy, day); split_coord(duw.y, diz, daz);
-#else
             split_coord(dsx * dfn - 0.5f, dix, dax); split_coord(dsy * dfn - 0.5f, diy, day); split_coord(dsz * dfn - 0.5f, diz, daz);
-#endif
             const uint32_t dsh = (uint32_t)(5 - lod_detail);
             const uint32_t didx = detail_level_offset(lod_detail) + ((((((uint32_t)(diz & dm)) << dsh) | (uint32_t)(diy & dm)) << dsh) | (uint32_t)(dix & dm));
             dq = *reinterpret_cast<const uint4*>(reinterpret_cast<const char*>(T.detail) + (didx << 4));
         }
         // ---- the arithmetic of density() (clouds.glsl:109-137) on the fetched cells
         CSKY_PRIO(CSKY_PRIO_MATH);
-#if CSKY_PK_FILTER
-        // experiment (round 5): the y / z stages of the cell pairs that share their weights as v_pk_fma_f32 (two IEEE FMAs per
-        // instruction, the same values bit for bit; 3.3 issue cycles per pair against 2 x 1.9, profiles/r04/valu_issue_time_gfx950.txt)
-        const v2f wrb = pk_fma(v2f{way, way}, v2f{lerp_h(wq.y, wax), lerp_h(wq.w, wax)}, v2f{lerp_h(wq.x, wax), lerp_h(wq.z, wax)});
-        const float wr = wrb.x, wb = wrb.y;
-#else
         const float wr = fmaf(way, lerp_h(wq.y, wax), lerp_h(wq.x, wax));       // texel scale 0..255 (weather_filter)
         const float wb = fmaf(way, lerp_h(wq.w, wax), lerp_h(wq.z, wax));
-#endif
         const float wc = fc.cov255 * wb;                                         // :123 (wb on the texel scale)
         const float g = density_height_gradient(fc, hf, wr);                    // :121
         const float omw = 1.0f - wc;
         if (g > omw) {                                                           // else: exact reject (1)
-#if CSKY_PK_FILTER
-            const v2f sy2 = v2f{say, say};
-            const v2f hi2 = pk_fma(sy2, v2f{lerp_h(tr.w, sax), lerp_h(tf.w, sax)}, v2f{lerp_h(tr.z, sax), lerp_h(tf.z, sax)});
-            const v2f lo2 = pk_fma(sy2, v2f{lerp_h(tr.y, sax), lerp_h(tf.y, sax)}, v2f{lerp_h(tr.x, sax), lerp_h(tf.x, sax)});
-            const v2f nf = pk_fma(v2f{saz, saz}, hi2, lo2) * v2f{1.0f / 255.0f, 1.0f / (8.0f * 255.0f)};
-            const float nr = nf.x, fbm = nf.y;
-#else
             const float nr = fmaf(saz, fmaf(say, lerp_h(tr.w, sax), lerp_h(tr.z, sax)), fmaf(say, lerp_h(tr.y, sax), lerp_h(tr.x, sax))) * (1.0f / 255.0f);
             const float fbm = fmaf(saz, fmaf(say, lerp_h(tf.w, sax), lerp_h(tf.z, sax)), fmaf(say, lerp_h(tf.y, sax), lerp_h(tf.x, sax))) * (1.0f / (8.0f * 255.0f));
-#endif
             const float omf = 1.0f - fbm, den1 = 1.0f + omf;
             float num = (nr + omf) * g - omw * den1;                            // :122, :124-125 as numerator / den1 (see density())
             if (num > 0.0f) {                                                    // else: reject (2)

@@ -499,9 +499,6 @@ constexpr int CQ_FLOATS = 5 * CQ_CAP + CQ_CAP / 4 + 3 * CQ_STEPS + 2 + 128 + 320
 #ifndef CSKY_EAGER_LIGHT
 #define CSKY_EAGER_LIGHT 1
 #endif
-#ifndef CSKY_LIGHT_UNROLL
-#define CSKY_LIGHT_UNROLL 0
-#endif
 #if CSKY_EAGER_LIGHT
 #define CSKY_LIGHT_SAMPLE sample_density_eager<true>
 #else
@@ -528,11 +525,7 @@ template <class TS, class Late>
 __device__ __forceinline__ void light_march_terms(const TS& T, const FrameConsts& fc, const int ls, const float nd, float ex, float ey, float ez, Late&& late,
                                                   float& Dr, float& Dg, float& Db, float& rq, float& dt) {
     float lx = ex, ly = ey, lz = ez, cd = 0.0f;
-#if CSKY_LIGHT_UNROLL
-#pragma unroll
-#else
-#pragma unroll 1                                                 // scalar j: one loop body (unrolling measured no faster, 6x the code)
-#endif
+#pragma unroll 1                                                 // scalar j: one loop body (unrolling measured no faster in rounds 2 and 5, 6x the code: profiles/r05/kernel_experiments.txt)
     for (int j = 0; j < 6; j++) {                                                                      // :186 (light_steps <= 6)
         if (j >= ls) break;
         advance(lx, ly, lz, fc.linc[j][0], fc.linc[j][1], fc.linc[j][2]);                              // :187

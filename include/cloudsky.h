@@ -166,12 +166,6 @@ int csky_copy_sky_lut_device(csky_ctx* ctx, void* d_out_rgba16f, void* hip_strea
  * csky_read_sky_lut / csky_copy_sky_lut_device return CSKY_ERR_STATE until the next csky_render_sky_lut*. */
 int csky_render_sky_lut_rows_device(csky_ctx* ctx, const csky_sky_params* p, int first_row, int row_stride, void* d_rows_out_rgba16f,
                                     size_t capacity_bytes, void* hip_stream);
-/* The rows have no reader on the rank that renders them, so they need not run IN FRONT of the march on its stream.  enabled = 1: the rows of
- * every following csky_render_sky_lut_rows_device call run on an internal side stream that starts where `hip_stream` stands at the call, and
- * `hip_stream` is ordered behind them by the NEXT csky_render_clouds_device call, after it has enqueued the march: rows and march overlap, and
- * whatever the caller enqueues on the stream after that march (the gather) sees both.  A caller that reads the rows without a march in between
- * keeps the default (0: rows in stream order); csky_sync and the next rows call also order them.  Results are identical either way. */
-int csky_set_lut_rows_overlap(csky_ctx* ctx, int enabled);
 /* The gathering rank's last step when N processes split a frame (one gather to rank 0): the gather leaves every member's compact
  * bands back to back (member m at d_gathered + m * member_stride_bytes); frame band k (band_bytes each: band_rows x row bytes; total_bands of
  * them) = member k % members, local band k / members.  Asynchronous on `hip_stream`; a deliberately narrow, HBM-bound copy that runs beside the

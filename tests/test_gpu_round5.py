@@ -44,50 +44,3 @@ def test_external_frame_import_and_release_leave_no_file_descriptor_behind(pkg, 
         assert after - before < 4, "%d descriptors before, %d after sixteen import / release cycles" % (before, after)
     finally:
         ex.close()
-
-
-def test_lut_rows_beside_the_march_give_the_same_rows_and_the_same_bands(gpu_ctx, oracle):
-    """csky_set_lut_rows_overlap: a rank's rows of the sky LUT run on a side stream beside the march that follows them on the caller's stream, which
-    is ordered behind them after the march is enqueued.  Eight frames rotating over four streams (rows + bands each, a copy behind every march on
-    its stream standing in for the gather): rows and bands are byte-identical to the in-order form, and a rows call that no march follows is
-    ordered by csky_sync."""
-    import torch
-    W, H, n = 512, 256, 8
-    bands = (8, 1, n, H // 8 // n)
-    suns = [np.array([np.cos(t), np.sin(t), 0.2], np.float32) / np.float32(np.sqrt(1.04)) for t in np.linspace(0.3, 2.6, 8)]
-    streams = [torch.cuda.Stream() for _ in range(4)]
-    nrow = (100 - 1 + n - 1) // n
-
-    def run(overlap):
-        gpu_ctx.set_lut_rows_overlap(overlap)
-        gpu_ctx.set_frames_in_flight(4)
-        rows = [torch.zeros(nrow * 200 * 8, dtype=torch.uint8, device="cuda") for _ in range(4)]
-        out = [torch.zeros((bands[3] * 8, W, 4), dtype=torch.int16, device="cuda") for _ in range(4)]
-        got = []
-        torch.cuda.synchronize()
-        for k, sun in enumerate(suns):
-            i = k % 4
-            gpu_ctx.render_sky_lut_rows_device(sun, 1, n, rows[i].data_ptr(), rows[i].numel(), 200, 100, streams[i].cuda_stream)
-            gpu_ctx.render_clouds_device(oracle.default_params(W, H, sun), W, bands, out[i].data_ptr(), W * 8, streams[i].cuda_stream)
-            with torch.cuda.stream(streams[i]):                  # the "gather": reads rows and bands in stream order behind the march
-                got.append((rows[i].clone(), out[i].clone()))
-        for s in streams:
-            s.synchronize()
-        lone = torch.zeros(nrow * 200 * 8, dtype=torch.uint8, device="cuda")
-        torch.cuda.synchronize()
-        gpu_ctx.render_sky_lut_rows_device(suns[3], 1, n, lone.data_ptr(), lone.numel(), 200, 100, streams[0].cuda_stream)
-        gpu_ctx.sync()                                           # no march follows: csky_sync orders the side stream
-        streams[0].synchronize()
-        gpu_ctx.set_frames_in_flight(1)
-        return got, lone.cpu()
-
-    try:
-        a, la = run(False)
-        b, lb = run(True)
-    finally:
-        gpu_ctx.set_lut_rows_overlap(False)
-        gpu_ctx.render_sky_lut(suns[0], 200, 100)                # leave the shared context with a whole LUT
-    for (ra, oa), (rb, ob) in zip(a, b):
-        assert bool((ra == rb).all().item()) and bool((oa == ob).all().item())
-    assert bool((la == lb).all().item()) and bool((la == a[3][0].cpu()).all().item()) and int(la.sum().item()) > 0
-    assert float(a[0][1].view(torch.float16)[..., 3].float().mean().item()) > 0.0
