@@ -1,9 +1,11 @@
 #!/bin/bash
-# Round-4 validation + evidence run (GPU box).  usage: bash tools/gpu_full_r04.sh   -> everything lands under gpurun_out/r04final/
-R=$PWD; O=$R/gpurun_out/r04final; mkdir -p $O
+# Round-5 validation + evidence run (GPU box).  usage: bash tools/gpu_full_r05.sh   -> everything lands under gpurun_out/r05final/
+R=$PWD; O=$R/gpurun_out/r05final; mkdir -p $O
 timeout -s KILL 900 python -m pytest tests -m gpu -q > $O/pytest_gpu_full.log 2>&1; tail -6 $O/pytest_gpu_full.log | tee $O/pytest_gpu.log
 timeout -s KILL 200 python __graft_entry__.py smoke 2>&1 | tail -1 | tee $O/smoke.log
 timeout -s KILL 400 python bench.py > $O/bench_C3_n1.json 2> $O/bench_C3_n1.err
+# the driver's own invocation (20 timed steps, 5 warm-up): value_as_asked (cold) next to value (after the clock pre-warm) in ONE line
+timeout -s KILL 300 python bench.py --gpus 1 --steps 20 --warmup 5 --no-cpu-baseline --no-pmc > $O/bench_C3_n1_driver_invocation.json 2>/dev/null
 cp gpurun_out/bench_pmc_C3.json $O/clouds_C3_pmc_live_from_bench.json 2>/dev/null
 timeout -s KILL 300 python bench.py --frames-in-flight 1 --no-cpu-baseline --no-pmc > $O/bench_C3_n1_one_frame_at_a_time.json 2>/dev/null
 # the rocprofv3 summaries the bench line's durations must agree with: the timed region as bench.py runs it, and one frame at a time (the dominant kernel alone)
@@ -23,5 +25,6 @@ python tools/isa_profile.py run --config C3 --out $O/census_counts_C3.json 2>&1 
 python tools/isa_profile.py report $O/census_counts_C3.json --out $O/census_report_C3.json > $O/census_report_C3.txt 2>&1
 timeout -s KILL 300 python tools/parity_stats.py 2>&1 | grep '^{' > $O/parity_stats.txt
 timeout -s KILL 300 python tools/parity_sweep.py 2>&1 | grep '^{' > $O/parity_sweep.txt
+timeout -s KILL 600 python tools/bc7_sensitivity.py 2>&1 | grep -v amdgpu.ids > $O/bc7_sensitivity.txt
 rm -rf $O/bench_trace $O/bench_trace_fif1
 ls -la $O
