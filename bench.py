@@ -370,6 +370,10 @@ def main():
     ap.add_argument("--no-prewarm", action="store_true", help="skip the ~120 ms of untimed frames at the end of the set-up that bring the GPU clocks up (see config.clock_prewarm_frames)")
     ap.add_argument("--whole-lut", action="store_true", help="N > 1: every rank renders the whole sky LUT (rounds 1-3) instead of its rows of it")
     ap.add_argument("--staged", action="store_true", help="single-process form: local band buffers + strided peer copies instead of in-place peer stores")
+    ap.add_argument("--shape-noise", default="", help="NOT the benchmark workload: knobs of the stand-in shape generator as key=value,... (csky_shape_noise_params: perlin_freq, "
+                                                        "perlin_octaves, worley_freq, perlin_gain, dilate, centre, contrast, offset), to see what the missing asset's character does to "
+                                                        "the frame time (config.workload says so; roofline census / executed_tap_bytes then describe another frame than the pinned one)")
+    ap.add_argument("--coverage", type=float, default=0.2, help="cloud_coverage of the push-constant block (0.2 = clouds_sky.tres = the benchmark workload)")
     args = ap.parse_args()
 
     if args.gpus > 1 and not args.single_process and "WORLD_SIZE" not in os.environ:
@@ -411,12 +415,21 @@ def main():
         th = np.radians(np.linspace(2.0, 178.0, 64))
         sweep = [default_params(W, H, (np.cos(t), np.sin(t), 0.0)) for t in th]      # one push-constant block + sun per frame
         sun = (np.cos(th[16]), np.sin(th[16]), 0.0)                                    # representative frame for the kernel-only timing
-    params, sun_n = default_params(W, H, sun)
+    params, sun_n = default_params(W, H, sun, coverage=args.coverage)
+    if sweep is not None and args.coverage != 0.2:
+        sweep = [default_params(W, H, (np.cos(t), np.sin(t), 0.0), coverage=args.coverage) for t in th]
     large, small, weather = gvcd_amd.assets.load_default_noise()
+    knobs = {}
+    if args.shape_noise:
+        for kv in args.shape_noise.split(","):
+            k, v = kv.split("=")
+            knobs[k.strip()] = int(v) if k.strip() in ("perlin_freq", "perlin_octaves", "worley_freq") else float(v)
+        large = gvcd_amd.assets.generate_shape_noise(gvcd_amd.assets.SHAPE_SEED, 128, **knobs)
+    off_workload = bool(knobs) or args.coverage != 0.2
 
     ctx = gvcd_amd.Context(local_rank)
     ctx.set_noise(large, small, weather)            # inputs -> HBM (mip chains + device layouts baked on the GPU, once)
-    if ctx.noise_inexact_coeffs() != 0:
+    if ctx.noise_inexact_coeffs() != 0 and not off_workload:      # (an off-workload volume that does not fit fp16 pairs marches on exact fp32 cells: another kernel instantiation, config says so)
         raise SystemExit("bench.py: the benchmark textures must bake exactly (fp16 finite differences)")
     ctx.set_march(primary, light)
     ctx.set_early_out(args.early_out)
@@ -699,7 +712,7 @@ def main():
         # ---- hardware counters of the cloud kernel, collected now (child processes; the timed region is over)
         pmc, pmc_note = None, "not collected: N > 1 or --no-pmc"
         pmc_cfg = "C5frame" if args.config == "C5" else args.config          # the sweep's frames cost the same: profile one of them
-        if world == 1 and not args.no_pmc:
+        if world == 1 and not args.no_pmc and not off_workload:
             sys.path.insert(0, os.path.join(ROOT, "tools"))
             import pmc_collect
             t_p = time.perf_counter()
@@ -714,7 +727,7 @@ def main():
         # profiles/r02), so cycles available = duration x the shader clock SAMPLED during that region (tools/sclk.py: amdgpu hwmon freq1_input).
         # Every region is re-run for >= 0.4 s with the sampler on; the headline `value` above was timed without it.
         clocks, census, census_note = None, None, "not collected: N > 1 or --no-pmc"
-        if world == 1 and not args.no_pmc:
+        if world == 1 and not args.no_pmc and not off_workload:
             import sclk
             import isa_profile
             pr = torch.cuda.get_device_properties(local_rank)
@@ -762,7 +775,7 @@ def main():
         # the contractual 80 B/sample: why the algorithmic figure exceeds the HBM peak without any work being skipped
         executed_taps = None
         tap_file = os.path.join(ROOT, "profiles", "r04", "executed_tap_bytes_C3.json")
-        if args.config == "C3" and world == 1 and os.path.exists(tap_file):
+        if args.config == "C3" and world == 1 and not off_workload and os.path.exists(tap_file):
             et = json.load(open(tap_file))
             executed_taps = {"bytes_per_launch": et["executed_tap_bytes"], "over_algorithmic": et["executed_over_algorithmic"], "primary": et["primary"]["bytes"], "light": et["light"]["bytes"],
                              "achieved_GBps_solo": et["executed_tap_bytes"] / (k_solo * 1e-3) / 1e9, "source": "profiles/r04/executed_tap_bytes_C3.json (host walk of cloud_core.h, lane-level)",
@@ -785,7 +798,9 @@ def main():
             "ranks_seen": ranks_seen, "per_rank_share_ms": share_ms, "gathered_frame_check": frame_check,
             "config": {"workload": "%s: %dx%d hemisphere, %d primary x %d light steps, sun (%.4f,%.4f,%.4f), clouds_sky.tres defaults, "
                                    "weather.bmp + worlnoise.bmp + generated 128^3 shape noise (seed 1), wind frozen"
-                                   % (args.config, W, H, primary, light, sun_n[0], sun_n[1], sun_n[2]),
+                                   % (args.config, W, H, primary, light, sun_n[0], sun_n[1], sun_n[2])
+                                   + ("  [NOT THE BENCHMARK WORKLOAD: cloud_coverage %g, shape-generator knobs %s]" % (args.coverage, knobs or "default") if off_workload else ""),
+                       "off_workload": off_workload, "incloud_fraction": f_incloud, "exact_fp32_cells": bool(ctx.noise_inexact_coeffs() != 0),
                        "texture_size": [W, H], "primary_steps": primary, "light_steps": light, "early_out_eps": args.early_out, "with_early_out": early,
                        "variant": gvcd_amd.lib().csky_variant_name(args.variant if args.variant is not None else gvcd_amd._lib.DEFAULT_VARIANT).decode(),
                        "parallelism": "bands%d%s%s" % (per, "+overlapped-gather" if overlap else "", " x %d frame groups" % G if G > 1 else ""), "frames_in_flight": fif, "frame_groups": G,
