@@ -59,6 +59,8 @@ def test_bench_line_contract_single_gpu():
     assert v["source"] == "census" and v["frame_identical_to_product"] is True
     for unit, ratio in v["census_over_hardware_counters"].items():
         assert ratio is None or abs(ratio - 1.0) < 0.03, (unit, ratio)
+    assert v["priced_by_measured_kind_fraction"] > 0.98                        #  nearly every executed VALU instruction is priced by a measurement of its own kind
+    assert v["scratch_instructions_per_wavefront"]["plain"] == 0.0             # no scratch access anywhere in clouds_kernel<3,1> (the persistent form: per tile only)
     ka, tr, cl = r["kernel_alone"], r["timed_region"], v["valu_by_class"]
     guide = (2.0 * cl["full"] + 4.0 * cl["half"] + 8.0 * (cl["trans"] + cl.get("quarter", 0)) + 4.0 * cl.get("lane", 0)) / 1024.0
     assert abs(guide - r["achieved"]) < 1e-6 * guide
@@ -107,7 +109,7 @@ def test_bench_gpus_2_starts_its_own_ranks():
     assert "gathered 2-rank frame vs single-rank frame" in out.stderr
 
 
-@pytest.mark.parametrize("mode", [("8", "1", None), ("4", "2", None), ("3", "1", "--staged")])
+@pytest.mark.parametrize("mode", [("8", "1", None), ("4", "2", None), ("3", "1", "--staged"), ("2", "1", None)])
 def test_bench_single_process_form(mode):
     """`--single-process`: N contexts behind ONE csky_multi handle (the form a GDExtension host can use), here all on GPU 0.  8 devices x 1 group is
     BASELINE config 4's split; 4 devices in 2 groups is the throughput form (consecutive frames alternate between two 2-way groups); --staged
@@ -126,7 +128,7 @@ def test_bench_single_process_form(mode):
     assert "-device frame vs single-context frame" in out.stderr
 
 
-@pytest.mark.parametrize("cfg", [("4", "2", "C3"), ("3", "3", "C5")])
+@pytest.mark.parametrize("cfg", [("4", "2", "C3"), ("3", "3", "C5"), ("2", "2", "C2")])
 def test_bench_frame_groups_process_form(cfg):
     """`--groups G` in the one-process-per-GPU form: consecutive frames go to G groups of ranks in turn, each group splits its frame and gathers it
     on rank 0 over its own communicator ({0} + the group).  Self-launched, all ranks on GPU 0 through gloo; G = world is pure frame parallelism
