@@ -144,3 +144,17 @@ def test_bench_frame_groups_process_form(cfg):
     assert d["n_gpus"] == int(n) and d["ranks_seen"] == int(n) and d["config"]["frame_groups"] == int(g) and d["config"]["finite"] is True
     assert d["gathered_frame_check"]["within_1_fp16_ulp_frac"] >= 0.9999 and d["gathered_frame_check"]["max_abs_diff"] <= 2e-3, d["gathered_frame_check"]
     assert "gathered %s-rank frame vs single-rank frame" % n in out.stderr
+
+
+def test_off_workload_runs_are_flagged_and_carry_no_census():
+    """`--shape-noise` / `--coverage` (round 5: what the frame time owes to the stand-in volume, profiles/r05/noise_sensitivity.txt) are NOT the benchmark
+    workload: the line says so, its roofline carries no census of another frame, and the in-cloud fraction it reports is the one that explains the time."""
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "4", "--warmup", "1", "--no-cpu-baseline", "--no-host-form",
+                          "--shape-noise", "perlin_freq=8,perlin_octaves=4,dilate=0.8", "--coverage", "0.25"], capture_output=True, text=True, cwd=ROOT, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    d = _last_json(out.stdout)
+    c = d["config"]
+    assert c["off_workload"] is True and "NOT THE BENCHMARK WORKLOAD" in c["workload"] and c["finite"] is True
+    assert d["roofline"]["frac"] is None and d["roofline"]["executed_tap_bytes"] is None and d["roofline"]["traffic"] is None
+    assert 0.2 < c["incloud_fraction"] < 0.4 and c["exact_fp32_cells"] is False          # (the benchmark workload: 0.152)
+    assert d["value_as_asked"] > 0 and d["ms_per_step"] > 1.0
