@@ -900,7 +900,14 @@ int csky_external_frame_import_fd(csky_ctx* c, int opaque_fd, size_t allocation_
     md.type = hipExternalMemoryHandleTypeOpaqueFd; md.handle.fd = dfd; md.size = allocation_bytes;
     { struct stat st; if (fstat(dfd, &st) == 0) { f->dfd_dev = st.st_dev; f->dfd_ino = st.st_ino; } }
     hipError_t e = hipImportExternalMemory(&f->mem, &md);
-    if (e != hipSuccess) (void)close(dfd); else f->dfd = dfd;
+    if (e != hipSuccess) (void)close(dfd);
+    else {
+        // who owns the duplicate now?  If the number no longer names what it named before the call, the runtime consumed it at import (CUDA's
+        // convention): nothing is left to close, and the number must not be looked at again -- a later descriptor of the SAME memory object
+        // (a second frame imported from one allocation) may reuse it.  Otherwise it is closed at release, if it is then still the same object.
+        struct stat st;
+        f->dfd = (fstat(dfd, &st) == 0 && st.st_dev == f->dfd_dev && st.st_ino == f->dfd_ino) ? dfd : -1;
+    }
     if (e == hipSuccess) {
         hipExternalMemoryBufferDesc bd; memset(&bd, 0, sizeof bd);
         bd.offset = offset; bd.size = frame_bytes;

@@ -44,3 +44,42 @@ def test_external_frame_import_and_release_leave_no_file_descriptor_behind(pkg, 
         assert after - before < 4, "%d descriptors before, %d after sixteen import / release cycles" % (before, after)
     finally:
         ex.close()
+
+
+def test_two_frames_of_one_allocation_survive_each_others_release(pkg, gpu_ctx):
+    """Two external frames imported from duplicates of ONE exported descriptor (a ring of textures inside one VkDeviceMemory): releasing the first must
+    not close anything the second -- or the caller -- still uses, whichever party the runtime makes the owner of the duplicate it is handed."""
+    import ctypes as C
+    import os
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+    import ext_frame_roundtrip as X
+    from bench import default_params
+    hip = X.load_hip()
+    W, H = 128, 64
+    frame = W * H * 8
+    try:
+        ex = X.ExportedAllocation(hip, 0, 4 * frame)
+    except RuntimeError as e:
+        pytest.skip("the runtime cannot export an allocation as a file descriptor here: %s" % e)
+    L = pkg.lib()
+    try:
+        gpu_ctx.set_variant(-1); gpu_ctx.set_schedule(-1); gpu_ctx.set_segments(0); gpu_ctx.set_early_out(0.0); gpu_ctx.set_march(64, 4)
+        p, sun = default_params(W, H, (1, 1, 0))
+        gpu_ctx.render_sky_lut(sun, 200, 100)
+        ref = gpu_ctx.render_clouds(p).view(np.uint16)
+        ex.fill(0)
+        e1, d1, e2, d2 = C.c_void_p(), C.c_void_p(), C.c_void_p(), C.c_void_p()
+        assert L.csky_external_frame_import_fd(gpu_ctx._h, os.dup(ex.fd), C.c_size_t(ex.size), C.c_size_t(0), C.c_size_t(frame), C.byref(e1), C.byref(d1)) == 0
+        keep = os.dup(ex.fd)                                     # a descriptor of the same object the caller holds on to (may take a number the runtime freed)
+        assert L.csky_external_frame_import_fd(gpu_ctx._h, os.dup(ex.fd), C.c_size_t(ex.size), C.c_size_t(2 * frame), C.c_size_t(frame), C.byref(e2), C.byref(d2)) == 0
+        L.csky_external_frame_release(e1)
+        os.fstat(keep)                                           # still open: the release closed nothing of the caller's
+        gpu_ctx.render_clouds_device(p, W, (H, 0, 1, 1), d2.value, W * 8, 0)
+        gpu_ctx.sync()
+        assert (ex.read(frame, 2 * frame).view(np.uint16).reshape(H, W, 4) == ref).all()
+        assert (ex.read(frame, 0) == 0).all()
+        L.csky_external_frame_release(e2)
+        os.fstat(keep); os.close(keep)
+    finally:
+        ex.close()
