@@ -746,6 +746,18 @@ void csko_composite_view(int out_w, int out_h, const float basis[9], float fov_y
 }
 
 /* ------------------------------------------------------------------ probes for structural tests */
+/* Sampler / store probes: the texel-fetch semantics of this file exported one tap at a time, so that oracle/glsl_exec (the reference's
+ * shader text executed under a C++ GLSL-subset shim, build container only) binds texture()/textureLod() to exactly these functions. */
+void csko_tap3d_repeat(const uint8_t *chain, int n0, int levels, int ch, float lod, const float s[3], float out[4]) {
+    out[0] = out[1] = out[2] = 0.0f; out[3] = 1.0f;
+    sample3d_repeat(chain, n0, levels, ch, lod, V3(s[0], s[1], s[2]), out);
+}
+void csko_tap_weather(const uint8_t *weather_rgb8, float sx, float sy, float out[3]) {
+    v3 r = sample_weather(weather_rgb8, sx, sy); out[0] = r.x; out[1] = r.y; out[2] = r.z;
+}
+void csko_tap_rgba16f_clamp(const uint16_t *t, int w, int h, float sx, float sy, float out[4]) {
+    v4 r = sample_rgba16f_clamp(t, w, h, sx, sy); out[0] = r.x; out[1] = r.y; out[2] = r.z; out[3] = r.w;
+}
 float csko_hash_probe(float px, float py, float pz) { return hash3(muls3(V3(px, py, pz), 10.0f)); }
 void csko_pixel_dir(const float params[28], int px, int py, float dir[3]) {
     cloud_params P; memcpy(&P, params, sizeof(P));

@@ -82,6 +82,12 @@ void csko_composite_view(int out_w, int out_h, const float basis[9], float fov_y
                          const uint16_t *sky_from, const uint16_t *sky_to, int sw, int sh, const uint16_t *trans, int tw, int th, float blend_amount,
                          float sun_disk_scale, const float light_dir[3], uint16_t *out_rgba16f);
 
+/* one-tap probes of the samplers above (REPEAT/LINEAR 3-D at an integer LOD; REPEAT/LINEAR weather; CLAMP/LINEAR RGBA16F):
+ * the bindings of oracle/glsl_exec's texture()/textureLod() */
+void csko_tap3d_repeat(const uint8_t *chain, int n0, int levels, int ch, float lod, const float s[3], float out[4]);
+void csko_tap_weather(const uint8_t *weather_rgb8, float sx, float sy, float out[3]);
+void csko_tap_rgba16f_clamp(const uint16_t *t, int w, int h, float sx, float sy, float out[4]);
+
 /* probes used by the structural tests */
 float csko_hash_probe(float px, float py, float pz);                     /* clouds.glsl:60-64 on pos*10 */
 void csko_pixel_dir(const float params[28], int px, int py, float dir[3]); /* clouds.glsl:260-262        */

@@ -1,0 +1,265 @@
+#!/usr/bin/env python
+"""TEST INFRASTRUCTURE ONLY -- runs in the build container, where /root/reference exists; never on the GPU box.
+
+Executes the reference's own shader TEXT on the CPU and writes the results as golden arrays (tests/golden/glslexec.npz):
+
+  1. reads /root/reference/cloud_sky/{transmittance-lut,sky-lut,clouds}.glsl at run time (nothing of it is stored in this repo: the
+     translation unit is written to a temporary directory outside the repository and deleted; the fixtures are arrays);
+  2. applies three mechanical, line-preserving rewrites (REWRITES below) -- everything else in the files is compiled verbatim, the
+     GLSL declarations it cannot parse as C++ (`layout(...)`, `uniform`, `in`, `restrict`, `writeonly`, `float`) being absorbed by six
+     #defines around the text;
+  3. compiles each file inside its own namespace against oracle/glsl_exec/glsl_shim.hpp (the GLSL-subset stand-in: vector types,
+     swizzles, built-ins, constant-folding model; samplers and fp16 stores bound to the C oracle's csko_tap_* / csko_f2h) with
+     g++ -O1 -ffp-contract=off, twice: "fold" (glslang-style double folding of constant expressions) and "float" (every
+     constant narrowed to fp32 at once, -fsingle-precision-constant);
+  4. plays the reference's dispatches (transmittance_lut.gd:77, sky_lut.gd:140, cloud_sky.gd:247) and saves what imageStore wrote.
+
+What this pins: the TRANSCRIPTION -- oracle/cloudsky_oracle.c and oracle/numpy_restatement.py are hand restatements by one reader; here
+the reference's text itself runs.  What it does not pin (the shim and the bound samplers are builder-defined stand-ins for the GLSL
+runtime): built-in function definitions, libm vs a GPU's transcendental units, sampler filtering, fp16 store rounding, BC7.  By the
+task's rules an oracle checked this way is still "parity unpinned"; DESIGN.md section 6 says so.
+
+Usage: python oracle/glsl_exec/make_glsl_fixtures.py [--out tests/golden/glslexec.npz] [--keep-tu DIR-outside-the-repo]
+"""
+import argparse
+import ctypes as C
+import hashlib
+import os
+import re
+import shutil
+import subprocess
+import sys
+import tempfile
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+REF = "/root/reference/cloud_sky"
+SHADERS = {"trans": "transmittance-lut.glsl", "sky": "sky-lut.glsl", "clouds": "clouds.glsl"}
+SKY_OF = {"cov50": "deg45"}
+SUNS = {"zenith": (0.0, 1.0, 0.0), "deg45": (1.0, 1.0, 0.0), "demo": (-0.998773, 0.0495291, 2.69869e-07)}
+
+# (pattern, replacement, why).  All three keep the line count, so compiler diagnostics cite the reference's own line numbers.
+REWRITES = [
+    # Godot's "#[compute]" section marker and the GLSL "#version" line are not C++ preprocessor directives
+    (re.compile(r"^(#\[compute\]|#version\b.*)$", re.M), "", "drop Godot's section marker and the #version line"),
+    # `out T name` parameter qualifier -> C++ reference parameter (`in` is absorbed by `#define in`)
+    (re.compile(r"\bout\s+(float|vec[234])\s+(\w+)"), r"\1 &\2", "out-parameters become references"),
+    # GLSL accepts an `f` suffix and gives the literal the same value as without it; in C++ the suffix would narrow the literal to
+    # float before the constant-folding model sees it
+    (re.compile(r"(?<![\w.])((?:\d+\.\d*|\.\d+|\d+)(?:[eE][+-]?\d+)?)f\b"), r"\1", "strip the float-literal suffix"),
+]
+
+PRELUDE = """#include "glsl_shim.hpp"
+"""
+OPEN = """namespace sh_%(name)s {
+using namespace gx;
+#define float gx::F
+#define in
+#define uniform struct
+#define layout(...)
+#define restrict
+#define writeonly
+#line 1 "%(file)s"
+"""
+CLOSE = """
+#undef float
+#undef in
+#undef uniform
+#undef layout
+#undef restrict
+#undef writeonly
+#line 1 "driver_%(name)s.inc"
+#include "driver_%(name)s.inc"
+} /* namespace sh_%(name)s */
+"""
+
+
+def rewrite(text):
+    n0 = text.count("\n")
+    counts = []
+    for pat, rep, why in REWRITES:
+        text, n = pat.subn(rep, text)
+        counts.append((why, n))
+    assert text.count("\n") == n0
+    return text, counts
+
+
+def build_variant(tmp, variant, texts):
+    """One shared object with the three shaders: variant 'fold' or 'float'."""
+    tu = os.path.join(tmp, "glslexec_%s.cpp" % variant)
+    with open(tu, "w") as f:
+        f.write(PRELUDE)
+        for name, fn in SHADERS.items():
+            f.write(OPEN % dict(name=name, file=fn))
+            f.write(texts[name])
+            f.write(CLOSE % dict(name=name))
+    so = os.path.join(tmp, "libglslexec_%s.so" % variant)
+    flags = ["-std=c++17", "-O1", "-fPIC", "-shared", "-ffp-contract=off", "-fno-fast-math", "-Wall", "-Wno-unused-variable",
+             "-Wno-unused-but-set-variable", "-Wno-unused-function", "-I", HERE]
+    flags += ["-DGX_FOLD_DOUBLE=1"] if variant == "fold" else ["-DGX_FOLD_DOUBLE=0", "-fsingle-precision-constant"]
+    cmd = ["g++"] + flags + ["-o", so, tu, os.path.join(ROOT, "oracle", "libcskoracle.so"), "-Wl,-rpath," + os.path.join(ROOT, "oracle")]
+    subprocess.check_call(cmd)
+    return so
+
+
+# Negative control (--mutation-check): one literal per shader gets two neighbouring digits swapped -- the kind of slip a hand
+# transcription makes -- and the fold variant is rebuilt; the output downstream of the change must move, otherwise "0 differences"
+# against the oracle would prove nothing.  (A change in the LAST digit of these literals moves 0-2 halfs: below fp16 resolution.)
+MUTATIONS = {"trans": ("1.16364243", "1.16346243"), "sky": ("17.92", "17.29"), "clouds": ("n.g * 0.625", "n.g * 0.652")}
+
+
+def ptr(a):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+class Exec:
+    def __init__(self, so):
+        self.L = C.CDLL(so)
+        self.L.gxe_transmittance.argtypes = [C.c_int, C.c_int, C.c_void_p]
+        self.L.gxe_sky_lut.argtypes = [C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p]
+        self.L.gxe_clouds.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]
+
+    def transmittance(self, w=256, h=64):
+        out = np.zeros((h, w, 4), np.uint16)
+        self.L.gxe_transmittance(w, h, ptr(out))
+        return out
+
+    def sky(self, sun, trans, w=200, h=100):
+        s = np.asarray(sun, np.float32)
+        out = np.zeros((h, w, 4), np.uint16)
+        self.L.gxe_sky_lut(w, h, ptr(s), ptr(trans), trans.shape[1], trans.shape[0], ptr(out))
+        return out
+
+    def clouds(self, otex, params, sky, rect):
+        p = np.ascontiguousarray(params, np.float32)
+        gx0, gy0, w, h = rect
+        out = np.zeros((h, w, 4), np.uint16)
+        self.L.gxe_clouds(C.byref(otex.c), ptr(p), ptr(sky), sky.shape[1], sky.shape[0], gx0, gy0, w, h, ptr(out))
+        return out
+
+
+def norm(s):
+    s = np.asarray(s, np.float64)
+    return (s / np.linalg.norm(s)).astype(np.float32)
+
+
+def extra_cases(O):
+    """Further push-constant blocks (name -> (28 floats, dispatched rectangle)): heavy cover, a low sun, and two seeded random
+    blocks that move every field the shader reads (wind offsets, time, weather_pos, ground / light colour, energy, density,
+    coverage, update_position) on a non-square texture rendered as an offset tile."""
+    c = {}
+    p = O.default_params(64, 32, (1.0, 1.0, 0.0), coverage=0.5, density=0.1)
+    c["cov50"] = (p, (0, 0, 64, 32))
+    e = np.deg2rad(3.0)
+    c["lowsun"] = (O.default_params(64, 32, (np.cos(e), np.sin(e), 0.0)), (0, 0, 64, 32))
+    rng = np.random.default_rng(20261001)
+    for i in range(2):
+        w, h = (96, 40) if i == 0 else (56, 72)
+        sun = rng.normal(size=3); sun[1] = abs(sun[1]) + 0.15
+        p = O.default_params(w, h, sun, coverage=float(rng.uniform(0.15, 0.6)), density=float(rng.uniform(0.02, 0.12)))
+        p[2:4] = (16, 8) if i == 0 else (8, 24)                                   # update_position
+        p[4:6] = rng.uniform(-5, 5, 2); p[6:8] = rng.uniform(-3, 3, 2); p[8:10] = rng.uniform(-0.05, 0.05, 2)
+        p[12:16] = rng.uniform(0, 1, 4); p[19] = rng.uniform(0.5, 2.0); p[20:23] = rng.uniform(0.3, 1.0, 3)
+        p[23] = rng.uniform(0, 10); p[27] = rng.uniform(0, 1)
+        c["rand%d" % i] = (p.astype(np.float32), (4, 2, 40, 24) if i == 0 else (0, 4, 32, 40))
+    return c
+
+
+def sparse_diff(a, b):
+    """b stored as (flat indices, values) where it differs from a."""
+    idx = np.flatnonzero(a.reshape(-1) != b.reshape(-1)).astype(np.int32)
+    return idx, b.reshape(-1)[idx].copy()
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--out", default=os.path.join(ROOT, "tests", "golden", "glslexec.npz"))
+    ap.add_argument("--keep-tu", default=None, help="directory OUTSIDE the repository to keep the generated translation units in")
+    ap.add_argument("--mutation-check", action="store_true", help="also run the negative control (MUTATIONS)")
+    a = ap.parse_args()
+    if not os.path.isdir(REF):
+        sys.exit("the reference tree is not present (%s): this script only runs in the build container" % REF)
+    if a.keep_tu and os.path.abspath(a.keep_tu).startswith(ROOT + os.sep):
+        sys.exit("--keep-tu must point outside the repository (the translation unit holds the reference's text)")
+    sys.path.insert(0, ROOT)
+    from oracle import oracle as O
+    import gvcd_amd
+    O.build()
+
+    texts, meta = {}, {}
+    for name, fn in SHADERS.items():
+        raw = open(os.path.join(REF, fn), encoding="utf-8").read()
+        texts[name], counts = rewrite(raw)
+        meta[name] = dict(sha256=hashlib.sha256(raw.encode("utf-8")).hexdigest(), lines=raw.count("\n"), rewrites=counts)
+        print("%-24s sha256 %s  %d lines; rewrites: %s" % (fn, meta[name]["sha256"][:16], meta[name]["lines"],
+                                                            ", ".join("%s x%d" % c for c in counts)))
+
+    tmp = tempfile.mkdtemp(prefix="glslexec_", dir=a.keep_tu or tempfile.gettempdir())
+    try:
+        ex = {v: Exec(build_variant(tmp, v, texts)) for v in ("fold", "float")}
+        noise = gvcd_amd.assets.load_default_noise()
+        otex = O.OracleTextures(*noise)
+        np_fix = np.load(os.path.join(ROOT, "tests", "golden", "clouds_np.npz"))
+        windy = np.ascontiguousarray(np_fix["windy_params"], np.float32)
+        windy_rect = (8, 4, 48, 24)
+        out = {}
+        res = {}
+        extra = extra_cases(O)
+        for v, e in ex.items():
+            r = {}
+            r["trans"] = e.transmittance()
+            for k, s in SUNS.items():
+                r["sky_" + k] = e.sky(norm(s), r["trans"])
+                r["clouds_" + k] = e.clouds(otex, O.default_params(64, 32, s), r["sky_" + k], (0, 0, 64, 32))
+            r["sky_windy"] = e.sky(windy[16:19], r["trans"])
+            r["clouds_windy"] = e.clouds(otex, windy, r["sky_windy"], windy_rect)
+            for k, (pc, rect) in extra.items():
+                if k in SKY_OF:                                                  # same sun as an earlier case: share its LUT
+                    r["clouds_" + k] = e.clouds(otex, pc, r["sky_" + SKY_OF[k]], rect)
+                    continue
+                r["sky_" + k] = e.sky(pc[16:19], r["trans"])
+                r["clouds_" + k] = e.clouds(otex, pc, r["sky_" + k], rect)
+            r["sky_below"] = e.sky(norm((0.3, -0.2, 0.5)), r["trans"])          # sun under the horizon: LUT only
+            res[v] = r
+        for k, arr in res["fold"].items():
+            out["fold_" + k] = arr
+        # the float variant: stored in full where a later stage consumes it (LUTs), as a sparse difference otherwise
+        for k, arr in res["float"].items():
+            idx, val = sparse_diff(res["fold"][k], arr)
+            out["float_" + k + "_idx"], out["float_" + k + "_val"] = idx, val
+            print("float vs fold  %-14s %6d of %7d halfs differ" % (k, idx.size, arr.size))
+        out["windy_params"] = windy
+        for k, (pc, rect) in extra.items():
+            out[k + "_params"], out[k + "_rect"] = pc, np.array(rect, np.int32)
+        out["extra_names"] = np.array(list(extra))
+        out["windy_rect"] = np.array(windy_rect, np.int32)
+        out["shader_sha256"] = np.array([meta[n]["sha256"] for n in SHADERS])
+        out["shader_names"] = np.array(list(SHADERS.values()))
+        out["inputs_sha256"] = np.array([gvcd_amd.assets.sha256(x) for x in noise])
+        if a.mutation_check:
+            for name, (lit, mut) in MUTATIONS.items():
+                assert texts[name].count(lit) >= 1, (name, lit)
+                t2 = dict(texts); t2[name] = texts[name].replace(lit, mut, 1)
+                mdir = os.path.join(tmp, "mut_" + name); os.makedirs(mdir)
+                m = Exec(build_variant(mdir, "fold", t2))
+                f = res["fold"]
+                if name == "trans":
+                    got, ref = m.transmittance(), f["trans"]
+                elif name == "sky":
+                    got, ref = m.sky(norm(SUNS["deg45"]), f["trans"]), f["sky_deg45"]
+                else:
+                    got, ref = m.clouds(otex, O.default_params(64, 32, SUNS["deg45"]), f["sky_deg45"], (0, 0, 64, 32)), f["clouds_deg45"]
+                nd = int((got != ref).sum())
+                print("mutation %-6s %-12s -> %-12s : %6d of %7d halfs move" % (name, lit, mut, nd, got.size))
+                assert nd > 0, "the comparison is blind to a changed literal in " + name
+        np.savez_compressed(a.out, **out)
+        print("wrote", a.out, os.path.getsize(a.out), "bytes")
+    finally:
+        if not a.keep_tu:
+            shutil.rmtree(tmp, ignore_errors=True)
+
+
+if __name__ == "__main__":
+    main()
