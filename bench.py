@@ -14,11 +14,13 @@ is fixed, each rank renders 1/N of it).  The 200x100 sky LUT is split the same w
 tail of its band buffer; rank 0 interleaves both out of the one gather): N identical LUTs would cost every rank 33 us of a
 whole chip per frame.
 
-Two protocols, both in the line (round 5).  `value_as_asked` / `ms_per_step_as_asked`: W warm-up steps and exactly K timed steps FIRST, on a GPU
-that has done nothing since the asset load -- the protocol exactly as asked, what rounds 1-3 reported as `value`.  Then ~120 ms of the workload's own
-frames, untimed, bring the GPU clocks up (`config.clock_prewarm_frames`; `--no-prewarm` leaves them out: the W warm-up steps asked for are 1-9 ms of
-activity for this path, too short for a GPU that idled through the imports; a short timed region reads 2 % (N = 1) to 9 % (a 1/8 share) under the
-steady state), and the same W + K run again -> `value` / `ms_per_step`, the steady-state rate of the renderer.
+Two protocols, both in the line.  Round 6: `value` / `ms_per_step` ARE the protocol exactly as asked -- W warm-up steps and exactly K timed steps, run
+FIRST on a GPU that has done nothing since the asset load (what rounds 1-3 reported as `value` and what the driver's own clock sees; `value_as_asked`
+is kept as an alias for one round).  Then ~120 ms of the workload's own frames, untimed, bring the GPU clocks up (`config.clock_prewarm_frames`;
+`--no-prewarm` leaves them out: the W warm-up steps asked for are 1-9 ms of activity for this path, too short for a GPU that idled through the imports;
+a short timed region reads 2 % (N = 1) to 9 % (a 1/8 share) under the steady state), and the same W + K run again -> `value_prewarmed` /
+`ms_per_step_prewarmed`, the steady-state rate of a renderer that is called every frame (rounds 4-5 reported THIS as `value`).
+`config.with_early_out`: a labelled NON-headline secondary at N = 1 with the north star's wave-ballot early-out (eps = 1e-3): rate + largest error.
 
 Consecutive frames are independent, so by default every rank keeps two frames in flight (alternating streams; EIGHT for a
 rank share of a quarter frame or less, whose launches do not fill the chip): the tail of frame k's launch overlaps the head of
@@ -226,21 +228,20 @@ def main_single_process(args):
         counter[0] = 0
         return e, n_run
 
-    # both protocols, as in the process-per-GPU form below: as asked (cold) first, then the clock pre-warm, then the same region again -> `value`
-    as_asked = None
+    # both protocols, as in the process-per-GPU form below: `value` = as asked (run first, cold); then the clock pre-warm and the same region again -> `value_prewarmed`
+    elapsed, n_last = region()
+    prewarmed = None
     prewarm_frames = 0
     if not args.no_prewarm:
-        e_cold, _ = region()
-        as_asked = {"value": W * H * args.steps / e_cold / 1e6, "ms_per_step": e_cold / args.steps * 1e3}
         est_ms = 1.7 * tiles_per_dev / 32768.0 * primary / 128.0
         prewarm_frames = int(min(1024, max(16, np.ceil(120.0 / max(est_ms, 1e-3))))) * G
         for _ in range(prewarm_frames):
             step()
         sync_all()
         counter[0] = 0
-    elapsed, counter[0] = region()
-    if as_asked is None:
-        as_asked = {"value": W * H * args.steps / elapsed / 1e6, "ms_per_step": elapsed / args.steps * 1e3}
+        e_warm, n_last = region()
+        prewarmed = {"value": W * H * args.steps / e_warm / 1e6, "ms_per_step": e_warm / args.steps * 1e3}
+    as_asked = {"value": W * H * args.steps / elapsed / 1e6, "ms_per_step": elapsed / args.steps * 1e3}
     # every device's share alone (one launch at a time on that device): what bounds the split
     share_ms = []
     for i in range(n):
@@ -249,13 +250,13 @@ def main_single_process(args):
         nb = (total - k + per - 1) // per
         ms, _ = m.ctx(i).time_clouds(params, W, (8, k, per, nb), warmup=1, iters=3)
         share_ms.append(ms)
-    fr = frames[(counter[0] - 1) % slots].view(torch.float16)
+    fr = frames[(n_last - 1) % slots].view(torch.float16)               # the last frame the last region rendered (region() returns how many it ran)
     alpha_mean = float(fr[..., 3].float().mean().item())
     finite = bool(torch.isfinite(fr.float()).all().item())
     if True:                                                              # the assembled frame must equal a single-context render of the same frame (outside the timed region)
         c0 = m.ctx(0)
         full = torch.zeros((H, W, 4), dtype=torch.int16, device=dev)
-        k_last = counter[0] - 1
+        k_last = n_last - 1
         fp, fs = (params, sun_n) if sweep is None else sweep[k_last % len(sweep)]
         c0.set_segments(1); c0.set_frames_in_flight(1)
         c0.render_sky_lut_device(fs, 200, 100, streams[0].cuda_stream)
@@ -273,6 +274,8 @@ def main_single_process(args):
         "metric": "Mrays/s + hemisphere fps, 2048x1024 @ 128x6 steps, 1/2/4/8 MI355X",
         "value": W * H * args.steps / elapsed / 1e6, "unit": "Mrays/s", "hemisphere_fps": args.steps / elapsed,
         "n_gpus": n, "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
+        "protocol": "as asked: W warm-up + K timed steps, run first (cold); the clock-pre-warmed figure is value_prewarmed",
+        "value_prewarmed": (prewarmed or as_asked)["value"], "ms_per_step_prewarmed": (prewarmed or as_asked)["ms_per_step"],
         "value_as_asked": as_asked["value"], "ms_per_step_as_asked": as_asked["ms_per_step"],
         "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
         "ranks_seen": len(m), "per_rank_share_ms": share_ms, "gathered_frame_check": frame_check,
@@ -354,7 +357,8 @@ def main():
     ap.add_argument("--variant", type=int, default=None)
     ap.add_argument("--early-out", type=float, default=0.0, help="wave early-out threshold on transmittance (0 = reference behaviour)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--also-early-out", action="store_true", help="add a secondary measurement with the wave early-out (eps = 1e-3) to the JSON line")
+    ap.add_argument("--also-early-out", action="store_true", help="(accepted, no effect: since round 6 the early-out secondary is part of every N = 1 line)")
+    ap.add_argument("--no-early-out-leg", action="store_true", help="skip the labelled non-headline early-out measurement (config.with_early_out)")
     ap.add_argument("--kernel-iters", type=int, default=1, help="solo (one launch in flight) cloud-kernel launches timed after the timed region")
     ap.add_argument("--no-pmc", action="store_true", help="skip the live rocprofv3 counter passes (roofline fractions become null)")
     ap.add_argument("--no-host-form", action="store_true", help="skip the value_host_form leg (frames delivered to pinned host memory): for profiling the timed region alone")
@@ -408,6 +412,20 @@ def main():
             dist.init_process_group("gloo", rank=rank, world_size=world)
         else:
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        # The unattended SCALE run must not print a plausible line from a broken launch: every rank checks that the communicator
+        # has the size asked for and that no two ranks sit on the same device; any rank that sees otherwise exits non-zero BEFORE anything is timed
+        # (all ranks see the same gathered list, so all of them exit: no JSON line, non-zero return code).
+        if dist.get_world_size() != args.gpus:
+            raise SystemExit("bench.py: --gpus %d but the process group has %d ranks" % (args.gpus, dist.get_world_size()))
+        if not debug_one_gpu or os.environ.get("CSKY_BENCH_FAKE_SHARED_DEVICE") == "1":
+            import socket
+            pr = torch.cuda.get_device_properties(local_rank)
+            ident = "%s|%s" % (socket.gethostname(), getattr(pr, "uuid", None) or "%s:%s:%s" % (getattr(pr, "pci_domain_id", 0), getattr(pr, "pci_bus_id", local_rank), getattr(pr, "pci_device_id", 0)))
+            idents = [None] * world
+            dist.all_gather_object(idents, ident)
+            if len(set(idents)) != world:
+                raise SystemExit("bench.py: %d ranks but only %d distinct devices (%s): one process per GPU is the contract (LOCAL_RANK must select the device)"
+                                 % (world, len(set(idents)), ", ".join(sorted(set(idents)))))
 
     W, H, primary, light, sun = CONFIGS[args.config]
     sweep = None
@@ -489,6 +507,7 @@ def main():
     pending = [None] * nbuf
     pend_frame = [0] * nbuf
     frame = [None]
+    frame_k = [0]                                    # index of the frame `frame[0]` holds (the checks below read this, not the step counter)
     counter = [0]
     taken = [0]                                      # frames this rank took part in: its buffer-set rotation
 
@@ -501,6 +520,7 @@ def main():
                 staged_g[o] = gathered[o].to(dev) if debug_one_gpu else gathered[o]      # (kept alive until the buffer set comes round again)
                 fg.assemble_device(pend_frame[o], staged_g[o], ctx, streams[o].cuda_stream, H, W, frame_out[o], LH if split_lut else 0, LW, lut_out[o] if split_lut else None)
                 frame[0] = frame_out[o]
+                frame_k[0] = pend_frame[o]
                 if split_lut:
                     sky_lut[0] = lut_out[o]
 
@@ -521,6 +541,7 @@ def main():
             ctx.render_clouds_device(fp, W, bands, local[bset].data_ptr(), W * 8, st_k)           # cloud_sky.gd:234-248
         if world == 1:
             frame[0] = local[bset]
+            frame_k[0] = k
             return
         with torch.cuda.stream(streams[bset]):       # the collective is ordered behind the CURRENT stream: make it this frame's
             src = local_b[bset].cpu() if debug_one_gpu else local_b[bset]
@@ -571,15 +592,14 @@ def main():
         counter[0] = 0; taken[0] = 0                 # every region sees the same frame sequence
         return e, kt, kl
 
-    # Both protocols in one line: FIRST the caller's W warm-up + K timed steps exactly as asked, on a GPU that has done
-    # nothing since the asset load -> `value_as_asked` / `ms_per_step_as_asked` (what rounds 1-3 reported as `value`); THEN the clock pre-warm, THEN the
-    # same W + K again -> `value`.  --no-prewarm: one region, the two are the same number.
-    as_asked = None
+    # Both protocols in one line.  Round 6: `value` / `ms_per_step` ARE the caller's W warm-up + K timed steps exactly as asked, run
+    # FIRST on a GPU that has done nothing since the asset load (rounds 1-3 and the driver's own clock measure this); THEN ~120 ms of untimed frames bring
+    # the clocks up and the same W + K run again -> `value_prewarmed` / `ms_per_step_prewarmed` (what rounds 4-5 called `value`).  `value_as_asked` stays
+    # as an alias of `value` for one round so that r05 and r06 records compare key by key.  --no-prewarm: one region, the two are the same number.
+    elapsed, k_total, k_launches = region()
+    prewarmed = None
     prewarm_frames = 0
     if not args.no_prewarm:
-        e_cold, _, _ = region()
-        as_asked = {"value": W * H * args.steps / e_cold / 1e6, "ms_per_step": e_cold / args.steps * 1e3, "hemisphere_fps": args.steps / e_cold,
-                    "what": "the same %d warm-up + %d timed steps run FIRST, before the clock pre-warm: exactly the protocol asked for, cold" % (args.warmup, args.steps)}
         est_ms = 1.7 * (((W + 7) // 8) * mb) / 32768.0 * primary / 128.0       # from the LARGEST rank share: every rank must run the same number of frames (collectives)
         prewarm_frames = int(min(1024, max(16, np.ceil(120.0 / max(est_ms, 1e-3))))) * G
         for _ in range(prewarm_frames):
@@ -589,11 +609,14 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
         counter[0] = 0; taken[0] = 0                 # the warm-up and the timed region see the same frame sequence as without the pre-warm
-    elapsed, k_total, k_launches = region()
-    counter[0] = args.warmup + args.steps            # (the checks below look at the last frame of the run)
-    if as_asked is None:
-        as_asked = {"value": W * H * args.steps / elapsed / 1e6, "ms_per_step": elapsed / args.steps * 1e3, "hemisphere_fps": args.steps / elapsed,
-                    "what": "--no-prewarm: the timed region IS the protocol as asked"}
+        e_warm, kt_w, kl_w = region()
+        prewarmed = {"value": W * H * args.steps / e_warm / 1e6, "ms_per_step": e_warm / args.steps * 1e3, "hemisphere_fps": args.steps / e_warm,
+                     "kernel_ms_in_flight": kt_w / max(1, kl_w),
+                     "what": "the same %d warm-up + %d timed steps run AGAIN after %d untimed frames (~120 ms) that bring the GPU clocks up: the steady state of a "
+                             "renderer that is called every frame; rounds 4-5 reported this as `value`" % (args.warmup, args.steps, prewarm_frames)}
+    as_asked = {"value": W * H * args.steps / elapsed / 1e6, "ms_per_step": elapsed / args.steps * 1e3, "hemisphere_fps": args.steps / elapsed,
+                "what": "alias of value / ms_per_step (round 6: the headline IS the protocol as asked): %d warm-up + %d timed steps run first, before any clock pre-warm"
+                        % (args.warmup, args.steps)}
 
     # dominant kernel (clouds_kernel): with two frames in flight a launch shares the GPU with its neighbour and lasts ~2 frame times, which
     # measures nothing: the roofline uses the kernel ALONE.  k_inflight = mean launch duration over the timed region (event pairs
@@ -666,21 +689,38 @@ def main():
                                                  "GB_per_s_to_host": W * H * 8 * nh / eh / 1e9}
         ctx.set_frames_in_flight(fif)
 
-    # secondary figure, N = 1 only: the same frames with the wave early-out the north star describes (T < 1e-3; bounded error
-    # <= 1e-3, within the stated parity tolerance).  NOT the headline: the reference has no early-out, so `value` keeps eps = 0.
+    # secondary figure, N = 1 only, labelled NON-HEADLINE: the same frames with the wave early-out the north star describes (a wave stops once all 64 lanes
+    # have T < eps = 1e-3; clouds.glsl:172-212 has no early-out, so `value` keeps eps = 0).  max_abs_err_vs_eps0 = the largest |difference| of any RGBA16F
+    # value between one frame rendered with and without it (the tail a ray drops is bounded by eps x the largest radiance).  --no-early-out-leg skips it.
     early = None
-    if world == 1 and args.early_out == 0.0 and args.also_early_out:
+    if world == 1 and args.early_out == 0.0 and not args.no_early_out_leg:
+        ref_frame = torch.zeros((bands[3] * bands[0], W, 4), dtype=torch.int16, device=dev)
+        eo_frame = torch.zeros_like(ref_frame)
+        s0e = streams[0].cuda_stream
+        ctx.render_sky_lut_device(sun_n, 200, 100, s0e)
+        ctx.render_clouds_device(params, W, bands, ref_frame.data_ptr(), W * 8, s0e)
         ctx.set_early_out(1e-3)
+        ctx.render_clouds_device(params, W, bands, eo_frame.data_ptr(), W * 8, s0e)
+        torch.cuda.synchronize()
+        a_e, b_e = ref_frame.view(torch.float16).float(), eo_frame.view(torch.float16).float()
+        n_eo = max(10, min(args.steps, 100))
         for _ in range(3):
             step()
+        drain()
         torch.cuda.synchronize()
         t1 = time.perf_counter()
-        for _ in range(10):
+        for _ in range(n_eo):
             step()
+        drain()
         torch.cuda.synchronize()
-        early = {"eps": 1e-3, "Mrays_per_s": W * H * 10 / (time.perf_counter() - t1) / 1e6}
+        e_eo = time.perf_counter() - t1
+        early = {"eps": 1e-3, "Mrays_per_s": W * H * n_eo / e_eo / 1e6, "ms_per_step": e_eo / n_eo * 1e3, "frames": n_eo,
+                 "max_abs_err_vs_eps0": float((a_e - b_e).abs().max().item()), "values_changed_frac": float((ref_frame != eo_frame).float().mean().item()),
+                 "headline": False, "what": "NOT the headline: wave-ballot early-out at T < 1e-3 (north_star), same frames, measured after the timed regions"}
         ctx.set_early_out(0.0)
+        counter[0] = 0; taken[0] = 0
         step()
+        drain()
         torch.cuda.synchronize()
 
     if rank == 0:
@@ -691,7 +731,7 @@ def main():
         if world > 1:                     # the gathered frame must equal a single-context full-frame render of the same push constants (outside the timed region)
             full = torch.zeros((H, W, 4), dtype=torch.int16, device=dev)
             ctx.set_segments(1)
-            fp_l, fs_l = (params, sun_n) if sweep is None else sweep[(counter[0] - 1) % len(sweep)]   # the LAST frame of the run (rank 0 holds it whatever group rendered it)
+            fp_l, fs_l = (params, sun_n) if sweep is None else sweep[frame_k[0] % len(sweep)]   # the frame rank 0 holds (the last one gathered, whatever group rendered it)
             ctx.render_sky_lut_device(fs_l, 200, 100, stream)
             ctx.render_clouds_device(fp_l, W, (H, 0, 1, 1), full.data_ptr(), W * 8, stream)
             torch.cuda.synchronize()
@@ -790,6 +830,8 @@ def main():
             "hemisphere_fps": args.steps / elapsed,
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3,
+            "protocol": "as asked: W warm-up + K timed steps, run first (cold); the clock-pre-warmed figure is value_prewarmed",
+            "value_prewarmed": (prewarmed or as_asked)["value"], "ms_per_step_prewarmed": (prewarmed or as_asked)["ms_per_step"], "prewarmed": prewarmed,
             "value_as_asked": as_asked["value"], "ms_per_step_as_asked": as_asked["ms_per_step"], "as_asked": as_asked,
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",

@@ -13,7 +13,8 @@
 #include <string>
 #include <vector>
 #include <unistd.h>
-#include <sys/stat.h>
+#include <sys/syscall.h>
+#include <cerrno>
 #include "../../include/cloudsky_internal.h"
 #include "kernels.h"
 #include "bake.h"
@@ -881,8 +882,20 @@ int csky_poll(csky_ctx* c, int64_t ticket) {
 }
 
 // ---- zero-copy interop: a frame that lives in memory another API allocated (cloudsky.h; gdext/unverified/zero_copy_vulkan.c is the Vulkan half) ----
-struct csky_external_frame { int device = 0; hipExternalMemory_t mem = nullptr; void* d_ptr = nullptr; size_t bytes = 0; hipExternalSemaphore_t sem = nullptr; hipEvent_t fence = nullptr; bool fenced = false;
-                             int dfd = -1; dev_t dfd_dev = 0; ino_t dfd_ino = 0; };   // the duplicate handed to the runtime and what it pointed at (see csky_external_frame_release)
+struct csky_external_frame { int device = 0; hipExternalMemory_t mem = nullptr; void* d_ptr = nullptr; size_t bytes = 0; hipExternalSemaphore_t sem = nullptr; hipEvent_t fence = nullptr; bool fenced = false; };
+
+// Does descriptor `a` still name the open file description that `b` names?  1 yes, 0 no, -1 cannot tell.  kcmp(KCMP_FILE) compares the kernel objects
+// themselves (device + inode identity is the same for EVERY dma-buf / anon-inode descriptor on kernels that share one anon inode, so it cannot
+// tell "ours" from a foreign descriptor that reused the number); where the kernel has no kcmp the answer is "cannot tell".
+static int same_open_file(int a, int b) {
+#ifdef SYS_kcmp
+    const long r = syscall(SYS_kcmp, (long)getpid(), (long)getpid(), 0L /* KCMP_FILE */, (long)a, (long)b);
+    if (r == 0) return 1;
+    if (r > 0) return 0;
+    if (errno == EBADF) return 0;                            // `a` is closed: whoever was handed the number consumed it
+#endif
+    return -1;
+}
 
 int csky_external_frame_import_fd(csky_ctx* c, int opaque_fd, size_t allocation_bytes, size_t offset, size_t frame_bytes, csky_external_frame** out, void** d_ptr) {
     if (!c || !out || !d_ptr) return fail(c, CSKY_ERR_INVALID, "csky_external_frame_import_fd: NULL argument");
@@ -898,15 +911,16 @@ int csky_external_frame_import_fd(csky_ctx* c, int opaque_fd, size_t allocation_
     const int dfd = dup(opaque_fd);
     if (dfd < 0) { delete f; return fail(c, CSKY_ERR_INVALID, "csky_external_frame_import_fd: dup(fd) failed"); }
     md.type = hipExternalMemoryHandleTypeOpaqueFd; md.handle.fd = dfd; md.size = allocation_bytes;
-    { struct stat st; if (fstat(dfd, &st) == 0) { f->dfd_dev = st.st_dev; f->dfd_ino = st.st_ino; } }
     hipError_t e = hipImportExternalMemory(&f->mem, &md);
     if (e != hipSuccess) (void)close(dfd);
     else {
-        // who owns the duplicate now?  If the number no longer names what it named before the call, the runtime consumed it at import (CUDA's
-        // convention): nothing is left to close, and the number must not be looked at again -- a later descriptor of the SAME memory object
-        // (a second frame imported from one allocation) may reuse it.  Otherwise it is closed at release, if it is then still the same object.
-        struct stat st;
-        f->dfd = (fstat(dfd, &st) == 0 && st.st_dev == f->dfd_dev && st.st_ino == f->dfd_ino) ? dfd : -1;
+        // Who owns the duplicate now is decided HERE, once, and the number is never looked at again (a later descriptor -- of this process, the engine
+        // or the Vulkan driver -- may reuse it).  CUDA's convention: the runtime consumed it at import.  ROCm's CLR maps the dma-buf during the call
+        // and does not say; a runtime that keeps neither the number nor closes it would leak one descriptor per imported frame.  So: if the number
+        // provably still names OUR open file description (same kernel object as the caller's descriptor, which nobody else can have closed), the
+        // runtime did not consume it and the mapping no longer needs it: close it now.  "No" or "cannot tell" (no kcmp in this kernel): leave it --
+        // leaking a descriptor is the safe side of closing a foreign one.
+        if (same_open_file(dfd, opaque_fd) == 1) (void)close(dfd);
     }
     if (e == hipSuccess) {
         hipExternalMemoryBufferDesc bd; memset(&bd, 0, sizeof bd);
@@ -965,13 +979,7 @@ void csky_external_frame_release(csky_external_frame* f) {
     if (f->fence) { (void)hipEventSynchronize(f->fence); (void)hipEventDestroy(f->fence); }   // never unmap memory a march may still be writing
     if (f->sem) (void)hipDestroyExternalSemaphore(f->sem);
     if (f->mem) (void)hipDestroyExternalMemory(f->mem);      // unmaps d_ptr
-    // The duplicate fd the runtime was handed: CUDA-style import takes the fd over, ROCm's documentation does not say, and a runtime
-    // that neither closes it at import nor at destroy would leak one fd per imported frame.  So: if the number still names the SAME object it
-    // named at import (device + inode; a number the runtime closed and someone else re-opened names another), nobody has closed it: do it here.
-    if (f->dfd >= 0) {
-        struct stat st;
-        if (fstat(f->dfd, &st) == 0 && st.st_dev == f->dfd_dev && st.st_ino == f->dfd_ino) (void)close(f->dfd);
-    }
+    // (the duplicate descriptor the runtime was handed was settled at import: csky_external_frame_import_fd)
     delete f;
 }
 
@@ -1142,7 +1150,7 @@ int csky_generate_shape_noise_tuned_device(csky_ctx* c, uint32_t seed, int n, co
     if (!out_rgba8 || n < 8 || n > 512 || (n & (n - 1))) return fail(c, CSKY_ERR_INVALID, "csky_generate_shape_noise_device: n must be a power of two in [8, 512]");
     ShapeNoiseParams P = shape_noise_defaults();
     if (params) {
-        if (n >= 64 && csky_check_shape_noise_params(params, n)) return fail(c, CSKY_ERR_INVALID, "csky_generate_shape_noise_tuned_device: %s", csky_assets_last_error());
+        if (csky_check_shape_noise_params(params, n)) return fail(c, CSKY_ERR_INVALID, "csky_generate_shape_noise_tuned_device: %s", csky_assets_last_error());
         memcpy(&P, params, sizeof P);
     }
     int rc; if ((rc = bind(c))) return rc;

@@ -42,10 +42,20 @@ void csky_shape_noise_default_params(csky_shape_noise_params* p) {
     memcpy(p, &d, sizeof d);
 }
 int csky_check_shape_noise_params(const csky_shape_noise_params* p, int n) {
-    // every octave needs at least one texel per cell (freq << octave <= n) or the lattice aliases; the curve's slope must be finite and positive
-    if (!p || p->perlin_freq < 1 || p->perlin_octaves < 1 || p->perlin_octaves > 8 || (p->perlin_freq << (p->perlin_octaves - 1)) > n || p->worley_freq < 1 || p->worley_freq * 16 > n ||
-        !(p->perlin_gain > 0.0f) || !(p->dilate >= 0.0f && p->dilate <= 1.0f) || !(p->contrast > 0.0f) || !(p->centre == p->centre) || !(p->offset == p->offset)) {
-        snprintf(g_asset_err, sizeof g_asset_err, "shape noise parameters out of range (perlin_freq << (octaves - 1) <= n, worley_freq * 16 <= n, gain > 0, 0 <= dilate <= 1, contrast > 0)");
+    // (1) Bounds that hold for every n: frequencies >= 1 -- the lattices wrap with `i % freq` -- and small enough that `freq << octave` and
+    //     `worley_freq * 16` cannot leave an int; 1..8 octaves (the fBm loop runs that many times per voxel); every float finite (+inf passes `> 0`, and a
+    //     NaN or an infinity reaching the UNORM8 conversion is undefined behaviour).  Nothing throws or aborts across the ABI, whatever the caller passes.
+    const int max_freq = 4096;
+    if (!p || p->perlin_freq < 1 || p->perlin_freq > max_freq || p->perlin_octaves < 1 || p->perlin_octaves > 8 || p->worley_freq < 1 || p->worley_freq > max_freq ||
+        !std::isfinite(p->perlin_gain) || !std::isfinite(p->dilate) || !std::isfinite(p->centre) || !std::isfinite(p->contrast) || !std::isfinite(p->offset) ||
+        !(p->perlin_gain > 0.0f) || !(p->dilate >= 0.0f && p->dilate <= 1.0f) || !(p->contrast > 0.0f)) {
+        snprintf(g_asset_err, sizeof g_asset_err, "shape noise parameters out of range (1 <= perlin_freq, worley_freq <= %d, 1 <= perlin_octaves <= 8, finite floats, gain > 0, 0 <= dilate <= 1, contrast > 0)", max_freq);
+        return CSKY_ERR_INVALID;
+    }
+    // (2) At least one texel per lattice cell in every octave, or the lattice aliases (64-bit: the bounds above already keep it far from overflow).  Volumes under
+    //     64^3 are previews whose default knobs break this rule by design; they keep (1) only.
+    if (n >= 64 && (((int64_t)p->perlin_freq << (p->perlin_octaves - 1)) > (int64_t)n || (int64_t)p->worley_freq * 16 > (int64_t)n)) {
+        snprintf(g_asset_err, sizeof g_asset_err, "shape noise parameters alias at n = %d (perlin_freq << (octaves - 1) <= n, worley_freq * 16 <= n)", n);
         return CSKY_ERR_INVALID;
     }
     return CSKY_OK;
@@ -57,7 +67,7 @@ int csky_generate_shape_noise(uint32_t seed, int n, uint8_t* out_rgba8) {
 int csky_generate_shape_noise_tuned(uint32_t seed, int n, const csky_shape_noise_params* params, uint8_t* out_rgba8) {
     if (!out_rgba8 || n < 8 || (n & (n - 1))) { snprintf(g_asset_err, sizeof g_asset_err, "generate_shape_noise: n must be a power of two >= 8"); return CSKY_ERR_INVALID; }
     csky::ShapeNoiseParams P = csky::shape_noise_defaults();
-    if (params) { if (n >= 64) { int rc = csky_check_shape_noise_params(params, n); if (rc) return rc; } memcpy(&P, params, sizeof P); }
+    if (params) { int rc = csky_check_shape_noise_params(params, n); if (rc) return rc; memcpy(&P, params, sizeof P); }
     unsigned hw = std::thread::hardware_concurrency();
     int nt = (int)(hw == 0 ? 1 : (hw > 32 ? 32 : hw));
     if (nt > n) nt = n;

@@ -153,3 +153,13 @@ def test_tuned_shape_generator_defaults_are_the_benchmark_volume_and_knobs_move_
             pkg.assets.generate_shape_noise(3, 64, **bad)
     with pytest.raises(TypeError):
         pkg.assets.generate_shape_noise(3, 64, no_such_knob=1)
+    # the n-independent bounds hold for the small preview volumes too (n < 64 used to skip every check: perlin_freq = 0 reached `i % 0`,
+    # SIGFPE across the ABI), shifts and products cannot wrap (perlin_freq = 1 << 30 with 3 octaves, worley_freq = 1 << 28), and an infinity is not "> 0"
+    inf = float("inf")
+    for n, bad in ((32, dict(perlin_freq=0)), (32, dict(worley_freq=0)), (16, dict(perlin_octaves=0)), (8, dict(perlin_octaves=1 << 20)), (32, dict(perlin_gain=inf)),
+                   (64, dict(perlin_freq=1 << 30, perlin_octaves=3)), (64, dict(worley_freq=1 << 28)), (128, dict(contrast=inf)), (64, dict(centre=inf)),
+                   (64, dict(offset=-inf)), (32, dict(offset=float("nan"))), (64, dict(perlin_freq=-4))):
+        with pytest.raises(pkg.CloudSkyError):
+            pkg.assets.generate_shape_noise(3, n, **bad)
+    small = pkg.assets.generate_shape_noise(3, 32)                      # the default knobs at a preview size still render (the texels-per-cell rule starts at 64)
+    assert small.shape == (32, 32, 32, 4) and small[..., 0].std() > 5

@@ -44,9 +44,14 @@ def test_bench_line_contract_single_gpu():
     assert d["config"]["workload"].startswith("C3: 2048x1024") and d["config"]["finite"] is True
     assert abs(d["value"] - 2048 * 1024 / d["ms_per_step"] / 1e3) < 1e-6 * d["value"]
     assert 100.0 < d["value"] < 1e5 and d["value_one_frame_at_a_time"]["value"] <= d["value"] * 1.15
-    # both protocols in the one line: the W + K steps exactly as asked, run first and cold, next to the same region after the clock pre-warm
-    assert abs(d["value_as_asked"] - 2048 * 1024 / d["ms_per_step_as_asked"] / 1e3) < 1e-6 * d["value_as_asked"] and d["as_asked"]["value"] == d["value_as_asked"]
-    assert d["config"]["clock_prewarm_frames"] > 0 and 0.5 * d["value"] < d["value_as_asked"] < 1.1 * d["value"]
+    # both protocols in the one line; round 6: `value` IS the W + K steps exactly as asked, run first and cold (`value_as_asked` = alias for
+    # one round), the same region after the clock pre-warm is `value_prewarmed`
+    assert d["value_as_asked"] == d["value"] and d["ms_per_step_as_asked"] == d["ms_per_step"] and d["as_asked"]["value"] == d["value"] and d["protocol"].startswith("as asked")
+    assert abs(d["value_prewarmed"] - 2048 * 1024 / d["ms_per_step_prewarmed"] / 1e3) < 1e-6 * d["value_prewarmed"] and d["prewarmed"]["value"] == d["value_prewarmed"]
+    assert d["config"]["clock_prewarm_frames"] > 0 and 0.5 * d["value_prewarmed"] < d["value"] < 1.1 * d["value_prewarmed"]
+    # the north star's wave early-out as a labelled secondary in every N = 1 line: never the headline, error bounded by eps x radiance
+    eo = d["config"]["with_early_out"]
+    assert eo["headline"] is False and eo["eps"] == 1e-3 and eo["Mrays_per_s"] > 0.95 * d["value"] and 0.0 < eo["max_abs_err_vs_eps0"] <= 4e-3 and d["config"]["early_out_eps"] == 0.0
     for k in ("value_host_form", "ranks_seen", "per_rank_share_ms"):
         assert k in d, k
     assert d["value_host_form"]["2_in_flight"]["Mrays_per_s"] > d["value_host_form"]["1_in_flight"]["Mrays_per_s"] > 100.0
@@ -107,6 +112,58 @@ def test_bench_gpus_2_starts_its_own_ranks():
     assert d["n_gpus"] == 2 and d["ranks_seen"] == 2 and len(d["per_rank_share_ms"]) == 2 and all(0.05 < x < 50 for x in d["per_rank_share_ms"])
     assert d["gathered_frame_check"]["within_1_fp16_ulp_frac"] >= 0.9999 and d["gathered_frame_check"]["max_abs_diff"] <= 2e-3, d["gathered_frame_check"]
     assert "gathered 2-rank frame vs single-rank frame" in out.stderr
+
+
+def _clean_env():
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env["CSKY_BENCH_ONE_GPU_DEBUG"] = "1"
+    return env
+
+
+def test_bench_gpus_8_process_form():
+    """The driver's SCALE command rehearsed at N = 8: `python bench.py --gpus 8 --steps 9 --warmup 2`, self-launched, one process
+    per rank, all eight on GPU 0 through gloo.  At N = 8 the defaults are the ones the real run uses: eight frames in flight (a 1/8 share is 4 096
+    tiles), the 100 sky-LUT rows split 13/13/13/13/12/12/12/12 behind the bands in the one gather, and 9 timed steps drain mid-rotation (9 mod 8 = 1)."""
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8", "--steps", "9", "--warmup", "2", "--no-cpu-baseline"],
+                         capture_output=True, text=True, cwd=ROOT, env=_clean_env(), timeout=900)
+    assert out.returncode == 0, (out.stdout[-1500:], out.stderr[-2500:])
+    d = _last_json(out.stdout)
+    assert d["n_gpus"] == 8 and d["ranks_seen"] == 8 and len(d["per_rank_share_ms"]) == 8 and all(0.05 < x < 50 for x in d["per_rank_share_ms"])
+    assert d["config"]["frames_in_flight"] == 8 and d["config"]["parallelism"].startswith("bands8+overlapped-gather") and d["config"]["finite"] is True
+    g = d["gathered_frame_check"]
+    assert g["within_1_fp16_ulp_frac"] >= 0.9999 and g["max_abs_diff"] <= 2e-3, g
+    assert g["sky_lut"] == {"rows_per_rank": 13, "assembled_equals_whole": True}, g
+    assert d["value"] == d["value_as_asked"] and d["value_prewarmed"] > 0 and d["steps"] == 9 and d["warmup"] == 2
+    assert "gathered 8-rank frame vs single-rank frame" in out.stderr
+
+
+def test_bench_gpus_8_sweep_in_eight_groups():
+    """BASELINE config 5 in the shape the driver would run it at N = 8 with --groups 8: pure frame parallelism over the 64-frame sun sweep, every
+    frame gathered on rank 0 (rank 0 keeps 8 x 2 buffer sets in flight)."""
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8", "--groups", "8", "--config", "C5", "--steps", "9", "--warmup", "2", "--no-cpu-baseline"],
+                         capture_output=True, text=True, cwd=ROOT, env=_clean_env(), timeout=1200)
+    assert out.returncode == 0, (out.stdout[-1500:], out.stderr[-2500:])
+    d = _last_json(out.stdout)
+    assert d["n_gpus"] == 8 and d["ranks_seen"] == 8 and d["config"]["frame_groups"] == 8 and d["config"]["finite"] is True
+    assert d["gathered_frame_check"]["within_1_fp16_ulp_frac"] >= 0.9999 and d["gathered_frame_check"]["max_abs_diff"] <= 2e-3, d["gathered_frame_check"]
+
+
+def test_bench_fails_loudly_when_ranks_share_a_device():
+    """The real (RCCL) path refuses to time anything when two ranks sit on one device or the communicator is not the size asked for: non-zero return
+    code and NO JSON line.  Rehearsed through gloo with the identity check forced on (CSKY_BENCH_FAKE_SHARED_DEVICE=1: both ranks are on GPU 0)."""
+    env = _clean_env()
+    env["CSKY_BENCH_FAKE_SHARED_DEVICE"] = "1"
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--no-cpu-baseline"],
+                         capture_output=True, text=True, cwd=ROOT, env=env, timeout=600)
+    assert out.returncode != 0 and not [l for l in out.stdout.splitlines() if l.startswith("{")], (out.returncode, out.stdout[-500:])
+    assert "distinct devices" in out.stderr
+    # ... and a launcher that starts fewer ranks than --gpus says
+    env = dict(os.environ, CSKY_BENCH_ONE_GPU_DEBUG="1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", str(_free_port()),
+           os.path.join(ROOT, "bench.py"), "--gpus", "4", "--steps", "2", "--warmup", "1", "--no-cpu-baseline"]
+    out = subprocess.run(cmd, capture_output=True, text=True, cwd=ROOT, env=env, timeout=600)
+    assert out.returncode != 0 and not [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert "WORLD_SIZE=2" in out.stderr
 
 
 @pytest.mark.parametrize("mode", [("8", "1", None), ("4", "2", None), ("3", "1", "--staged"), ("2", "1", None)])
