@@ -251,6 +251,17 @@ def main_single_process(args):
         ms, _ = m.ctx(i).time_clouds(params, W, (8, k, per, nb), warmup=1, iters=3)
         share_ms.append(ms)
     fr = frames[(n_last - 1) % slots].view(torch.float16)               # the last frame the last region rendered (region() returns how many it ran)
+    # the handle's preconditions (peer access of every device to the first) and, outside the timed regions, HIP-event timings of one more frame:
+    # every device's march of its bands and (staged form) its peer copy -- csky_multi_get_stats
+    sync_all()
+    m.set_timing(True)
+    fp_t, fs_t = (params, sun_n) if sweep is None else sweep[0]
+    m.render_sky_lut(fs_t, 200, 100)
+    scratch = torch.zeros((H, W, 4), dtype=torch.int16, device=dev)
+    m.render_clouds_device(fp_t, W, H, scratch.data_ptr(), W * 8, streams[0].cuda_stream)
+    multi_stats = m.stats()
+    multi_stats["warning"] = m.last_warning()
+    m.set_timing(False)
     alpha_mean = float(fr[..., 3].float().mean().item())
     finite = bool(torch.isfinite(fr.float()).all().item())
     if True:                                                              # the assembled frame must equal a single-context render of the same frame (outside the timed region)
@@ -278,7 +289,7 @@ def main_single_process(args):
         "value_prewarmed": (prewarmed or as_asked)["value"], "ms_per_step_prewarmed": (prewarmed or as_asked)["ms_per_step"],
         "value_as_asked": as_asked["value"], "ms_per_step_as_asked": as_asked["ms_per_step"],
         "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-        "ranks_seen": len(m), "per_rank_share_ms": share_ms, "gathered_frame_check": frame_check,
+        "ranks_seen": len(m), "per_rank_share_ms": share_ms, "gathered_frame_check": frame_check, "multi_stats": multi_stats,
         "config": {"workload": "%s: %dx%d hemisphere, %d primary x %d light steps, sun (%.4f,%.4f,%.4f), clouds_sky.tres defaults, weather.bmp + worlnoise.bmp "
                                "+ generated 128^3 shape noise (seed 1), wind frozen" % (args.config, W, H, primary, light, sun_n[0], sun_n[1], sun_n[2]),
                    "texture_size": [W, H], "primary_steps": primary, "light_steps": light, "early_out_eps": args.early_out,

@@ -17,7 +17,7 @@
  *      vkGetMemoryFdKHR -> fd; csky_external_frame_import_fd(ctx, fd, ...) -> device pointer of the image's texels in HIP's address space.
  *   3. Ordering.  Preferred: an exportable VkSemaphore (VkExportSemaphoreCreateInfo{OPAQUE_FD}) -> vkGetSemaphoreFdKHR ->
  *      csky_external_frame_import_semaphore_fd.  MEASURED on the MI355X box: ROCm 7.2's Linux runtime answers hipErrorNotSupported to
- *      hipImportExternalSemaphore (a drm_syncobj fd, which is what an amdgpu opaque-fd semaphore is; tools/ext_semaphore_probe.py), so on this
+ *      hipImportExternalSemaphore (a drm_syncobj fd, which is what an amdgpu opaque-fd semaphore is; profiles/r03/external_semaphore_probe.txt), so on this
  *      runtime the image is created WITHOUT a semaphore and ordered by the host: csky_external_frame_fence() behind the march,
  *      csky_external_frame_ready() polled at the start of the next update pass (csky_zc_ready below).
  *   4. GDScript wraps the VkImage: rid = rd.texture_create_from_extension(TEXTURE_TYPE_2D, DATA_FORMAT_R16G16B16A16_SFLOAT, TEXTURE_SAMPLES_1,

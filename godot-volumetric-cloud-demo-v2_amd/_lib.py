@@ -48,6 +48,16 @@ class ShapeNoiseParams(C.Structure):
                 ("centre", C.c_float), ("contrast", C.c_float), ("offset", C.c_float)]
 
 
+MULTI_STATS_MAX = 16
+
+
+class MultiStats(C.Structure):
+    """csky_multi_stats (include/cloudsky_internal.h)."""
+    _fields_ = [("n_devices", C.c_int32), ("staged", C.c_int32), ("all_peer", C.c_int32), ("groups", C.c_int32), ("frames_in_flight", C.c_int32), ("timing", C.c_int32),
+                ("device_id", C.c_int32 * MULTI_STATS_MAX), ("peer_access", C.c_int32 * MULTI_STATS_MAX), ("march_ms", C.c_float * MULTI_STATS_MAX),
+                ("copy_ms", C.c_float * MULTI_STATS_MAX)]
+
+
 def shape_noise_params(**knobs):
     """The generator's defaults with the given fields replaced."""
     p = ShapeNoiseParams()
@@ -115,6 +125,9 @@ SYMBOLS = [
     ("csky_multi_device_count", C.c_int, [C.c_void_p]),
     ("csky_multi_ctx", C.c_void_p, [C.c_void_p, C.c_int]),
     ("csky_multi_last_error", C.c_char_p, [C.c_void_p]),
+    ("csky_multi_last_warning", C.c_char_p, [C.c_void_p]),
+    ("csky_multi_set_timing", C.c_int, [C.c_void_p, C.c_int]),
+    ("csky_multi_get_stats", C.c_int, [C.c_void_p, C.c_void_p]),
     ("csky_multi_set_noise", C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     ("csky_multi_set_noise_mips", C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     ("csky_multi_set_frames_in_flight", C.c_int, [C.c_void_p, C.c_int]),
@@ -153,7 +166,7 @@ SYMBOLS = [
 
 
 DEFAULT_VARIANT = 3   # include/cloudsky.h CSKY_DEFAULT_VARIANT ("compact"); set_variant(-1) selects it
-ABI_VERSION = 6       # include/cloudsky.h CSKY_ABI_VERSION
+ABI_VERSION = 7       # include/cloudsky.h CSKY_ABI_VERSION
 
 
 def library_path():
@@ -536,6 +549,22 @@ class MultiContext:
 
     def __len__(self):
         return self._L.csky_multi_device_count(self._h)
+
+    def last_warning(self):
+        """"" or what csky_multi_create fell back on (a device without peer access to the first: staged copies, whole LUT on the first device)."""
+        return (self._L.csky_multi_last_warning(self._h) or b"").decode()
+
+    def set_timing(self, enabled=True):
+        self._chk(self._L.csky_multi_set_timing(self._h, 1 if enabled else 0))
+
+    def stats(self):
+        """Preconditions + (set_timing) the last frame's per-device march / peer-copy milliseconds; waits for the handle's work."""
+        st = MultiStats()
+        self._chk(self._L.csky_multi_get_stats(self._h, C.byref(st)))
+        n = min(st.n_devices, MULTI_STATS_MAX)
+        return dict(n_devices=st.n_devices, staged=bool(st.staged), all_peer=bool(st.all_peer), groups=st.groups, frames_in_flight=st.frames_in_flight, timing=bool(st.timing),
+                    device_id=list(st.device_id[:n]), peer_access=list(st.peer_access[:n]), march_ms=[round(float(x), 4) for x in st.march_ms[:n]],
+                    copy_ms=[round(float(x), 4) for x in st.copy_ms[:n]])
 
     def ctx(self, i):
         """The per-device context (borrowed: per-context settings such as set_variant / set_schedule go through it)."""

@@ -105,11 +105,7 @@ struct csky_ctx {
 };
 
 namespace {
-#ifdef CSKY_TIMELINE
-constexpr size_t CSKY_STATS_WORDS = 2 + 4 * 4 * 70000;   // + {t0, t1, where, what} per wavefront of up to 70 000 workgroups (analysis build)
-#else
 constexpr size_t CSKY_STATS_WORDS = 2 + 128;             // [0..1] the kernel's own tallies; then 256 32-bit basic-block counters of the census build (tools/isa_profile.py; zero in the product build)
-#endif
 thread_local char g_err[512];
 
 int fail(csky_ctx* c, int code, const char* fmt, ...) {
@@ -265,7 +261,7 @@ int clouds_dev(csky_ctx* c, const csky_cloud_params* p, int tile_w, const csky_b
     g.pitch_px = (uint32_t)(pitch_bytes / 8); g.out_full = out_full ? 1 : 0;
     // Launch-size policy: ray segments (more, shorter wavefronts) when the launch is too small to fill the chip with whole-ray
     // wavefronts, and the cost-feedback order (mode 7) when it is only a few resident workgroups deep.  Measured with
-    // tools/crossover.py, "compact" variant, kernel ms at 256 / 1024 / 4096 / 8192 / 16384 / 32768 tiles of 8x8 rays
+    // profiles/r01/launch_size_crossover_compact.txt (the script was retired with round 5's tools purge), "compact" variant, kernel ms at 256 / 1024 / 4096 / 8192 / 16384 / 32768 tiles of 8x8 rays
     // (= 1/128 .. 1/1 of the headline frame; profiles/r01/launch_size_crossover_compact.txt):
     //   whole rays, slab rows per XCD   (seg 1, sched 5)    0.50  0.56  0.58  0.94  1.39  2.15   <- full frames
     //   whole rays, cost feedback       (seg 1, sched 7)    0.50  0.51  0.66  0.80  1.10  2.18   <- 1/2 frame (one of 2 GPUs)
@@ -310,7 +306,7 @@ int clouds_dev(csky_ctx* c, const csky_cloud_params* p, int tile_w, const csky_b
     const int slot = c->fc_cur;
     // Persistent launch form (kernels.hip::clouds_kernel_persistent): as many workgroups as the chip holds, their wavefronts pop
     // footprints from per-XCD sequences of the launch order and, at the end, from the other XCDs' sequences.  Measured
-    // (tools/persistent_ab.sh, profiles/r02/persistent_launch_ab.txt), ms per frame plain -> persistent: whole frame with two frames
+    // (profiles/r02/persistent_launch_ab.txt), ms per frame plain -> persistent: whole frame with two frames
     // in flight 1.806 -> 1.724 (bench.py, alternating runs), 1/2 frame 0.938 -> 0.882; one frame at a time 2.12 -> 2.17 (plain
     // launches refill freed slots at least as well when nothing else is in flight), 1/4 frame 0.477 -> 0.539 (barely deeper than
     // the resident grid), 4096x2048 6.13 -> 6.19 (no tail to fill), cost-feedback order 1.90 -> 2.09.  So: whole-ray launches of
@@ -428,7 +424,7 @@ int csky_create(csky_ctx** out, int device_id) {
     if ((e = hipMalloc(reinterpret_cast<void**>(&c->d_heads), RING * 16 * sizeof(uint32_t))) != hipSuccess) return bail("hipMalloc", e);
     if ((e = hipMemset(c->d_heads, 0, RING * 16 * sizeof(uint32_t))) != hipSuccess) return bail("hipMemset", e);   // persistent launches leave them zero
     { int cus = 0; (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device_id); c->resident_wgs = (cus > 0 ? cus : 256) * cloud_resident_workgroups_per_cu(); }
-    // A/B switch of tools/persistent_ab.sh: 0 = never, 1 = the policy of clouds_dev (default), 2 = every whole-ray launch
+    // A/B switch (CSKY_PERSISTENT; the A/B of profiles/r02/persistent_launch_ab.txt): 0 = never, 1 = the policy of clouds_dev (default), 2 = every whole-ray launch
     if (const char* pe = getenv("CSKY_PERSISTENT")) c->persistent = atoi(pe);
     if (const char* pe = getenv("CSKY_PERSISTENT_WGS")) { const int n = atoi(pe); if (n > 0) c->resident_wgs = n; }
     *out = c;
@@ -949,7 +945,7 @@ int csky_external_frame_signal(csky_ctx* c, csky_external_frame* f, void* hip_st
     return CSKY_OK;
 }
 // Host-side ordering for runtimes that cannot import a semaphore (ROCm 7.2 on Linux answers hipErrorNotSupported for every handle type,
-// tools/ext_semaphore_probe.py): an event behind the march that the host polls before it lets the engine sample the image.
+// profiles/r03/external_semaphore_probe.txt): an event behind the march that the host polls before it lets the engine sample the image.
 int csky_external_frame_fence(csky_ctx* c, csky_external_frame* f, void* hip_stream) {
     if (!c || !f) return fail(c, CSKY_ERR_INVALID, "csky_external_frame_fence: NULL argument");
     int rc; if ((rc = bind(c))) return rc;
@@ -1052,41 +1048,6 @@ int csky_time_clouds(csky_ctx* c, const csky_cloud_params* p, int tile_w, const 
     HIPCHK(c, hipMemcpy(st, c->d_stats, 16, hipMemcpyDeviceToHost));
     c->last_stats.rays = (uint64_t)tile_w * rows; c->last_stats.incloud_samples = st[0]; c->last_stats.primary_samples = st[1] * (uint64_t)c->primary_steps;
     if (stats) *stats = c->last_stats;
-#ifdef CSKY_TIMELINE
-    if (const char* path = getenv("CSKY_TIMELINE")) {        // analysis build: one more launch, per-wavefront timestamps -> file
-        HIPCHK(c, hipMemsetAsync(c->d_stats, 0, 16, c->stream));
-        if ((rc = clouds_dev(c, p, tile_w, bands, c->d_frame, pitch, c->stream, c->d_stats, false))) return rc;
-        HIPCHK(c, hipStreamSynchronize(c->stream));
-        const size_t n = std::min((size_t)c->order_grid_ring[c->fc_cur], (size_t)70000) * 16;
-        std::vector<unsigned long long> h(n);
-        HIPCHK(c, hipMemcpy(h.data(), c->d_stats + 2, n * 8, hipMemcpyDeviceToHost));
-        if (FILE* f = fopen(path, "wb")) { fwrite(h.data(), 8, n, f); fclose(f); }
-        // CSKY_TIMELINE_PAIR=K: K frames, two in flight on two streams (what bench.py's timed region does), every launch with its own
-        // timestamp region -> <path>.pair (K regions of 16 * grid words; tools/timeline_pair.py)
-        if (const char* pk = getenv("CSKY_TIMELINE_PAIR")) {
-            const int K = atoi(pk) > 0 ? atoi(pk) : 8;
-            const int fif_saved = c->frames_in_flight;
-            c->frames_in_flight = 2;
-            hipStream_t ss[2];
-            for (int i = 0; i < 2; i++) HIPCHK(c, hipStreamCreateWithFlags(&ss[i], hipStreamNonBlocking));
-            if ((rc = clouds_dev(c, p, tile_w, bands, c->d_frame, pitch, ss[0], nullptr, true))) return rc;      // settles the geometry: grid of the two-in-flight policy
-            HIPCHK(c, hipDeviceSynchronize());
-            const size_t grid = (size_t)c->order_grid_ring[c->fc_cur], per = 2 + 16 * grid;
-            unsigned long long* big = nullptr;
-            HIPCHK(c, hipMalloc(reinterpret_cast<void**>(&big), (size_t)K * per * 8));
-            HIPCHK(c, hipMemset(big, 0, (size_t)K * per * 8));
-            for (int k = 0; k < K; k++)
-                if ((rc = clouds_dev(c, p, tile_w, bands, c->d_frame, pitch, ss[k & 1], big + (size_t)k * per, true))) return rc;
-            HIPCHK(c, hipDeviceSynchronize());
-            std::vector<unsigned long long> hb((size_t)K * per);
-            HIPCHK(c, hipMemcpy(hb.data(), big, hb.size() * 8, hipMemcpyDeviceToHost));
-            const std::string pp = std::string(path) + ".pair";
-            if (FILE* f = fopen(pp.c_str(), "wb")) { unsigned long long hd[2] = {(unsigned long long)K, (unsigned long long)per}; fwrite(hd, 8, 2, f); fwrite(hb.data(), 8, hb.size(), f); fclose(f); }
-            (void)hipFree(big); for (int i = 0; i < 2; i++) (void)hipStreamDestroy(ss[i]);
-            c->frames_in_flight = fif_saved;
-        }
-    }
-#endif
     return CSKY_OK;
 }
 
@@ -1214,7 +1175,15 @@ struct csky_multi {
     uint2* d_frame = nullptr; size_t frame_px = 0;   // host-buffer form: internal frame on the first device
     std::vector<hipEvent_t> ev_lut;       // [device]: its rows of the sky LUT have been stored into the first device's LUT (csky_multi_render_sky_lut)
     hipEvent_t ev_lut_begin = nullptr;    // on the first device's prologue stream: the readers of the LUT slot about to be rewritten are behind this
+    // preconditions + instrumentation (round 6): which devices can store into the first device's memory, and -- while csky_multi_set_timing is on --
+    // timing events around every device's march and its staged peer copy of the LAST frame enqueued
+    std::vector<int> peer_ok;             // [device]: 1 = hipDeviceCanAccessPeer(device, first) and it was enabled (1 for the first device itself)
+    bool all_peer = true;                 // false: some device has no peer access -> staged copies (the runtime bounces them) + the whole LUT on the first device
+    bool timing = false;
+    std::vector<hipEvent_t> tm[3];        // [0] before the march, [1] after it, [2] after the staged copy; [device]
+    std::vector<int> tm_valid;            // [device]: 0 none, 1 march only, 2 march + copy
     char err[512] = {0};
+    char warn[512] = {0};
 };
 namespace {
 int mfail(csky_multi* m, int code, const char* fmt, ...) {
@@ -1258,20 +1227,42 @@ int csky_multi_create(csky_multi** out, const int* device_ids, int n) {
         }
         for (int k = 0; k < RING; k++) { m->d_stage[k].push_back(nullptr); m->stage_px[k].push_back(0); }
         { hipEvent_t ev = nullptr; if ((e = hipEventCreateWithFlags(&ev, hipEventDisableTiming)) != hipSuccess) return bail(CSKY_ERR_HIP, "hipEventCreate", e); m->ev_lut.push_back(ev); }
+        for (int k = 0; k < 3; k++) m->tm[k].push_back(nullptr);
+        m->tm_valid.push_back(0);
+        int ok = 1;
         if (di != d0) {                                          // the march on device di stores into the frame on d0: xGMI peer access
             int can = 0;
             if ((e = hipDeviceCanAccessPeer(&can, di, d0)) != hipSuccess) return bail(CSKY_ERR_HIP, "hipDeviceCanAccessPeer", e);
-            if (!can) { mfail(nullptr, CSKY_ERR_NO_DEVICE, "csky_multi_create: device %d cannot access device %d (peer access is required)", di, d0); csky_multi_destroy(m); return CSKY_ERR_NO_DEVICE; }
-            e = hipDeviceEnablePeerAccess(d0, 0);
-            if (e != hipSuccess && e != hipErrorPeerAccessAlreadyEnabled) return bail(CSKY_ERR_HIP, "hipDeviceEnablePeerAccess", e);
-            (void)hipGetLastError();
+            if (can) {
+                e = hipDeviceEnablePeerAccess(d0, 0);
+                if (e != hipSuccess && e != hipErrorPeerAccessAlreadyEnabled) can = 0;
+                (void)hipGetLastError();
+            }
+            ok = can;
         }
+        // test hook: pretend device INDEX i (> 0) has no peer access -- also when it IS the first device's GPU, which is all a single-GPU box can offer
+        if (const char* fk = getenv("CSKY_MULTI_FAKE_NO_PEER")) if (i > 0 && atoi(fk) == i) ok = 0;
+        m->peer_ok.push_back(ok);
+        if (!ok) {
+            // No peer access between this device and the first one (no xGMI / PCIe P2P route, IOMMU policy, a container without the devices' links): the
+            // in-place form cannot work for it.  Not fatal: the whole handle falls back to the STAGED form -- every device renders into a local band
+            // buffer and hipMemcpy2DAsync moves the bands (the runtime bounces them through host memory where it must) -- and the first device renders the
+            // whole sky LUT itself.  Slower; the caller is told (csky_multi_last_warning), and csky_multi_get_stats says which devices.
+            const size_t at = strlen(m->warn);
+            snprintf(m->warn + at, sizeof m->warn - at, "%sdevice %d (index %d) has no peer access to device %d", at ? "; " : "csky_multi_create: ", di, i, d0);
+            m->all_peer = false;
+        }
+    }
+    if (!m->all_peer) {
+        const size_t at = strlen(m->warn);
+        snprintf(m->warn + at, sizeof m->warn - at, ": falling back to staged band copies and a whole sky LUT on the first device (slower than in-place xGMI stores)");
+        m->staged = true;
     }
     if ((e = hipSetDevice(d0)) != hipSuccess) return bail(CSKY_ERR_HIP, "hipSetDevice", e);
     for (int sl = 0; sl < MULTI_SLOTS; sl++)
         if ((e = hipEventCreateWithFlags(&m->ev_begin[sl], hipEventDisableTiming)) != hipSuccess) return bail(CSKY_ERR_HIP, "hipEventCreate", e);
     if ((e = hipEventCreateWithFlags(&m->ev_lut_begin, hipEventDisableTiming)) != hipSuccess) return bail(CSKY_ERR_HIP, "hipEventCreate", e);
-    if (const char* se = getenv("CSKY_MULTI_STAGED")) m->staged = atoi(se) != 0;   // A/B switch for the driver's 8-GPU node
+    if (const char* se = getenv("CSKY_MULTI_STAGED")) m->staged = (atoi(se) != 0) || !m->all_peer;   // A/B switch for the driver's 8-GPU node (never off without peer access)
     *out = m;
     return CSKY_OK;
 }
@@ -1285,6 +1276,7 @@ void csky_multi_destroy(csky_multi* m) {
         for (int k = 0; k < RING - 1; k++) if (i < m->side[k].size() && m->side[k][i]) (void)hipStreamDestroy(m->side[k][i]);
         for (int k = 0; k < RING; k++) if (i < m->d_stage[k].size() && m->d_stage[k][i]) (void)hipFree(m->d_stage[k][i]);
         if (i < m->ev_lut.size() && m->ev_lut[i]) (void)hipEventDestroy(m->ev_lut[i]);
+        for (int k = 0; k < 3; k++) if (i < m->tm[k].size() && m->tm[k][i]) (void)hipEventDestroy(m->tm[k][i]);
     }
     if (!m->ctx.empty()) {
         (void)hipSetDevice(m->ctx[0]->device);
@@ -1300,6 +1292,39 @@ void csky_multi_destroy(csky_multi* m) {
 int csky_multi_device_count(const csky_multi* m) { return m ? (int)m->ctx.size() : 0; }
 csky_ctx* csky_multi_ctx(csky_multi* m, int i) { return (m && i >= 0 && i < (int)m->ctx.size()) ? m->ctx[i] : nullptr; }
 const char* csky_multi_last_error(const csky_multi* m) { return m ? m->err : g_err; }
+const char* csky_multi_last_warning(const csky_multi* m) { return m ? m->warn : ""; }
+int csky_multi_set_timing(csky_multi* m, int enabled) {
+    if (!m) return mfail(nullptr, CSKY_ERR_INVALID, "csky_multi_set_timing: handle is NULL");
+    const int rc = csky_multi_sync(m); if (rc) return rc;
+    if (enabled)
+        for (size_t i = 0; i < m->ctx.size(); i++) {
+            if ((hipSetDevice(m->ctx[i]->device)) != hipSuccess) return mfail(m, CSKY_ERR_HIP, "csky_multi_set_timing: hipSetDevice failed");
+            for (int k = 0; k < 3; k++) if (!m->tm[k][i] && hipEventCreate(&m->tm[k][i]) != hipSuccess) return mfail(m, CSKY_ERR_HIP, "csky_multi_set_timing: hipEventCreate failed");
+        }
+    m->timing = enabled != 0;
+    for (auto& v : m->tm_valid) v = 0;
+    return CSKY_OK;
+}
+int csky_multi_get_stats(csky_multi* m, csky_multi_stats* out) {
+    if (!m || !out) return mfail(m, CSKY_ERR_INVALID, "csky_multi_get_stats: NULL argument");
+    memset(out, 0, sizeof *out);
+    const int rc = csky_multi_sync(m); if (rc) return rc;       // the events of the last frame must have completed
+    const int n = (int)m->ctx.size();
+    out->n_devices = n; out->staged = m->staged ? 1 : 0; out->all_peer = m->all_peer ? 1 : 0; out->groups = m->groups; out->frames_in_flight = m->fif;
+    out->timing = m->timing ? 1 : 0;
+    for (int i = 0; i < n && i < CSKY_MULTI_STATS_MAX; i++) {
+        out->device_id[i] = m->ctx[i]->device; out->peer_access[i] = m->peer_ok[i];
+        out->march_ms[i] = out->copy_ms[i] = -1.0f;
+        if (m->tm_valid[i] >= 1) {
+            if (hipSetDevice(m->ctx[i]->device) != hipSuccess) return mfail(m, CSKY_ERR_HIP, "csky_multi_get_stats: hipSetDevice failed");
+            float ms = 0.0f;
+            if (hipEventElapsedTime(&ms, m->tm[0][i], m->tm[1][i]) == hipSuccess) out->march_ms[i] = ms; else (void)hipGetLastError();
+            if (m->tm_valid[i] >= 2) { if (hipEventElapsedTime(&ms, m->tm[1][i], m->tm[2][i]) == hipSuccess) out->copy_ms[i] = ms; else (void)hipGetLastError(); }
+            else out->copy_ms[i] = 0.0f;                         // in-place form: the stores ARE the march
+        }
+    }
+    return CSKY_OK;
+}
 
 int csky_multi_set_noise(csky_multi* m, const uint8_t* large, const uint8_t* small, const uint8_t* weather) {
     if (!m) return mfail(nullptr, CSKY_ERR_INVALID, "csky_multi_set_noise: handle is NULL");
@@ -1336,6 +1361,7 @@ int csky_multi_set_groups(csky_multi* m, int groups) {
 int csky_multi_set_staged(csky_multi* m, int staged) {
     if (!m) return mfail(nullptr, CSKY_ERR_INVALID, "csky_multi_set_staged: handle is NULL");
     const int rc = csky_multi_sync(m); if (rc) return rc;
+    if (!staged && !m->all_peer) return mfail(m, CSKY_ERR_STATE, "csky_multi_set_staged: the in-place form needs peer access from every device to the first (%s)", m->warn);
     m->staged = staged != 0;
     return CSKY_OK;
 }
@@ -1364,7 +1390,9 @@ int csky_multi_render_sky_lut(csky_multi* m, const csky_sky_params* p) {
         if ((rc = bind(c))) return mpass(m, i, rc);
         if (!c->have_trans && (rc = render_trans_dev(c, 256, 64, c->pro))) return mpass(m, i, rc);   // transmittance_lut.gd:6 default size
         hipError_t e = i ? hipStreamWaitEvent(c->pro, m->ev_lut_begin, 0) : hipSuccess;
-        if (e == hipSuccess) e = launch_sky_lut_rows(w, h, i, n, p->sun_direction, c->d_trans_f, c->tw, c->th, reinterpret_cast<uint2*>(c0->sky_h_ring[k]), c0->sky_f_ring[k], c->pro);
+        // rows i, i + n, ... stored into the first device's LUT -- or, when some device cannot reach that memory, every row by the first device itself
+        if (e == hipSuccess && (m->all_peer || i == 0))
+            e = launch_sky_lut_rows(w, h, m->all_peer ? i : 0, m->all_peer ? n : 1, p->sun_direction, c->d_trans_f, c->tw, c->th, reinterpret_cast<uint2*>(c0->sky_h_ring[k]), c0->sky_f_ring[k], c->pro);
         if (e == hipSuccess) e = hipEventRecord(m->ev_lut[i], c->pro);
         if (e != hipSuccess) return mfail(m, CSKY_ERR_HIP, "csky_multi_render_sky_lut: device index %d: %s", i, hipGetErrorString(e));
         for (int q = 0; q < 3; q++) c->sky_sun[q] = p->sun_direction[q];
@@ -1401,6 +1429,8 @@ int csky_multi_render_clouds_device(csky_multi* m, const csky_cloud_params* p, i
         hipStream_t s = (i == 0) ? consumer : (dslot ? m->side[dslot - 1][i] : c->stream);
         if (i != 0 && hipStreamWaitEvent(s, m->ev_begin[slot], 0) != hipSuccess) return mfail(m, CSKY_ERR_HIP, "csky_multi_render_clouds_device: hipStreamWaitEvent failed");
         const csky_bands b = {8, k, per, nb};
+        const bool tmg = m->timing && m->tm[0][i];
+        if (tmg) { m->tm_valid[i] = 0; if (hipEventRecord(m->tm[0][i], s) != hipSuccess) return mfail(m, CSKY_ERR_HIP, "csky_multi_render_clouds_device: hipEventRecord failed"); }
         if (m->staged && i != 0) {
             // Fallback for nodes where fine-grained remote stores from inside the march stall: the device renders its bands into a compact local
             // buffer and one strided peer copy (a band = 8 rows, n bands apart in the frame) moves them over xGMI behind the march.
@@ -1413,6 +1443,7 @@ int csky_multi_render_clouds_device(csky_multi* m, const csky_cloud_params* p, i
             }
             uint2* st = m->d_stage[dslot][i];
             if ((rc = clouds_dev(c, p, tile_w, &b, st, (size_t)tile_w * 8, s, nullptr, true, /*out_full=*/false))) return mpass(m, i, rc);
+            if (tmg && hipEventRecord(m->tm[1][i], s) == hipSuccess) m->tm_valid[i] = 1;
             const size_t band_bytes = (size_t)8 * tile_w * 8;
             char* dst0 = (char*)d_out + (size_t)k * 8 * pitch;
             hipError_t e;
@@ -1423,8 +1454,10 @@ int csky_multi_render_clouds_device(csky_multi* m, const csky_cloud_params* p, i
                     e = hipMemcpy2DAsync(dst0 + (size_t)bnd * per * 8 * pitch, pitch, (char*)st + (size_t)bnd * band_bytes, (size_t)tile_w * 8, (size_t)tile_w * 8, 8, hipMemcpyDeviceToDevice, s);
             }
             if (e != hipSuccess) return mfail(m, CSKY_ERR_HIP, "csky_multi_render_clouds_device: peer copy failed: %s", hipGetErrorString(e));
+            if (tmg && m->tm_valid[i] == 1 && hipEventRecord(m->tm[2][i], s) == hipSuccess) m->tm_valid[i] = 2;
         } else {
             if ((rc = clouds_dev(c, p, tile_w, &b, (uint2*)d_out, pitch, s, nullptr, true, /*out_full=*/true))) return mpass(m, i, rc);
+            if (tmg && hipEventRecord(m->tm[1][i], s) == hipSuccess) m->tm_valid[i] = 1;
         }
         if (i != 0 && hipEventRecord(m->ev_done[slot][i], s) != hipSuccess) return mfail(m, CSKY_ERR_HIP, "csky_multi_render_clouds_device: hipEventRecord failed");
     }

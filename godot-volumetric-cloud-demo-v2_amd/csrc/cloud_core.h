@@ -242,7 +242,7 @@ extern thread_local int csky_stage;
 
 // a + f*d for an fp16 pair packed in one dword: lo = texel(x) = a, hi = texel(x+1) - texel(x) = d (the x-neighbour DIFFERENCE is
 // stored, not the neighbour: an integer in [-2040, 2040], exact in fp16).  On gfx950 this is ONE v_fma_mix_f32: the f16 -> f32
-// widening is free inside the FMA (4.4 cycles; byte texels needed cvt + cvt + sub + fma = 17, tools/ubench/valu_rates.hip), and
+// widening is free inside the FMA (4.4 cycles; byte texels needed cvt + cvt + sub + fma = 17, profiles/r01/valu_issue_rates_gfx950.txt; today's measurement: tools/ubench/valu_rates2.hip), and
 // it is literally the reference sampler's a + (b - a)*f with an exact (b - a).
 CSKY_HD float lerp_h(uint32_t p, float f) {
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -266,37 +266,6 @@ CSKY_HD float lerp_h2(uint32_t a_lo_b_hi, float f) {
     return fmaf(hi, f, fmaf(lo, -f, lo));
 #endif
 }
-
-// EXPERIMENT BUILD ONLY (`make filter16` -> libcloudsky_filter16.so, -DCSKY_FILTER16=1; never the default, never the headline: `dtype` stays f32).
-// Round 6, VERDICT r5 item 4: the one axis the exact kernel has not explored is precision where the reference itself has none -- its taps are
-// filtered by a hardware sampler with ~8-bit weights on BC7-decoded texels, this kernel filters in fp32 through half-rate v_fma_mix_f32 (4 per cell
-// and channel + 3 FMAs).  Here the y and z stages of a polynomial cell run in PACKED fp16: a cell stores (c_even, c_odd) fp16 pairs, value =
-// (c0 + c1 fx) + fy (c2 + c3 fx) [+ fz (...)], so  Q = P0 + fy P1  on both halves at once (v_pk_fma_f16, weights (fy, fy) from one v_cvt_pk_f16_f32),
-// likewise z, and only the last stage  lo + fx * hi  widens to fp32 (one v_fma_mix_f32).  Per channel 3 packed + 1 mix instead of 4 mix + 3 FMA;
-// a whole sample 12 packed + 4 mix + 5 conversions instead of 16 mix + 11 FMA.  Intermediates round to 11 bits: ~3e-4 of a texel's range.
-#ifndef CSKY_FILTER16
-#define CSKY_FILTER16 0
-#endif
-#if CSKY_FILTER16
-CSKY_HD uint32_t pk_weight(float f) {                                   // (f, f) as two fp16, round to nearest
-#if defined(__HIP_DEVICE_COMPILE__)
-    uint32_t r; asm("v_cvt_pk_f16_f32 %0, %1, %1" : "=v"(r) : "v"(f)); return r;
-#else
-    const uint32_t h = f2h(f); return h | (h << 16);
-#endif
-}
-CSKY_HD uint32_t pk_fma(uint32_t w, uint32_t b, uint32_t a) {          // a + w * b on both fp16 halves
-#if defined(__HIP_DEVICE_COMPILE__)
-    uint32_t r; asm("v_pk_fma_f16 %0, %1, %2, %3" : "=v"(r) : "v"(w), "v"(b), "v"(a)); return r;
-#else
-    const uint32_t lo = f2h(fmaf(h2f((uint16_t)(w & 0xffffu)), h2f((uint16_t)(b & 0xffffu)), h2f((uint16_t)(a & 0xffffu))));
-    const uint32_t hi = f2h(fmaf(h2f((uint16_t)(w >> 16)), h2f((uint16_t)(b >> 16)), h2f((uint16_t)(a >> 16))));
-    return lo | (hi << 16);
-#endif
-}
-CSKY_HD float cell2_pk(uint32_t p0, uint32_t p1, float ax, uint32_t wy) { return lerp_h(pk_fma(wy, p1, p0), ax); }
-CSKY_HD float cell3_pk(const uint4& t, float ax, uint32_t wy, uint32_t wz) { return lerp_h(pk_fma(wz, pk_fma(wy, t.w, t.z), pk_fma(wy, t.y, t.x)), ax); }
-#endif
 
 // Texel coordinate -> (floor as int, fraction).  gfx950 has v_cvt_flr_i32_f32 (float -> int with floor rounding) and
 // v_fract_f32, so the pair costs 2 instructions instead of floor + cvt + sub; u - floor(u) is exact in fp32 and v_fract returns
@@ -324,13 +293,8 @@ CSKY_HD void weather_fetch(const uint4* __restrict__ w, float sx, float sy, uint
     q = *reinterpret_cast<const uint4*>(reinterpret_cast<const char*>(w) + ((((uint32_t)y0 << 9) | (uint32_t)x0) << 4));
 }
 CSKY_HD void weather_filter(const uint4& q, float ax, float ay, float& wr, float& wb) {
-#if CSKY_FILTER16
-    const uint32_t wy = pk_weight(ay);
-    wr = cell2_pk(q.x, q.y, ax, wy); wb = cell2_pk(q.z, q.w, ax, wy);
-#else
     wr = fmaf(ay, lerp_h(q.y, ax), lerp_h(q.x, ax));                        // polynomial cell: (c0 + c1 fx) + fy (c2 + c3 fx)
     wb = fmaf(ay, lerp_h(q.w, ax), lerp_h(q.z, ax));
-#endif
 }
 CSKY_HD void weather_tap(const uint4* __restrict__ w, float sx, float sy, float& wr, float& wb) {
     uint4 q; float ax, ay;
@@ -400,10 +364,6 @@ CSKY_HD void shape_tap(const TS& T, int lvl, float sx, float sy, float sz, float
     (void)base;
     const uint4* __restrict__ t = reinterpret_cast<const uint4*>(sb + ((shape_level_offset(lvl) + shape_cell_offset((uint32_t)x0, (uint32_t)y0, (uint32_t)z0, sh)) << 5));
     const uint4 tr = t[0], tf = t[1];             // (marking these loads non-temporal to spare the L1 for the other textures: 1.70 -> 2.48 ms; the cells ARE re-used)
-#if CSKY_FILTER16
-    { const uint32_t wy = pk_weight(ay), wz = pk_weight(az);
-      r = cell3_pk(tr, ax, wy, wz) * (1.0f / 255.0f); fbm = cell3_pk(tf, ax, wy, wz) * (1.0f / (8.0f * 255.0f)); return; }
-#endif
     r = fmaf(az, fmaf(ay, lerp_h(tr.w, ax), lerp_h(tr.z, ax)), fmaf(ay, lerp_h(tr.y, ax), lerp_h(tr.x, ax))) * (1.0f / 255.0f);
     fbm = fmaf(az, fmaf(ay, lerp_h(tf.w, ax), lerp_h(tf.z, ax)), fmaf(ay, lerp_h(tf.y, ax), lerp_h(tf.x, ax))) * (1.0f / (8.0f * 255.0f));
 #endif
@@ -440,9 +400,6 @@ CSKY_HD float detail_tap(const TS& T, int lvl, float sx, float sy, float sz) {
     }
     const uint32_t sh = (uint32_t)(5 - lvl), idx = detail_level_offset(lvl) + ((((((uint32_t)z0 << sh) | (uint32_t)y0) << sh)) | (uint32_t)x0);
     const uint4 q = *reinterpret_cast<const uint4*>(reinterpret_cast<const char*>(T.detail) + (idx << 4));
-#if CSKY_FILTER16
-    return cell3_pk(q, ax, pk_weight(ay), pk_weight(az)) * (1.0f / (8.0f * 255.0f));
-#endif
     return fmaf(az, fmaf(ay, lerp_h(q.w, ax), lerp_h(q.z, ax)), fmaf(ay, lerp_h(q.y, ax), lerp_h(q.x, ax))) * (1.0f / (8.0f * 255.0f));   // polynomial cell
 }
 
@@ -548,6 +505,12 @@ CSKY_HD float sample_density(const TS& T, const FrameConsts& fc, float px, float
 // (Round-2 experiment, measured and removed: the cells of detail LODs 2..4 / 3..4 staged in LDS per workgroup and served to the light march
 // with one ds_read_b128 per tap: frames bit-identical, C3 2.16 / 2.08 ms against 2.05 ms (LODs 2..4 need 9.3 KB and cost a wavefront per SIMD;
 // LODs 3..4 remove 2 of 28 gathers per in-cloud sample and add a workgroup barrier + staging): profiles/r02/layout_lds_ab.txt.)
+// (Round 6, measured and removed, profiles/r06/fp16_filter_ab.txt -- the one experiment on PRECISION, VERDICT r5 item 4: the y / z stages of every
+// polynomial cell in packed fp16 -- Q = P0 + fy P1 on both halves of a cell's (c_even, c_odd) fp16 pairs with v_pk_fma_f16, weights from one
+// v_cvt_pk_f16_f32, only the last stage lo + fx hi widened by v_fma_mix_f32: 69.5 M v_fma_mix + 69.5 M v_fmac per C3 frame became 69.5 M v_pk_fma_f16 +
+// 30.2 M v_cvt_pk, VALU instructions -3.6 %, and the kernel got 0.8 % SLOWER alone (1.957 vs 1.940 ms) and 0.5 % slower two in flight: v_pk_fma_f16 and
+// v_cvt_pk_f16_f32 issue at the half rate v_fma_mix_f32 does.  The frame left the 2-ulp gate (75 % of the values bit-identical, max |d| 1.8e-2, PSNR 74-81 dB)
+// and stayed inside SURVEY 8(c)'s stated tolerance (99.96-99.99 % within 2e-3 + 1e-2 |ref|).  Exactness costs nothing here: the kernel chapter is closed.)
 // (Round 5, measured and removed, profiles/r05/kernel_experiments.txt: v_pk_fma_f32 for the y / z stages of the cell pairs: no gain; packed (x, z)
 // coordinate chains, v_pk_mul / v_pk_add: frame identical, +4.6 % time.)
 // sample_density() with all of a sample's texture fetches issued up front ("eager"): the addresses of the weather, shape and detail
@@ -599,24 +562,14 @@ CSKY_HD float sample_density_eager(const TS& T, const FrameConsts& fc, float px,
         }
         // ---- the arithmetic of density() (clouds.glsl:109-137) on the fetched cells
         CSKY_PRIO(CSKY_PRIO_MATH);
-#if CSKY_FILTER16
-        const uint32_t wwy = pk_weight(way);
-        const float wr = cell2_pk(wq.x, wq.y, wax, wwy), wb = cell2_pk(wq.z, wq.w, wax, wwy);
-#else
         const float wr = fmaf(way, lerp_h(wq.y, wax), lerp_h(wq.x, wax));       // texel scale 0..255 (weather_filter)
         const float wb = fmaf(way, lerp_h(wq.w, wax), lerp_h(wq.z, wax));
-#endif
         const float wc = fc.cov255 * wb;                                         // :123 (wb on the texel scale)
         const float g = density_height_gradient(fc, hf, wr);                    // :121
         const float omw = 1.0f - wc;
         if (g > omw) {                                                           // else: exact reject (1)
-#if CSKY_FILTER16
-            const uint32_t swy = pk_weight(say), swz = pk_weight(saz);
-            const float nr = cell3_pk(tr, sax, swy, swz) * (1.0f / 255.0f), fbm = cell3_pk(tf, sax, swy, swz) * (1.0f / (8.0f * 255.0f));
-#else
             const float nr = fmaf(saz, fmaf(say, lerp_h(tr.w, sax), lerp_h(tr.z, sax)), fmaf(say, lerp_h(tr.y, sax), lerp_h(tr.x, sax))) * (1.0f / 255.0f);
             const float fbm = fmaf(saz, fmaf(say, lerp_h(tf.w, sax), lerp_h(tf.z, sax)), fmaf(say, lerp_h(tf.y, sax), lerp_h(tf.x, sax))) * (1.0f / (8.0f * 255.0f));
-#endif
             const float omf = 1.0f - fbm, den1 = 1.0f + omf;
             float num = (nr + omf) * g - omw * den1;                            // :122, :124-125 as numerator / den1 (see density())
             if (num > 0.0f) {                                                    // else: reject (2)
@@ -624,11 +577,7 @@ CSKY_HD float sample_density_eager(const TS& T, const FrameConsts& fc, float px,
                 num = num * (wc * fast_rcp(1.0f - omw));
 #endif
                 float hfbm;
-#if CSKY_FILTER16
-                if (tap) hfbm = cell3_pk(dq, dax, pk_weight(day), pk_weight(daz)) * (1.0f / (8.0f * 255.0f));
-#else
                 if (tap) hfbm = fmaf(daz, fmaf(day, lerp_h(dq.w, dax), lerp_h(dq.z, dax)), fmaf(day, lerp_h(dq.y, dax), lerp_h(dq.x, dax))) * (1.0f / (8.0f * 255.0f));
-#endif
                 else if (EAGER_DETAIL) hfbm = T.detail_lod5;
                 else hfbm = detail_tap(T, lod_detail, dsx, dsy, dsz);           // :132-133, fetched now
                 const float k = sat(hf * 4.0f);

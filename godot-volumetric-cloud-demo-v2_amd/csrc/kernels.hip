@@ -906,7 +906,7 @@ __global__ __launch_bounds__(1024) void clouds_kernel_lds(TexSet T, const FrameC
 #define CSKY_COMPACT_WAVES 7   // waves/SIMD asked of the "compact" variant.  With the eager light-march fetches (three gathers of a sample in flight
                                // together) 7 waves x 72 VGPRs beat 8 waves x 64 VGPRs + spills: whole frame 1.83 -> 1.80 ms, 1/4 frame 0.49 -> 0.48
 #endif
-// One workgroup's footprint (4 tiles / SEG): `logical` = slab * tiles_x + bx, `rec` = its position in the launch order (timeline build).
+// One workgroup's footprint (4 tiles / SEG): `logical` = slab * tiles_x + bx, `rec` = its position in the launch order (the persistent form: its cost-feedback slot).
 template <int VARIANT, int SEG, class TS = TexSet>
 __device__ __forceinline__ void render_block(TS T, const FrameConsts* __restrict__ fcp, const RenderGeom& G, const uint32_t logical, const uint32_t rec,
                                              uint2* __restrict__ out, unsigned long long* __restrict__ stats, uint32_t* __restrict__ wg_cost, const int tile_of_wave = -1) {
@@ -923,9 +923,6 @@ __device__ __forceinline__ void render_block(TS T, const FrameConsts* __restrict
     const int band = lr / G.band_rows, rib = lr - band * G.band_rows;
     const int gy = (G.first_band + band * G.band_stride) * G.band_rows + rib;
 
-#ifdef CSKY_TIMELINE
-    const unsigned long long tl0 = wall_clock64();             // analysis build only (make timeline, tools/timeline.py)
-#endif
     const FrameConsts& fc = *fcp;
     T.detail_lds = nullptr;                                    // compile-time constant here: the LDS tap path folds away
     Ray ray = ray_setup(fc, valid ? gx : 0, valid ? gy : 0);
@@ -959,15 +956,6 @@ __device__ __forceinline__ void render_block(TS T, const FrameConsts* __restrict
         const uint32_t lo = (uint32_t)f2h(o.r) | ((uint32_t)f2h(o.g) << 16), hi = (uint32_t)f2h(o.b) | ((uint32_t)f2h(o.a) << 16);
         out[(size_t)(G.out_full ? gy : lr) * G.pitch_px + gx] = make_uint2(lo, hi);  // imageStore, clouds.glsl:264
     }
-#ifdef CSKY_TIMELINE
-    if (stats && lane == 0) {                                  // per wavefront: start, end (100 MHz ticks), XCD | HW_ID, workgroup id | lane 0's samples
-        unsigned xcc, hwid;
-        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
-        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid));
-        unsigned long long* tl = stats + 2 + 4 * ((size_t)rec * 4 + (tile_of_wave >= 0 ? tile : wave));
-        tl[0] = tl0; tl[1] = wall_clock64(); tl[2] = ((unsigned long long)xcc << 32) | hwid; tl[3] = ((unsigned long long)logical << 32) | o.incloud;
-    }
-#endif
     if (stats || wg_cost) {
         unsigned ic = o.incloud, ab = (ray.above && seg == 0) ? 1u : 0u;
         for (int off = 32; off > 0; off >>= 1) { ic += __shfl_down(ic, off); ab += __shfl_down(ab, off); }

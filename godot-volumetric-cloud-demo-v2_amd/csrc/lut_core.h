@@ -27,7 +27,7 @@ CSKY_HD F4 operator*(F4 a, float s) { return f4(a.x * s, a.y * s, a.z * s, a.w *
 // cases; OCML's float versions are 1-ulp functions, and the Hillaire integration S - S*exp(-dt*ext) (S:270) cancels and amplifies
 // that ulp to 3-4 fp16 ulp of the sky LUT.  On the device they are therefore evaluated in double and rounded once (correctly
 // rounded except ~1e-8 of the cases): these kernels are 16 384 + 20 000 x 30 lanes, the fp64 rate is irrelevant (25 us).
-// Measured on MI355X over 75 suns (tools/lut_time.py): all through double (3, the default) transmittance LUT bit-identical, sky LUT worst 1 ulp,
+// Measured on MI355X over 75 suns (round 3's LUT timing script, retired; the parity side is tests/test_gpu_round2.py's sun sweep): all through double (3, the default) transmittance LUT bit-identical, sky LUT worst 1 ulp,
 // 0.09 % of texels off, 33.0 us per back-to-back launch; every exp only (2) or the step exps only (1) worst 3 ulp, 0.8 % off, 27 us; none (0)
 // worst 3 ulp, 1.5 % off, 25.6 us: the log / pow / sin / cos matter as much as the exps, and exactness costs 7 us of a kernel that runs on the
 // prologue stream beside the march.

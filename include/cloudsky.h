@@ -40,7 +40,7 @@ extern "C" {
 #define CSKY_ERR_IO (-4)         /* asset file problem                                       */
 #define CSKY_ERR_STATE (-5)      /* e.g. clouds requested before noise / LUTs exist          */
 
-#define CSKY_ABI_VERSION 6  /* 6: the measurement / tuning / test entry points moved to cloudsky_internal.h (same library), csky_generate_shape_noise_tuned[_device]; 5: csky_last_warning (warnings no longer sit in csky_last_error), exact fp32-coefficient texture cells, csky_render_sky_lut_rows_device, csky_interleave_bands_device, csky_encode_bc7, rings eight deep; 4: csky_submit_* / csky_collect, csky_multi_set_groups / _set_staged, csky_composite_view, csky_external_frame_* (incl. _fence / _ready / _wait); 3: csky_set_noise_mips, csky_decode_bc7, csky_load_ctex[3d]; 2: csky_multi_*, device asset builders */
+#define CSKY_ABI_VERSION 7  /* 7: csky_multi_last_warning (csky_multi_create no longer fails without peer access: it falls back to staged copies and says so); 6: the measurement / tuning / test entry points moved to cloudsky_internal.h (same library), csky_generate_shape_noise_tuned[_device]; 5: csky_last_warning (warnings no longer sit in csky_last_error), exact fp32-coefficient texture cells, csky_render_sky_lut_rows_device, csky_interleave_bands_device, csky_encode_bc7, rings eight deep; 4: csky_submit_* / csky_collect, csky_multi_set_groups / _set_staged, csky_composite_view, csky_external_frame_* (incl. _fence / _ready / _wait); 3: csky_set_noise_mips, csky_decode_bc7, csky_load_ctex[3d]; 2: csky_multi_*, device asset builders */
 
 typedef struct csky_ctx csky_ctx; /* opaque: owns every device allocation, the HIP stream and events */
 
@@ -203,7 +203,7 @@ int csky_poll(csky_ctx* ctx, int64_t ticket);
  * (a hipMemCreate allocation exported as a dma-buf fd: tools/ext_frame_roundtrip.py, tests/test_gpu_round3.py).
  * The library takes ownership of the fds on success; on ANY failure the caller still owns them (the runtime is handed a duplicate).
  * Ordering without a semaphore: ROCm 7.2 on Linux refuses hipImportExternalSemaphore for every handle type (hipErrorNotSupported,
- * tools/ext_semaphore_probe.py; ..._import_semaphore_fd then returns CSKY_ERR_HIP and the frame stays usable).  ..._fence records an event
+ * profiles/r03/external_semaphore_probe.txt; ..._import_semaphore_fd then returns CSKY_ERR_HIP and the frame stays usable).  ..._fence records an event
  * behind the march on its stream; the host polls ..._ready (1 = the frame is complete, 0 = still marching) or blocks in ..._wait before it
  * lets the engine sample the image -- the reference draws with textures finished in EARLIER passes (cloud_sky.gd:137-148), so the poll
  * at the start of the next pass normally finds the frame done. */
@@ -263,7 +263,7 @@ int csky_set_frames_in_flight(csky_ctx* ctx, int frames);
  * One host thread drives n devices.  Rays are independent and the reference already renders disjoint tiles addressed by
  * update_position with frozen parameters (cloud_sky.gd:54-55,142,156-161): device i of n renders the 8-row bands i, i+n, ...
  * (interleaved for balance) with the same push-constant block, inputs replicated, and its wavefronts store their pixels
- * STRAIGHT into the frame on the first device through xGMI peer access (64 contiguous bytes per tile row): there is no staging
+ * STRAIGHT into the frame on the first device through xGMI peer access (where a device has none: csky_multi_last_warning) (64 contiguous bytes per tile row): there is no staging
  * buffer, no gather step and no host hop.  Every device renders its own copy of the two LUTs (36 K texels: cheaper than a
  * broadcast).  Events order the consumer stream on the first device behind all marches.  A device id may appear more than once
  * (two contexts sharing one GPU): meaningless for speed, it lets a single-GPU box exercise the n > 1 path.
@@ -275,6 +275,10 @@ void csky_multi_destroy(csky_multi* m);
 int csky_multi_device_count(const csky_multi* m);
 csky_ctx* csky_multi_ctx(csky_multi* m, int i);
 const char* csky_multi_last_error(const csky_multi* m);
+/* "" or what csky_multi_create had to fall back on: a device without peer access to the first one (hipDeviceCanAccessPeer says no, or enabling it
+ * failed) switches the WHOLE handle to the staged form (csky_multi_set_staged(1), which then cannot be switched off) and makes the first device
+ * render the whole sky LUT.  Same frames, slower; the text names the devices. */
+const char* csky_multi_last_warning(const csky_multi* m);
 int csky_multi_set_noise(csky_multi* m, const uint8_t* large_rgba8, const uint8_t* small_rgb8, const uint8_t* weather_rgb8);
 int csky_multi_set_noise_mips(csky_multi* m, const uint8_t* large_chain_rgba8, const uint8_t* small_chain_rgb8, const uint8_t* weather_rgb8);
 /* n = 2..8: the caller keeps n frames in flight (per frame group) by rotating n consumer streams between consecutive

@@ -25,6 +25,19 @@ int csky_get_cloud_stats(csky_ctx* ctx, csky_cloud_stats* stats); /* tallies of 
  * recorded since the last call (all of them: the event pool grows on demand), returns the sum of their durations and their
  * number, and resets. */
 int csky_set_kernel_timing(csky_ctx* ctx, int enabled);
+/* The multi-device handle's preconditions and, while csky_multi_set_timing is on, HIP-event timings of the LAST frame enqueued: per device the
+ * march of its bands and (staged form) the peer copy of those bands into the first device's frame -- the "7 concurrent P2P copies" of SURVEY 8(e).
+ * csky_multi_get_stats waits for the handle's work (csky_multi_sync).  march_ms / copy_ms: -1 = not measured; copy_ms 0 in the in-place form. */
+#define CSKY_MULTI_STATS_MAX 16
+typedef struct csky_multi_stats {
+    int32_t n_devices, staged, all_peer, groups, frames_in_flight, timing;
+    int32_t device_id[CSKY_MULTI_STATS_MAX];
+    int32_t peer_access[CSKY_MULTI_STATS_MAX];   /* 1 = this device can store into the first device's memory (1 for the first device) */
+    float march_ms[CSKY_MULTI_STATS_MAX];
+    float copy_ms[CSKY_MULTI_STATS_MAX];
+} csky_multi_stats;
+int csky_multi_set_timing(csky_multi* m, int enabled);
+int csky_multi_get_stats(csky_multi* m, csky_multi_stats* out);
 int csky_get_kernel_ms(csky_ctx* ctx, float* total_ms, int* launches);
 /* Kernel variant selector for A/B measurement (csky_variant_name lists them).  -1 = the default = the fastest measured
  * (CSKY_DEFAULT_VARIANT, "compact").  Unknown ids -> CSKY_ERR_INVALID. */

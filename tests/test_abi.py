@@ -17,7 +17,7 @@ def header_symbols(name="cloudsky.h"):
 
 # the lab bench: what a host binding the product header must NOT see
 LAB_BENCH = {"csky_time_clouds", "csky_get_cloud_stats", "csky_set_kernel_timing", "csky_get_kernel_ms", "csky_set_variant", "csky_variant_count", "csky_variant_name",
-             "csky_set_height_window", "csky_set_schedule", "csky_set_segments", "csky_read_baked_texture", "csky_test_sqrt_shell", "csky_census_clouds", "csky_encode_bc7", "csky_encode_bc7_quality"}
+             "csky_set_height_window", "csky_set_schedule", "csky_set_segments", "csky_read_baked_texture", "csky_test_sqrt_shell", "csky_census_clouds", "csky_encode_bc7", "csky_encode_bc7_quality", "csky_multi_set_timing", "csky_multi_get_stats"}
 
 
 def test_header_symbols_exported(pkg):

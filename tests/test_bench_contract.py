@@ -183,6 +183,11 @@ def test_bench_single_process_form(mode):
     assert d["gathered_frame_check"]["within_1_fp16_ulp_frac"] >= 0.9999 and d["gathered_frame_check"]["max_abs_diff"] <= 2e-3, d["gathered_frame_check"]
     assert d["config"]["frame_groups"] == int(g) and d["config"]["finite"] is True and d["config"]["alpha_mean"] > 0.05
     assert "-device frame vs single-context frame" in out.stderr
+    ms = d["multi_stats"]                                      # csky_multi_get_stats: preconditions + the per-device timings of one frame
+    assert ms["n_devices"] == int(n) and ms["all_peer"] is True and ms["warning"] == "" and ms["peer_access"] == [1] * int(n) and ms["staged"] is (extra == "--staged")
+    per = int(n) // int(g)
+    timed = [x for x in ms["march_ms"] if x > 0]
+    assert len(timed) == per and all(x < 50 for x in timed), ms   # one frame = the devices of ONE group
 
 
 @pytest.mark.parametrize("cfg", [("4", "2", "C3"), ("3", "3", "C5"), ("2", "2", "C2")])

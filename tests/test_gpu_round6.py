@@ -52,3 +52,68 @@ def test_cloud_frames_vs_executed_shader_text(gpu_ctx, gx, variant):
         worst[k] = (info["within0"], info["max_ulp"])
     gpu_ctx.set_variant(-1)
     assert min(v[0] for v in worst.values()) > 0.98, worst
+
+
+def test_multi_handle_reports_its_preconditions_and_times_its_devices(pkg, noise, oracle):
+    """csky_multi proves its preconditions and measures itself.  n = 2 and n = 8 contexts on device 0: every device reports peer
+    access, the in-place form is in use, and with csky_multi_set_timing every device's march of the last frame is timed (copy_ms 0: the stores ARE
+    the march); in the staged form the peer copy is timed too."""
+    p = oracle.default_params(512, 256, (1.0, 1.0, 0.0))
+    for n in (2, 8):
+        m = pkg.MultiContext([0] * n)
+        try:
+            assert m.last_warning() == ""
+            m.set_noise(*noise)
+            m.set_timing(True)
+            m.render_sky_lut(norm((1.0, 1.0, 0.0)))
+            a = m.render_clouds(p)
+            st = m.stats()
+            assert st["n_devices"] == n and st["all_peer"] and not st["staged"] and st["timing"] and st["peer_access"] == [1] * n
+            assert all(0.0 < x < 50.0 for x in st["march_ms"]) and st["copy_ms"] == [0.0] * n, st
+            m.set_staged(True)
+            b = m.render_clouds(p)
+            st = m.stats()
+            assert st["staged"] and all(0.0 < x < 50.0 for x in st["march_ms"]) and st["copy_ms"][0] == 0.0 and all(0.0 < x < 50.0 for x in st["copy_ms"][1:]), st
+            assert (a.view(np.uint16) == b.view(np.uint16)).all()
+        finally:
+            m.close()
+
+
+def test_multi_handle_falls_back_when_a_device_has_no_peer_access(pkg, noise, oracle, monkeypatch):
+    """A device that cannot store into the first device's memory (faked here for device INDEX 2: CSKY_MULTI_FAKE_NO_PEER) no longer fails
+    csky_multi_create: the handle switches to staged copies + a whole sky LUT on the first device, says so in csky_multi_last_warning, refuses to
+    switch the staged form off, and renders the same frame."""
+    p = oracle.default_params(512, 256, (1.0, 1.0, 0.0))
+    ref = pkg.MultiContext([0, 0, 0, 0])
+    try:
+        ref.set_noise(*noise)
+        ref.render_sky_lut(norm((1.0, 1.0, 0.0)))
+        want = ref.render_clouds(p)
+        want_lut = ref.ctx(0).read_sky_lut()
+    finally:
+        ref.close()
+    monkeypatch.setenv("CSKY_MULTI_FAKE_NO_PEER", "2")
+    m = pkg.MultiContext([0, 0, 0, 0])
+    try:
+        w = m.last_warning()
+        assert "index 2" in w and "no peer access" in w and "staged" in w, w
+        st = m.stats()
+        assert st["peer_access"] == [1, 1, 0, 1] and not st["all_peer"] and st["staged"]
+        with pytest.raises(pkg.CloudSkyError):
+            m.set_staged(False)
+        m.set_noise(*noise)
+        m.render_sky_lut(norm((1.0, 1.0, 0.0)))
+        got = m.render_clouds(p)
+        assert (got.view(np.uint16) == want.view(np.uint16)).all()
+        assert (m.ctx(0).read_sky_lut().view(np.uint16) == want_lut.view(np.uint16)).all()
+    finally:
+        m.close()
+
+
+def test_shape_generator_on_the_device_refuses_what_the_host_refuses(gpu_ctx, pkg):
+    """the n-independent parameter bounds guard the device twin too (perlin_freq = 0 at n = 32 used to reach `i % 0` inside the kernel)."""
+    for n, bad in ((32, dict(perlin_freq=0)), (16, dict(worley_freq=0)), (64, dict(perlin_freq=1 << 30, perlin_octaves=3)), (32, dict(perlin_octaves=1 << 20)),
+                   (32, dict(contrast=float("inf")))):
+        with pytest.raises(pkg.CloudSkyError):
+            gpu_ctx.generate_shape_noise(1, n, **bad)
+    assert (gpu_ctx.generate_shape_noise(3, 32) == pkg.assets.generate_shape_noise(3, 32)).all()

@@ -5,7 +5,7 @@
 
 Without --asm the device assembly of csrc/kernels.hip is produced with the Makefile's flags (hipcc -save-temps, gfx950, with
 -gline-tables-only so that every instruction carries the source line it came from).  The census is STATIC: one entry per basic
-block with the histogram of its instructions by issue class and the loop nest it sits in.  tools/census_weights.py combines it
+block with the histogram of its instructions by issue class and the loop nest it sits in.  tools/isa_profile.py combines it
 with the dynamic block counts measured on the GPU (the census build of the kernel) into the VALU-issue roofline of bench.py.
 
 Issue classes (cycles per wave64 instruction per SIMD, measured on gfx950: profiles/r02/issue_cost_calibration.json):

@@ -36,15 +36,6 @@ CSRC = os.path.join(ROOT, "godot-volumetric-cloud-demo-v2_amd", "csrc")
 LLVM = "/opt/rocm/lib/llvm/bin"
 KERNELS = {"plain": "_ZN4csky13clouds_kernelILi3ELi1ENS_6TexSetE", "persistent": "_ZN4csky24clouds_kernel_persistentILi3E"}
 FLAGS = ["-O3", "-std=c++17", "-fPIC", "-fno-slp-vectorize", "--offload-arch=gfx950", "-Wno-unused-function", "-Wno-unknown-pragmas", "-Wno-pass-failed"]
-# CSKY_CENSUS_VARIANT=filter16: census of an EXPERIMENT build instead of the product (its own libcloudsky_census_filter16.so / .json, compared with
-# libcloudsky_filter16.so); unset = the product, what bench.py uses
-VARIANT_DEFINES = {"filter16": ["-DCSKY_FILTER16=1"]}
-VAR = os.environ.get("CSKY_CENSUS_VARIANT", "")
-if VAR:
-    FLAGS = FLAGS + VARIANT_DEFINES[VAR]
-SUFFIX = "_" + VAR if VAR else ""
-CENSUS_SO = os.path.join(ROOT, "godot-volumetric-cloud-demo-v2_amd", "libcloudsky_census%s.so" % SUFFIX)
-CENSUS_JSON = os.path.join(ROOT, "godot-volumetric-cloud-demo-v2_amd", "libcloudsky_census%s.json" % SUFFIX)
 N_CTR_VGPR = 4                      # 256 block counters per kernel
 CENSUS_BYTE_OFFSET = 16             # the kernel's own two 64-bit tallies come first in the stats buffer
 
@@ -192,7 +183,7 @@ def cmd_build(args):
     run([LLVM + "/clang-offload-bundler", "-type=o", "-bundle-align=4096", "-targets=host-x86_64-unknown-linux-gnu,hipv4-amdgcn-amd-amdhsa--gfx950", "-input=/dev/null",
          "-input=dev.out", "-output=dev.hipfb"])
     run(["/opt/rocm/bin/hipcc"] + FLAGS + ["--cuda-host-only", "-Xclang", "-fcuda-include-gpubinary", "-Xclang", "dev.hipfb", "-c", os.path.join(CSRC, "kernels.hip"), "-o", "kernels_host.o"])
-    out = CENSUS_SO
+    out = os.path.join(ROOT, "godot-volumetric-cloud-demo-v2_amd", "libcloudsky_census.so")
     subprocess.check_call(["/opt/rocm/bin/hipcc"] + FLAGS + ["-shared", "-o", out, os.path.join(work, "kernels_host.o"), "bc7enc.hip", "api.cpp", "assets.cpp", "godot_import.cpp"], cwd=CSRC)
     # static census of the PRODUCT assembly (block indices are shared with the instrumentation: same splitting rule)
     static = {}
@@ -205,15 +196,16 @@ def cmd_build(args):
     sys.path.insert(0, os.path.join(ROOT, "tools"))
     import pmc_collect
     static["source_hash"] = pmc_collect.source_hash()
-    json.dump(static, open(CENSUS_JSON, "w"))
-    print("built %s (%s basic blocks instrumented), static census -> %s" % (out, info, os.path.basename(CENSUS_JSON)))
+    json.dump(static, open(os.path.join(ROOT, "godot-volumetric-cloud-demo-v2_amd", "libcloudsky_census.json"), "w"))
+    print("built %s (%s basic blocks instrumented), static census -> libcloudsky_census.json" % (out, info))
     if own:
         shutil.rmtree(work, ignore_errors=True)
 
 
 def census_available():
     """(ok, why): the census library exists and was built from the kernel sources as they are now"""
-    lib, js = CENSUS_SO, CENSUS_JSON
+    lib = os.path.join(ROOT, "godot-volumetric-cloud-demo-v2_amd", "libcloudsky_census.so")
+    js = os.path.join(ROOT, "godot-volumetric-cloud-demo-v2_amd", "libcloudsky_census.json")
     if not (os.path.exists(lib) and os.path.exists(js)):
         return False, "libcloudsky_census.so not built (python tools/isa_profile.py build)"
     import pmc_collect
@@ -224,8 +216,8 @@ def census_available():
 
 def run_counts(config, quiet=False):
     """GPU box: counts of one frame of `config` for the plain kernel and (CSKY_PERSISTENT=2) the persistent form."""
-    lib = CENSUS_SO
-    static = json.load(open(CENSUS_JSON))
+    lib = os.path.join(ROOT, "godot-volumetric-cloud-demo-v2_amd", "libcloudsky_census.so")
+    static = json.load(open(os.path.join(ROOT, "godot-volumetric-cloud-demo-v2_amd", "libcloudsky_census.json")))
     res = {"config": config, "source_hash": static["source_hash"], "kernels": {}}
     args = argparse.Namespace(config=config)
     for tag in ("plain", "persistent"):
@@ -246,8 +238,6 @@ def run_counts(config, quiet=False):
         # the product library's frame of the same workload
         env2 = dict(os.environ, CSKY_PERSISTENT="2" if tag == "persistent" else "0")
         env2.pop("CSKY_LIBRARY", None)
-        if VAR:                                                   # an experiment build's census is compared with that experiment's own library
-            env2["CSKY_LIBRARY"] = os.path.join(ROOT, "godot-volumetric-cloud-demo-v2_amd", "libcloudsky_%s.so" % VAR)
         code2 = code.replace("cnt=c.census_clouds(p, W, (8,0,1,H//8), 256)\n", "cnt=[]\n")
         r2 = subprocess.run([sys.executable, "-c", code2], env=env2, capture_output=True, text=True, timeout=300)
         d2 = json.loads([l for l in r2.stdout.splitlines() if l.startswith("{")][-1])

@@ -116,6 +116,10 @@ KERNEL_SCALAR(k_mix16, "v_mul_f32 %0, %0, %8\n v_fma_f32 %1, %1, %8, %9\n v_add_
 KERNEL_SCALAR(k_mix16_trans, "v_mul_f32 %0, %0, %8\n v_fma_f32 %1, %1, %8, %9\n v_add_f32 %2, %2, %8\n v_fmac_f32 %3, %8, %9\n v_fma_mix_f32 %4, %12, %8, %4 op_sel:[0,0,0] op_sel_hi:[1,0,0]\n v_rcp_f32 %5, %5\n v_cvt_flr_i32_f32 %6, %9\n v_fract_f32 %7, %7\n"
                              " v_mul_f32 %0, %0, %9\n v_fmac_f32 %1, %8, %9\n v_sub_f32 %2, %2, %9\n v_fma_mix_f32 %3, %13, %8, %3 op_sel:[1,0,0] op_sel_hi:[1,0,0]\n v_and_b32 %5, %5, %12\n v_lshlrev_b32 %6, 3, %6\n v_mul_f32 %7, %7, %8\n v_fma_f32 %4, %4, %8, %9")
 
+// round 6 (the packed-fp16 filter experiment, profiles/r06/fp16_filter_ab.txt): what the two instructions it swapped in cost to issue
+KERNEL_SCALAR(k_pk_fma_f16, "v_pk_fma_f16 %0, %12, %13, %0\n v_pk_fma_f16 %1, %12, %13, %1\n v_pk_fma_f16 %2, %12, %13, %2\n v_pk_fma_f16 %3, %12, %13, %3\n v_pk_fma_f16 %4, %12, %13, %4\n v_pk_fma_f16 %5, %12, %13, %5\n v_pk_fma_f16 %6, %12, %13, %6\n v_pk_fma_f16 %7, %12, %13, %7")
+KERNEL_SCALAR(k_cvt_pk_f16, "v_cvt_pk_f16_f32 %0, %8, %9\n v_cvt_pk_f16_f32 %1, %9, %8\n v_cvt_pk_f16_f32 %2, %8, %9\n v_cvt_pk_f16_f32 %3, %9, %8\n v_cvt_pk_f16_f32 %4, %8, %9\n v_cvt_pk_f16_f32 %5, %9, %8\n v_cvt_pk_f16_f32 %6, %8, %9\n v_cvt_pk_f16_f32 %7, %9, %8")
+
 typedef void (*kern_t)(float*, Stamp*, int, float);
 struct Test { const char* name; kern_t k; int valu_per_8; };   // VALU instructions among the 8 of one body line
 
@@ -181,6 +185,7 @@ int main(int argc, char** argv) {
     hipDeviceProp_t prop; CHK(hipGetDeviceProperties(&prop, 0));
     const int cus = prop.multiProcessorCount;
     const bool diff = argc > 1 && !strcmp(argv[1], "diff");
+    const char* only = getenv("VALU_RATES_ONLY");              // substring filter on the kind names (a short run for one question)
     if (!diff)
     printf("# %s, %d CUs, clockRate %d kHz.  cycles = s_memtime ticks per wave64 VALU instruction per SIMD with W waves resident per SIMD;\n"
            "# MHz = s_memtime / s_memrealtime (100 MHz) over the same interval = the clock the chip actually sustained\n", prop.gcnArchName, cus, prop.clockRate);
@@ -201,6 +206,7 @@ int main(int argc, char** argv) {
         {"v_add_lshl_u32", k_add_lshl, 8}, {"v_or3_b32", k_or3, 8}, {"v_readfirstlane_b32", k_readfirstlane, 8}, {"v_mbcnt_lo/hi", k_mbcnt, 8}, {"v_sub_f32", k_sub, 8},
         {"v_fmamk_f32", k_fmamk, 8}, {"mix16 (census proportions)", k_mix16, 16}, {"mix16 with 1 rcp", k_mix16_trans, 16},
         {"v_pk_fma_f32 3 src", k_pk_fma, 8}, {"v_pk_fma_f32 2 src", k_pk_fma_2src, 8}, {"v_pk_mul_f32", k_pk_mul, 8}, {"v_pk_add_f32", k_pk_add, 8},
+        {"v_pk_fma_f16", k_pk_fma_f16, 8}, {"v_cvt_pk_f16_f32", k_cvt_pk_f16, 8},
     };
     if (diff) {                                                // valu_rates2 diff [out.json]
         Sclk clk;
@@ -209,11 +215,11 @@ int main(int argc, char** argv) {
         FILE* js = argc > 2 ? fopen(argv[2], "w") : nullptr;
         if (js) fprintf(js, "{");
         bool first = true;
-        for (const Test& t : tests) { if (run_diff(t, d_out, d_st, cus, clk, js, first)) return 1; first = false; }
+        for (const Test& t : tests) { if (only && !strstr(only, t.name)) continue; if (run_diff(t, d_out, d_st, cus, clk, js, first)) return 1; first = false; }
         if (js) { fprintf(js, "\n}\n"); fclose(js); }
         return 0;
     }
-    for (const Test& t : tests) if (run(t, d_out, d_st, h, cus)) return 1;
+    for (const Test& t : tests) { if (only && !strstr(only, t.name)) continue; if (run(t, d_out, d_st, h, cus)) return 1; }
     // the peak the spec sheet quotes: 157.3 TFLOP/s = 256 CUs x 4 SIMDs x 64 FLOP/clk x 2.4 GHz.  64 FLOP/clk/SIMD is reached by
     // a wave64 v_fma_f32 every 2 cycles OR a wave64 v_pk_fma_f32 (2 FMAs per lane) every 4 cycles: compare with the rows above.
     return 0;
