@@ -91,8 +91,6 @@ struct csky_ctx {
     long long order_key_ring[RING][4];     // csky_create fills them with -1
     // cost-feedback schedule (mode 7): per-workgroup costs of the last launch -> heaviest-first order of the next one
     uint32_t* d_wg_cost = nullptr; uint32_t* d_lpt_order = nullptr; uint32_t* d_lpt_hist = nullptr; size_t lpt_cap = 0;
-    // EXPERIMENT (round 6; CSKY_SPLIT_PCT / CSKY_SPLIT_PRIO in the environment at csky_create): a feedback-ordered launch as TWO launches
-    int split_pct = 0, split_prio = 0; hipStream_t split_stream = nullptr; hipEvent_t ev_split[2] = {nullptr, nullptr};
     uint32_t* d_heads = nullptr; int persistent = 1; int resident_wgs = 0;   // persistent launches: 2 ring slots x (8 per-XCD pop counters + exit counter)
     bool lpt_valid[RING] = {}; long long lpt_key[RING][11];   // csky_create fills the keys with -1
     // optional per-launch timing of the cloud kernel (csky_set_kernel_timing): HIP event pairs recorded around the launch on ITS stream
@@ -365,23 +363,9 @@ int clouds_dev(csky_ctx* c, const csky_cloud_params* p, int tile_w, const csky_b
     const uint32_t* const use_order = c->lpt_valid[slot] ? lorder : d_static;
     const int use_grid = c->lpt_valid[slot] ? nblocks : static_grid;
     if (kt) HIPCHK(c, hipEventRecord(kt[0], s));
-    if (c->split_pct > 0 && c->lpt_valid[slot] && !heads && nblocks >= 64) {
-        // the heaviest (100 - pct) % of the workgroups on the caller's stream, the lightest pct % on a second stream (lowest priority with CSKY_SPLIT_PRIO=1)
-        // so that they back-fill the first launch's tail
-        const int nB = (int)((long long)nblocks * c->split_pct / 100), nA = nblocks - nB;
-        if (!c->split_stream) {
-            int least = 0, greatest = 0; (void)hipDeviceGetStreamPriorityRange(&least, &greatest);
-            HIPCHK(c, hipStreamCreateWithPriority(&c->split_stream, hipStreamNonBlocking, c->split_prio ? least : greatest + (least - greatest) / 2));
-            for (int k = 0; k < 2; k++) HIPCHK(c, hipEventCreateWithFlags(&c->ev_split[k], hipEventDisableTiming));
-        }
-        HIPCHK(c, hipEventRecord(c->ev_split[0], s));
-        HIPCHK(c, hipStreamWaitEvent(c->split_stream, c->ev_split[0], 0));
-        hipError_t le = launch_clouds(variant, seg, texset(c), c->d_fc, g, use_order, nA, d_out, d_stats, cost, s, nullptr, resident, t32p);
-        if (le == hipSuccess) le = launch_clouds(variant, seg, texset(c), c->d_fc, g, use_order + nA, nB, d_out, d_stats, cost, c->split_stream, nullptr, resident, t32p);
-        if (le != hipSuccess) return fail(c, CSKY_ERR_HIP, "cloud kernel launch failed: %s", hipGetErrorString(le));
-        HIPCHK(c, hipEventRecord(c->ev_split[1], c->split_stream));
-        HIPCHK(c, hipStreamWaitEvent(s, c->ev_split[1], 0));
-    } else
+    // (Round 6, measured and removed, profiles/r06/split_tail_ab.txt: this launch as TWO -- the heaviest 60-90 % of the feedback order here, the lightest 10-40 % on a
+    // second stream at equal or lowest priority to back-fill the tail: one frame at a time 2.00 -> 2.00-2.05 ms, frames identical.  The tail is the last wavefronts'
+    // serial chains, not idle slots; the next frame fills it.)
     {
         const hipError_t le = launch_clouds(variant, seg, texset(c), c->d_fc, g, use_order, use_grid, d_out, d_stats, cost, s, heads, resident, t32p);
         if (le != hipSuccess) { if (heads) (void)hipMemsetAsync(heads, 0, 16 * sizeof(uint32_t), s); return fail(c, CSKY_ERR_HIP, "cloud kernel launch failed: %s", hipGetErrorString(le)); }
@@ -445,8 +429,6 @@ int csky_create(csky_ctx** out, int device_id) {
     { int cus = 0; (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device_id); c->resident_wgs = (cus > 0 ? cus : 256) * cloud_resident_workgroups_per_cu(); }
     // A/B switch (CSKY_PERSISTENT; the A/B of profiles/r02/persistent_launch_ab.txt): 0 = never, 1 = the policy of clouds_dev (default), 2 = every whole-ray launch
     if (const char* pe = getenv("CSKY_PERSISTENT")) c->persistent = atoi(pe);
-    if (const char* pe = getenv("CSKY_SPLIT_PCT")) c->split_pct = atoi(pe);
-    if (const char* pe = getenv("CSKY_SPLIT_PRIO")) c->split_prio = atoi(pe);
     if (const char* pe = getenv("CSKY_PERSISTENT_WGS")) { const int n = atoi(pe); if (n > 0) c->resident_wgs = n; }
     *out = c;
     return CSKY_OK;
