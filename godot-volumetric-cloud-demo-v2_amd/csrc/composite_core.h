@@ -103,7 +103,7 @@ CSKY_HD C3 composite_pixel(const CompositeArgs& A, int i, int j) {
     }
     sl = smoothstepf(0.002f, 1.0f, sl);                                                  // G:91
     if (sqrtf(sl * sl + sl * sl + sl * sl) > 0.0f) {                                     // G:92
-        const float vpy = 6.360f + 0.0002f;                                              // viewPos, G:74
+        const float vpy = (float)(6.360 + 0.0002);                                       // viewPos, G:74: a constant expression, glslang folds it in double and narrows once
         // rayIntersectSphere(viewPos, dir, groundRadiusMM) >= 0, G:61-70,93
         const float b = 0.0f * ex + vpy * ey + 0.0f * ez, c = (0.0f * 0.0f + vpy * vpy + 0.0f * 0.0f) - 6.360f * 6.360f;
         float hit;
@@ -115,7 +115,7 @@ CSKY_HD C3 composite_pixel(const CompositeArgs& A, int i, int j) {
             const float height = sqrtf(0.0f * 0.0f + vpy * vpy + 0.0f * 0.0f);
             const float sunCos = (0.0f / height) * A.sun[0] + (vpy / height) * A.sun[1] + (0.0f / height) * A.sun[2];
             float tux = 256.0f * clampf(0.5f + 0.5f * sunCos, 0.0f, 1.0f);
-            float tuy = 64.0f * fmaxf(0.0f, fminf(1.0f, (height - 6.360f) / (6.460f - 6.360f)));
+            float tuy = 64.0f * fmaxf(0.0f, fminf(1.0f, (height - 6.360f) / (float)(6.460 - 6.360)));   // (the constant difference folds to 0.1, not to 6.46f - 6.36f)
             tux /= 256.0f; tuy /= 64.0f;
             const float ux = tux * (float)A.tw - 0.5f, uy = tuy * (float)A.th - 0.5f;
             const float fx0 = floorf(ux), fy0 = floorf(uy), ax = ux - fx0, ay = uy - fy0;

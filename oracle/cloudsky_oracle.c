@@ -677,7 +677,9 @@ static v3 getValFromTLUT(const comp_ctx *c, v3 pos, v3 sunDir) {
     v3 up = divs3(pos, height);
     float sunCosZenithAngle = dot3(up, sunDir);
     float ux = 256.0f * clampf(0.5f + 0.5f * sunCosZenithAngle, 0.0f, 1.0f);
-    float uy = 64.0f * fmaxf(0.0f, fminf(1.0f, (height - groundRadiusMM) / (atmosphereRadiusMM - groundRadiusMM)));
+    /* atmosphereRadiusMM - groundRadiusMM is a constant expression: glslang folds it in double (0.1), it is NOT 6.46f - 6.36f = 0.0999999 (found by executing
+     * the shader text, oracle/glsl_exec: 3 halfs of the demo-scene panorama were 1 ulp off) */
+    float uy = 64.0f * fmaxf(0.0f, fminf(1.0f, (height - groundRadiusMM) / (float)(6.460 - 6.360)));
     ux /= 256.0f; uy /= 64.0f;
     v4 t = tap16_clamp(c->tr, c->tw, c->th, ux, uy);
     return V3(t.x, t.y, t.z);
@@ -688,7 +690,7 @@ static v3 get_atmo(const comp_ctx *c, v3 dir) {
     v3 col = g_getValFromSkyLUT(c, dir);
     v3 sunLum = sunWithBloom(c, dir, c->sun);
     sunLum = V3(smoothstep1(0.002f, 1.0f, sunLum.x), smoothstep1(0.002f, 1.0f, sunLum.y), smoothstep1(0.002f, 1.0f, sunLum.z));
-    const v3 viewPos = V3(0.0f, groundRadiusMM + 0.0002f, 0.0f);                /* G:74 */
+    const v3 viewPos = V3(0.0f, (float)(6.360 + 0.0002), 0.0f);                 /* G:74: a constant expression, folded in double then narrowed */
     if (length3(sunLum) > 0.0f) {
         if (rayIntersectSphere(viewPos, dir, groundRadiusMM) >= 0.0f) sunLum = muls3(sunLum, 0.0f);
         else sunLum = mul3(sunLum, getValFromTLUT(c, viewPos, c->sun));
@@ -711,16 +713,22 @@ static v3 sky_composite(const comp_ctx *c, v3 EYEDIR) {
     v3 b = V3(clampf(background.x, 0.0f, 100.0f), clampf(background.y, 0.0f, 100.0f), clampf(background.z, 0.0f, 100.0f));
     return mix3(a, b, k);
 }
+/* EYEDIR of pixel (i, j) of the out_w x out_h panorama (the build-side mapping described above); exported so that oracle/glsl_exec drives the
+ * reference's own sky() with bit-identical directions */
+void csko_panorama_eyedir(int out_w, int out_h, int i, int j, float eye[3]) {
+    float u = ((float)i + 0.5f) / (float)out_w, v = ((float)j + 0.5f) / (float)out_h;
+    float az = (u * 2.0f - 1.0f) * G_PI, el = (0.5f - v) * G_PI;
+    eye[0] = cosf(el) * cosf(az); eye[1] = sinf(el); eye[2] = cosf(el) * sinf(az);
+}
 void csko_composite(int out_w, int out_h, const uint16_t *cloud_from, const uint16_t *cloud_to, int cw, int ch, const uint16_t *sky_from,
                     const uint16_t *sky_to, int sw, int sh, const uint16_t *trans, int tw, int th, float blend_amount,
                     float sun_disk_scale, const float light_dir[3], uint16_t *out_rgba16f) {
     comp_ctx c = {cloud_from, cloud_to, cw, ch, sky_from, sky_to, sw, sh, trans, tw, th, blend_amount, sun_disk_scale,
                   V3(light_dir[0], light_dir[1], light_dir[2])};
     for (int j = 0; j < out_h; j++) for (int i = 0; i < out_w; i++) {
-        float u = ((float)i + 0.5f) / (float)out_w, v = ((float)j + 0.5f) / (float)out_h;
-        float az = (u * 2.0f - 1.0f) * G_PI, el = (0.5f - v) * G_PI;
-        v3 eye = V3(cosf(el) * cosf(az), sinf(el), cosf(el) * sinf(az));
-        v3 col = sky_composite(&c, eye);
+        float e[3];
+        csko_panorama_eyedir(out_w, out_h, i, j, e);
+        v3 col = sky_composite(&c, V3(e[0], e[1], e[2]));
         uint16_t *o = out_rgba16f + ((size_t)j * out_w + i) * 4;
         o[0] = csko_f2h(col.x); o[1] = csko_f2h(col.y); o[2] = csko_f2h(col.z); o[3] = csko_f2h(1.0f);
     }

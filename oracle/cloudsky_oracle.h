@@ -78,6 +78,7 @@ void csko_clouds_bands(const csko_textures *tex, const float params[28], int pri
 void csko_composite(int out_w, int out_h, const uint16_t *cloud_from, const uint16_t *cloud_to, int cw, int ch, const uint16_t *sky_from,
                     const uint16_t *sky_to, int sw, int sh, const uint16_t *trans, int tw, int th, float blend_amount,
                     float sun_disk_scale, const float light_dir[3], uint16_t *out_rgba16f);
+void csko_panorama_eyedir(int out_w, int out_h, int i, int j, float eye[3]);   /* EYEDIR of panorama pixel (i, j): csko_composite's mapping */
 void csko_composite_view(int out_w, int out_h, const float basis[9], float fov_y_degrees, const uint16_t *cloud_from, const uint16_t *cloud_to, int cw, int ch,
                          const uint16_t *sky_from, const uint16_t *sky_to, int sw, int sh, const uint16_t *trans, int tw, int th, float blend_amount,
                          float sun_disk_scale, const float light_dir[3], uint16_t *out_rgba16f);

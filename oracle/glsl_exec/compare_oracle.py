@@ -10,7 +10,7 @@ import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path[:0] = [ROOT, os.path.join(ROOT, "tests")]
 from conftest import SUNS, norm  # noqa: E402
-from glslexec_fixture import GlslExec, SKY_OF  # noqa: E402
+from glslexec_fixture import COMPOSITES, GlslExec, SKY_OF  # noqa: E402
 from oracle import oracle as O  # noqa: E402
 import gvcd_amd  # noqa: E402
 
@@ -42,6 +42,11 @@ def main():
         img, st = O.clouds(otex, pc, gx.fold("sky_" + sky), rect=rect, return_stats=True)
         for v, get in (("fold", gx.fold), ("float", gx.flt)):
             rep(("clouds_" + k, v), img, get("clouds_" + k), "(alpha mean %.3f, %d in-cloud samples)" % (img[..., 3].astype(np.float32).mean(), st["incloud_samples"]))
+    for k, c in COMPOSITES.items():
+        w, h = c["size"]
+        o = O.composite(gx.fold("clouds_" + c["from"]), gx.fold("clouds_" + c["to"]), gx.fold("sky_" + c["from"]), gx.fold("sky_" + c["to"]), t, norm(SUNS[c["sun"]]),
+                        blend_amount=c["blend"], sun_disk_scale=c["disk"], out_w=w, out_h=h)
+        rep(("composite_" + k, "fold"), o, gx.fold("composite_" + k), "(clouds.gdshader sky(), %d x %d panorama)" % (w, h))
 
 
 if __name__ == "__main__":

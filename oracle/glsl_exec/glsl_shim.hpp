@@ -2,7 +2,7 @@
  * glsl_shim.hpp -- TEST INFRASTRUCTURE ONLY (build container only; nothing here travels to the GPU box or into the product).
  *
  * A C++17 stand-in for the subset of the GLSL 4.50 *language and built-in library* that the reference's three compute shaders
- * use (cloud_sky/clouds.glsl, cloud_sky/sky-lut.glsl, cloud_sky/transmittance-lut.glsl), so that their TEXT -- read from
+ * and its sky shader use (cloud_sky/clouds.glsl, cloud_sky/sky-lut.glsl, cloud_sky/transmittance-lut.glsl, cloud_sky/clouds.gdshader), so that their TEXT -- read from
  * /root/reference at run time by make_glsl_fixtures.py, never stored in this repository -- compiles with g++ and runs on the CPU.
  * The purpose: take the two hand restatements (oracle/cloudsky_oracle.c, oracle/numpy_restatement.py) out of the trusted base.
  * What stays builder-defined, and is therefore NOT pinned by this exercise, is exactly what this header defines:
@@ -17,7 +17,7 @@
  * from constant expressions, and operators / constructors / built-ins applied to them -- at compile time in DOUBLE and narrows
  * the result to float where it meets a run-time value [recalled: glslang Constant.cpp folds on TConstUnion::dConst].  The shim
  * models that with a per-value flag `k` ("is a constant expression"): k-flagged operands combine in double and stay flagged,
- * anything else is narrowed to float first and combines in float.  "Is a constant expression" is decided the way the language
+ * anything else is narrowed to float first and combines in float (a built-in call folds only if ALL its arguments are flagged).  "Is a constant expression" is decided the way the language
  * does, from the expression's form, which C++ exposes as its value category and constness:
  *     literal                      -> flagged
  *     const-qualified variable     -> keeps the flag of its initialiser      (C++: const lvalue)
@@ -292,12 +292,19 @@ GX_FN1(abs, s_abs) GX_FN1(floor, s_floor) GX_FN1(sign, s_sign)
     }
 GX_FN2(pow, s_pow) GX_FN2(atan, s_atan2) GX_FN2(max, s_max) GX_FN2(min, s_min)
 #undef GX_FN2
+/* A built-in is folded only when ALL of its arguments are constant expressions (then glslang evaluates the whole call in double); otherwise the GPU runs
+ * it, in float, on the narrowed arguments: smoothstep(0.6, 1.0, x) computes 1.0f - 0.6f = 0.39999998 at run time, not the double 0.4 (found by executing
+ * clouds.gdshader: 3 halfs of a panorama moved by 1 ulp while this header still folded `e1 - e0` inside the call). */
+inline void unfold3(F &a, F &b, F &c) { if (!(a.k && b.k && c.k)) { a = narrow(a); b = narrow(b); c = narrow(c); } }
 inline F s_fract(F a) { return s_sub(a, s_floor(a)); }
-inline F s_clamp(F x, F lo, F hi) { return s_min(s_max(x, lo), hi); }
-inline F s_mix(F a, F b, F t) { return s_add(s_mul(a, s_sub(F(1.0), t)), s_mul(b, t)); }
+inline F s_clamp(F x, F lo, F hi) { unfold3(x, lo, hi); return s_min(s_max(x, lo), hi); }
+inline F s_mix(F a, F b, F t) { unfold3(a, b, t); const F one = a.k ? F(1.0) : F(1.0f); return s_add(s_mul(a, s_sub(one, t)), s_mul(b, t)); }
 inline F s_smoothstep(F e0, F e1, F x) {
-    F t = s_clamp(s_div(s_sub(x, e0), s_sub(e1, e0)), F(0.0), F(1.0));
-    return s_mul(s_mul(t, t), s_sub(F(3.0), s_mul(F(2.0), t)));
+    unfold3(e0, e1, x);
+    const bool k = e0.k;
+    F t = s_div(s_sub(x, e0), s_sub(e1, e0));
+    t = s_min(s_max(t, k ? F(0.0) : F(0.0f)), k ? F(1.0) : F(1.0f));
+    return s_mul(s_mul(t, t), s_sub(k ? F(3.0) : F(3.0f), s_mul(k ? F(2.0) : F(2.0f), t)));
 }
 template <class A, int N = dim_v<A>, class = std::enable_if_t<(N >= 0 && tr<dec<A>>::gx)>>
 inline typename vec_of<N>::type fract(A &&a) { return build<N>([&](int i) { return s_fract(comp(std::forward<A>(a), i)); }); }
@@ -308,22 +315,29 @@ inline typename vec_of<N>::type fract(A &&a) { return build<N>([&](int i) { retu
     }
 GX_FN3(clamp, s_clamp) GX_FN3(mix, s_mix) GX_FN3(smoothstep, s_smoothstep)
 #undef GX_FN3
+/* the components of a vector argument, with the all-or-nothing rule: one run-time component makes the whole call a run-time call */
+template <int N, class A> inline void load_vec(A &&a, F (&v)[N], bool &allk) { for (int i = 0; i < N; i++) { v[i] = comp(std::forward<A>(a), i); allk = allk && v[i].k; } }
+template <int N> inline void unfold(F (&v)[N], bool allk) { if (!allk) for (int i = 0; i < N; i++) v[i] = narrow(v[i]); }
 template <class A, class B, int N = bdim<A, B>::value, class = std::enable_if_t<(N >= 2 && dim_v<A> == dim_v<B>)>>
 inline F dot(A &&a, B &&b) {
-    F s = s_mul(comp(std::forward<A>(a), 0), comp(std::forward<B>(b), 0));
-    for (int i = 1; i < N; i++) s = s_add(s, s_mul(comp(std::forward<A>(a), i), comp(std::forward<B>(b), i)));
+    F x[N], y[N]; bool k = true;
+    load_vec<N>(std::forward<A>(a), x, k); load_vec<N>(std::forward<B>(b), y, k); unfold<N>(x, k); unfold<N>(y, k);
+    F s = s_mul(x[0], y[0]);
+    for (int i = 1; i < N; i++) s = s_add(s, s_mul(x[i], y[i]));
     return s;
 }
-template <class A, int N = dim_v<A>, class = std::enable_if_t<(N >= 2)>>
-inline F length(A &&a) {
-    F s = s_mul(comp(std::forward<A>(a), 0), comp(std::forward<A>(a), 0));
-    for (int i = 1; i < N; i++) s = s_add(s, s_mul(comp(std::forward<A>(a), i), comp(std::forward<A>(a), i)));
+template <int N> inline F length_of(const F (&x)[N]) {
+    F s = s_mul(x[0], x[0]);
+    for (int i = 1; i < N; i++) s = s_add(s, s_mul(x[i], x[i]));
     return s_sqrt(s);
 }
 template <class A, int N = dim_v<A>, class = std::enable_if_t<(N >= 2)>>
+inline F length(A &&a) { F x[N]; bool k = true; load_vec<N>(std::forward<A>(a), x, k); unfold<N>(x, k); return length_of<N>(x); }
+template <class A, int N = dim_v<A>, class = std::enable_if_t<(N >= 2)>>
 inline typename vec_of<N>::type normalize(A &&a) {
-    F l = length(std::forward<A>(a));
-    return build<N>([&](int i) { return s_div(comp(std::forward<A>(a), i), l); });
+    F x[N]; bool k = true; load_vec<N>(std::forward<A>(a), x, k); unfold<N>(x, k);
+    const F l = length_of<N>(x);
+    return build<N>([&](int i) { return s_div(x[i], l); });
 }
 
 /* ------------------------------------------------------------------------------------------------ integer vectors, matrix */
@@ -368,6 +382,8 @@ template <class P> inline vec4 textureLod(const sampler3D &s, P &&pnt, F lod) {
     csko_tap3d_repeat(s.chain, s.n0, s.levels, s.ch, lod.f(), c, o);
     return vec4(F(o[0]), F(o[1]), F(o[2]), F(o[3]));
 }
+inline vec4 texture(const sampler2D &s, const vec2 &uv);
+inline vec4 textureLod(const sampler2D &s, const vec2 &uv, F) { return texture(s, uv); }   /* single-level 2-D images: every LOD is level 0 */
 inline vec4 texture(const sampler2D &s, const vec2 &uv) {
     float o[4] = {0, 0, 0, 1};
     if (s.kind == 0) csko_tap_weather((const uint8_t *)s.data, uv.x.f(), uv.y.f(), o);

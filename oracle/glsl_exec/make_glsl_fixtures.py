@@ -3,7 +3,7 @@
 
 Executes the reference's own shader TEXT on the CPU and writes the results as golden arrays (tests/golden/glslexec.npz):
 
-  1. reads /root/reference/cloud_sky/{transmittance-lut,sky-lut,clouds}.glsl at run time (nothing of it is stored in this repo: the
+  1. reads /root/reference/cloud_sky/{transmittance-lut,sky-lut,clouds}.glsl and clouds.gdshader at run time (nothing of it is stored in this repo: the
      translation unit is written to a temporary directory outside the repository and deleted; the fixtures are arrays);
   2. applies three mechanical, line-preserving rewrites (REWRITES below) -- everything else in the files is compiled verbatim, the
      GLSL declarations it cannot parse as C++ (`layout(...)`, `uniform`, `in`, `restrict`, `writeonly`, `float`) being absorbed by six
@@ -36,8 +36,11 @@ import numpy as np
 HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(os.path.dirname(HERE))
 REF = "/root/reference/cloud_sky"
-SHADERS = {"trans": "transmittance-lut.glsl", "sky": "sky-lut.glsl", "clouds": "clouds.glsl"}
+SHADERS = {"trans": "transmittance-lut.glsl", "sky": "sky-lut.glsl", "clouds": "clouds.glsl", "composite": "clouds.gdshader"}
 SKY_OF = {"cov50": "deg45"}
+# compositor cases: blend between two cloud frames / sky LUTs of the fixture, the directional light of `sun`, panorama size
+COMPOSITES = {"blend35": dict(**{"from": "zenith", "to": "deg45"}, sun="deg45", blend=0.35, disk=2.0, size=(256, 128)),
+              "demo": dict(**{"from": "demo", "to": "demo"}, sun="demo", blend=0.0, disk=1.0, size=(192, 96))}
 SUNS = {"zenith": (0.0, 1.0, 0.0), "deg45": (1.0, 1.0, 0.0), "demo": (-0.998773, 0.0495291, 2.69869e-07)}
 
 # (pattern, replacement, why).  All three keep the line count, so compiler diagnostics cite the reference's own line numbers.
@@ -50,6 +53,15 @@ REWRITES = [
     # float before the constant-folding model sees it
     (re.compile(r"(?<![\w.])((?:\d+\.\d*|\.\d+|\d+)(?:[eE][+-]?\d+)?)f\b"), r"\1", "strip the float-literal suffix"),
 ]
+
+# clouds.gdshader is Godot shading language, not GLSL: two more line-preserving rewrites, applied to that file only, and the engine's built-ins declared in
+# front of the text (EXTRA_PRELUDE: `PI` is what Godot's shader compiler emits for it, Math_PI = 3.14159265358979323846 [recalled]; EYEDIR is the view direction
+# of the pixel, LIGHT0_DIRECTION the direction towards the first directional light, COLOR the sky pass's output)
+GDSHADER_REWRITES = [
+    (re.compile(r"^(shader_type\b.*|render_mode\b.*)$", re.M), "", "drop the shader_type / render_mode statements"),
+    (re.compile(r"^(uniform\s+\w+\s+\w+)\s*:[^;=]*", re.M), r"\1", "drop the uniform hints (filter / repeat / hint_range / source_color)"),
+]
+EXTRA_PRELUDE = {"composite": "const gx::F PI = 3.14159265358979323846;\ngx::vec3 EYEDIR, LIGHT0_DIRECTION, COLOR;\n"}
 
 PRELUDE = """#include "glsl_shim.hpp"
 """
@@ -76,10 +88,10 @@ CLOSE = """
 """
 
 
-def rewrite(text):
+def rewrite(text, name=""):
     n0 = text.count("\n")
     counts = []
-    for pat, rep, why in REWRITES:
+    for pat, rep, why in (GDSHADER_REWRITES if name == "composite" else []) + REWRITES:
         text, n = pat.subn(rep, text)
         counts.append((why, n))
     assert text.count("\n") == n0
@@ -92,7 +104,10 @@ def build_variant(tmp, variant, texts):
     with open(tu, "w") as f:
         f.write(PRELUDE)
         for name, fn in SHADERS.items():
-            f.write(OPEN % dict(name=name, file=fn))
+            head = OPEN % dict(name=name, file=fn)
+            if name in EXTRA_PRELUDE:                              # the engine's built-ins, in front of the #line that restarts the numbering
+                head = head.replace("#line 1", EXTRA_PRELUDE[name] + "#line 1")
+            f.write(head)
             f.write(texts[name])
             f.write(CLOSE % dict(name=name))
     so = os.path.join(tmp, "libglslexec_%s.so" % variant)
@@ -107,7 +122,7 @@ def build_variant(tmp, variant, texts):
 # Negative control (--mutation-check): one literal per shader gets two neighbouring digits swapped -- the kind of slip a hand
 # transcription makes -- and the fold variant is rebuilt; the output downstream of the change must move, otherwise "0 differences"
 # against the oracle would prove nothing.  (A change in the LAST digit of these literals moves 0-2 halfs: below fp16 resolution.)
-MUTATIONS = {"trans": ("1.16364243", "1.16346243"), "sky": ("17.92", "17.29"), "clouds": ("n.g * 0.625", "n.g * 0.652")}
+MUTATIONS = {"trans": ("1.16364243", "1.16346243"), "sky": ("17.92", "17.29"), "clouds": ("n.g * 0.625", "n.g * 0.652"), "composite": ("/ 50.0", "/ 05.0")}
 
 
 def ptr(a):
@@ -120,6 +135,15 @@ class Exec:
         self.L.gxe_transmittance.argtypes = [C.c_int, C.c_int, C.c_void_p]
         self.L.gxe_sky_lut.argtypes = [C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p]
         self.L.gxe_clouds.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]
+        self.L.gxe_composite.argtypes = [C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_int,
+                                         C.c_float, C.c_float, C.c_void_p, C.c_void_p]
+
+    def composite(self, cloud_from, cloud_to, sky_from, sky_to, trans, light_dir, blend, disk_scale, out_w, out_h):
+        ld = np.asarray(light_dir, np.float32)
+        out = np.zeros((out_h, out_w, 4), np.uint16)
+        self.L.gxe_composite(out_w, out_h, ptr(cloud_from), ptr(cloud_to), cloud_from.shape[1], cloud_from.shape[0], ptr(sky_from), ptr(sky_to), sky_from.shape[1],
+                             sky_from.shape[0], ptr(trans), trans.shape[1], trans.shape[0], blend, disk_scale, ptr(ld), ptr(out))
+        return out
 
     def transmittance(self, w=256, h=64):
         out = np.zeros((h, w, 4), np.uint16)
@@ -191,7 +215,7 @@ def main():
     texts, meta = {}, {}
     for name, fn in SHADERS.items():
         raw = open(os.path.join(REF, fn), encoding="utf-8").read()
-        texts[name], counts = rewrite(raw)
+        texts[name], counts = rewrite(raw, name)
         meta[name] = dict(sha256=hashlib.sha256(raw.encode("utf-8")).hexdigest(), lines=raw.count("\n"), rewrites=counts)
         print("%-24s sha256 %s  %d lines; rewrites: %s" % (fn, meta[name]["sha256"][:16], meta[name]["lines"],
                                                             ", ".join("%s x%d" % c for c in counts)))
@@ -222,6 +246,9 @@ def main():
                 r["sky_" + k] = e.sky(pc[16:19], r["trans"])
                 r["clouds_" + k] = e.clouds(otex, pc, r["sky_" + k], rect)
             r["sky_below"] = e.sky(norm((0.3, -0.2, 0.5)), r["trans"])          # sun under the horizon: LUT only
+            for k, c in COMPOSITES.items():                                      # clouds.gdshader sky() over a panorama, from this variant's own textures
+                r["composite_" + k] = e.composite(r["clouds_" + c["from"]], r["clouds_" + c["to"]], r["sky_" + c["from"]], r["sky_" + c["to"]], r["trans"],
+                                                  norm(SUNS[c["sun"]]), c["blend"], c["disk"], *c["size"])
             res[v] = r
         for k, arr in res["fold"].items():
             out["fold_" + k] = arr
@@ -249,6 +276,10 @@ def main():
                     got, ref = m.transmittance(), f["trans"]
                 elif name == "sky":
                     got, ref = m.sky(norm(SUNS["deg45"]), f["trans"]), f["sky_deg45"]
+                elif name == "composite":
+                    c = COMPOSITES["blend35"]
+                    got = m.composite(f["clouds_" + c["from"]], f["clouds_" + c["to"]], f["sky_" + c["from"]], f["sky_" + c["to"]], f["trans"], norm(SUNS[c["sun"]]), c["blend"], c["disk"], *c["size"])
+                    ref = f["composite_blend35"]
                 else:
                     got, ref = m.clouds(otex, O.default_params(64, 32, SUNS["deg45"]), f["sky_deg45"], (0, 0, 64, 32)), f["clouds_deg45"]
                 nd = int((got != ref).sum())

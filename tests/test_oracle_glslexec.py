@@ -14,7 +14,7 @@ import numpy as np
 import pytest
 
 from conftest import ROOT, SUNS, norm, ulp_diff
-from glslexec_fixture import GlslExec, SKY_OF
+from glslexec_fixture import COMPOSITES, GlslExec, SKY_OF
 
 
 @pytest.fixture(scope="module")
@@ -28,7 +28,7 @@ def _same(a, b):
 
 def test_fixture_was_made_from_the_shipped_inputs(gx, pkg, noise):
     assert [str(s) for s in gx.z["inputs_sha256"]] == [pkg.assets.sha256(x) for x in noise]
-    assert [str(s) for s in gx.z["shader_names"]] == ["transmittance-lut.glsl", "sky-lut.glsl", "clouds.glsl"]
+    assert [str(s) for s in gx.z["shader_names"]] == ["transmittance-lut.glsl", "sky-lut.glsl", "clouds.glsl", "clouds.gdshader"]
 
 
 def test_transmittance_lut_bit_identical(gx, o_trans):
@@ -61,6 +61,19 @@ def test_cloud_frames_bit_identical(gx, oracle, otex):
     assert n_incloud_px > 5000                                           # the frames are not empty sky
 
 
+def test_compositor_bit_identical(gx, oracle):
+    """clouds.gdshader's sky() executed per pixel of a panorama (the oracle's EYEDIR mapping) against csko_composite on the same five
+    textures: a blend between two cloud frames / sky LUTs with the sun disc and bloom in view, and the demo scene's grazing sun."""
+    for k, c in COMPOSITES.items():
+        w, h = c["size"]
+        o = oracle.composite(gx.fold("clouds_" + c["from"]), gx.fold("clouds_" + c["to"]), gx.fold("sky_" + c["from"]), gx.fold("sky_" + c["to"]), gx.fold("trans"),
+                             norm(SUNS[c["sun"]]), blend_amount=c["blend"], sun_disk_scale=c["disk"], out_w=w, out_h=h)
+        ref = gx.fold("composite_" + k)
+        assert _same(o, ref), (k, int((o.view(np.uint16) != ref.view(np.uint16)).sum()))
+        rgb = ref[..., :3].astype(np.float32)
+        assert rgb.max() > 0.5 and rgb.std() > 0.05, k                       # the sun's bloom and a structured sky are in the picture
+
+
 def test_numpy_restatement_agrees_with_executed_text(gx):
     """The second hand restatement (oracle/numpy_restatement.py -> tests/golden/*_np.npz) against the executed text, at the tolerance
     its own tests use (numpy's SIMD exp/log/pow differ from glibc's in the last fp32 bit)."""
@@ -79,7 +92,7 @@ def test_fixture_regenerates_from_the_reference_text(gx, tmp_path):
     r = subprocess.run([sys.executable, os.path.join(ROOT, "oracle", "glsl_exec", "make_glsl_fixtures.py"), "--out", out, "--mutation-check"],
                        capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
-    assert r.stdout.count("mutation ") == 3
+    assert r.stdout.count("mutation ") == 4
     new = np.load(out)
     assert sorted(new.files) == sorted(gx.z.files)
     for k in new.files:
@@ -90,7 +103,7 @@ def test_no_shader_text_in_the_repository():
     """The generated translation unit lives in a temporary directory; nothing under the repository may hold the reference's GLSL in
     any form.  Distinctive statements of the three shaders must not appear in any tracked text file outside oracle/ (whose C and
     numpy restatements cite and paraphrase them by design)."""
-    needles = ["uniform sampler3D large_scale_noise", "vec4 march(vec3 pos", "float powder_sugar_effect = 1.0 - exp",
+    needles = ["uniform sampler2D sky_blend_from_texture : filter_linear", "vec3 sunWithBloom(vec3 rayDir, vec3 sunDir) {", "uniform sampler3D large_scale_noise", "vec4 march(vec3 pos", "float powder_sugar_effect = 1.0 - exp",
                "vec4 compute_inscattering(vec3 ray_origin", "layout(push_constant, std430) uniform Params"]
     files = subprocess.run(["git", "-C", ROOT, "ls-files"], capture_output=True, text=True).stdout.split()
     for f in files:
