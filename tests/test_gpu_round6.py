@@ -6,7 +6,7 @@ import numpy as np
 import pytest
 
 from conftest import SUNS, cloud_tight, norm, ulp_diff
-from glslexec_fixture import GlslExec, SKY_OF
+from glslexec_fixture import COMPOSITES, GlslExec, SKY_OF
 
 pytestmark = pytest.mark.gpu
 
@@ -52,6 +52,18 @@ def test_cloud_frames_vs_executed_shader_text(gpu_ctx, gx, variant):
         worst[k] = (info["within0"], info["max_ulp"])
     gpu_ctx.set_variant(-1)
     assert min(v[0] for v in worst.values()) > 0.98, worst
+
+
+def test_compositor_vs_executed_shader_text(gpu_ctx, gx):
+    """csky_composite_sky against clouds.gdshader's own sky() executed per panorama pixel: the gate of the HIP-vs-oracle compositor
+    test, <= 2 fp16 ulp.  The context's own transmittance LUT is bit-identical to the fixture's (test_luts_vs_executed_shader_text)."""
+    gpu_ctx.render_transmittance(256, 64)
+    for k, c in COMPOSITES.items():
+        w, h = c["size"]
+        img = gpu_ctx.composite_sky(gx.fold("clouds_" + c["from"]), gx.fold("clouds_" + c["to"]), gx.fold("sky_" + c["from"]), gx.fold("sky_" + c["to"]),
+                                    norm(SUNS[c["sun"]]), c["blend"], c["disk"], w, h)
+        d = ulp_diff(img, gx.fold("composite_" + k))
+        assert d.max() <= 2 and (d > 0).mean() < 0.02, (k, d.max(), (d > 0).mean())
 
 
 def test_multi_handle_reports_its_preconditions_and_times_its_devices(pkg, noise, oracle):
