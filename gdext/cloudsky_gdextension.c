@@ -16,6 +16,7 @@
  *                                                                   cloud_sky.gd:234-248         (pc = `_fill_push_constant()`, 28 floats)
  *   get_status() -> int                                             0 or the CSKY_ERR_* code of the last call
  *   get_last_error() -> String
+ *   get_last_warning() -> String                                    "" or the caveat of the last call that succeeded with one (create_multi's staged fallback, ...)
  * Throughput path (round 3): the blocking render_clouds() costs march + 16 MiB device-to-host copy per frame, one frame at a time.
  *   create_multi(device_ids: PackedInt32Array) -> int               the GPUs of the node behind this one object (csky_multi_*): every device
  *                                                                   renders its bands of each frame straight into the frame on the first one
@@ -381,6 +382,16 @@ static void m_get_last_error(void *ud, GDExtensionClassInstancePtr inst, const G
     (void)ud; (void)a;
     G.string_new(r, ((CloudSkyHIP *)inst)->err);
 }
+/* "" or the caveat of the last call that succeeded with one: csky_multi_create's fallback (a device without peer access: staged copies), else the context's
+ * csky_last_warning (textures that do not fit fp16 cells, hardware queues) */
+static void m_get_last_warning(void *ud, GDExtensionClassInstancePtr inst, const GDExtensionConstTypePtr *a, GDExtensionTypePtr r) {
+    CloudSkyHIP *self = (CloudSkyHIP *)inst;
+    const char *w = "";
+    (void)ud; (void)a;
+    if (self->multi && csky_multi_last_warning(self->multi)[0]) w = csky_multi_last_warning(self->multi);
+    else if (self->ctx) w = csky_last_warning(self->ctx);
+    G.string_new(r, w);
+}
 
 /* ---- method table + the generic Variant-call trampoline ----------------------------------------------------------------- */
 typedef struct {
@@ -415,6 +426,7 @@ static const csky_method METHODS[] = {
     {"release_frame", m_release_frame, 1, GDEXTENSION_VARIANT_TYPE_INT, {GDEXTENSION_VARIANT_TYPE_INT}, {"slot"}},
     {"get_status", m_get_status, 0, GDEXTENSION_VARIANT_TYPE_INT, {GDEXTENSION_VARIANT_TYPE_NIL}, {0}},
     {"get_last_error", m_get_last_error, 0, GDEXTENSION_VARIANT_TYPE_STRING, {GDEXTENSION_VARIANT_TYPE_NIL}, {0}},
+    {"get_last_warning", m_get_last_warning, 0, GDEXTENSION_VARIANT_TYPE_STRING, {GDEXTENSION_VARIANT_TYPE_NIL}, {0}},
 };
 #define N_METHODS ((int)(sizeof METHODS / sizeof METHODS[0]))
 

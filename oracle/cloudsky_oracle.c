@@ -8,6 +8,9 @@
  * Build: gcc -O2 -ffp-contract=off -fno-fast-math (oracle/Makefile).  Every arithmetic
  * expression keeps the GLSL's left-to-right association; all maths is float (never double)
  * except compile-time constant folding, which glslang performs in double before narrowing.
+ * Round 6: bit-identical, on every fixture, to the reference's own shader text executed under
+ * oracle/glsl_exec (tests/test_oracle_glslexec.py; the one discrepancy that run found -- two constant
+ * expressions of the compositor evaluated in float here -- is fixed below, G:74 / G:82).
  *
  * Third-party behaviour that is NOT in the reference tree (Godot Engine >= 4.2 / Vulkan):
  *   - sampler filtering: restated from the Vulkan spec texel-coordinate rules (u = s*size,

@@ -2,7 +2,9 @@
 
 Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import this module, and only as
 the checker / reported baseline.  PARITY UNPINNED (see cloudsky_oracle.h): the reference has no golden
-vectors and cannot be run; the oracle is cross-checked against oracle/numpy_restatement.py fixtures.
+vectors and cannot be run; the oracle is cross-checked against oracle/numpy_restatement.py fixtures and is
+bit-identical to the reference's own shader text executed under oracle/glsl_exec (a builder-written GLSL
+stand-in: strong evidence about the transcription, not a pin).
 """
 import ctypes as C
 import os

@@ -152,9 +152,9 @@ int main(int argc, char **argv) {
     void *so;
     static const char *expect[] = {"create", "set_noise", "set_march", "render_transmittance", "render_sky_lut", "render_clouds", "get_status", "get_last_error",
                                    "create_multi", "set_noise_mips", "set_frames", "submit_clouds", "collect", "is_ready",
-                                   "import_frame_fd", "render_clouds_into", "frame_ready", "release_frame"};
-    static const int expect_argc[] = {1, 3, 2, 1, 1, 3, 0, 0, 1, 3, 1, 3, 1, 1, 2, 2, 1, 1};
-    enum { N_EXPECT = 18 };
+                                   "import_frame_fd", "render_clouds_into", "frame_ready", "release_frame", "get_last_warning"};
+    static const int expect_argc[] = {1, 3, 2, 1, 1, 3, 0, 0, 1, 3, 1, 3, 1, 1, 2, 2, 1, 1, 0};
+    enum { N_EXPECT = 19 };
     int i;
     if (argc < 2) return 2;
     so = dlopen(argv[1], RTLD_NOW);
@@ -194,6 +194,9 @@ int main(int argc, char **argv) {
         memset(&vr, 0, sizeof vr);
         method("get_last_error")->call_func(method("get_last_error")->method_userdata, R.instance, NULL, 0, &vr, &ce);
         if (vr.type != GDEXTENSION_VARIANT_TYPE_STRING || !strstr(vr.u.s, "create()")) return 24;
+        memset(&vr, 0, sizeof vr);
+        method("get_last_warning")->call_func(method("get_last_warning")->method_userdata, R.instance, NULL, 0, &vr, &ce);
+        if (ce.error != GDEXTENSION_CALL_OK || vr.type != GDEXTENSION_VARIANT_TYPE_STRING || vr.u.s[0] != 0) return 27;      /* no context yet: "" */
         if (ptrcall_int("submit_clouds", a) != CSKY_ERR_STATE) return 25;             /* the asynchronous form before create() */
         { int64_t t = 0; GDExtensionConstTypePtr ta[1] = {&t}; if (ptrcall_bytes("collect", ta).size != 0 || ptrcall_int("is_ready", ta) != CSKY_ERR_STATE) return 26; }
     }
