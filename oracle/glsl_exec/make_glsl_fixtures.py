@@ -37,7 +37,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(os.path.dirname(HERE))
 REF = "/root/reference/cloud_sky"
 SHADERS = {"trans": "transmittance-lut.glsl", "sky": "sky-lut.glsl", "clouds": "clouds.glsl", "composite": "clouds.gdshader"}
-SKY_OF = {"cov50": "deg45"}
+SKY_OF = {"cov50": "deg45", "fine": "deg45", "c3edge": "deg45", "c3mid": "deg45"}
 # compositor cases: blend between two cloud frames / sky LUTs of the fixture, the directional light of `sun`, panorama size
 COMPOSITES = {"blend35": dict(**{"from": "zenith", "to": "deg45"}, sun="deg45", blend=0.35, disk=2.0, size=(256, 128)),
               "demo": dict(**{"from": "demo", "to": "demo"}, sun="demo", blend=0.0, disk=1.0, size=(192, 96))}
@@ -178,6 +178,11 @@ def extra_cases(O):
     c["cov50"] = (p, (0, 0, 64, 32))
     e = np.deg2rad(3.0)
     c["lowsun"] = (O.default_params(64, 32, (np.cos(e), np.sin(e), 0.0)), (0, 0, 64, 32))
+    # a finer hemisphere (160 x 80: 2.5x the angular sampling, grazing rays down to 0.7 degrees of elevation) and the horizon band of the headline
+    # texture size itself (rows 0..5 and columns 0..47 of 2048 x 1024: the zero row / column and the longest steps the benchmark frame contains)
+    c["fine"] = (O.default_params(160, 80, (1.0, 1.0, 0.0)), (0, 0, 160, 80))
+    c["c3edge"] = (O.default_params(2048, 1024, (1.0, 1.0, 0.0)), (0, 0, 48, 6))
+    c["c3mid"] = (O.default_params(2048, 1024, (1.0, 1.0, 0.0)), (300, 300, 24, 12))                  # a partly cloudy patch of the benchmark frame (alpha 0.41 .. 1.0)
     rng = np.random.default_rng(20261001)
     for i in range(2):
         w, h = (96, 40) if i == 0 else (56, 72)

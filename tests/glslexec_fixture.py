@@ -7,7 +7,7 @@ import os
 import numpy as np
 
 PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "glslexec.npz")
-SKY_OF = {"cov50": "deg45"}          # cases that share an earlier case's sun (and therefore its sky LUT)
+SKY_OF = {"cov50": "deg45", "fine": "deg45", "c3edge": "deg45", "c3mid": "deg45"}          # cases that share an earlier case's sun (and therefore its sky LUT)
 # clouds.gdshader sky() over a panorama (oracle/glsl_exec/make_glsl_fixtures.py COMPOSITES): textures blended, light, blend_amount, sun_disk_scale, size
 COMPOSITES = {"blend35": dict(**{"from": "zenith", "to": "deg45"}, sun="deg45", blend=0.35, disk=2.0, size=(256, 128)),
               "demo": dict(**{"from": "demo", "to": "demo"}, sun="demo", blend=0.0, disk=1.0, size=(192, 96))}
