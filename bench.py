@@ -431,7 +431,12 @@ def main():
         if not debug_one_gpu or os.environ.get("CSKY_BENCH_FAKE_SHARED_DEVICE") == "1":
             import socket
             pr = torch.cuda.get_device_properties(local_rank)
-            ident = "%s|%s" % (socket.gethostname(), getattr(pr, "uuid", None) or "%s:%s:%s" % (getattr(pr, "pci_domain_id", 0), getattr(pr, "pci_bus_id", local_rank), getattr(pr, "pci_device_id", 0)))
+            # the PHYSICAL identity: PCI domain:bus:device (plain ints in torch's device properties; a device index would be 0 on every rank under a launcher
+            # that narrows each rank's visibility to one GPU, and the `uuid` property is an opaque object whose text is not portable); no PCI fields: the index
+            if isinstance(getattr(pr, "pci_bus_id", None), int):
+                ident = "%s|pci %04x:%02x:%02x" % (socket.gethostname(), getattr(pr, "pci_domain_id", 0) or 0, pr.pci_bus_id, getattr(pr, "pci_device_id", 0) or 0)
+            else:
+                ident = "%s|device index %d" % (socket.gethostname(), local_rank)
             idents = [None] * world
             dist.all_gather_object(idents, ident)
             if len(set(idents)) != world:
