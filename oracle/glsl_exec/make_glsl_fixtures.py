@@ -30,6 +30,7 @@ import shutil
 import subprocess
 import sys
 import tempfile
+import time
 
 import numpy as np
 
@@ -255,6 +256,13 @@ def main():
                 r["composite_" + k] = e.composite(r["clouds_" + c["from"]], r["clouds_" + c["to"]], r["sky_" + c["from"]], r["sky_" + c["to"]], r["trans"],
                                                   norm(SUNS[c["sun"]]), c["blend"], c["disk"], *c["size"])
             res[v] = r
+        # one WHOLE frame at BASELINE config 2's size (512 x 256, zenith sun; the shader's own 128 x 6 steps), fold variant only, stored as its SHA-256: the
+        # oracle must reproduce all 524 288 halfs to the bit (tests/test_oracle_glslexec.py) without a megabyte of fixture
+        t0 = time.time()
+        big = ex["fold"].clouds(otex, O.default_params(512, 256, SUNS["zenith"]), res["fold"]["sky_zenith"], (0, 0, 512, 256))
+        out["c2size_sha256"] = np.array(hashlib.sha256(big.tobytes()).hexdigest())
+        out["c2size_alpha_mean"] = np.float32(big.view(np.float16)[..., 3].astype(np.float32).mean())
+        print("whole 512 x 256 frame executed in %.0f s, sha256 %s, alpha mean %.3f" % (time.time() - t0, str(out["c2size_sha256"])[:16], out["c2size_alpha_mean"]))
         for k, arr in res["fold"].items():
             out["fold_" + k] = arr
         # the float variant: stored in full where a later stage consumes it (LUTs), as a sparse difference otherwise

@@ -61,6 +61,16 @@ def test_cloud_frames_bit_identical(gx, oracle, otex):
     assert n_incloud_px > 5000                                           # the frames are not empty sky
 
 
+def test_whole_c2_size_frame_bit_identical(gx, oracle, otex):
+    """All 131 072 rays of a 512 x 256 hemisphere (BASELINE config 2's size; zenith sun, the shader's literal 128 x 6 steps): the executed text's frame is
+    committed as its SHA-256, the oracle must hash to the same."""
+    import hashlib
+    from bench import usable_cores
+    img = oracle.clouds(otex, oracle.default_params(512, 256, SUNS["zenith"]), gx.fold("sky_zenith"), nthreads=max(1, min(oracle.max_threads(), usable_cores())))
+    assert abs(float(img[..., 3].astype(np.float32).mean()) - float(gx.z["c2size_alpha_mean"])) < 1e-6
+    assert hashlib.sha256(np.ascontiguousarray(img).view(np.uint16).tobytes()).hexdigest() == str(gx.z["c2size_sha256"])
+
+
 def test_compositor_bit_identical(gx, oracle):
     """clouds.gdshader's sky() executed per pixel of a panorama (the oracle's EYEDIR mapping) against csko_composite on the same five
     textures: a blend between two cloud frames / sky LUTs with the sun disc and bloom in view, and the demo scene's grazing sun."""
