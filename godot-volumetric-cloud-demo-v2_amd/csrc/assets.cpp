@@ -65,28 +65,35 @@ int csky_generate_shape_noise(uint32_t seed, int n, uint8_t* out_rgba8) {
     return csky_generate_shape_noise_tuned(seed, n, &p, out_rgba8);
 }
 int csky_generate_shape_noise_tuned(uint32_t seed, int n, const csky_shape_noise_params* params, uint8_t* out_rgba8) {
-    if (!out_rgba8 || n < 8 || (n & (n - 1))) { snprintf(g_asset_err, sizeof g_asset_err, "generate_shape_noise: n must be a power of two >= 8"); return CSKY_ERR_INVALID; }
+    if (!out_rgba8 || n < 8 || n > 1024 || (n & (n - 1))) { snprintf(g_asset_err, sizeof g_asset_err, "generate_shape_noise: n must be a power of two in [8, 1024]"); return CSKY_ERR_INVALID; }
     csky::ShapeNoiseParams P = csky::shape_noise_defaults();
     if (params) { int rc = csky_check_shape_noise_params(params, n); if (rc) return rc; memcpy(&P, params, sizeof P); }
     unsigned hw = std::thread::hardware_concurrency();
     int nt = (int)(hw == 0 ? 1 : (hw > 32 ? 32 : hw));
     if (nt > n) nt = n;
     std::vector<std::thread> th;
-    for (int t = 0; t < nt; t++) {
-        int z0 = (int)((long)n * t / nt), z1 = (int)((long)n * (t + 1) / nt);
-        th.emplace_back(shape_rows, seed, n, P, z0, z1, out_rgba8);
-    }
+    int done_to = 0;                                             // slices [0, done_to) are owned by a started thread
+    try {                                                        // (thread creation can throw: nothing crosses the ABI; the rest is rendered here)
+        for (int t = 0; t < nt; t++) {
+            int z0 = (int)((long)n * t / nt), z1 = (int)((long)n * (t + 1) / nt);
+            th.emplace_back(shape_rows, seed, n, P, z0, z1, out_rgba8);
+            done_to = z1;
+        }
+    } catch (...) {}
+    if (done_to < n) shape_rows(seed, n, P, done_to, n, out_rgba8);
     for (auto& t : th) t.join();
     return CSKY_OK;
 }
 
 int csky_generate_detail_noise(uint32_t seed, int n, uint8_t* out_rgb8) {
-    if (!out_rgb8 || n < 8 || (n & (n - 1))) { snprintf(g_asset_err, sizeof g_asset_err, "generate_detail_noise: n must be a power of two >= 8"); return CSKY_ERR_INVALID; }
+    if (!out_rgb8 || n < 8 || n > 1024 || (n & (n - 1))) { snprintf(g_asset_err, sizeof g_asset_err, "generate_detail_noise: n must be a power of two in [8, 1024]"); return CSKY_ERR_INVALID; }
     for (int z = 0; z < n; z++) for (int y = 0; y < n; y++) for (int x = 0; x < n; x++) csky::detail_voxel(seed, n, x, y, z, out_rgb8 + ((((size_t)z * n + y) * n + x) * 3));
     return CSKY_OK;
 }
 
 size_t csky_mip_offset(int n, int level, int ch) {
+    if (n < 1 || ch < 1) return 0;
+    if (level > 31) level = 31;                                  // n >> l is 0 from l = 31 at the latest (a shift by >= 32 is undefined)
     size_t off = 0;
     for (int l = 0; l < level; l++) { size_t m = (size_t)(n >> l); off += m * m * m * (size_t)ch; }
     return off;
@@ -95,7 +102,7 @@ size_t csky_mip_offset(int n, int level, int ch) {
 // 3-D mip chain, 2x2x2 box, integer round-half-up.  `vol` holds level 0 on entry and must have room for
 // csky_mip_offset(n, levels, ch) bytes.
 int csky_build_mips(uint8_t* vol, int n, int ch, int levels) {
-    if (!vol || n < 1 || ch < 1 || levels < 1 || (n >> (levels - 1)) < 1) { snprintf(g_asset_err, sizeof g_asset_err, "build_mips: bad arguments"); return CSKY_ERR_INVALID; }
+    if (!vol || n < 1 || ch < 1 || levels < 1 || levels > 31 || (n >> (levels - 1)) < 1) { snprintf(g_asset_err, sizeof g_asset_err, "build_mips: bad arguments"); return CSKY_ERR_INVALID; }
     for (int l = 1; l < levels; l++) {
         const uint8_t* src = vol + csky_mip_offset(n, l - 1, ch);
         uint8_t* dst = vol + csky_mip_offset(n, l, ch);
@@ -110,21 +117,23 @@ int csky_build_mips(uint8_t* vol, int n, int ch, int levels) {
 }
 
 // Uncompressed 24-bpp BMP -> tightly packed RGB8, top row first (what Godot's / PIL's loaders present).
-int csky_load_bmp_rgb8(const char* path, int* w, int* h, uint8_t* out, size_t out_capacity) {
-    FILE* f = fopen(path, "rb");
-    if (!f) { snprintf(g_asset_err, sizeof g_asset_err, "load_bmp: cannot open %s", path); return CSKY_ERR_IO; }
+static int load_bmp_impl(const char* path, int* w, int* h, uint8_t* out, size_t out_capacity) {
+    FILE* f = path ? fopen(path, "rb") : nullptr;
+    if (!f) { snprintf(g_asset_err, sizeof g_asset_err, "load_bmp: cannot open %s", path ? path : "(null)"); return CSKY_ERR_IO; }
     uint8_t hd[54];
     if (fread(hd, 1, 54, f) != 54 || hd[0] != 'B' || hd[1] != 'M') { fclose(f); snprintf(g_asset_err, sizeof g_asset_err, "load_bmp: %s is not a BMP", path); return CSKY_ERR_IO; }
     uint32_t off; int32_t bw, bh; uint16_t bpp; uint32_t comp;
     memcpy(&off, hd + 10, 4); memcpy(&bw, hd + 18, 4); memcpy(&bh, hd + 22, 4); memcpy(&bpp, hd + 28, 2); memcpy(&comp, hd + 30, 4);
-    if (bpp != 24 || comp != 0 || bw <= 0 || bh == 0) { fclose(f); snprintf(g_asset_err, sizeof g_asset_err, "load_bmp: only uncompressed 24-bpp supported (%s)", path); return CSKY_ERR_IO; }
+    // (sizes beyond 65536 are no texture of this path and would make `-bh`, the row buffer and the index arithmetic below a liability)
+    if (bpp != 24 || comp != 0 || bw <= 0 || bw > 65536 || bh == 0 || bh > 65536 || bh < -65536) { fclose(f); snprintf(g_asset_err, sizeof g_asset_err, "load_bmp: only uncompressed 24-bpp supported (%s)", path); return CSKY_ERR_IO; }
     const bool bottom_up = bh > 0; const int H = bh > 0 ? bh : -bh, W = bw;
     if (w) *w = W; if (h) *h = H;
     if (!out) { fclose(f); return CSKY_OK; }                       // size query
     if (out_capacity < (size_t)W * H * 3) { fclose(f); snprintf(g_asset_err, sizeof g_asset_err, "load_bmp: output buffer too small"); return CSKY_ERR_INVALID; }
     const size_t stride = ((size_t)W * 3 + 3) & ~(size_t)3;
-    std::vector<uint8_t> row(stride);
-    fseek(f, (long)off, SEEK_SET);
+    std::vector<uint8_t> row;
+    try { row.resize(stride); } catch (...) { fclose(f); snprintf(g_asset_err, sizeof g_asset_err, "load_bmp: out of memory"); return CSKY_ERR_IO; }
+    if (fseek(f, (long)off, SEEK_SET) != 0) { fclose(f); snprintf(g_asset_err, sizeof g_asset_err, "load_bmp: bad pixel-data offset in %s", path); return CSKY_ERR_IO; }
     for (int r = 0; r < H; r++) {
         if (fread(row.data(), 1, stride, f) != stride) { fclose(f); snprintf(g_asset_err, sizeof g_asset_err, "load_bmp: truncated %s", path); return CSKY_ERR_IO; }
         uint8_t* o = out + (size_t)(bottom_up ? H - 1 - r : r) * W * 3;
@@ -134,12 +143,14 @@ int csky_load_bmp_rgb8(const char* path, int* w, int* h, uint8_t* out, size_t ou
     return CSKY_OK;
 }
 
+int csky_load_bmp_rgb8(const char* path, int* w, int* h, uint8_t* out, size_t out_capacity) { return load_bmp_impl(path, w, h, out, out_capacity); }
+
 // Truevision TGA (types 2 = uncompressed and 10 = RLE true colour, 24 or 32 bpp, either origin) -> tightly packed RGBA8,
 // top row first: the container of the reference's shape noise cloud_sky/perlworlnoise.tga (16384 x 128, 128 slices;
 // missing from the reference checkout but loadable here when a user has it).
 int csky_load_tga_rgba8(const char* path, int* w, int* h, uint8_t* out, size_t out_capacity) {
-    FILE* f = fopen(path, "rb");
-    if (!f) { snprintf(g_asset_err, sizeof g_asset_err, "load_tga: cannot open %s", path); return CSKY_ERR_IO; }
+    FILE* f = path ? fopen(path, "rb") : nullptr;
+    if (!f) { snprintf(g_asset_err, sizeof g_asset_err, "load_tga: cannot open %s", path ? path : "(null)"); return CSKY_ERR_IO; }
     uint8_t hd[18];
     if (fread(hd, 1, 18, f) != 18) { fclose(f); snprintf(g_asset_err, sizeof g_asset_err, "load_tga: %s is truncated", path); return CSKY_ERR_IO; }
     const int id_len = hd[0], cmap_type = hd[1], type = hd[2], W = hd[12] | (hd[13] << 8), H = hd[14] | (hd[15] << 8), bpp = hd[16];
