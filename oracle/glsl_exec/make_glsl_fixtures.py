@@ -208,6 +208,7 @@ def main():
     ap.add_argument("--out", default=os.path.join(ROOT, "tests", "golden", "glslexec.npz"))
     ap.add_argument("--keep-tu", default=None, help="directory OUTSIDE the repository to keep the generated translation units in")
     ap.add_argument("--mutation-check", action="store_true", help="also run the negative control (MUTATIONS)")
+    ap.add_argument("--compile-only", action="store_true", help="compile the reference's text under the shim (both variants) and stop: the build check of __graft_entry__.build()")
     a = ap.parse_args()
     if not os.path.isdir(REF):
         sys.exit("the reference tree is not present (%s): this script only runs in the build container" % REF)
@@ -229,6 +230,9 @@ def main():
     tmp = tempfile.mkdtemp(prefix="glslexec_", dir=a.keep_tu or tempfile.gettempdir())
     try:
         ex = {v: Exec(build_variant(tmp, v, texts)) for v in ("fold", "float")}
+        if a.compile_only:
+            print("compiled the four shader files under the shim (fold + float variants)")
+            return
         noise = gvcd_amd.assets.load_default_noise()
         otex = O.OracleTextures(*noise)
         np_fix = np.load(os.path.join(ROOT, "tests", "golden", "clouds_np.npz"))
