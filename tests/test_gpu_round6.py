@@ -129,3 +129,43 @@ def test_shape_generator_on_the_device_refuses_what_the_host_refuses(gpu_ctx, pk
         with pytest.raises(pkg.CloudSkyError):
             gpu_ctx.generate_shape_noise(1, n, **bad)
     assert (gpu_ctx.generate_shape_noise(3, 32) == pkg.assets.generate_shape_noise(3, 32)).all()
+
+
+def test_rccl_calls_of_the_multi_rank_path_in_a_world_of_one():
+    """No second GPU exists here, so RCCL cannot move a byte between devices -- but every torch.distributed call bench.py's N > 1 path makes can at least be
+    issued on the real backend (nccl = RCCL) with the dtypes, streams and options it uses: init with device_id, the identity all_gather_object, new_group,
+    the asynchronous byte gather of FrameGroups on a side stream with wait() under that stream, all_reduce MAX of the float64 timing, all_reduce SUM of the
+    share vector, barrier.  A call the backend rejects (dtype, async gather, object collectives) fails here instead of on the driver's 8-GPU node."""
+    import os
+    import subprocess
+    import sys
+    import textwrap
+    code = textwrap.dedent('''
+        import os, sys
+        sys.path.insert(0, %r)
+        import torch, torch.distributed as dist
+        from gvcd_amd import tiling
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER_PORT", "29531")
+        torch.cuda.set_device(0); dev = torch.device("cuda", 0)
+        dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+        ids = [None]; dist.all_gather_object(ids, "host|pci 0000:0a:00"); assert ids == ["host|pci 0000:0a:00"]
+        fg = tiling.FrameGroups(0, 1, 1, dist)
+        sub = dist.new_group([0])
+        side = torch.cuda.Stream(device=dev)
+        src = torch.arange(4096, dtype=torch.int16, device=dev).view(torch.uint8)
+        gathered = torch.empty((1, src.numel()), dtype=torch.uint8, device=dev)
+        with torch.cuda.stream(side):
+            w = fg.gather(0, src, gathered, async_op=True)
+            w.wait()
+        side.synchronize()
+        assert (gathered[0] == src).all()
+        dist.gather(src, gather_list=[gathered[0]], dst=0, group=sub)
+        t = torch.tensor([1.25], dtype=torch.float64, device=dev); dist.all_reduce(t, op=dist.ReduceOp.MAX); assert float(t.item()) == 1.25
+        s = torch.zeros(1, dtype=torch.float64, device=dev); s[0] = 0.5; dist.all_reduce(s, op=dist.ReduceOp.SUM); assert float(s.item()) == 0.5
+        dist.barrier(); torch.cuda.synchronize()
+        dist.destroy_process_group()
+        print("rccl world-of-one ok")
+    ''') % (os.path.dirname(os.path.dirname(os.path.abspath(__file__))),)
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300, env=env)
+    assert r.returncode == 0 and "rccl world-of-one ok" in r.stdout, (r.stdout[-800:], r.stderr[-2500:])
