@@ -298,17 +298,19 @@ def main():
         # ... and the BENCHMARK frame itself: BASELINE configs[2], 2048 x 1024 @ 128 x 6, sun (1,1,0)/sqrt 2 -- all 2 097 152 rays of the executed text, as its
         # SHA-256 plus one hash per 64-row band (to localise a difference, should one ever appear).  ~8 core-minutes.
         if not a.skip_c3:
-            t0 = time.time()
-            c3 = whole_frame_parallel(os.path.join(tmp, "libglslexec_fold.so"), noise, res["fold"]["sky_deg45"], O.default_params(2048, 1024, SUNS["deg45"]), 2048, 1024)
-            out["c3_sha256"] = np.array(hashlib.sha256(c3.tobytes()).hexdigest())
-            out["c3_band_sha256"] = np.array([hashlib.sha256(c3[y:y + 64].tobytes()).hexdigest()[:16] for y in range(0, 1024, 64)])
-            out["c3_alpha_mean"] = np.float32(c3.view(np.float16)[..., 3].astype(np.float32).mean())
-            print("whole 2048 x 1024 benchmark frame executed in %.0f s on %d processes, sha256 %s, alpha mean %.4f"
-                  % (time.time() - t0, max(1, min(8, os.cpu_count() or 1)), str(out["c3_sha256"])[:16], out["c3_alpha_mean"]))
+            for sk in ("deg45", "zenith", "demo"):                 # deg45 = the timed benchmark frame; the other two are the parity frames of SURVEY 8(d)
+                t0 = time.time()
+                c3 = whole_frame_parallel(os.path.join(tmp, "libglslexec_fold.so"), noise, res["fold"]["sky_" + sk], O.default_params(2048, 1024, SUNS[sk]), 2048, 1024)
+                sfx = "" if sk == "deg45" else "_" + sk
+                out["c3%s_sha256" % sfx] = np.array(hashlib.sha256(c3.tobytes()).hexdigest())
+                out["c3%s_band_sha256" % sfx] = np.array([hashlib.sha256(c3[y:y + 64].tobytes()).hexdigest()[:16] for y in range(0, 1024, 64)])
+                out["c3%s_alpha_mean" % sfx] = np.float32(c3.view(np.float16)[..., 3].astype(np.float32).mean())
+                print("whole 2048 x 1024 benchmark frame (sun %s) executed in %.0f s on %d processes, sha256 %s, alpha mean %.4f"
+                      % (sk, time.time() - t0, max(1, min(8, os.cpu_count() or 1)), str(out["c3%s_sha256" % sfx])[:16], out["c3%s_alpha_mean" % sfx]))
         else:                                                      # keep what the committed fixture holds (a quick regeneration skips the 8 core-minutes)
             old = np.load(a.out) if os.path.exists(a.out) else {}
-            for k in ("c3_sha256", "c3_band_sha256", "c3_alpha_mean"):
-                if k in old:
+            for k in list(getattr(old, "files", [])):
+                if k.startswith("c3"):
                     out[k] = old[k]
         for k, arr in res["fold"].items():
             out["fold_" + k] = arr

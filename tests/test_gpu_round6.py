@@ -175,6 +175,9 @@ def test_benchmark_frame_hip_vs_oracle_vs_executed_text(gpu_ctx, gx, oracle, ora
     """The chain at full benchmark size (BASELINE configs[2], 2 097 152 rays): the frame the reference's own shader text wrote (committed as hashes) IS the
     oracle's frame, and the HIP frame of the same push constants is within the tight gate of it -- one test, the same arrays."""
     import hashlib
+    for sk, key in (("zenith", "c3_zenith_sha256"), ("demo", "c3_demo_sha256")):      # the two parity frames of SURVEY 8(d): the oracle IS the executed text there too
+        fr, _ = oracle_frames(2048, 1024, sk)
+        assert hashlib.sha256(np.ascontiguousarray(fr).view(np.uint16).tobytes()).hexdigest() == str(gx.z[key]), sk
     ref, st_o = oracle_frames(2048, 1024, "deg45")
     assert hashlib.sha256(np.ascontiguousarray(ref).view(np.uint16).tobytes()).hexdigest() == str(gx.z["c3_sha256"])
     gpu_ctx.set_variant(-1); gpu_ctx.set_march(128, 6); gpu_ctx.set_early_out(0.0)
