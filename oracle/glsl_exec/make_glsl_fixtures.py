@@ -307,10 +307,19 @@ def main():
                 out["c3%s_alpha_mean" % sfx] = np.float32(c3.view(np.float16)[..., 3].astype(np.float32).mean())
                 print("whole 2048 x 1024 benchmark frame (sun %s) executed in %.0f s on %d processes, sha256 %s, alpha mean %.4f"
                       % (sk, time.time() - t0, max(1, min(8, os.cpu_count() or 1)), str(out["c3%s_sha256" % sfx])[:16], out["c3%s_alpha_mean" % sfx]))
+            # BASELINE configs[4] (C5): the two grazing end points of the 64-frame sun sweep, theta = 2 and 178 degrees, as WHOLE 4096 x 2048 frames, each from
+            # the sky LUT the executed sky-lut.glsl renders for that sun (so the hash covers LUT + frame); ~4 minutes each on 8 processes
+            for theta in (2.0, 178.0):
+                t0 = time.time()
+                sun = (np.cos(np.radians(theta)), np.sin(np.radians(theta)), 0.0)
+                sky = ex["fold"].sky(norm(sun), res["fold"]["trans"])
+                c5 = whole_frame_parallel(os.path.join(tmp, "libglslexec_fold.so"), noise, sky, O.default_params(4096, 2048, sun), 4096, 2048, band=64)
+                out["c5_theta%d_sha256" % int(theta)] = np.array(hashlib.sha256(c5.tobytes()).hexdigest())
+                print("whole 4096 x 2048 frame (C5 sweep end point theta = %g) executed in %.0f s, sha256 %s" % (theta, time.time() - t0, str(out["c5_theta%d_sha256" % int(theta)])[:16]))
         else:                                                      # keep what the committed fixture holds (a quick regeneration skips the 8 core-minutes)
             old = np.load(a.out) if os.path.exists(a.out) else {}
             for k in list(getattr(old, "files", [])):
-                if k.startswith("c3"):
+                if k.startswith(("c3", "c5")):
                     out[k] = old[k]
         for k, arr in res["fold"].items():
             out["fold_" + k] = arr

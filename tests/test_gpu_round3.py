@@ -231,6 +231,11 @@ def test_c5_sweep_end_points_full_size_vs_oracle(gpu_ctx, oracle, otex, o_trans,
     ref, st_o = oracle.clouds(otex, p, sk_o, nthreads=max(1, min(oracle.max_threads(), usable_cores())), return_stats=True)
     ok, info = cloud_tight(img, ref)
     assert ok and info["within1"] >= 0.9998 and info["beyond2_pixels"] <= 1e-4 * W * H, (theta, info)
+    # round 6: this oracle frame IS the frame the reference's own shader text wrote when executed (sky-lut.glsl for this sun, then clouds.glsl over all
+    # 8 388 608 rays; tests/golden/glslexec.npz holds its SHA-256)
+    import hashlib
+    from glslexec_fixture import GlslExec
+    assert hashlib.sha256(np.ascontiguousarray(ref).view(np.uint16).tobytes()).hexdigest() == str(GlslExec().z["c5_theta%d_sha256" % int(theta)])
     assert st["primary_samples"] == st_o["primary_samples"]
     assert abs(int(st["incloud_samples"]) - int(st_o["incloud_samples"])) <= 2e-6 * st_o["incloud_samples"] + 1
     print("C5 sweep end point theta = %g: %s" % (theta, info))
