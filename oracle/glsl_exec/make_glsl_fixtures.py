@@ -295,6 +295,22 @@ def main():
         out["c2size_sha256"] = np.array(hashlib.sha256(big.tobytes()).hexdigest())
         out["c2size_alpha_mean"] = np.float32(big.view(np.float16)[..., 3].astype(np.float32).mean())
         print("whole 512 x 256 frame executed in %.0f s, sha256 %s, alpha mean %.3f" % (time.time() - t0, str(out["c2size_sha256"])[:16], out["c2size_alpha_mean"]))
+        # BASELINE config 2 marches 64 primary x 4 light steps; the shader has the literals 128.0 (clouds.glsl:228) and 6 (:186).  The build generalises both
+        # (csky_set_march; the oracle's primary_steps / light_steps).  To execute THAT configuration the two literals are substituted -- nothing else -- and the
+        # whole 512 x 256 frame of config 2 is hashed: it pins the generalisation (RANDOM_VECTORS[0..3], LOD = j, the distant sample unchanged).
+        t0 = time.time()
+        lit = [("float steps = 128.0;", "float steps = 64.0;"), ("for (int j = 0; j < 6; j++)", "for (int j = 0; j < 4; j++)")]
+        t2 = dict(texts)
+        for was, now in lit:
+            assert t2["clouds"].count(was) == 1, was
+            t2["clouds"] = t2["clouds"].replace(was, now)
+        d64 = os.path.join(tmp, "steps64x4"); os.makedirs(d64)
+        e64 = Exec(build_variant(d64, "fold", t2))
+        c2 = e64.clouds(otex, O.default_params(512, 256, SUNS["zenith"]), res["fold"]["sky_zenith"], (0, 0, 512, 256))
+        out["c2_64x4_sha256"] = np.array(hashlib.sha256(c2.tobytes()).hexdigest())
+        out["c2_64x4_patch"] = c2[100:116, 200:232].copy()                    # a 32 x 16 patch in the clear, for a readable failure
+        print("BASELINE config 2 (512 x 256 @ 64 x 4: the two step literals substituted) executed in %.0f s, sha256 %s, alpha mean %.3f"
+              % (time.time() - t0, str(out["c2_64x4_sha256"])[:16], c2.view(np.float16)[..., 3].astype(np.float32).mean()))
         # ... and the BENCHMARK frame itself: BASELINE configs[2], 2048 x 1024 @ 128 x 6, sun (1,1,0)/sqrt 2 -- all 2 097 152 rays of the executed text, as its
         # SHA-256 plus one hash per 64-row band (to localise a difference, should one ever appear).  ~8 core-minutes.
         if not a.skip_c3:

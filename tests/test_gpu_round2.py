@@ -72,6 +72,11 @@ def test_full_frame_c2_vs_oracle_tight(gpu_ctx, oracle, otex, o_skies):
         ok, info = cloud_tight(img, ref)
         assert ok, info
         _count_gate(st, st_o)
+        # round 6: this oracle frame IS what the reference's own shader text writes when executed with its two step literals (128.0, 6) replaced by this
+        # configuration's 64 and 4 (tests/golden/glslexec.npz, oracle/glsl_exec/make_glsl_fixtures.py): the build's generalisation of the march is pinned
+        import hashlib
+        from glslexec_fixture import GlslExec
+        assert hashlib.sha256(np.ascontiguousarray(ref).view(np.uint16).tobytes()).hexdigest() == str(GlslExec().z["c2_64x4_sha256"])
     finally:
         gpu_ctx.set_march(128, 6)
 

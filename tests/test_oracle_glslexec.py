@@ -71,6 +71,17 @@ def test_whole_c2_size_frame_bit_identical(gx, oracle, otex):
     assert hashlib.sha256(np.ascontiguousarray(img).view(np.uint16).tobytes()).hexdigest() == str(gx.z["c2size_sha256"])
 
 
+def test_config_2_with_its_own_step_counts_bit_identical(gx, oracle, otex):
+    """BASELINE config 2 as specified: 512 x 256 @ 64 primary x 4 light steps.  The shader has the literals 128.0 and 6; the executed text had exactly those two
+    substituted (make_glsl_fixtures.py), the oracle takes them as arguments: the build's generalisation of the march is pinned too."""
+    import hashlib
+    from bench import usable_cores
+    img = oracle.clouds(otex, oracle.default_params(512, 256, SUNS["zenith"]), gx.fold("sky_zenith"), primary_steps=64, light_steps=4,
+                        nthreads=max(1, min(oracle.max_threads(), usable_cores())))
+    assert _same(img[100:116, 200:232], gx.z["c2_64x4_patch"])
+    assert hashlib.sha256(np.ascontiguousarray(img).view(np.uint16).tobytes()).hexdigest() == str(gx.z["c2_64x4_sha256"])
+
+
 def test_whole_benchmark_frame_bit_identical(gx, oracle_frames):
     """BASELINE configs[2] itself -- 2048 x 1024 @ 128 x 6, sun (1,1,0)/sqrt 2, all 2 097 152 rays: the frame the reference's own shader text wrote (executed in
     the build container, committed as its SHA-256 + one hash per 64-row band) against the oracle's frame, the one every whole-frame `-m gpu` gate compares the HIP
