@@ -298,12 +298,8 @@ int clouds_dev(csky_ctx* c, const csky_cloud_params* p, int tile_w, const csky_b
     }
     if (variant == 2) seg = 16;
     int mode = c->sched_mode >= 0 ? c->sched_mode : auto_mode;
-#ifdef CSKY_FOOT16
-    const int bw = seg == 1 ? 16 : (seg == 5 ? 8 : (seg == 16 ? 128 : 32 / seg)), bh = seg == 1 ? 16 : 8;   // EXPERIMENT BUILD: 16 x 16 footprints for whole-ray workgroups
-#else
-    const int bw = seg == 5 ? 8 : (seg == 16 ? 128 : 32 / seg), bh = 8;   // workgroup footprint = bw x 8 pixels (seg 5: one tile; seg 16: the 16-wavefront "lds" strip)
-#endif
-    const int tiles_x = (g.tile_w + bw - 1) / bw, slabs = (g.n_bands * g.band_rows + bh - 1) / bh, nblocks = tiles_x * slabs;
+    const int bw = seg == 5 ? 8 : (seg == 16 ? 128 : 32 / seg);   // workgroup footprint = bw x 8 pixels (seg 5: one tile; seg 16: the 16-wavefront "lds" strip)
+    const int tiles_x = (g.tile_w + bw - 1) / bw, slabs = (g.n_bands * g.band_rows + 7) >> 3, nblocks = tiles_x * slabs;
     bool feedback = mode == 7 && queued && seg != 5;             // kernels that record per-workgroup costs
     if (mode == 7 && !feedback) mode = waves >= 12288 ? 5 : 2;
     const int static_mode = mode == 7 ? (waves >= 12288 ? 5 : 2) : mode;   // order of the first launch of a geometry under feedback

@@ -910,21 +910,17 @@ __global__ __launch_bounds__(1024) void clouds_kernel_lds(TexSet T, const FrameC
 template <int VARIANT, int SEG, class TS = TexSet>
 __device__ __forceinline__ void render_block(TS T, const FrameConsts* __restrict__ fcp, const RenderGeom& G, const uint32_t logical, const uint32_t rec,
                                              uint2* __restrict__ out, unsigned long long* __restrict__ stats, uint32_t* __restrict__ wg_cost, const int tile_of_wave = -1) {
-#ifdef CSKY_FOOT16
-    constexpr bool SQ = SEG == 1;                              // EXPERIMENT BUILD: whole-ray workgroups cover 16 x 16 pixels (2 x 2 tiles) instead of 32 x 8
-#else
-    constexpr bool SQ = false;
-#endif
-    constexpr int BW = SQ ? 16 : 32 / SEG;                     // workgroup footprint width in pixels
-    constexpr int BH = SQ ? 16 : 8;
+    constexpr int BW = 32 / SEG;                               // workgroup footprint width in pixels
+    // (Round 6, measured and removed, profiles/r06/foot16_ab.txt: 16 x 16-pixel footprints (2 x 2 tiles) for whole-ray workgroups: frame identical, kernel alone
+    // +4.4 %, two frames in flight unchanged)
     const int tiles_x = (G.tile_w + BW - 1) / BW;
     const int local_rows = G.n_bands * G.band_rows;
     const int slab = (int)logical / tiles_x, bx = (int)logical - slab * tiles_x;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int tile = tile_of_wave >= 0 ? tile_of_wave : wave / SEG, seg = tile_of_wave >= 0 ? 0 : wave - tile * SEG;   // tile_of_wave: SEG == 1 only
     // (lanes in Morton order or in 2x2 quads inside the tile instead of rows of 8: 1.701 / 1.700 vs 1.702 ms per frame, no difference)
-    const int gx = bx * BW + (SQ ? (tile & 1) : tile) * 8 + (lane & 7);
-    const int lr = slab * BH + (SQ ? (tile >> 1) * 8 : 0) + (lane >> 3);
+    const int gx = bx * BW + tile * 8 + (lane & 7);
+    const int lr = slab * 8 + (lane >> 3);
     const bool valid = gx < G.tile_w && lr < local_rows;
     const int band = lr / G.band_rows, rib = lr - band * G.band_rows;
     const int gy = (G.first_band + band * G.band_stride) * G.band_rows + rib;
